@@ -1,0 +1,85 @@
+"""Seeded input builders shared by the golden generator (tests/golden/make_golden.py), the oracle
+tests and the GPU parity tests, so all three see byte-identical inputs."""
+import torch
+
+from streamflow_amd import synthetic as syn
+
+CORR_CASES = {"corr_odd": (1, 32, 17, 19, 21), "corr_b2": (2, 16, 16, 18, 22)}       # B, D, h, w, seed
+UPDATE_CASES = {"update_T4": (1, 4, 9, 12, 51), "update_T3_b2": (2, 3, 8, 8, 52),
+                "update_T2": (1, 2, 7, 10, 53)}                                      # B, T, h, w, seed
+SKBLOCK_CASES = [("encoder.convc1", 324, 256, syn.K_CONV), ("encoder.convf2", 128, 64, syn.K_CONV),
+                 ("encoder.conv", 256, 126, syn.K_CONV), ("gru", 640, 128, syn.GRU_CONV),
+                 ("flow_head", 384, 6, syn.K_CONV)]
+SKBLOCK_SEED, SKBLOCK_HW = 41, (9, 10)
+FORWARD_CASES = {"forward_T4": (1, 4, 128, 192, 4, 71, False),
+                 "forward_T3_b2_init": (2, 3, 128, 128, 3, 72, True),
+                 "forward_demo256": (1, 4, 256, 256, 4, 73, False)}                   # B,T,H,W,iters,seed,init
+GMA_CASE = (31, 2, 12, 16)                                                           # seed, BT, h, w
+UPSAMPLE_SEED = 61
+
+
+def _grid(B, h, w):
+    xs = torch.arange(w, dtype=torch.float32).view(1, w).expand(h, w)
+    ys = torch.arange(h, dtype=torch.float32).view(h, 1).expand(h, w)
+    return torch.stack([xs, ys], 0)[None].repeat(B, 1, 1, 1)
+
+
+def bilinear_inputs():
+    img = syn.randn(11, "bs.img", (5, 3, 6, 7))
+    crd = syn.randn(11, "bs.coords", (5, 4, 9, 2), 3.0) + 3.0
+    crd[0, 0, :, :] = torch.tensor([[0.0, 0.0], [6.0, 5.0], [-1.0, 2.0], [7.0, 2.0], [3.0, -1.0],
+                                    [3.0, 6.0], [2.5, 2.5], [6.0, 0.0], [0.0, 5.0]])
+    return img, crd
+
+
+def corr_inputs(tag):
+    B, D, h, w, seed = CORR_CASES[tag]
+    f1 = syn.randn(seed, "corr.f1", (B, D, h, w))
+    f2 = syn.randn(seed, "corr.f2", (B, D, h, w))
+    coords = _grid(B, h, w) + syn.randn(seed, "corr.flow", (B, 2, h, w), 3.0)
+    coords[:, :, 0, 0] = torch.tensor([-6.0, 2.0])                       # window partly outside
+    coords[:, :, 1, 1] = torch.tensor([float(w + 9), float(h + 9)])      # fully outside
+    coords[:, :, 2, 2] = torch.tensor([3.0, 4.0])                        # exactly integer
+    coords[:, :, 3, 3] = torch.tensor([float(w - 1), float(h - 1)])      # last cell
+    return f1, f2, coords, _grid(B, h, w)
+
+
+def gma_inputs():
+    seed, BT, h, w = GMA_CASE
+    P = syn.make_params(seed, 4)
+    inp = torch.relu(syn.randn(seed, "gma.inp", (BT, 128, h, w)))
+    mf = syn.randn(seed, "gma.mf", (BT, 128, h, w))
+    return P, inp, mf
+
+
+def skblock_inputs(name, cin):
+    h, w = SKBLOCK_HW
+    return syn.randn(SKBLOCK_SEED, "sk.x." + name, (2, cin, h, w))
+
+
+def update_inputs(tag):
+    B, T, h, w, seed = UPDATE_CASES[tag]
+    Pn = T - 1
+    N = h * w
+    P = syn.make_params(seed, T)
+    nets = torch.tanh(syn.randn(seed, "ub.nets", (B * Pn, 128, h, w)))
+    inps = torch.relu(syn.randn(seed, "ub.inps", (B * Pn, 128, h, w)))
+    corrs = syn.randn(seed, "ub.corrs", (B * Pn, 324, h, w))
+    flows = syn.randn(seed, "ub.flows", (B * Pn, 2, h, w), 2.0)
+    attn = torch.softmax(syn.randn(seed, "ub.attn", (B * Pn, 1, N, N), 2.0), dim=-1)
+    return P, nets, inps, corrs, flows, attn
+
+
+def upsample_inputs():
+    flow = syn.randn(UPSAMPLE_SEED, "up.flow", (2, 2, 9, 11), 3.0)
+    mask = syn.randn(UPSAMPLE_SEED, "up.mask", (2, 576, 9, 11), 2.0)
+    return flow, mask
+
+
+def forward_inputs(tag):
+    B, T, H, W, iters, seed, use_init = FORWARD_CASES[tag]
+    h, w = H // 8, W // 8
+    P = syn.make_params(seed, T)
+    fmaps, cnets = syn.make_features(seed, B, T, h, w)
+    finit = [syn.randn(seed, f"flow_init{i}", (B, 2, h, w), 1.5) for i in range(T - 1)] if use_init else None
+    return P, fmaps, cnets, finit, iters
