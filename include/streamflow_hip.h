@@ -1,0 +1,152 @@
+/* streamflow_hip.h -- C ABI of libstreamflow_hip.so (MI355X / gfx950 only).
+ *
+ * The reference (littlespray/StreamFlow) is pure Python/PyTorch and has no FFI or plugin registry
+ * (SURVEY.md section 8b): its "interface" for the hot path is the Python call surface of
+ * core/corr.py, core/utils/utils.py, core/gma.py, core/update.py and core/models/streamflow.py.
+ * Each entry point below replaces the library kernels one of those call sites dispatches to; the
+ * reference file:line it stands in for is cited per function.  The Python classes in
+ * streamflow_amd/ keep the reference signatures and state-dict keys and call these through ctypes.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to fp32 data unless stated; the caller owns all memory
+ *     (inputs, outputs, workspaces); the library never allocates or frees device memory and keeps
+ *     no global state besides a thread-local error string.
+ *   - `stream` is a hipStream_t passed as void*; every call only ENQUEUES work on it (no host sync,
+ *     no default-stream use), so calls may be captured into a HIP graph.
+ *   - return value: 0 on success, negative SF_ERR_* otherwise; sf_last_error() gives the message.
+ *   - feature planes are "channel-major": tensor [n_img][C][P] with P = h*w contiguous (NCHW).
+ */
+#ifndef STREAMFLOW_HIP_H
+#define STREAMFLOW_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SF_VERSION 100
+
+enum {
+    SF_OK = 0,
+    SF_ERR_BAD_ARG = -1,     /* null pointer, non-positive dim, unsupported combination */
+    SF_ERR_UNSUPPORTED = -2, /* shape outside what the kernels are built for            */
+    SF_ERR_HIP = -3          /* a HIP runtime call failed (message holds hipGetErrorString) */
+};
+
+int sf_version(void);
+const char* sf_last_error(void);
+
+/* ---- a5: coords_grid  (core/utils/utils.py:82-85) --------------------------------------------
+ * out [batch][2][ht][wd]; out[b][0][y][x] = x, out[b][1][y][x] = y (exact small integers). */
+int sf_coords_grid(float* out, int batch, int ht, int wd, void* stream);
+
+/* ---- a4: bilinear_sampler  (core/utils/utils.py:65-79; F.grid_sample bilinear/zeros/align_corners)
+ * img [M][C][Hi][Wi], coords [M][Ho][Wo][2] pixel (x,y)  ->  out [M][C][Ho][Wo].
+ * mask_out (optional, may be NULL): [M][Ho][Wo][1] in-bounds indicator as the reference's mask=True. */
+int sf_bilinear_sampler(const float* img, const float* coords, float* out, float* mask_out,
+                        int M, int C, int Hi, int Wi, int Ho, int Wo, void* stream);
+
+/* ---- a1+a2: CorrBlock.__init__  (core/corr.py:7-21,46-54) -------------------------------------
+ * One launch builds the 4-level pyramids of `pairs` frame pairs of `B` clips.
+ * Features: clip b, pair t reads f1 + b*f_clip_stride + t*f_pair_stride and the same offset from f2,
+ * each a [D][h*w] plane set (for a single reference-style call: pairs=1, f_clip_stride=D*h*w).
+ * Volumes: level l of (pair t, clip b, source pixel i) is the [h>>l][w>>l] map at
+ * lvl{l} + t*lvl_pair_stride[l] + (b*h*w + i)*(h>>l)*(w>>l)   (floor pooling over the TARGET dims),
+ * i.e. per pair exactly the reference's corr_pyramid[l] of shape [B*h*w, 1, h>>l, w>>l].
+ * Level 0 = f1^T f2 / sqrt(D); levels 1..3 are pooled in the GEMM epilogue while the tile is still in
+ * registers, so every pyramid cell is written once and level 0 is never re-read.
+ * lvl_pair_stride: HOST array of 4 strides in floats (ignored when pairs == 1; may be NULL then).
+ * num_levels must be 4 (streamflow.py:38).  precision: 0 = exact fp32 MFMA (k-ordered fmaf chain). */
+int sf_corr_build_pyramid(const float* f1, const float* f2, int64_t f_clip_stride, int64_t f_pair_stride,
+                          float* lvl0, float* lvl1, float* lvl2, float* lvl3,
+                          const int64_t* lvl_pair_stride, int B, int pairs, int D, int h, int w,
+                          int num_levels, int precision, void* stream);
+
+/* ---- a3: CorrBlock.__call__  (core/corr.py:23-44) ----------------------------------------------
+ * Image index img = b*pairs + t.  coords [B*pairs][2][h][w] (ch0 = x, ch1 = y)  ->
+ * out[img][l*(2r+1)^2 + a*(2r+1) + b'][p] samples level l of (pair t, clip b) at
+ * (x/2^l + a - r, y/2^l + b' - r), bilinear, zeros outside (first window axis moves x, corr.py:31-37).
+ * out image img starts at out + img*out_img_stride (floats), channel stride h*w, so the caller can
+ * write straight into a wider concatenation buffer.  Volumes are addressed as in
+ * sf_corr_build_pyramid.  radius must be 4, num_levels 4. */
+int sf_corr_lookup(const float* lvl0, const float* lvl1, const float* lvl2, const float* lvl3,
+                   const int64_t* lvl_pair_stride, const float* coords, float* out,
+                   int64_t out_img_stride, int B, int pairs, int h, int w, int num_levels, int radius,
+                   void* stream);
+
+/* ---- generic fused GEMM: every 1x1 conv / nn.Linear / einsum on the path ------------------------
+ * C[z][m][n] = epilogue( alpha * ( sum_k A[z][m][k] * B[z][k][n] + bias[m] ) )
+ * replaces: nn.Conv2d 1x1 in PCBlock4_Deep_nopool_res (update.py:18-28), convf1 (update.py:323),
+ * to_qk/to_v (gma.py:48,82), einsum QK^T (gma.py:60) and attn@v (gma.py:97), timm Linear layers
+ * (update.py:466-479), mask head (update.py:756-759; 3x3 conv as implicit GEMM). */
+enum { SF_LAYOUT_K_MAJOR = 0,   /* A[k*lda + m]   /  B[k*ldb + n]   (rows of k)            */
+       SF_LAYOUT_K_MINOR = 1 }; /* A[m*lda + k]   /  B[n*ldb + k]   (k contiguous)          */
+enum { SF_EPI_NONE = 0,         /* C = v                              v = alpha*(acc+bias)   */
+       SF_EPI_GELU = 1,         /* C = gelu(v)                        exact erf GELU         */
+       SF_EPI_RELU = 2,         /* C = max(v,0)                                              */
+       SF_EPI_RES = 3,          /* C = R + v                                                 */
+       SF_EPI_RES_GELU = 4,     /* C = gelu(R + v)                                           */
+       SF_EPI_RES_GELU_DW1 = 5, /* t = gelu(R + v); C = gelu(t + dw_w[m]*t + dw_b[m])        */
+       SF_EPI_AXPY = 6 };       /* C = R + gamma[0]*v     (gma.py:102)                       */
+
+typedef struct SfGemm {
+    const float* A; const float* B; float* C;
+    const float* bias;            /* [M] or NULL */
+    const float* R;               /* residual (same row/col addressing as C, own strides) or NULL */
+    const float* dw_w; const float* dw_b;   /* [M] each, for SF_EPI_RES_GELU_DW1 */
+    const float* gamma;           /* device scalar for SF_EPI_AXPY */
+    int32_t M, N, K, batch;
+    int64_t lda, ldb, ldc, ldr;
+    int64_t strideA, strideB, strideC, strideR;   /* per batch index z (floats) */
+    int32_t a_layout, b_layout;
+    /* grouped rows (K_MAJOR B, and R): row k lives at (k / group)*group_stride + (k % group)*ld.
+       group = 0 means "no grouping".  Used to read '(B T) C H W -> B (T C) H W' views in place. */
+    int32_t b_group; int64_t b_group_stride;
+    int32_t r_group; int64_t r_group_stride;
+    /* implicit 3x3 conv (pad 1) on a K_MAJOR B: K = 9*Cin, k = tap*Cin + c, tap = ky*3+kx; needs h*w == N */
+    int32_t conv3x3, h, w;
+    float alpha;
+    int32_t epilogue;
+    int32_t precision;            /* 0 = exact fp32 MFMA */
+} SfGemm;
+
+int sf_gemm(const SfGemm* g, void* stream);
+
+/* ---- row softmax in place (gma.py:63): x [rows][cols] ------------------------------------------ */
+int sf_softmax_rows(float* x, int64_t rows, int cols, void* stream);
+
+/* ---- depthwise KxK conv + bias + residual + GELU  (update.py:33-34 with kernel in {7,15}) -------
+ * y = gelu(x + dwconv(x) + b);  plane (img, c) of x is the [h][w] map at x + img*x_img_stride + c*h*w
+ * (same for y with y_img_stride); wgt [C][K][K], bias [C]. */
+int sf_dwconv_res_gelu(const float* x, int64_t x_img_stride, const float* wgt, const float* bias, float* y,
+                       int64_t y_img_stride, int n_img, int C, int h, int w, int ksize, void* stream);
+
+/* ---- LayerNorm over channels of channel-major planes (update.py:462-463,481-483) --------------
+ * x,y [n_img][C][P] (image strides given in floats), normalises each (img,p) column over C. */
+int sf_layernorm_cm(const float* x, int64_t x_img_stride, const float* gamma, const float* beta,
+                    float* y, int64_t y_img_stride, int n_img, int C, int P, float eps, void* stream);
+
+/* ---- per-pixel attention over the T-1 tokens (timm Attention core, update.py:466-474) ----------
+ * qkv [B*TT][3*C][P] (rows [q|k|v]) -> out [B*TT][C][P]; softmax(q k^T / sqrt(C)) v over t. */
+int sf_temporal_attn(const float* qkv, float* out, int B, int TT, int C, int P, void* stream);
+
+/* ---- context split (streamflow.py:119-122): cnets [n_img][2*hdim][P] ->
+ * nets = tanh(first half) (written with nets_img_stride), inps = relu(second half). */
+int sf_context_split(const float* cnets, float* nets, int64_t nets_img_stride, float* inps,
+                     int64_t inps_img_stride, int n_img, int hdim, int P, void* stream);
+
+/* ---- flow bookkeeping (streamflow.py:133,138) ----------------------------------------------------
+ * coords1 += delta (if delta != NULL); flow = coords1 - grid; flow written to up to two places. */
+int sf_flow_update(float* coords1, const float* delta, float* flow_a, int64_t flow_a_img_stride,
+                   float* flow_b, int64_t flow_b_img_stride, int n_img, int h, int w, void* stream);
+
+/* ---- K12 convex upsampling (streamflow.py:82-93) -------------------------------------------------
+ * flow [n][2][h][w], mask [n][9*64][h][w] -> out [n][2][8h][8w]. */
+int sf_upsample_flow(const float* flow, const float* mask, float* out, int n, int h, int w, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STREAMFLOW_HIP_H */

@@ -1,0 +1,106 @@
+"""ctypes binding of libstreamflow_hip.so (the C ABI declared in include/streamflow_hip.h).
+
+There is NO fallback: if the shared library is missing, fails to load, or a tensor is not a
+contiguous fp32 CUDA(HIP) tensor, the call raises.  The product path never routes through
+PyTorch ops or the CPU oracle.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch  # noqa: F401  (imported first so the process-wide HIP runtime is torch's libamdhip64)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libstreamflow_hip.so")
+
+LAYOUT_K_MAJOR, LAYOUT_K_MINOR = 0, 1
+EPI_NONE, EPI_GELU, EPI_RELU, EPI_RES, EPI_RES_GELU, EPI_RES_GELU_DW1, EPI_AXPY = range(7)
+
+_vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
+
+
+class SfGemm(C.Structure):
+    _fields_ = [
+        ("A", _vp), ("B", _vp), ("C", _vp), ("bias", _vp), ("R", _vp), ("dw_w", _vp), ("dw_b", _vp), ("gamma", _vp),
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("batch", C.c_int32),
+        ("lda", _i64), ("ldb", _i64), ("ldc", _i64), ("ldr", _i64),
+        ("strideA", _i64), ("strideB", _i64), ("strideC", _i64), ("strideR", _i64),
+        ("a_layout", C.c_int32), ("b_layout", C.c_int32),
+        ("b_group", C.c_int32), ("b_group_stride", _i64),
+        ("r_group", C.c_int32), ("r_group_stride", _i64),
+        ("conv3x3", C.c_int32), ("h", C.c_int32), ("w", C.c_int32),
+        ("alpha", _f), ("epilogue", C.c_int32), ("precision", C.c_int32),
+    ]
+
+
+# name -> (restype, argtypes); must list every symbol of include/streamflow_hip.h
+SIGNATURES = {
+    "sf_version": (_i, []),
+    "sf_last_error": (C.c_char_p, []),
+    "sf_coords_grid": (_i, [_vp, _i, _i, _i, _vp]),
+    "sf_bilinear_sampler": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "sf_corr_build_pyramid": (_i, [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, C.POINTER(_i64), _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "sf_corr_lookup": (_i, [_vp, _vp, _vp, _vp, C.POINTER(_i64), _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _vp]),
+    "sf_gemm": (_i, [C.POINTER(SfGemm), _vp]),
+    "sf_softmax_rows": (_i, [_vp, _i64, _i, _vp]),
+    "sf_dwconv_res_gelu": (_i, [_vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _vp]),
+    "sf_layernorm_cm": (_i, [_vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _i, _f, _vp]),
+    "sf_temporal_attn": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "sf_context_split": (_i, [_vp, _vp, _i64, _vp, _i64, _i, _i, _i, _vp]),
+    "sf_flow_update": (_i, [_vp, _vp, _vp, _i64, _vp, _i64, _i, _i, _i, _vp]),
+    "sf_upsample_flow": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """Load the shared library (once).  Raises RuntimeError if it is not there."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built. "
+            "Run `python -m streamflow_amd.build` (needs hipcc); there is no CPU/PyTorch fallback.")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise RuntimeError(f"failed to load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise RuntimeError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    if lib.sf_version() < 100:
+        raise RuntimeError("libstreamflow_hip.so is too old; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str = "") -> None:
+    if status != 0:
+        msg = load().sf_last_error().decode(errors="replace")
+        raise RuntimeError(f"libstreamflow_hip {what} failed ({status}): {msg}")
+
+
+def ptr(t: Optional[torch.Tensor], offset_floats: int = 0) -> Optional[int]:
+    """Raw device pointer of a contiguous fp32 HIP tensor (+ element offset)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("streamflow_amd kernels need tensors on the MI355X (cuda:N); got a CPU tensor "
+                           "(there is no CPU fallback)")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"expected float32, got {t.dtype}")
+    if not t.is_contiguous():
+        raise RuntimeError("expected a contiguous tensor")
+    return t.data_ptr() + 4 * offset_floats
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream

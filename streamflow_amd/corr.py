@@ -1,0 +1,59 @@
+"""CorrBlock with the reference's interface (core/corr.py:6-54), backed by the HIP kernels."""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import ops
+from .ops import Planes
+
+
+class CorrBlock:
+    """All-pairs correlation pyramid + windowed lookup for ONE frame pair.
+
+    ``CorrBlock(fmap1, fmap2, num_levels=4, radius=4)`` builds ``corr_pyramid`` (list of
+    ``[B*h*w, 1, h>>l, w>>l]`` tensors, reference corr.py:13-21) in a single fused kernel;
+    ``blk(coords)`` returns ``[B, 4*81, h, w]`` float32 contiguous (corr.py:23-44).
+    """
+
+    def __init__(self, fmap1: torch.Tensor, fmap2: torch.Tensor, num_levels: int = 4, radius: int = 4):
+        if num_levels != 4 or radius != 4:
+            raise RuntimeError("CorrBlock: the HIP path is built for num_levels=4, radius=4 "
+                               "(the only values the StreamFlow model uses, streamflow.py:38-39)")
+        f1 = fmap1.contiguous().float()
+        f2 = fmap2.contiguous().float()
+        ops._dev_check(f1)
+        ops._dev_check(f2)
+        B, D, h, w = f1.shape
+        self.num_levels, self.radius = num_levels, radius
+        self.shape = (B, h, w)
+        N = h * w
+        lv = [torch.empty(B * N, 1, h >> l, w >> l, dtype=torch.float32, device=f1.device) for l in range(4)]
+        ops.corr_build(f1.data_ptr(), f2.data_ptr(), D * N, 0, lv, None, B, 1, D, h, w)
+        self._keep = (f1, f2)
+        self.corr_pyramid = lv
+
+    def __call__(self, coords: torch.Tensor) -> torch.Tensor:
+        B, h, w = self.shape
+        c = coords.contiguous().float()
+        ops._dev_check(c)
+        assert tuple(c.shape) == (B, 2, h, w), (c.shape, self.shape)
+        out = torch.empty(B, 4 * 81, h, w, dtype=torch.float32, device=c.device)
+        ops.corr_lookup(self.corr_pyramid, None, Planes.of(c), Planes.of(out), B, 1, h, w)
+        return out
+
+    @staticmethod
+    def corr(fmap1: torch.Tensor, fmap2: torch.Tensor) -> torch.Tensor:
+        """[B,h,w,1,h,w] = f1^T f2 / sqrt(D) (corr.py:46-54)."""
+        f1 = fmap1.contiguous().float()
+        f2 = fmap2.contiguous().float()
+        ops._dev_check(f1)
+        ops._dev_check(f2)
+        B, D, h, w = f1.shape
+        N = h * w
+        out = torch.empty(B, N, N, dtype=torch.float32, device=f1.device)
+        ops.gemm_raw(A=f1.data_ptr(), B=f2.data_ptr(), C=out.data_ptr(), M=N, N=N, K=D, batch=B, lda=N, ldb=N, ldc=N,
+                     strideA=D * N, strideB=D * N, strideC=N * N, a_layout=ops.LAYOUT_K_MAJOR,
+                     b_layout=ops.LAYOUT_K_MAJOR, alpha=1.0 / math.sqrt(D), epilogue=ops.EPI_NONE)
+        return out.view(B, h, w, 1, h, w)

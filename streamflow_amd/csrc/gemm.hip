@@ -1,0 +1,330 @@
+// Fused fp32 GEMM on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32, k-ordered fma chain).
+//
+//   C[z][m][n] = epilogue( alpha * ( sum_k A[z][m][k] * B[z][k][n] + bias[m] ) )
+//
+// Every 1x1 convolution / nn.Linear / einsum of the StreamFlow update block goes through this one
+// kernel family (reference call sites are listed in include/streamflow_hip.h at sf_gemm).
+// Activations are channel-major planes [C][P] (P = h*w contiguous), so a 1x1 conv is
+// W[Cout][Cin] x X[Cin][P]: "M" = output channels, "N" = pixels, "K" = input channels.
+//
+// Tiling (wave64, 4 waves / workgroup): the workgroup owns a BM x 128 output tile, each wave a
+// (TM*32) x (TN*32) sub-tile held as TM*TN accumulators of 16 VGPRs.  A and B tiles of depth BK are
+// staged through LDS in k-major rows ([k][m] / [k][n], row stride = tile + 4 floats, so the MFMA
+// operand reads `lds[k][lane&31]` hit 32 distinct banks per half-wave) with register double
+// buffering: global loads for tile t+1 are issued before the MFMAs of tile t and written to the
+// other LDS buffer afterwards (one barrier per k-tile).
+#include "sf_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kThreads = 256;
+
+template <int V>
+struct Regs {
+    float4 v[V > 0 ? V : 1];
+};
+
+// ---------------------------------------------------------------------------------------------
+// tile loaders: global -> registers.  X = M (for A) or N (for B).
+// K-major source: element (k, x) at base + row(k) + x.   K-minor source: base + x*ld + k.
+// ---------------------------------------------------------------------------------------------
+struct SrcDesc {
+    const float* base;
+    int64_t ld;
+    int X, K;
+    int group;            // grouped rows (K-major only), 0 = none
+    int64_t group_stride;
+    int conv3x3, h, w, cin;
+    bool vec_ok;          // 16-byte loads allowed (base and ld aligned)
+};
+
+__device__ __forceinline__ int64_t krow_offset(const SrcDesc& s, int k) {
+    if (s.group > 0) return (int64_t)(k / s.group) * s.group_stride + (int64_t)(k % s.group) * s.ld;
+    return (int64_t)k * s.ld;
+}
+
+template <int BX, int BK, int NV>
+__device__ __forceinline__ void load_kmajor(const SrcDesc& s, int k0, int x0, int tid, Regs<NV>& r) {
+    constexpr int C4 = BX / 4;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int idx = tid + j * kThreads;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (idx < BK * C4) {
+            const int k = k0 + idx / C4;
+            const int x = x0 + (idx % C4) * 4;
+            if (k < s.K) {
+                if (s.conv3x3) {
+                    const int tap = k / s.cin, c = k - tap * s.cin;
+                    const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+                    const float* p = s.base + (int64_t)c * s.ld;
+                    float t[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int n = x + i;
+                        float val = 0.f;
+                        if (n < s.X) {
+                            const int yy = n / s.w + dy, xx = n % s.w + dx;
+                            if (yy >= 0 && yy < s.h && xx >= 0 && xx < s.w) val = p[yy * s.w + xx];
+                        }
+                        t[i] = val;
+                    }
+                    v = make_float4(t[0], t[1], t[2], t[3]);
+                } else {
+                    const float* p = s.base + krow_offset(s, k) + x;
+                    if (s.vec_ok && x + 3 < s.X) {
+                        v = *reinterpret_cast<const float4*>(p);
+                    } else {
+                        if (x + 0 < s.X) v.x = p[0];
+                        if (x + 1 < s.X) v.y = p[1];
+                        if (x + 2 < s.X) v.z = p[2];
+                        if (x + 3 < s.X) v.w = p[3];
+                    }
+                }
+            }
+        }
+        r.v[j] = v;
+    }
+}
+
+template <int BX, int BK, int NV, int STRIDE>
+__device__ __forceinline__ void store_kmajor(float* lds, int tid, const Regs<NV>& r) {
+    constexpr int C4 = BX / 4;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int idx = tid + j * kThreads;
+        if (idx < BK * C4) {
+            const int k = idx / C4, x = (idx % C4) * 4;
+            *reinterpret_cast<float4*>(lds + k * STRIDE + x) = r.v[j];
+        }
+    }
+}
+
+template <int BX, int BK, int NV>
+__device__ __forceinline__ void load_kminor(const SrcDesc& s, int k0, int x0, int tid, Regs<NV>& r) {
+    constexpr int K4 = BK / 4;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int idx = tid + j * kThreads;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (idx < BX * K4) {
+            const int x = x0 + idx / K4;
+            const int k = k0 + (idx % K4) * 4;
+            if (x < s.X) {
+                const float* p = s.base + (int64_t)x * s.ld + k;
+                if (s.vec_ok && k + 3 < s.K) {
+                    v = *reinterpret_cast<const float4*>(p);
+                } else {
+                    if (k + 0 < s.K) v.x = p[0];
+                    if (k + 1 < s.K) v.y = p[1];
+                    if (k + 2 < s.K) v.z = p[2];
+                    if (k + 3 < s.K) v.w = p[3];
+                }
+            }
+        }
+        r.v[j] = v;
+    }
+}
+
+template <int BX, int BK, int NV, int STRIDE>
+__device__ __forceinline__ void store_kminor(float* lds, int tid, const Regs<NV>& r) {
+    constexpr int K4 = BK / 4;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int idx = tid + j * kThreads;
+        if (idx < BX * K4) {
+            const int x = idx / K4, k = (idx % K4) * 4;
+            lds[(k + 0) * STRIDE + x] = r.v[j].x;
+            lds[(k + 1) * STRIDE + x] = r.v[j].y;
+            lds[(k + 2) * STRIDE + x] = r.v[j].z;
+            lds[(k + 3) * STRIDE + x] = r.v[j].w;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// kernel
+// ---------------------------------------------------------------------------------------------
+template <int WM, int WN, int TM, int TN, int BK, int ALAY, int BLAY>
+__global__ __launch_bounds__(kThreads) void gemm_f32_mfma(const SfGemm g) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int SA = BM + 4, SB = BN + 4;
+    constexpr int NVA = (BM * BK / 4 + kThreads - 1) / kThreads;
+    constexpr int NVB = (BN * BK / 4 + kThreads - 1) / kThreads;
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    __shared__ __attribute__((aligned(16))) float smem[2 * BK * (SA + SB)];
+    float* sA = smem;
+    float* sB = smem + 2 * BK * SA;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM, z = blockIdx.z;
+
+    SrcDesc da, db;
+    da.base = g.A + (int64_t)z * g.strideA;
+    da.ld = g.lda; da.X = g.M; da.K = g.K; da.group = 0; da.group_stride = 0;
+    da.conv3x3 = 0; da.h = da.w = da.cin = 0;
+    da.vec_ok = ((g.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(da.base) & 15) == 0);
+    db.base = g.B + (int64_t)z * g.strideB;
+    db.ld = g.ldb; db.X = g.N; db.K = g.K; db.group = g.b_group; db.group_stride = g.b_group_stride;
+    db.conv3x3 = g.conv3x3; db.h = g.h; db.w = g.w; db.cin = g.conv3x3 ? g.K / 9 : 0;
+    db.vec_ok = ((g.ldb & 3) == 0) && ((g.b_group_stride & 3) == 0) &&
+                ((reinterpret_cast<uintptr_t>(db.base) & 15) == 0);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    Regs<NVA> ra;
+    Regs<NVB> rb;
+    const int nk = (g.K + BK - 1) / BK;
+
+    auto load_tiles = [&](int kt) {
+        if (ALAY == SF_LAYOUT_K_MAJOR) load_kmajor<BM, BK, NVA>(da, kt * BK, m0, tid, ra);
+        else load_kminor<BM, BK, NVA>(da, kt * BK, m0, tid, ra);
+        if (BLAY == SF_LAYOUT_K_MAJOR) load_kmajor<BN, BK, NVB>(db, kt * BK, n0, tid, rb);
+        else load_kminor<BN, BK, NVB>(db, kt * BK, n0, tid, rb);
+    };
+    auto store_tiles = [&](int buf) {
+        if (ALAY == SF_LAYOUT_K_MAJOR) store_kmajor<BM, BK, NVA, SA>(sA + buf * BK * SA, tid, ra);
+        else store_kminor<BM, BK, NVA, SA>(sA + buf * BK * SA, tid, ra);
+        if (BLAY == SF_LAYOUT_K_MAJOR) store_kmajor<BN, BK, NVB, SB>(sB + buf * BK * SB, tid, rb);
+        else store_kminor<BN, BK, NVB, SB>(sB + buf * BK * SB, tid, rb);
+    };
+
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+
+    const int khalf = lane >> 5, l31 = lane & 31;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) load_tiles(kt + 1);
+        const float* pa = sA + cur * BK * SA + wm * TM * 32 + l31;
+        const float* pb = sB + cur * BK * SB + wn * TN * 32 + l31;
+#pragma unroll
+        for (int ks = 0; ks < BK / 2; ++ks) {
+            const int kk = 2 * ks + khalf;
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = pa[kk * SA + i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = pb[kk * SB + j * 32];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) store_tiles(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue -------------------------------------------------------------------------------
+    float* C = g.C + (int64_t)z * g.strideC;
+    const float* R = g.R ? g.R + (int64_t)z * g.strideR : nullptr;
+    const float gam = (g.epilogue == SF_EPI_AXPY) ? g.gamma[0] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+            if (m >= g.M) continue;
+            const float bias = g.bias ? g.bias[m] : 0.f;
+            int64_t roff = 0;
+            if (R) roff = (g.r_group > 0) ? (int64_t)(m / g.r_group) * g.r_group_stride + (int64_t)(m % g.r_group) * g.ldr
+                                          : (int64_t)m * g.ldr;
+            float dww = 0.f, dwb = 0.f;
+            if (g.epilogue == SF_EPI_RES_GELU_DW1) { dww = g.dw_w[m]; dwb = g.dw_b[m]; }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + (wn * TN + j) * 32 + l31;
+                if (n >= g.N) continue;
+                float v = g.alpha * (acc[i][j][r] + bias);
+                switch (g.epilogue) {
+                    case SF_EPI_GELU: v = sf::gelu_erf(v); break;
+                    case SF_EPI_RELU: v = fmaxf(v, 0.f); break;
+                    case SF_EPI_RES: v = R[roff + n] + v; break;
+                    case SF_EPI_RES_GELU: v = sf::gelu_erf(R[roff + n] + v); break;
+                    case SF_EPI_RES_GELU_DW1: {
+                        const float t = sf::gelu_erf(R[roff + n] + v);
+                        v = sf::gelu_erf(t + (dww * t + dwb));
+                        break;
+                    }
+                    case SF_EPI_AXPY: v = R[roff + n] + gam * v; break;
+                    default: break;
+                }
+                C[(int64_t)m * g.ldc + n] = v;
+            }
+        }
+    }
+}
+
+template <int WM, int WN, int TM, int TN, int BK>
+int launch_cfg(const SfGemm& g, hipStream_t st) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    dim3 grid(sf::ceil_div(g.N, BN), sf::ceil_div(g.M, BM), g.batch);
+    const int lay = g.a_layout * 2 + g.b_layout;
+    switch (lay) {
+        case 0: hipLaunchKernelGGL((gemm_f32_mfma<WM, WN, TM, TN, BK, 0, 0>), grid, dim3(kThreads), 0, st, g); break;
+        case 1: hipLaunchKernelGGL((gemm_f32_mfma<WM, WN, TM, TN, BK, 0, 1>), grid, dim3(kThreads), 0, st, g); break;
+        case 2: hipLaunchKernelGGL((gemm_f32_mfma<WM, WN, TM, TN, BK, 1, 0>), grid, dim3(kThreads), 0, st, g); break;
+        default: hipLaunchKernelGGL((gemm_f32_mfma<WM, WN, TM, TN, BK, 1, 1>), grid, dim3(kThreads), 0, st, g); break;
+    }
+    return sf::check_launch("sf_gemm");
+}
+
+// Workgroup tile choice: minimise the estimated makespan in units of (32x32xK wave tiles per SIMD),
+// assuming 256 CUs with every workgroup resident; ties go to the larger tile (less L2 traffic).
+int pick_bm(const SfGemm& g) {
+    const int cands[3] = {128, 64, 32};
+    long best = -1;
+    int best_bm = 128;
+    for (int c = 0; c < 3; ++c) {
+        const int bm = cands[c];
+        const long wgs = (long)sf::ceil_div(g.M, bm) * sf::ceil_div(g.N, 128) * g.batch;
+        const long span = ((wgs + 255) / 256) * (bm / 32);
+        if (best < 0 || span < best) { best = span; best_bm = bm; }
+    }
+    return best_bm;
+}
+
+}  // namespace
+
+extern "C" int sf_gemm(const SfGemm* gp, void* stream) {
+    SF_REQUIRE(gp != nullptr, "sf_gemm: null descriptor");
+    const SfGemm& g = *gp;
+    SF_REQUIRE(g.A && g.B && g.C, "sf_gemm: null A/B/C");
+    SF_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0 && g.batch > 0, "sf_gemm: bad dims M=%d N=%d K=%d batch=%d", g.M, g.N,
+               g.K, g.batch);
+    SF_REQUIRE(g.a_layout >= 0 && g.a_layout <= 1 && g.b_layout >= 0 && g.b_layout <= 1, "sf_gemm: bad layout");
+    SF_REQUIRE(g.epilogue >= SF_EPI_NONE && g.epilogue <= SF_EPI_AXPY, "sf_gemm: bad epilogue %d", g.epilogue);
+    SF_REQUIRE(g.precision == 0, "sf_gemm: precision %d not supported", g.precision);
+    if (g.epilogue == SF_EPI_RES || g.epilogue == SF_EPI_RES_GELU || g.epilogue == SF_EPI_RES_GELU_DW1 ||
+        g.epilogue == SF_EPI_AXPY)
+        SF_REQUIRE(g.R != nullptr, "sf_gemm: epilogue %d needs R", g.epilogue);
+    if (g.epilogue == SF_EPI_RES_GELU_DW1) SF_REQUIRE(g.dw_w && g.dw_b, "sf_gemm: DW1 epilogue needs dw_w/dw_b");
+    if (g.epilogue == SF_EPI_AXPY) SF_REQUIRE(g.gamma != nullptr, "sf_gemm: AXPY epilogue needs gamma");
+    if (g.conv3x3) {
+        SF_REQUIRE(g.b_layout == SF_LAYOUT_K_MAJOR && g.b_group == 0, "sf_gemm: conv3x3 needs a plain K-major B");
+        SF_REQUIRE(g.K % 9 == 0 && g.h > 0 && g.w > 0 && g.h * g.w == g.N, "sf_gemm: conv3x3 needs K=9*Cin, h*w=N");
+    }
+    if (g.b_group) SF_REQUIRE(g.b_layout == SF_LAYOUT_K_MAJOR, "sf_gemm: b_group needs a K-major B");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const bool kminor = (g.a_layout == SF_LAYOUT_K_MINOR) || (g.b_layout == SF_LAYOUT_K_MINOR);
+    const int bm = pick_bm(g);
+    if (kminor) {   // k-contiguous operands: deeper k-tile so each row contributes a full 128-byte line
+        if (bm == 128) return launch_cfg<2, 2, 2, 2, 32>(g, st);
+        if (bm == 64) return launch_cfg<1, 4, 2, 1, 32>(g, st);
+        return launch_cfg<1, 4, 1, 1, 32>(g, st);
+    }
+    if (bm == 128) return launch_cfg<2, 2, 2, 2, 16>(g, st);
+    if (bm == 64) return launch_cfg<1, 4, 2, 1, 16>(g, st);
+    return launch_cfg<1, 4, 1, 1, 16>(g, st);
+}

@@ -1,0 +1,318 @@
+// Error plumbing + the small HBM-bound kernels of the StreamFlow update loop:
+// coords grid, context split, flow bookkeeping, row softmax, channel LayerNorm, per-pixel temporal
+// attention, convex upsampling.  All are coalesced along the pixel axis (P contiguous).
+#include "sf_common.h"
+
+namespace sf {
+
+char* err_buf() {
+    static thread_local char buf[512] = {0};
+    return buf;
+}
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(err_buf(), 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+}  // namespace sf
+
+extern "C" int sf_version(void) { return SF_VERSION; }
+extern "C" const char* sf_last_error(void) { return sf::err_buf(); }
+
+namespace {
+
+constexpr int kBlock = 256;
+
+// ---- coords_grid ----------------------------------------------------------------------------------
+__global__ void coords_grid_kernel(float* out, int batch, int ht, int wd) {
+    const int P = ht * wd;
+    const int64_t total = (int64_t)batch * 2 * P;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int p = (int)(i % P);
+        const int c = (int)((i / P) & 1);
+        out[i] = (float)(c == 0 ? p % wd : p / wd);
+    }
+}
+
+// ---- context split: nets = tanh(cnets[:, :hdim]), inps = relu(cnets[:, hdim:]) ------------------------
+__global__ void context_split_kernel(const float* cnets, float* nets, int64_t nets_stride, float* inps,
+                                     int64_t inps_stride, int n_img, int hdim, int P) {
+    const int64_t per_img = (int64_t)2 * hdim * P;
+    const int64_t total = per_img * n_img;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int img = (int)(i / per_img);
+        const int64_t rem = i - (int64_t)img * per_img;
+        const int c = (int)(rem / P), p = (int)(rem % P);
+        const float v = cnets[i];
+        if (c < hdim) nets[img * nets_stride + (int64_t)c * P + p] = tanhf(v);
+        else inps[img * inps_stride + (int64_t)(c - hdim) * P + p] = fmaxf(v, 0.f);
+    }
+}
+
+// ---- coords1 += delta; flow = coords1 - grid ---------------------------------------------------------
+__global__ void flow_update_kernel(float* coords1, const float* delta, float* fa, int64_t fa_stride, float* fb,
+                                   int64_t fb_stride, int n_img, int h, int w) {
+    const int P = h * w;
+    const int64_t total = (int64_t)n_img * 2 * P;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int p = (int)(i % P);
+        const int c = (int)((i / P) & 1);
+        const int img = (int)(i / (2 * (int64_t)P));
+        float v = coords1[i];
+        if (delta) {
+            v += delta[i];
+            coords1[i] = v;
+        }
+        const float f = v - (float)(c == 0 ? p % w : p / w);
+        if (fa) fa[img * fa_stride + (int64_t)c * P + p] = f;
+        if (fb) fb[img * fb_stride + (int64_t)c * P + p] = f;
+    }
+}
+
+// ---- row softmax (one workgroup per row) -------------------------------------------------------------
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__global__ __launch_bounds__(kBlock) void softmax_rows_kernel(float* x, int cols) {
+    __shared__ float red[kBlock / 64];
+    float* row = x + (int64_t)blockIdx.x * cols;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float m = -INFINITY;
+    for (int c = tid; c < cols; c += kBlock) m = fmaxf(m, row[c]);
+    m = wave_max(m);
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float s = 0.f;
+    for (int c = tid; c < cols; c += kBlock) {
+        const float e = expf(row[c] - m);
+        row[c] = e;
+        s += e;
+    }
+    s = wave_sum(s);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    s = (red[0] + red[1]) + (red[2] + red[3]);
+    const float inv = 1.0f / s;
+    for (int c = tid; c < cols; c += kBlock) row[c] *= inv;
+}
+
+// ---- LayerNorm over channels (channel-major planes) -------------------------------------------------
+__global__ __launch_bounds__(kBlock) void layernorm_cm_kernel(const float* x, int64_t xs, const float* gamma,
+                                                               const float* beta, float* y, int64_t ys, int C, int P,
+                                                               float eps) {
+    const int p = blockIdx.x * kBlock + threadIdx.x;
+    if (p >= P) return;
+    const float* xp = x + (int64_t)blockIdx.y * xs + p;
+    float* yp = y + (int64_t)blockIdx.y * ys + p;
+    float mean = 0.f;
+    for (int c = 0; c < C; ++c) mean += xp[(int64_t)c * P];
+    mean /= (float)C;
+    float var = 0.f;
+    for (int c = 0; c < C; ++c) {
+        const float d = xp[(int64_t)c * P] - mean;
+        var += d * d;
+    }
+    const float rstd = 1.0f / sqrtf(var / (float)C + eps);
+    for (int c = 0; c < C; ++c) yp[(int64_t)c * P] = (xp[(int64_t)c * P] - mean) * rstd * gamma[c] + beta[c];
+}
+
+// ---- attention over the TT tokens of one pixel ---------------------------------------------------------
+template <int TT>
+__global__ __launch_bounds__(kBlock) void temporal_attn_kernel(const float* qkv, float* out, int C, int P) {
+    const int p = blockIdx.x * kBlock + threadIdx.x;
+    if (p >= P) return;
+    const int b = blockIdx.y;
+    const int64_t img = (int64_t)3 * C * P;      // one token image of qkv
+    const float* base = qkv + (int64_t)b * TT * img + p;
+    float s[TT][TT];
+#pragma unroll
+    for (int t = 0; t < TT; ++t)
+#pragma unroll
+        for (int u = 0; u < TT; ++u) s[t][u] = 0.f;
+    for (int c = 0; c < C; ++c) {
+        float q[TT], k[TT];
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+            q[t] = base[t * img + (int64_t)c * P];
+            k[t] = base[t * img + (int64_t)(C + c) * P];
+        }
+#pragma unroll
+        for (int t = 0; t < TT; ++t)
+#pragma unroll
+            for (int u = 0; u < TT; ++u) s[t][u] = fmaf(q[t], k[u], s[t][u]);
+    }
+    const float scale = 1.0f / sqrtf((float)C);
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+        float m = -INFINITY;
+#pragma unroll
+        for (int u = 0; u < TT; ++u) {
+            s[t][u] *= scale;
+            m = fmaxf(m, s[t][u]);
+        }
+        float sum = 0.f;
+#pragma unroll
+        for (int u = 0; u < TT; ++u) {
+            s[t][u] = expf(s[t][u] - m);
+            sum += s[t][u];
+        }
+        const float inv = 1.0f / sum;
+#pragma unroll
+        for (int u = 0; u < TT; ++u) s[t][u] *= inv;
+    }
+    float* obase = out + (int64_t)b * TT * C * P + p;
+    for (int c = 0; c < C; ++c) {
+        float v[TT];
+#pragma unroll
+        for (int u = 0; u < TT; ++u) v[u] = base[u * img + (int64_t)(2 * C + c) * P];
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+            float o = 0.f;
+#pragma unroll
+            for (int u = 0; u < TT; ++u) o = fmaf(s[t][u], v[u], o);
+            obase[(int64_t)t * C * P + (int64_t)c * P] = o;
+        }
+    }
+}
+
+// ---- convex 8x upsampling ---------------------------------------------------------------------------
+// One workgroup per (image, low-res row y, 32-pixel x segment).  Thread = (sub-pixel s = i*8+j, 4 of the
+// 32 pixels): mask reads are coalesced along x inside one channel plane; the 8x8 outputs of the segment
+// are staged in LDS and written as full 256-float rows.
+constexpr int kUpSeg = 32;
+__global__ __launch_bounds__(kBlock) void upsample_kernel(const float* flow, const float* mask, float* out, int h,
+                                                          int w) {
+    __shared__ float nb[2][9][kUpSeg];                 // 8*flow at the 3x3 neighbours
+    __shared__ float stage[2][8][kUpSeg * 8 + 1];
+    const int P = h * w;
+    const int x0 = blockIdx.x * kUpSeg, y = blockIdx.y, n = blockIdx.z;
+    const int tid = threadIdx.x;
+    const float* fl = flow + (int64_t)n * 2 * P;
+    for (int i = tid; i < 2 * 9 * kUpSeg; i += kBlock) {
+        const int xl = i % kUpSeg, k = (i / kUpSeg) % 9, c = i / (9 * kUpSeg);
+        const int yy = y + k / 3 - 1, xx = x0 + xl + k % 3 - 1;
+        float v = 0.f;
+        if (yy >= 0 && yy < h && xx >= 0 && xx < w) v = 8.0f * fl[(int64_t)c * P + yy * w + xx];
+        nb[c][k][xl] = v;
+    }
+    __syncthreads();
+    const float* mk = mask + (int64_t)n * 576 * P + (int64_t)y * w;
+    // 64 sub-pixels x 32 pixels = 2048 items, 8 per thread; consecutive threads -> consecutive x
+    for (int it = tid; it < 64 * kUpSeg; it += kBlock) {
+        const int xl = it % kUpSeg, s = it / kUpSeg;
+        const int x = x0 + xl;
+        if (x < w) {
+            float lg[9], m = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                lg[k] = mk[(int64_t)(k * 64 + s) * P + x];
+                m = fmaxf(m, lg[k]);
+            }
+            float sum = 0.f, ax = 0.f, ay = 0.f;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const float e = expf(lg[k] - m);
+                sum += e;
+                ax = fmaf(e, nb[0][k][xl], ax);
+                ay = fmaf(e, nb[1][k][xl], ay);
+            }
+            const float inv = 1.0f / sum;
+            const int i = s >> 3, j = s & 7;
+            stage[0][i][xl * 8 + j] = ax * inv;
+            stage[1][i][xl * 8 + j] = ay * inv;
+        }
+    }
+    __syncthreads();
+    const int W8 = w * 8;
+    const int valid = min(kUpSeg, w - x0) * 8;
+    for (int it = tid; it < 2 * 8 * kUpSeg * 8; it += kBlock) {
+        const int col = it % (kUpSeg * 8), i = (it / (kUpSeg * 8)) % 8, c = it / (kUpSeg * 64);
+        if (col < valid)
+            out[((int64_t)n * 2 + c) * (int64_t)(h * 8) * W8 + (int64_t)(y * 8 + i) * W8 + x0 * 8 + col] =
+                stage[c][i][col];
+    }
+}
+
+inline int grid_for(int64_t total) {
+    int64_t b = (total + kBlock - 1) / kBlock;
+    return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+
+}  // namespace
+
+extern "C" int sf_coords_grid(float* out, int batch, int ht, int wd, void* stream) {
+    SF_REQUIRE(out && batch > 0 && ht > 0 && wd > 0, "sf_coords_grid: bad args");
+    hipLaunchKernelGGL(coords_grid_kernel, dim3(grid_for((int64_t)batch * 2 * ht * wd)), dim3(kBlock), 0,
+                       (hipStream_t)stream, out, batch, ht, wd);
+    return sf::check_launch("sf_coords_grid");
+}
+
+extern "C" int sf_context_split(const float* cnets, float* nets, int64_t nets_img_stride, float* inps,
+                                int64_t inps_img_stride, int n_img, int hdim, int P, void* stream) {
+    SF_REQUIRE(cnets && nets && inps && n_img > 0 && hdim > 0 && P > 0, "sf_context_split: bad args");
+    hipLaunchKernelGGL(context_split_kernel, dim3(grid_for((int64_t)n_img * 2 * hdim * P)), dim3(kBlock), 0,
+                       (hipStream_t)stream, cnets, nets, nets_img_stride, inps, inps_img_stride, n_img, hdim, P);
+    return sf::check_launch("sf_context_split");
+}
+
+extern "C" int sf_flow_update(float* coords1, const float* delta, float* flow_a, int64_t flow_a_img_stride,
+                              float* flow_b, int64_t flow_b_img_stride, int n_img, int h, int w, void* stream) {
+    SF_REQUIRE(coords1 && n_img > 0 && h > 0 && w > 0, "sf_flow_update: bad args");
+    hipLaunchKernelGGL(flow_update_kernel, dim3(grid_for((int64_t)n_img * 2 * h * w)), dim3(kBlock), 0,
+                       (hipStream_t)stream, coords1, delta, flow_a, flow_a_img_stride, flow_b, flow_b_img_stride,
+                       n_img, h, w);
+    return sf::check_launch("sf_flow_update");
+}
+
+extern "C" int sf_softmax_rows(float* x, int64_t rows, int cols, void* stream) {
+    SF_REQUIRE(x && rows > 0 && cols > 0, "sf_softmax_rows: bad args");
+    SF_REQUIRE(rows <= 0x7fffffffLL, "sf_softmax_rows: too many rows");
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(kBlock), 0, (hipStream_t)stream, x, cols);
+    return sf::check_launch("sf_softmax_rows");
+}
+
+extern "C" int sf_layernorm_cm(const float* x, int64_t x_img_stride, const float* gamma, const float* beta, float* y,
+                               int64_t y_img_stride, int n_img, int C, int P, float eps, void* stream) {
+    SF_REQUIRE(x && gamma && beta && y && n_img > 0 && C > 0 && P > 0, "sf_layernorm_cm: bad args");
+    hipLaunchKernelGGL(layernorm_cm_kernel, dim3(sf::ceil_div(P, kBlock), n_img), dim3(kBlock), 0,
+                       (hipStream_t)stream, x, x_img_stride, gamma, beta, y, y_img_stride, C, P, eps);
+    return sf::check_launch("sf_layernorm_cm");
+}
+
+extern "C" int sf_temporal_attn(const float* qkv, float* out, int B, int TT, int C, int P, void* stream) {
+    SF_REQUIRE(qkv && out && B > 0 && C > 0 && P > 0, "sf_temporal_attn: bad args");
+    dim3 grid(sf::ceil_div(P, kBlock), B), block(kBlock);
+    hipStream_t st = (hipStream_t)stream;
+    switch (TT) {
+        case 1: hipLaunchKernelGGL(temporal_attn_kernel<1>, grid, block, 0, st, qkv, out, C, P); break;
+        case 2: hipLaunchKernelGGL(temporal_attn_kernel<2>, grid, block, 0, st, qkv, out, C, P); break;
+        case 3: hipLaunchKernelGGL(temporal_attn_kernel<3>, grid, block, 0, st, qkv, out, C, P); break;
+        case 4: hipLaunchKernelGGL(temporal_attn_kernel<4>, grid, block, 0, st, qkv, out, C, P); break;
+        case 5: hipLaunchKernelGGL(temporal_attn_kernel<5>, grid, block, 0, st, qkv, out, C, P); break;
+        case 6: hipLaunchKernelGGL(temporal_attn_kernel<6>, grid, block, 0, st, qkv, out, C, P); break;
+        case 7: hipLaunchKernelGGL(temporal_attn_kernel<7>, grid, block, 0, st, qkv, out, C, P); break;
+        default: return sf::fail(SF_ERR_UNSUPPORTED, "sf_temporal_attn: T-1=%d tokens not supported (1..7)", TT);
+    }
+    return sf::check_launch("sf_temporal_attn");
+}
+
+extern "C" int sf_upsample_flow(const float* flow, const float* mask, float* out, int n, int h, int w, void* stream) {
+    SF_REQUIRE(flow && mask && out && n > 0 && h > 0 && w > 0, "sf_upsample_flow: bad args");
+    hipLaunchKernelGGL(upsample_kernel, dim3(sf::ceil_div(w, kUpSeg), h, n), dim3(kBlock), 0, (hipStream_t)stream,
+                       flow, mask, out, h, w);
+    return sf::check_launch("sf_upsample_flow");
+}

@@ -1,0 +1,316 @@
+"""Fused, pre-planned execution of the StreamFlow hot path on one MI355X.
+
+Covers reference core/models/streamflow.py:110-147 (the refinement loop) with everything it
+calls: corr.py (volume + pyramid + lookup), gma.py (Attention/Aggregate), update.py
+(SKUpdateBlock_TAM_v3 and its SKBlocks, motion encoder, temporal transformer block, mask head) and
+the convex upsampling.  Weights are repacked once (K-major, padded) at construction; all
+activation buffers for a given (clips, frames, h, w) are carved once out of a single workspace, so a
+forward is a fixed sequence of kernel launches with constant pointers -- capturable as one HIP
+graph (``use_graph=True``) and replayed per clip.
+
+Image index convention everywhere: img = clip * (T-1) + pair   (the reference's '(B T)' packing).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib, ops
+from .ops import (EPI_AXPY, EPI_GELU, EPI_NONE, EPI_RELU, EPI_RES, EPI_RES_GELU, EPI_RES_GELU_DW1, LAYOUT_K_MAJOR,
+                  LAYOUT_K_MINOR, PackedLinear, Planes, Workspace)
+
+HDIM = 128
+COR_PLANES = 324
+
+
+class SKBlockWeights:
+    """Packed parameters of one PCBlock4_Deep_nopool_res (reference update.py:12-29)."""
+
+    def __init__(self, sd: Dict[str, torch.Tensor], prefix: str, device):
+        g = lambda n: sd[prefix + "." + n]
+        self.ffn1_0 = PackedLinear(g("ffn1.0.weight"), g("ffn1.0.bias"), device)
+        self.ffn1_2 = PackedLinear(g("ffn1.2.weight"), g("ffn1.2.bias"), device)
+        self.pw = PackedLinear(g("pw.weight"), g("pw.bias"), device)
+        self.ffn2_0 = PackedLinear(g("ffn2.0.weight"), g("ffn2.0.bias"), device)
+        self.ffn2_2 = PackedLinear(g("ffn2.2.weight"), g("ffn2.2.bias"), device)
+        self.c_in, self.c_mid, self.c_out = self.ffn1_0.K, self.ffn1_0.M, self.ffn2_2.M
+        f32 = lambda t: t.detach().to(device=device, dtype=torch.float32).contiguous()
+        w0 = g("conv_list.0.weight")
+        if w0.shape[-1] != 1:
+            raise RuntimeError("SKBlock: first depthwise kernel must be 1x1 (k_conv=[1,K]), got %s" % (tuple(w0.shape),))
+        self.dw1_w = f32(w0.reshape(-1))
+        self.dw1_b = f32(g("conv_list.0.bias"))
+        wk = g("conv_list.1.weight")
+        self.k = int(wk.shape[-1])
+        self.dwk_w = f32(wk.reshape(wk.shape[0], -1))
+        self.dwk_b = f32(g("conv_list.1.bias"))
+
+
+def _scratch(buf: Planes, n_img: int, rows: int) -> Planes:
+    """Reinterpret a scratch allocation as contiguous [n_img][rows][P] planes."""
+    assert n_img * rows <= buf.n_img * buf.rows, "scratch too small"
+    return Planes(buf.base, buf.off, rows * buf.P, n_img, rows, buf.P)
+
+
+def run_skblock(W: SKBlockWeights, X: Planes, Y: Planes, hid: Planes, xa: Planes, xb: Planes, h: int, w: int,
+                final_gelu: bool = False) -> None:
+    """One PCBlock4_Deep_nopool_res forward, op order of reference update.py:30-36:
+    x1 = gelu(x + ffn1(x)); x2 = gelu(x1 + dw1x1(x1)); x3 = gelu(x2 + dwKxK(x2)); x4 = gelu(x3 + pw(x3));
+    y = ffn2(x4).  hid/xa/xb are scratch allocations (capacity >= n_img*c_mid / n_img*c_in rows)."""
+    C = W.c_in
+    assert X.rows == C and Y.rows == W.c_out and X.n_img == Y.n_img
+    hidden = _scratch(hid, X.n_img, W.c_mid)
+    a, b = _scratch(xa, X.n_img, C), _scratch(xb, X.n_img, C)
+    ops.gemm(W.ffn1_0, X, hidden, EPI_GELU)
+    # x1 = gelu(x + ffn1(x)); x2 = gelu(x1 + dw1x1(x1))  (both fused in the epilogue)
+    ops.gemm(W.ffn1_2, hidden, a, EPI_RES_GELU_DW1, R=X, dw_w=W.dw1_w, dw_b=W.dw1_b)
+    ops.dwconv_res_gelu(a, W.dwk_w, W.dwk_b, b, h, w, W.k)                     # x3 = gelu(x2 + dwKxK(x2))
+    ops.gemm(W.pw, b, a, EPI_RES_GELU, R=b)                                     # x4 = gelu(x3 + pw(x3))
+    ops.gemm(W.ffn2_0, a, hidden, EPI_GELU)
+    ops.gemm(W.ffn2_2, hidden, Y, EPI_GELU if final_gelu else EPI_NONE)
+
+
+class HotPathWeights:
+    """All hot-path parameters, repacked for the kernels.  `sd` uses the reference state-dict keys
+    (SURVEY.md section 8b); a leading 'module.' (DataParallel) is stripped."""
+
+    def __init__(self, sd: Dict[str, torch.Tensor], device, T: Optional[int] = None):
+        sd = {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}
+        u = "update_block"
+        e = u + ".encoder"
+        tb = u + ".transformer_block.transformer_block"
+        f32 = lambda t: t.detach().to(device=device, dtype=torch.float32).contiguous()
+        self.device = device
+        self.to_qk = PackedLinear(sd["att.to_qk.weight"], None, device)
+        if self.to_qk.M != 2 * HDIM:
+            raise RuntimeError("only num_heads=1, dim_head=128 is supported (canonical StreamFlow configuration)")
+        self.convc1 = SKBlockWeights(sd, e + ".convc1", device)
+        self.convc2 = SKBlockWeights(sd, e + ".convc2", device)
+        self.convf1 = PackedLinear(sd[e + ".convf1.weight"], sd[e + ".convf1.bias"], device)
+        self.convf2 = SKBlockWeights(sd, e + ".convf2", device)
+        self.conv = SKBlockWeights(sd, e + ".conv", device)
+        self.to_v = PackedLinear(sd[u + ".aggregator.to_v.weight"], None, device)
+        self.gamma = f32(sd[u + ".aggregator.gamma"])
+        self.gru = SKBlockWeights(sd, u + ".gru", device)
+        self.flow_head = SKBlockWeights(sd, u + ".flow_head", device)
+        self.pairs = self.flow_head.c_in // HDIM
+        if T is not None and self.pairs != T - 1:
+            raise RuntimeError(f"flow_head expects T-1={self.pairs} pairs, model was asked for T={T}")
+        self.mask0 = PackedLinear(sd[u + ".mask.0.weight"], sd[u + ".mask.0.bias"], device, conv3x3=True)
+        self.mask2 = PackedLinear(sd[u + ".mask.2.weight"], sd[u + ".mask.2.bias"], device)
+        self.ln1_w, self.ln1_b = f32(sd[tb + ".norm1.weight"]), f32(sd[tb + ".norm1.bias"])
+        self.ln2_w, self.ln2_b = f32(sd[tb + ".norm2.weight"]), f32(sd[tb + ".norm2.bias"])
+        self.qkv = PackedLinear(sd[tb + ".attn.qkv.weight"], sd.get(tb + ".attn.qkv.bias"), device)
+        self.proj = PackedLinear(sd[tb + ".attn.proj.weight"], sd[tb + ".attn.proj.bias"], device)
+        self.fc1 = PackedLinear(sd[tb + ".mlp.fc1.weight"], sd[tb + ".mlp.fc1.bias"], device)
+        self.fc2 = PackedLinear(sd[tb + ".mlp.fc2.weight"], sd[tb + ".mlp.fc2.bias"], device)
+
+
+class _Plan:
+    """Buffers for one (clips, pairs, h, w) shape."""
+
+    def __init__(self, W: HotPathWeights, Bc: int, h: int, w: int, D: int, device):
+        Pn = W.pairs
+        n, P = Bc * Pn, h * w
+        self.Bc, self.Pn, self.h, self.w, self.n, self.P, self.D = Bc, Pn, h, w, n, P, D
+        if (h >> 3) < 1 or (w >> 3) < 1:
+            raise RuntimeError(f"feature grid {h}x{w} too small for a 4-level pyramid (need >= 8x8)")
+        if (h >> 3) < 2 or (w >> 3) < 2:
+            # the reference divides by (W-1) of the coarsest level (utils.py:69-70): size-1 levels give NaN there
+            raise RuntimeError(f"feature grid {h}x{w}: coarsest pyramid level would be 1 pixel wide; the reference "
+                               "is undefined there (needs images >= 128 px per side)")
+        dims = [(h >> l, w >> l) for l in range(4)]
+        self.lvl_pair_stride = [Bc * P * hl * wl for hl, wl in dims]
+        self.lvls = [torch.empty(Pn * s, dtype=torch.float32, device=device) for s in self.lvl_pair_stride]
+        self.attn = torch.empty(n, P, P, dtype=torch.float32, device=device)
+        spec = [("qk", 2 * HDIM), ("corr", COR_PLANES), ("flow", 2), ("hid", 960), ("xa", 640), ("xb", 640),
+                ("cor256", 256), ("cat256", 256), ("f128", 128),
+                ("concat", 640),                       # [nets | inps | mf | mf_global | mf_temporal]
+                ("v128", 128), ("ln128", 128), ("qkv", 384), ("att128", 128), ("tx128", 128), ("h256", 256),
+                ("delta", 2),                          # == [Bc][2*Pn][P]
+                ("m256", 256), ("mask", 576), ("coords1", 2)]
+        ws = Workspace(sum(n * r * P + 64 for _, r in spec), device)
+        self.ws = ws
+        for name, r in spec:
+            setattr(self, name, ws.take(n, r, P))
+        self.nets = self.concat.slice(0, 128)
+        self.inps = self.concat.slice(128, 256)
+        self.mf = self.concat.slice(256, 384)
+        self.mfg = self.concat.slice(384, 512)
+        self.mft = self.concat.slice(512, 640)
+        # flow-head view of nets: '(B T) C H W -> B (T C) H W' without a copy
+        self.nets_grouped = Planes(self.concat.base, self.concat.off, Pn * self.concat.img_stride, Bc, HDIM * Pn, P,
+                                   group=HDIM, group_stride=self.concat.img_stride)
+        self.delta_fh = Planes(self.delta.base, self.delta.off, 2 * Pn * P, Bc, 2 * Pn, P)
+        self.up = torch.empty(n, 2, 8 * h, 8 * w, dtype=torch.float32, device=device)
+        # static input staging (so a captured graph sees constant pointers)
+        self.fmaps_in = None
+        self.cnets_in = None
+        self.graph = None
+        self.graph_key = None
+
+
+class HotPathEngine:
+    """`forward(fmaps, cnets, iters)` == reference loop in test_mode (streamflow.py:110-147)."""
+
+    def __init__(self, state_dict: Dict[str, torch.Tensor], device="cuda:0", T: Optional[int] = None,
+                 use_graph: bool = False):
+        _lib.load()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("HotPathEngine needs an MI355X device (cuda:N); there is no CPU fallback")
+        self.W = HotPathWeights(state_dict, self.device, T)
+        self.use_graph = use_graph
+        self._plans: Dict[Tuple[int, int, int, int], _Plan] = {}
+
+    # ---------------------------------------------------------------------------------------------
+    def plan(self, Bc: int, h: int, w: int, D: int) -> _Plan:
+        key = (Bc, h, w, D)
+        if key not in self._plans:
+            self._plans[key] = _Plan(self.W, Bc, h, w, D, self.device)
+        return self._plans[key]
+
+    # ---------------------------------------------------------------------------------------------
+    def _setup(self, pl: _Plan, fmaps: torch.Tensor, cnets: torch.Tensor) -> None:
+        """Everything before the iteration loop: volumes, context split, GMA attention matrix."""
+        W = self.W
+        Bc, Pn, h, w, P, n, D = pl.Bc, pl.Pn, pl.h, pl.w, pl.P, pl.n, pl.D
+        T = Pn + 1
+        # a1+a2: all pairs, one launch.  pair t = (frame t, frame t+1)
+        ops.corr_build(fmaps.data_ptr(), fmaps.data_ptr() + 4 * D * P, T * D * P, D * P, pl.lvls, pl.lvl_pair_stride,
+                       Bc, Pn, D, h, w)
+        # streamflow.py:119-122: nets = tanh(.), inps = relu(.)
+        ops.context_split(cnets, pl.nets, pl.inps, HDIM)
+        # a6: attn = softmax(scale * q k^T) over the context features (gma.py:53-65), computed once
+        ops.gemm(W.to_qk, pl.inps, pl.qk, EPI_NONE)
+        ops.gemm_raw(A=pl.qk.ptr, B=pl.qk.ptr + 4 * HDIM * P, C=pl.attn.data_ptr(), M=P, N=P, K=HDIM, batch=n,
+                     lda=P, ldb=P, ldc=P, strideA=pl.qk.img_stride, strideB=pl.qk.img_stride, strideC=P * P,
+                     a_layout=LAYOUT_K_MAJOR, b_layout=LAYOUT_K_MAJOR, alpha=float(HDIM) ** -0.5, epilogue=EPI_NONE)
+        ops.softmax_rows(pl.attn, n * P, P)
+
+    def _iteration(self, pl: _Plan, with_mask: bool) -> None:
+        W = self.W
+        Bc, Pn, h, w, P, n = pl.Bc, pl.Pn, pl.h, pl.w, pl.P, pl.n
+        sk = lambda Wt, X, Y, fg=False: run_skblock(Wt, X, Y, pl.hid, pl.xa, pl.xb, h, w, fg)
+        # a3: correlation features for all pairs (streamflow.py:132)
+        ops.corr_lookup(pl.lvls, pl.lvl_pair_stride, pl.coords1, pl.corr, Bc, Pn, h, w)
+        # a9: motion encoder (update.py:329-339)
+        sk(W.convc1, pl.corr, pl.cor256, True)                     # cor = gelu(convc1(corr))
+        sk(W.convc2, pl.cor256, pl.cat256.slice(0, 192))
+        ops.gemm(W.convf1, pl.flow, pl.f128, EPI_NONE)
+        sk(W.convf2, pl.f128, pl.cat256.slice(192, 256))
+        sk(W.conv, pl.cat256, pl.mf.slice(0, HDIM - 2))            # mf = cat(out, flow); flow rows kept by flow_update
+        # a7: global aggregation  mfg = mf + gamma * attn @ to_v(mf)   (gma.py:91-104)
+        ops.gemm(W.to_v, pl.mf, pl.v128, EPI_NONE)
+        ops.gemm_raw(A=pl.v128.ptr, B=pl.attn.data_ptr(), C=pl.mfg.ptr, R=pl.mf.ptr, gamma=W.gamma.data_ptr(),
+                     M=HDIM, N=P, K=P, batch=n, lda=P, ldb=P, ldc=P, ldr=P, strideA=pl.v128.img_stride,
+                     strideB=P * P, strideC=pl.mfg.img_stride, strideR=pl.mf.img_stride,
+                     a_layout=LAYOUT_K_MINOR, b_layout=LAYOUT_K_MINOR, alpha=1.0, epilogue=EPI_AXPY)
+        # a10: temporal transformer block over the T-1 tokens of each pixel (update.py:481-484,770)
+        ops.layernorm_cm(pl.mf, W.ln1_w, W.ln1_b, pl.ln128)
+        ops.gemm(W.qkv, pl.ln128, pl.qkv, EPI_NONE)
+        ops.temporal_attn(pl.qkv, pl.att128, Bc, Pn, HDIM)
+        ops.gemm(W.proj, pl.att128, pl.tx128, EPI_RES, R=pl.mf)
+        ops.layernorm_cm(pl.tx128, W.ln2_w, W.ln2_b, pl.ln128)
+        ops.gemm(W.fc1, pl.ln128, pl.h256, EPI_GELU)
+        ops.gemm(W.fc2, pl.h256, pl.mft, EPI_RES, R=pl.tx128)
+        # "gru": SKBlock(640 -> 128) over cat[nets, inps, mf, mfg, mft]; new nets overwrite the nets slice
+        sk(W.gru, pl.concat, pl.nets)
+        # flow head sees all T-1 hidden states of a clip jointly (update.py:774)
+        sk(W.flow_head, pl.nets_grouped, pl.delta_fh)
+        if with_mask:                                               # update.py:756-759,777
+            ops.gemm(W.mask0, pl.nets, pl.m256, EPI_RELU, hw=(h, w))
+            ops.gemm(W.mask2, pl.m256, pl.mask, EPI_NONE, alpha=0.25)
+        # streamflow.py:138 + :133 for the next iteration
+        ops.flow_update(pl.coords1, pl.delta, pl.flow, pl.mf.slice(HDIM - 2, HDIM), n, h, w)
+
+    def _run(self, pl: _Plan, fmaps: torch.Tensor, cnets: torch.Tensor, iters: int, all_masks: bool) -> None:
+        self._setup(pl, fmaps, cnets)
+        for it in range(iters):
+            self._iteration(pl, with_mask=all_masks or it == iters - 1)
+        flow_t = pl.flow.tensor().view(pl.n, 2, pl.h, pl.w)
+        mask_t = pl.mask.tensor().view(pl.n, 576, pl.h, pl.w)
+        _lib.check(_lib.load().sf_upsample_flow(flow_t.data_ptr(), mask_t.data_ptr(), pl.up.data_ptr(), pl.n, pl.h,
+                                                pl.w, _lib.stream()), "sf_upsample_flow")
+
+    # ---------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def forward(self, fmaps: torch.Tensor, cnets: torch.Tensor, iters: int = 15,
+                flow_init: Optional[Sequence[torch.Tensor]] = None, all_masks: bool = False
+                ) -> Tuple[List[torch.Tensor], List[torch.Tensor]]:
+        """fmaps [B,T,D,h,w], cnets [B,T-1,256,h,w] fp32 on the GPU.
+        Returns (flows_up, flows_lowres): T-1 tensors [B,2,8h,8w] and [B,2,h,w] (views into engine buffers,
+        valid until the next forward of the same shape)."""
+        ops._dev_check(fmaps)
+        ops._dev_check(cnets)
+        Bc, T, D, h, w = fmaps.shape
+        if T - 1 != self.W.pairs or tuple(cnets.shape) != (Bc, T - 1, 2 * HDIM, h, w):
+            raise RuntimeError(f"shape mismatch: fmaps {tuple(fmaps.shape)}, cnets {tuple(cnets.shape)}, "
+                               f"weights built for T={self.W.pairs + 1}")
+        pl = self.plan(Bc, h, w, D)
+        n, P = pl.n, pl.P
+        coords1 = pl.coords1.tensor().view(n, 2, h, w)
+        _lib.check(_lib.load().sf_coords_grid(coords1.data_ptr(), n, h, w, _lib.stream()), "sf_coords_grid")
+        if flow_init is not None:                          # streamflow.py:114-115
+            for i, f in enumerate(flow_init):
+                coords1.view(Bc, T - 1, 2, h, w)[:, i] += f.to(coords1)
+        ops.flow_update(pl.coords1, None, pl.flow, pl.mf.slice(HDIM - 2, HDIM), n, h, w)
+        if self.use_graph:
+            self._forward_graph(pl, fmaps, cnets, iters, all_masks)
+        else:
+            self._run(pl, fmaps, cnets, iters, all_masks)
+        up = pl.up.view(Bc, T - 1, 2, 8 * h, 8 * w)
+        low = pl.flow.tensor().view(Bc, T - 1, 2, h, w)
+        return [up[:, i] for i in range(T - 1)], [low[:, i] for i in range(T - 1)]
+
+    @torch.no_grad()
+    def forward_all_iterations(self, fmaps: torch.Tensor, cnets: torch.Tensor, iters: int = 12,
+                               flow_init: Optional[Sequence[torch.Tensor]] = None) -> List[List[torch.Tensor]]:
+        """Training-mode return of the reference (streamflow.py:139-149): for every pair, the list of upsampled
+        predictions after each iteration (mask head + convex upsampling run every iteration; no graph)."""
+        ops._dev_check(fmaps)
+        ops._dev_check(cnets)
+        Bc, T, D, h, w = fmaps.shape
+        pl = self.plan(Bc, h, w, D)
+        n = pl.n
+        coords1 = pl.coords1.tensor().view(n, 2, h, w)
+        _lib.check(_lib.load().sf_coords_grid(coords1.data_ptr(), n, h, w, _lib.stream()), "sf_coords_grid")
+        if flow_init is not None:
+            for i, f in enumerate(flow_init):
+                coords1.view(Bc, T - 1, 2, h, w)[:, i] += f.to(coords1)
+        ops.flow_update(pl.coords1, None, pl.flow, pl.mf.slice(HDIM - 2, HDIM), n, h, w)
+        self._setup(pl, fmaps, cnets)
+        preds: List[List[torch.Tensor]] = [[] for _ in range(T - 1)]
+        for _ in range(iters):
+            self._iteration(pl, with_mask=True)
+            up = ops.upsample_flow(pl.flow.tensor().view(n, 2, h, w), pl.mask.tensor().view(n, 576, h, w))
+            up = up.view(Bc, T - 1, 2, 8 * h, 8 * w)
+            for i in range(T - 1):
+                preds[i].append(up[:, i])
+        return preds
+
+    def _forward_graph(self, pl: _Plan, fmaps, cnets, iters, all_masks) -> None:
+        key = (iters, all_masks)
+        if pl.fmaps_in is None:
+            pl.fmaps_in = torch.empty_like(fmaps)
+            pl.cnets_in = torch.empty_like(cnets)
+        pl.fmaps_in.copy_(fmaps)
+        pl.cnets_in.copy_(cnets)
+        if pl.graph is None or pl.graph_key != key:
+            # warm-up outside capture, then capture the whole clip as one graph.  The loop state (coords1, flow)
+            # is re-initialised by the caller before every replay, so the graph itself is stateless.
+            state = (pl.coords1.tensor().clone(), pl.flow.tensor().clone(), pl.mf.tensor().clone())
+            s = torch.cuda.Stream(device=self.device)
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                self._run(pl, pl.fmaps_in, pl.cnets_in, 1, all_masks)
+            torch.cuda.current_stream().wait_stream(s)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=s):
+                self._run(pl, pl.fmaps_in, pl.cnets_in, iters, all_masks)
+            pl.graph, pl.graph_key = g, key
+            pl.coords1.tensor().copy_(state[0])
+            pl.flow.tensor().copy_(state[1])
+            pl.mf.tensor().copy_(state[2])
+        pl.graph.replay()

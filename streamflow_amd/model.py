@@ -1,0 +1,131 @@
+"""Model-forward API of the reference, kept as the drop-in surface:
+
+* ``SKFlow_MF8(args).forward(images: list[T x [B,3,H,W] in 0..255], iters, flow_init, upsample, test_mode)``
+  (reference core/models/streamflow.py:30-149)
+* ``StreamFlowT4(ckpt).forward(images [B,T,3,H,W] in [-1,1], iters=15, flow_init, upsample, test_mode=True)``
+  (reference demo.py:376-470)
+
+State-dict keys of the hot path (``att.*``, ``update_block.*``) are the reference's, so published
+checkpoints load.  The refinement loop runs in :class:`streamflow_amd.engine.HotPathEngine` (HIP kernels);
+the encoders are stand-ins (see encoders.py).
+"""
+from __future__ import annotations
+
+from argparse import Namespace
+from typing import List, Optional, Sequence
+
+import torch
+import torch.nn as nn
+
+from .encoders import ENCODERS
+from .engine import HotPathEngine
+from .gma import Attention
+from .update import SKUpdateBlock_TAM_v3
+
+UPDATE_BLOCKS = {"SKUpdateBlock_TAM_v3": SKUpdateBlock_TAM_v3}
+
+
+def default_args(T: int = 4, Encoder: str = "PatchEncoder", **kw) -> Namespace:
+    """The canonical StreamFlow flag set (reference scripts/infer.sh:12-26, train_mf.py:375,396,462)."""
+    a = Namespace(model_name="SKFlow_MF8", Encoder=Encoder, UpdateBlock="SKUpdateBlock_TAM_v3",
+                  MotionEncoder="SKMotionEncoder6_Deep_nopool_res", use_gma=True, k_conv=[1, 15],
+                  PCUpdater_conv=[1, 7], T=T, num_heads=1, decoder_dim=256, mixed_precision=False, dropout=0,
+                  corr_levels=4, corr_radius=4, use_graph=False)
+    for k, v in kw.items():
+        setattr(a, k, v)
+    return a
+
+
+class SKFlow_MF8(nn.Module):
+    def __init__(self, args: Namespace):
+        super().__init__()
+        self.args = args
+        if getattr(args, "decoder_dim", None) is None:
+            args.decoder_dim = 256
+        self.context_dim = cdim = args.decoder_dim // 2
+        self.hidden_dim = args.decoder_dim // 2
+        args.corr_levels = 4                                   # reference streamflow.py:38-39
+        args.corr_radius = 4
+        if args.Encoder not in ENCODERS:
+            raise RuntimeError(f"Encoder '{args.Encoder}' is not available in this build (have {list(ENCODERS)}); "
+                               "Twins_CSC is scoped as the next component (SURVEY.md 8f)")
+        if args.UpdateBlock not in UPDATE_BLOCKS:
+            raise RuntimeError(f"UpdateBlock '{args.UpdateBlock}' is not built (have {list(UPDATE_BLOCKS)})")
+        self.fnet = ENCODERS[args.Encoder](args, norm_fn="instance")
+        self.cnet = ENCODERS[args.Encoder](args, norm_fn="batch")
+        self.update_block = UPDATE_BLOCKS[args.UpdateBlock](args)
+        if not args.use_gma:
+            raise RuntimeError("use_gma=False is not built")
+        self.att = Attention(args=args, dim=cdim, heads=args.num_heads, max_pos_size=160, dim_head=cdim)
+        self.ratio = 8
+        self._engine: Optional[HotPathEngine] = None
+        self._engine_key = None
+
+    # -- engine management -----------------------------------------------------------------------
+    def _hot_state(self):
+        return {k: v for k, v in self.state_dict().items() if k.startswith(("att.", "update_block."))}
+
+    def engine(self, device) -> HotPathEngine:
+        params = [p for n, p in self.named_parameters() if n.startswith(("att.", "update_block."))]
+        key = (str(device),) + tuple((p.data_ptr(), p._version) for p in params)
+        if self._engine is None or self._engine_key != key:
+            self._engine = HotPathEngine(self._hot_state(), device=device, T=self.args.T,
+                                         use_graph=bool(getattr(self.args, "use_graph", False)))
+            self._engine_key = key
+        return self._engine
+
+    # -- forward ------------------------------------------------------------------------------------
+    def _features(self, images: torch.Tensor):
+        fmaps = self.fnet(images).float().contiguous()
+        cnets = self.cnet(images[:, :-1]).float().contiguous()
+        return fmaps, cnets
+
+    @torch.no_grad()
+    def forward(self, images: Sequence[torch.Tensor], iters: int = 12, flow_init=None, upsample: bool = True,
+                test_mode: bool = False):
+        """images: list of T tensors [B,3,H,W] with values in 0..255 (reference streamflow.py:95-100)."""
+        imgs = torch.stack(list(images), dim=1)
+        imgs = 2 * (imgs / 255.0) - 1.0
+        return self._forward_normalised(imgs, iters, flow_init, test_mode)
+
+    def _forward_normalised(self, imgs: torch.Tensor, iters: int, flow_init, test_mode: bool):
+        B, T, C, H, W = imgs.shape
+        if H % 8 or W % 8:
+            raise RuntimeError("H and W must be multiples of 8 (pad with InputPadder first)")
+        fmaps, cnets = self._features(imgs)
+        eng = self.engine(imgs.device)
+        if test_mode:
+            ups, low = eng.forward(fmaps, cnets, iters=iters, flow_init=flow_init)
+            ups = [u.clone() for u in ups]
+            if flow_init is None:
+                return ups
+            return ups, [l.clone() for l in low]
+        # training-mode return (reference streamflow.py:149): every iteration's upsampled prediction per pair
+        preds: List[List[torch.Tensor]] = eng.forward_all_iterations(fmaps, cnets, iters=iters, flow_init=flow_init)
+        return preds
+
+
+class StreamFlowT4(SKFlow_MF8):
+    """Self-contained T=4 model of the reference's demo (demo.py:376-470): images [B,T,3,H,W] already in [-1,1],
+    iters=15, test_mode=True by default.  `ckpt` may be a path ({'model': state_dict} or a bare dict, keys optionally
+    prefixed 'module.'); hot-path keys are loaded strictly, encoder keys are skipped (stand-in encoder)."""
+
+    def __init__(self, ckpt: Optional[str] = None, Encoder: str = "PatchEncoder", use_graph: bool = True):
+        super().__init__(default_args(T=4, Encoder=Encoder, use_graph=use_graph))
+        if ckpt is not None:
+            obj = torch.load(ckpt, map_location="cpu")
+            sd = obj["model"] if isinstance(obj, dict) and "model" in obj else obj
+            sd = {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}
+            hot = {k: v for k, v in sd.items() if k.startswith(("att.", "update_block."))}
+            mine = {k for k in self.state_dict() if k.startswith(("att.", "update_block."))}
+            if set(hot) != mine:
+                raise RuntimeError(f"checkpoint hot-path keys mismatch: missing {sorted(mine - set(hot))[:5]}, "
+                                   f"unexpected {sorted(set(hot) - mine)[:5]}")
+            self.load_state_dict(hot, strict=False)
+        for p in self.parameters():
+            p.requires_grad = False
+
+    @torch.no_grad()
+    def forward(self, images: torch.Tensor, iters: int = 15, flow_init=None, upsample: bool = True,
+                test_mode: bool = True):
+        return self._forward_normalised(images, iters, flow_init, test_mode)

@@ -1,0 +1,230 @@
+"""Tensor-level wrappers over the C ABI (streamflow_amd/_lib.py).
+
+Internal data layout: every activation is a set of *channel-major planes* ``[n_img][rows][P]``
+(P = h*w contiguous, i.e. NCHW) living inside a flat fp32 device buffer; a :class:`Planes`
+object is a (pointer, image stride, rows) view of it, so concatenations (``torch.cat`` in the
+reference) are just kernels writing into row slices of a wider buffer.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, replace
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import (EPI_AXPY, EPI_GELU, EPI_NONE, EPI_RELU, EPI_RES, EPI_RES_GELU, EPI_RES_GELU_DW1,  # noqa: F401
+                   LAYOUT_K_MAJOR, LAYOUT_K_MINOR, SfGemm)
+
+
+def _dev_check(t: torch.Tensor) -> None:
+    if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
+        raise RuntimeError("streamflow_amd ops need contiguous float32 tensors on the GPU "
+                           f"(got device={t.device}, dtype={t.dtype}, contiguous={t.is_contiguous()}); "
+                           "there is no CPU fallback")
+
+
+@dataclass(frozen=True)
+class Planes:
+    """View of channel-major planes [n_img][rows][P] inside ``base`` (a flat fp32 device tensor)."""
+    base: torch.Tensor
+    off: int            # float offset of (img 0, row 0)
+    img_stride: int     # floats between consecutive images
+    n_img: int
+    rows: int
+    P: int
+    group: int = 0          # rows per group for '(B T) C -> B (T C)' views (0 = plain)
+    group_stride: int = 0
+
+    @staticmethod
+    def of(t: torch.Tensor) -> "Planes":
+        """Wrap a contiguous [n, C, h, w] or [n, C, P] tensor."""
+        _dev_check(t)
+        n, c = t.shape[0], t.shape[1]
+        p = t.numel() // (n * c)
+        return Planes(t, 0, c * p, n, c, p)
+
+    @property
+    def ptr(self) -> int:
+        return self.base.data_ptr() + 4 * self.off
+
+    def slice(self, r0: int, r1: int) -> "Planes":
+        assert 0 <= r0 < r1 <= self.rows and self.group == 0
+        return replace(self, off=self.off + r0 * self.P, rows=r1 - r0)
+
+    def tensor(self) -> torch.Tensor:
+        """Materialise as a [n_img, rows, P] torch view (only for contiguous-row, ungrouped views)."""
+        assert self.group == 0
+        return torch.as_strided(self.base, (self.n_img, self.rows, self.P), (self.img_stride, self.P, 1),
+                                self.base.storage_offset() + self.off)
+
+
+class Workspace:
+    """Bump allocator over one flat device buffer; `take` hands out contiguous [n_img][rows][P] planes."""
+
+    def __init__(self, floats: int, device):
+        self.buf = torch.empty(int(floats), dtype=torch.float32, device=device)
+        self.top = 0
+
+    def take(self, n_img: int, rows: int, P: int) -> Planes:
+        size = n_img * rows * P
+        start = (self.top + 63) // 64 * 64          # 256-byte aligned
+        if start + size > self.buf.numel():
+            raise RuntimeError("workspace exhausted")
+        self.top = start + size
+        return Planes(self.buf, start, rows * P, n_img, rows, P)
+
+    def take_flat(self, floats: int) -> torch.Tensor:
+        start = (self.top + 63) // 64 * 64
+        if start + floats > self.buf.numel():
+            raise RuntimeError("workspace exhausted")
+        self.top = start + floats
+        return self.buf[start:start + floats]
+
+
+class PackedLinear:
+    """A 1x1-conv / Linear weight [Cout, Cin(,1,1)] repacked K-major ([Cin][Cout padded to 4]) for sf_gemm."""
+
+    def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor], device, conv3x3: bool = False):
+        w = weight.detach().to(device=device, dtype=torch.float32)
+        if conv3x3:                                   # [Cout, Cin, 3, 3] -> k = (ky*3+kx)*Cin + c
+            cout = w.shape[0]
+            w2 = w.permute(2, 3, 1, 0).reshape(-1, cout)
+        else:
+            w2 = w.reshape(w.shape[0], -1).t()
+        self.K, self.M = w2.shape
+        self.lda = (self.M + 3) // 4 * 4
+        wt = torch.zeros(self.K, self.lda, dtype=torch.float32, device=device)
+        wt[:, : self.M] = w2
+        self.wt = wt.contiguous()
+        self.bias = None if bias is None else bias.detach().to(device=device, dtype=torch.float32).contiguous()
+        self.conv3x3 = conv3x3
+
+
+def gemm(A: PackedLinear, X: Planes, Y: Planes, epilogue: int = EPI_NONE, R: Optional[Planes] = None,
+         dw_w: Optional[torch.Tensor] = None, dw_b: Optional[torch.Tensor] = None, alpha: float = 1.0,
+         hw: Optional[Sequence[int]] = None) -> None:
+    """Y[img] = epilogue(alpha * (W @ X[img] + bias)) for every image (batched over grid.z)."""
+    assert X.rows * (9 if A.conv3x3 else 1) == A.K, (X.rows, A.K)
+    assert Y.rows == A.M and X.n_img == Y.n_img and X.P == Y.P, (Y.rows, A.M)
+    g = SfGemm()
+    g.A, g.B, g.C = A.wt.data_ptr(), X.ptr, Y.ptr
+    g.bias = None if A.bias is None else A.bias.data_ptr()
+    g.M, g.N, g.K, g.batch = A.M, X.P, A.K, X.n_img
+    g.lda, g.ldb, g.ldc = A.lda, X.P, Y.P
+    g.strideA, g.strideB, g.strideC = 0, X.img_stride, Y.img_stride
+    g.a_layout, g.b_layout = LAYOUT_K_MAJOR, LAYOUT_K_MAJOR
+    g.b_group, g.b_group_stride = X.group, X.group_stride
+    if R is not None:
+        assert R.rows == A.M and R.n_img == Y.n_img
+        g.R, g.ldr, g.strideR = R.ptr, R.P, R.img_stride
+        g.r_group, g.r_group_stride = R.group, R.group_stride
+    if dw_w is not None:
+        g.dw_w, g.dw_b = dw_w.data_ptr(), dw_b.data_ptr()
+    if A.conv3x3:
+        g.conv3x3, g.h, g.w = 1, int(hw[0]), int(hw[1])
+    g.alpha, g.epilogue, g.precision = float(alpha), int(epilogue), 0
+    _lib.check(_lib.load().sf_gemm(C.byref(g), _lib.stream()), "sf_gemm")
+
+
+def gemm_raw(**kw) -> None:
+    """Fully explicit sf_gemm call (used for the attention logits and attn @ v contractions)."""
+    g = SfGemm()
+    g.alpha = 1.0
+    for k, v in kw.items():
+        setattr(g, k, v)
+    _lib.check(_lib.load().sf_gemm(C.byref(g), _lib.stream()), "sf_gemm")
+
+
+def dwconv_res_gelu(X: Planes, wgt: torch.Tensor, bias: torch.Tensor, Y: Planes, h: int, w: int, k: int) -> None:
+    assert X.rows == Y.rows == wgt.shape[0] and X.P == h * w
+    _lib.check(_lib.load().sf_dwconv_res_gelu(X.ptr, X.img_stride, wgt.data_ptr(), bias.data_ptr(), Y.ptr,
+                                              Y.img_stride, X.n_img, X.rows, h, w, k, _lib.stream()),
+               "sf_dwconv_res_gelu")
+
+
+def layernorm_cm(X: Planes, gamma: torch.Tensor, beta: torch.Tensor, Y: Planes, eps: float = 1e-5) -> None:
+    _lib.check(_lib.load().sf_layernorm_cm(X.ptr, X.img_stride, gamma.data_ptr(), beta.data_ptr(), Y.ptr,
+                                           Y.img_stride, X.n_img, X.rows, X.P, eps, _lib.stream()),
+               "sf_layernorm_cm")
+
+
+def temporal_attn(QKV: Planes, OUT: Planes, B: int, TT: int, C_: int) -> None:
+    assert QKV.img_stride == 3 * C_ * QKV.P and OUT.img_stride == C_ * OUT.P and QKV.n_img == B * TT
+    _lib.check(_lib.load().sf_temporal_attn(QKV.ptr, OUT.ptr, B, TT, C_, QKV.P, _lib.stream()), "sf_temporal_attn")
+
+
+def softmax_rows(x: torch.Tensor, rows: int, cols: int) -> None:
+    _lib.check(_lib.load().sf_softmax_rows(x.data_ptr(), rows, cols, _lib.stream()), "sf_softmax_rows")
+
+
+def coords_grid(batch: int, ht: int, wd: int, device) -> torch.Tensor:
+    out = torch.empty(batch, 2, ht, wd, dtype=torch.float32, device=device)
+    _lib.ptr(out)
+    _lib.check(_lib.load().sf_coords_grid(out.data_ptr(), batch, ht, wd, _lib.stream()), "sf_coords_grid")
+    return out
+
+
+def context_split(cnets: torch.Tensor, nets: Planes, inps: Planes, hdim: int) -> None:
+    """cnets [n_img, 2*hdim, P]-like contiguous tensor."""
+    _dev_check(cnets)
+    _lib.check(_lib.load().sf_context_split(cnets.data_ptr(), nets.ptr, nets.img_stride, inps.ptr, inps.img_stride,
+                                            nets.n_img, hdim, nets.P, _lib.stream()), "sf_context_split")
+
+
+def flow_update(coords1: Planes, delta: Optional[Planes], flow_a: Optional[Planes], flow_b: Optional[Planes],
+                n_img: int, h: int, w: int) -> None:
+    assert coords1.img_stride == 2 * h * w and (delta is None or delta.img_stride == 2 * h * w)
+    _lib.check(_lib.load().sf_flow_update(
+        coords1.ptr, None if delta is None else delta.ptr,
+        None if flow_a is None else flow_a.ptr, 0 if flow_a is None else flow_a.img_stride,
+        None if flow_b is None else flow_b.ptr, 0 if flow_b is None else flow_b.img_stride,
+        n_img, h, w, _lib.stream()), "sf_flow_update")
+
+
+def upsample_flow(flow: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+    """flow [n,2,h,w], mask [n,576,h,w] -> [n,2,8h,8w] (reference streamflow.py:82-93)."""
+    _dev_check(flow)
+    _dev_check(mask)
+    n, _, h, w = flow.shape
+    out = torch.empty(n, 2, 8 * h, 8 * w, dtype=torch.float32, device=flow.device)
+    _lib.check(_lib.load().sf_upsample_flow(flow.data_ptr(), mask.data_ptr(), out.data_ptr(), n, h, w, _lib.stream()),
+               "sf_upsample_flow")
+    return out
+
+
+def pair_strides(arr: Optional[Sequence[int]]):
+    if arr is None:
+        return None
+    return (C.c_int64 * 4)(*[int(a) for a in arr])
+
+
+def corr_build(f1_ptr: int, f2_ptr: int, clip_stride: int, pair_stride: int, lvls: Sequence[torch.Tensor],
+               lvl_pair_stride: Optional[Sequence[int]], B: int, pairs: int, D: int, h: int, w: int) -> None:
+    _lib.check(_lib.load().sf_corr_build_pyramid(
+        f1_ptr, f2_ptr, clip_stride, pair_stride, lvls[0].data_ptr(), lvls[1].data_ptr(), lvls[2].data_ptr(),
+        lvls[3].data_ptr(), pair_strides(lvl_pair_stride), B, pairs, D, h, w, 4, 0, _lib.stream()),
+        "sf_corr_build_pyramid")
+
+
+def corr_lookup(lvls: Sequence[torch.Tensor], lvl_pair_stride: Optional[Sequence[int]], coords: Planes,
+                out: Planes, B: int, pairs: int, h: int, w: int) -> None:
+    assert out.rows == 324 and out.n_img == B * pairs and coords.img_stride == 2 * h * w
+    _lib.check(_lib.load().sf_corr_lookup(
+        lvls[0].data_ptr(), lvls[1].data_ptr(), lvls[2].data_ptr(), lvls[3].data_ptr(),
+        pair_strides(lvl_pair_stride), coords.ptr, out.ptr, out.img_stride, B, pairs, h, w, 4, 4,
+        _lib.stream()), "sf_corr_lookup")
+
+
+def bilinear_sampler(img: torch.Tensor, coords: torch.Tensor, want_mask: bool = False):
+    _dev_check(img)
+    _dev_check(coords)
+    M, Cc, Hi, Wi = img.shape
+    _, Ho, Wo, _ = coords.shape
+    out = torch.empty(M, Cc, Ho, Wo, dtype=torch.float32, device=img.device)
+    mask = torch.empty(M, Ho, Wo, 1, dtype=torch.float32, device=img.device) if want_mask else None
+    _lib.check(_lib.load().sf_bilinear_sampler(img.data_ptr(), coords.data_ptr(), out.data_ptr(),
+                                               None if mask is None else mask.data_ptr(), M, Cc, Hi, Wi, Ho, Wo,
+                                               _lib.stream()), "sf_bilinear_sampler")
+    return (out, mask) if want_mask else out

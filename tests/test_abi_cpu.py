@@ -1,0 +1,103 @@
+"""CPU: the C-ABI library loads and exports every symbol include/streamflow_hip.h declares; host-side
+logic (weight packing, state-dict contract, loud failure without a GPU)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from streamflow_amd import _lib, build
+    if not os.path.exists(_lib.LIB_PATH):
+        build.build(verbose=False)
+    return _lib.load()
+
+
+def test_every_declared_symbol_is_exported(lib):
+    from streamflow_amd import _lib
+    hdr = open(os.path.join(REPO, "include", "streamflow_hip.h")).read()
+    declared = set(re.findall(r"^\s*(?:int|const char\*)\s+(sf_\w+)\s*\(", hdr, flags=re.M))
+    assert len(declared) >= 14
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+    assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
+    assert lib.sf_version() == 100
+
+
+def test_struct_layout_matches_header():
+    from streamflow_amd._lib import SfGemm
+    # 8 pointers + 4 i32 + 8 i64 + 2 i32 + (i32,pad,i64)*2 + 3 i32 + f32 + 2 i32  (natural alignment)
+    assert ctypes.sizeof(SfGemm) == 208
+    assert SfGemm.lda.offset == 80 and SfGemm.b_group_stride.offset == 160 and SfGemm.alpha.offset == 196
+
+
+def test_bad_arguments_return_error_codes(lib):
+    assert lib.sf_coords_grid(None, 1, 4, 4, None) == -1
+    assert b"sf_coords_grid" in lib.sf_last_error()
+    assert lib.sf_gemm(None, None) == -1
+
+
+def test_cpu_tensors_fail_loudly():
+    import streamflow_amd as sfa
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        sfa.coords_grid(1, 4, 4, device="cpu")
+    with pytest.raises(RuntimeError, match="no CPU"):
+        sfa.CorrBlock(torch.zeros(1, 8, 16, 16), torch.zeros(1, 8, 16, 16))
+    with pytest.raises(RuntimeError):
+        sfa.HotPathEngine({}, device="cpu")
+
+
+def test_state_dict_contract_strict_load():
+    """Keys/shapes of the reference checkpoint contract load with strict=True, with and
+    without the DataParallel 'module.' prefix handled by the checkpoint loader."""
+    import streamflow_amd as sfa
+    from streamflow_amd import synthetic as syn
+    for T in (2, 3, 4):
+        m = sfa.SKFlow_MF8(sfa.default_args(T=T, Encoder="InjectEncoder"))
+        P = syn.make_params(0, T)
+        m.load_state_dict(dict(P), strict=True)
+        sd = m.state_dict()
+        assert set(sd) == set(P)
+        for k in P:
+            assert tuple(sd[k].shape) == tuple(P[k].shape), k
+    assert sum(v.numel() for v in syn.make_params(0, 4).values()) == 5780737 + 32768
+
+
+def test_checkpoint_loader_accepts_module_prefix(tmp_path):
+    import streamflow_amd as sfa
+    from streamflow_amd import synthetic as syn
+    P = syn.make_params(1, 4)
+    ck = tmp_path / "ck.pth"
+    torch.save({"model": {"module." + k: v for k, v in P.items()}}, ck)
+    m = sfa.StreamFlowT4(str(ck), Encoder="InjectEncoder")
+    assert torch.equal(m.state_dict()["update_block.gru.pw.weight"], P["update_block.gru.pw.weight"])
+    bad = dict(P)
+    bad.pop("update_block.aggregator.gamma")
+    torch.save(bad, ck)
+    with pytest.raises(RuntimeError, match="mismatch"):
+        sfa.StreamFlowT4(str(ck), Encoder="InjectEncoder")
+
+
+def test_packed_linear_layout():
+    from streamflow_amd.ops import PackedLinear
+    w = torch.arange(6 * 5, dtype=torch.float32).view(6, 5, 1, 1)
+    p = PackedLinear(w, None, "cpu")
+    assert (p.K, p.M, p.lda) == (5, 6, 8)
+    assert torch.equal(p.wt[:, :6], w.view(6, 5).t()) and p.wt[:, 6:].abs().sum() == 0
+    w3 = torch.randn(4, 3, 3, 3)
+    p3 = PackedLinear(w3, None, "cpu", conv3x3=True)
+    assert p3.K == 27 and p3.wt[(1 * 3 + 2) * 3 + 1, 2] == w3[2, 1, 1, 2]
+
+
+def test_input_padder_matches_reference_formula():
+    from streamflow_amd import InputPadder
+    p = InputPadder((1, 3, 436, 1024))
+    x = torch.zeros(1, 3, 436, 1024)
+    (y,) = p.pad(x)
+    assert y.shape[-2:] == (440, 1024) and p._pad == [0, 0, 2, 2]
+    assert p.unpad(y).shape == x.shape
