@@ -1,0 +1,241 @@
+#!/usr/bin/env python3
+"""Headline benchmark: flow-fields/sec of the StreamFlow hot path at Sintel shape (436x1024 padded to
+440x1024 -> 55x128 feature grid), T=4 frames (3 flow fields per clip), iters=15, one clip per GPU per step.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+
+A "step" = one full pass of the hot path over one clip per rank: corr volumes + pyramids for the 3 pairs,
+context split, GMA attention matrix, 15 refinement iterations (lookup, motion encoder, aggregate, temporal
+block, gru, flow head), mask head + convex 8x upsampling of the final flows.  Inputs (encoder features,
+random-init weights of the reference architecture) are synthetic and already resident in HBM.  Clips are
+independent, so N GPUs run N replicas with no data-path collective (torch.distributed is used only for the
+barrier and the max-over-ranks timing the contract asks for).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+WORKLOADS = {
+    # name: (H, W, T, iters)
+    "sintel": (440, 1024, 4, 15),
+    "demo256": (256, 256, 4, 4),
+    "kitti": (376, 1248, 2, 15),
+}
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: exact-fp32 MFMA = fp32 vector peak
+PEAK_HBM_GBPS = 8000.0             # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+
+
+def log(msg: str) -> None:
+    print(f"[bench +{time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+_T0 = time.perf_counter()
+
+
+def usable_cores() -> int:
+    """Host cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except OSError:
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                q = int(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                p = int(f.read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except OSError:
+            pass
+    return max(1, n)
+
+
+def shard(n_items: int, world: int, rank: int):
+    """Round-robin partition of independent clips over ranks."""
+    return list(range(rank, n_items, world))
+
+
+def timed_steps(step_fn, steps: int, warmup: int, world: int, sync_fn, barrier_fn, allreduce_max_fn) -> float:
+    """W untimed warm-up steps, then exactly K steps bracketed by barrier + device sync; MAX over ranks."""
+    for _ in range(warmup):
+        step_fn()
+    sync_fn()
+    barrier_fn()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step_fn()
+    sync_fn()
+    barrier_fn()
+    dt = time.perf_counter() - t0
+    return allreduce_max_fn(dt)
+
+
+def cpu_baseline(fmaps, cnets, params, iters_total: int, sample_iters: int, pairs: int):
+    """The CPU oracle (PyTorch-CPU restatement of the reference path, kind='port') on the host cores,
+    bounded: setup + `sample_iters` iterations are timed, the clip time is extrapolated linearly in the
+    iteration count (every iteration does identical work)."""
+    from oracle import streamflow_oracle as orc
+    cores = min(usable_cores(), 64)
+    torch.set_num_threads(cores)
+    log(f"cpu baseline: oracle on {cores} host threads (os.cpu_count()={os.cpu_count()})")
+    t0 = time.perf_counter()
+    ups1, _ = orc.hotpath_forward(fmaps, cnets, params, 1)
+    t1 = time.perf_counter()
+    log(f"cpu baseline: setup+1 iteration took {t1 - t0:.1f}s")
+    ups2, _ = orc.hotpath_forward(fmaps, cnets, params, sample_iters)
+    t2 = time.perf_counter()
+    per_iter = max(((t2 - t1) - (t1 - t0)) / (sample_iters - 1), 1e-9)
+    setup = max((t1 - t0) - per_iter, 0.0)
+    clip = setup + iters_total * per_iter
+    return {"value": pairs / clip, "unit": "flow-fields/s", "cores": cores, "kind": "port",
+            "sample": f"oracle timed for setup+1 and setup+{sample_iters} iterations of one clip "
+                      f"({t1 - t0:.1f}s + {t2 - t1:.1f}s), extrapolated to {iters_total} iterations: {clip:.1f} s/clip",
+            "s_per_clip": clip}, ups2
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="sintel", choices=list(WORKLOADS))
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
+    ap.add_argument("--all-masks", action="store_true",
+                    help="run the mask head every iteration as the reference literally does (outputs identical; "
+                         "the default skips the 14 mask heads whose results test_mode discards)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-breakdown", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 "
+                         "--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from streamflow_amd import ops, synthetic as syn
+    from streamflow_amd.engine import HotPathEngine
+
+    H, W, T, iters = WORKLOADS[args.workload]
+    h, w, B = H // 8, W // 8, 1
+    pairs = T - 1
+    params = syn.make_params(0, T)
+    fmaps_c, cnets_c = syn.make_features(1000 + rank, B, T, h, w)
+    fmaps, cnets = fmaps_c.to(dev), cnets_c.to(dev)
+    eng = HotPathEngine(params, device=dev, T=T, use_graph=not args.no_graph)
+
+    def step():
+        eng.forward(fmaps, cnets, iters=iters, all_masks=args.all_masks)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    def allreduce_max(x: float) -> float:
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    log(f"rank {rank}/{world}: engine ready, workload {args.workload}, graph={not args.no_graph}")
+    step()
+    torch.cuda.synchronize()
+    log("first step done (includes graph capture)")
+    dt = timed_steps(step, args.steps, args.warmup, world, torch.cuda.synchronize, barrier, allreduce_max)
+    log(f"timed region: {args.steps} steps in {dt:.3f}s")
+    fields = world * B * pairs * args.steps
+    result = {
+        "metric": "flow_fields_per_sec", "value": fields / dt, "unit": "flow-fields/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp32", "data": "synthetic",
+        "config": {"workload": f"{args.workload}_{H}x{W}_T{T}_iters{iters}", "clips_per_gpu_per_step": B,
+                   "flow_fields_per_clip": pairs, "feature_grid": [h, w], "parallelism": f"replicas{world}",
+                   "hip_graph": not args.no_graph, "mask_head_every_iteration": bool(args.all_masks),
+                   "precision": "exact fp32 (v_mfma_f32_32x32x2_f32)"},
+    }
+
+    if rank == 0 and not args.no_kernel_breakdown:
+        # instrumented eager pass: HIP events around every launch on the launch stream
+        eager = HotPathEngine(params, device=dev, T=T, use_graph=False)
+        eager._plans = eng._plans                       # reuse buffers
+        eager.forward(fmaps, cnets, iters=iters, all_masks=args.all_masks)
+        reps = 2
+        ops.PROFILER = ops.Profiler()
+        for _ in range(reps):
+            eager.forward(fmaps, cnets, iters=iters, all_masks=args.all_masks)
+        summ = ops.PROFILER.summary()
+        ops.PROFILER = None
+        log("instrumented pass done")
+        kern = {}
+        for name, d in summ.items():
+            ms = d["ms"] / reps
+            kern[name] = {"launches_per_clip": d["launches"] // reps, "ms_per_clip": round(ms, 4),
+                          "avg_us": round(1e3 * ms / max(d["launches"] // reps, 1), 2),
+                          "tflops": round(d["flops"] / reps / (ms * 1e-3) / 1e12, 2) if d["flops"] else None,
+                          "gbps_algorithmic": round(d["bytes"] / reps / (ms * 1e-3) / 1e9, 1) if d["bytes"] else None}
+        result["kernels"] = kern
+        dom = max(kern, key=lambda k: kern[k]["ms_per_clip"])
+        if kern[dom]["tflops"]:
+            result["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": kern[dom]["tflops"],
+                                  "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": round(kern[dom]["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                                  "method": "sum of algorithmic FLOPs / sum of HIP-event durations over all launches "
+                                            "of the kernel family in one instrumented clip"}
+        else:
+            result["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": kern[dom]["gbps_algorithmic"],
+                                  "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                                  "frac": round((kern[dom]["gbps_algorithmic"] or 0) / PEAK_HBM_GBPS, 4),
+                                  "traffic": None}
+        # north-star sub-metric: corr build + lookup against the HBM roofline (algorithmic bytes)
+        cb, cl = kern.get("corr_build"), kern.get("corr_lookup")
+        if cb and cl:
+            tot_b = (summ["corr_build"]["bytes"] + summ["corr_lookup"]["bytes"]) / reps
+            tot_ms = cb["ms_per_clip"] + cl["ms_per_clip"]
+            result["roofline_corr"] = {"bound": "hbm", "unit": "GB/s", "peak": PEAK_HBM_GBPS,
+                                       "build_gbps": cb["gbps_algorithmic"], "lookup_gbps": cl["gbps_algorithmic"],
+                                       "build_tflops": cb["tflops"], "build_plus_lookup_ms_per_clip": round(tot_ms, 4),
+                                       "achieved": round(tot_b / (tot_ms * 1e-3) / 1e9, 1),
+                                       "frac": round(tot_b / (tot_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4)}
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import streamflow_oracle as orc
+        sample_iters = 2 if args.workload != "demo256" else 3
+        base, ups_cpu = cpu_baseline(fmaps_c, cnets_c, params, iters, sample_iters, pairs)
+        result["cpu_baseline"] = base
+        chk = HotPathEngine(params, device=dev, T=T, use_graph=False)
+        chk._plans = eng._plans
+        ups_gpu, _ = chk.forward(fmaps, cnets, iters=sample_iters)
+        result["epe_vs_oracle"] = {"value": max(orc.epe(a.cpu(), b) for a, b in zip(ups_gpu, ups_cpu)),
+                                   "unit": "px", "iters": sample_iters,
+                                   "note": "max over the 3 pairs of mean EPE, HIP path vs CPU oracle, full shape"}
+
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

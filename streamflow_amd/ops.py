@@ -18,6 +18,44 @@ from ._lib import (EPI_AXPY, EPI_GELU, EPI_NONE, EPI_RELU, EPI_RES, EPI_RES_GELU
                    LAYOUT_K_MAJOR, LAYOUT_K_MINOR, SfGemm)
 
 
+class Profiler:
+    """Per-launch HIP-event timing on the stream the kernels are launched on (torch's current stream).
+    Used by bench.py's instrumented pass: every wrapped op records (name, algorithmic flops, algorithmic
+    bytes, start event, end event)."""
+
+    def __init__(self):
+        self.records = []
+
+    def launch(self, name, flops, nbytes, fn):
+        s = torch.cuda.Event(enable_timing=True)
+        e = torch.cuda.Event(enable_timing=True)
+        s.record()
+        fn()
+        e.record()
+        self.records.append((name, float(flops), float(nbytes), s, e))
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, fl, by, s, e in self.records:
+            d = out.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+            d["launches"] += 1
+            d["ms"] += s.elapsed_time(e)
+            d["flops"] += fl
+            d["bytes"] += by
+        return out
+
+
+PROFILER: Optional[Profiler] = None
+
+
+def _launch(name: str, flops: float, nbytes: float, fn) -> None:
+    if PROFILER is None:
+        fn()
+    else:
+        PROFILER.launch(name, flops, nbytes, fn)
+
+
 def _dev_check(t: torch.Tensor) -> None:
     if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
         raise RuntimeError("streamflow_amd ops need contiguous float32 tensors on the GPU "
@@ -125,7 +163,8 @@ def gemm(A: PackedLinear, X: Planes, Y: Planes, epilogue: int = EPI_NONE, R: Opt
     if A.conv3x3:
         g.conv3x3, g.h, g.w = 1, int(hw[0]), int(hw[1])
     g.alpha, g.epilogue, g.precision = float(alpha), int(epilogue), 0
-    _lib.check(_lib.load().sf_gemm(C.byref(g), _lib.stream()), "sf_gemm")
+    _launch("gemm", 2.0 * g.M * g.N * g.K * g.batch, 0,
+            lambda: _lib.check(_lib.load().sf_gemm(C.byref(g), _lib.stream()), "sf_gemm"))
 
 
 def gemm_raw(**kw) -> None:
@@ -134,29 +173,36 @@ def gemm_raw(**kw) -> None:
     g.alpha = 1.0
     for k, v in kw.items():
         setattr(g, k, v)
-    _lib.check(_lib.load().sf_gemm(C.byref(g), _lib.stream()), "sf_gemm")
+    name = "gemm_attn" if g.a_layout == LAYOUT_K_MINOR else "gemm"
+    _launch(name, 2.0 * g.M * g.N * g.K * g.batch, 0,
+            lambda: _lib.check(_lib.load().sf_gemm(C.byref(g), _lib.stream()), "sf_gemm"))
 
 
 def dwconv_res_gelu(X: Planes, wgt: torch.Tensor, bias: torch.Tensor, Y: Planes, h: int, w: int, k: int) -> None:
     assert X.rows == Y.rows == wgt.shape[0] and X.P == h * w
-    _lib.check(_lib.load().sf_dwconv_res_gelu(X.ptr, X.img_stride, wgt.data_ptr(), bias.data_ptr(), Y.ptr,
-                                              Y.img_stride, X.n_img, X.rows, h, w, k, _lib.stream()),
-               "sf_dwconv_res_gelu")
+    _launch("dwconv%d" % k, 2.0 * k * k * X.n_img * X.rows * h * w, 8.0 * X.n_img * X.rows * h * w,
+            lambda: _lib.check(_lib.load().sf_dwconv_res_gelu(X.ptr, X.img_stride, wgt.data_ptr(), bias.data_ptr(),
+                                                              Y.ptr, Y.img_stride, X.n_img, X.rows, h, w, k,
+                                                              _lib.stream()), "sf_dwconv_res_gelu"))
 
 
 def layernorm_cm(X: Planes, gamma: torch.Tensor, beta: torch.Tensor, Y: Planes, eps: float = 1e-5) -> None:
-    _lib.check(_lib.load().sf_layernorm_cm(X.ptr, X.img_stride, gamma.data_ptr(), beta.data_ptr(), Y.ptr,
-                                           Y.img_stride, X.n_img, X.rows, X.P, eps, _lib.stream()),
-               "sf_layernorm_cm")
+    _launch("layernorm", 0, 8.0 * X.n_img * X.rows * X.P,
+            lambda: _lib.check(_lib.load().sf_layernorm_cm(X.ptr, X.img_stride, gamma.data_ptr(), beta.data_ptr(),
+                                                           Y.ptr, Y.img_stride, X.n_img, X.rows, X.P, eps,
+                                                           _lib.stream()), "sf_layernorm_cm"))
 
 
 def temporal_attn(QKV: Planes, OUT: Planes, B: int, TT: int, C_: int) -> None:
     assert QKV.img_stride == 3 * C_ * QKV.P and OUT.img_stride == C_ * OUT.P and QKV.n_img == B * TT
-    _lib.check(_lib.load().sf_temporal_attn(QKV.ptr, OUT.ptr, B, TT, C_, QKV.P, _lib.stream()), "sf_temporal_attn")
+    _launch("temporal_attn", 0, 16.0 * QKV.n_img * C_ * QKV.P,
+            lambda: _lib.check(_lib.load().sf_temporal_attn(QKV.ptr, OUT.ptr, B, TT, C_, QKV.P, _lib.stream()),
+                               "sf_temporal_attn"))
 
 
 def softmax_rows(x: torch.Tensor, rows: int, cols: int) -> None:
-    _lib.check(_lib.load().sf_softmax_rows(x.data_ptr(), rows, cols, _lib.stream()), "sf_softmax_rows")
+    _launch("softmax_rows", 0, 8.0 * rows * cols,
+            lambda: _lib.check(_lib.load().sf_softmax_rows(x.data_ptr(), rows, cols, _lib.stream()), "sf_softmax_rows"))
 
 
 def coords_grid(batch: int, ht: int, wd: int, device) -> torch.Tensor:
@@ -176,11 +222,11 @@ def context_split(cnets: torch.Tensor, nets: Planes, inps: Planes, hdim: int) ->
 def flow_update(coords1: Planes, delta: Optional[Planes], flow_a: Optional[Planes], flow_b: Optional[Planes],
                 n_img: int, h: int, w: int) -> None:
     assert coords1.img_stride == 2 * h * w and (delta is None or delta.img_stride == 2 * h * w)
-    _lib.check(_lib.load().sf_flow_update(
+    _launch("flow_update", 0, 0, lambda: _lib.check(_lib.load().sf_flow_update(
         coords1.ptr, None if delta is None else delta.ptr,
         None if flow_a is None else flow_a.ptr, 0 if flow_a is None else flow_a.img_stride,
         None if flow_b is None else flow_b.ptr, 0 if flow_b is None else flow_b.img_stride,
-        n_img, h, w, _lib.stream()), "sf_flow_update")
+        n_img, h, w, _lib.stream()), "sf_flow_update"))
 
 
 def upsample_flow(flow: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
@@ -202,19 +248,27 @@ def pair_strides(arr: Optional[Sequence[int]]):
 
 def corr_build(f1_ptr: int, f2_ptr: int, clip_stride: int, pair_stride: int, lvls: Sequence[torch.Tensor],
                lvl_pair_stride: Optional[Sequence[int]], B: int, pairs: int, D: int, h: int, w: int) -> None:
-    _lib.check(_lib.load().sf_corr_build_pyramid(
-        f1_ptr, f2_ptr, clip_stride, pair_stride, lvls[0].data_ptr(), lvls[1].data_ptr(), lvls[2].data_ptr(),
-        lvls[3].data_ptr(), pair_strides(lvl_pair_stride), B, pairs, D, h, w, 4, 0, _lib.stream()),
-        "sf_corr_build_pyramid")
+    N = h * w
+    cells = sum((h >> l) * (w >> l) for l in range(4))
+    # algorithmic bytes per (clip, pair): both feature maps read once + every pyramid cell written once
+    nbytes = B * pairs * (2.0 * N * D * 4 + 4.0 * N * cells)
+    _launch("corr_build", 2.0 * N * N * D * B * pairs, nbytes, lambda: _lib.check(
+        _lib.load().sf_corr_build_pyramid(
+            f1_ptr, f2_ptr, clip_stride, pair_stride, lvls[0].data_ptr(), lvls[1].data_ptr(), lvls[2].data_ptr(),
+            lvls[3].data_ptr(), pair_strides(lvl_pair_stride), B, pairs, D, h, w, 4, 0, _lib.stream()),
+        "sf_corr_build_pyramid"))
 
 
 def corr_lookup(lvls: Sequence[torch.Tensor], lvl_pair_stride: Optional[Sequence[int]], coords: Planes,
                 out: Planes, B: int, pairs: int, h: int, w: int) -> None:
     assert out.rows == 324 and out.n_img == B * pairs and coords.img_stride == 2 * h * w
-    _lib.check(_lib.load().sf_corr_lookup(
+    N = h * w
+    # algorithmic bytes per image: 10x10 footprint x 4 levels read + coords + 324 output channels
+    nbytes = B * pairs * (N * 4 * 100 * 4.0 + N * 2 * 4.0 + N * 324 * 4.0)
+    _launch("corr_lookup", 0, nbytes, lambda: _lib.check(_lib.load().sf_corr_lookup(
         lvls[0].data_ptr(), lvls[1].data_ptr(), lvls[2].data_ptr(), lvls[3].data_ptr(),
         pair_strides(lvl_pair_stride), coords.ptr, out.ptr, out.img_stride, B, pairs, h, w, 4, 4,
-        _lib.stream()), "sf_corr_lookup")
+        _lib.stream()), "sf_corr_lookup"))
 
 
 def bilinear_sampler(img: torch.Tensor, coords: torch.Tensor, want_mask: bool = False):
