@@ -32,6 +32,7 @@ WORKLOADS = {
     "kitti": (376, 1248, 2, 15),
 }
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: exact-fp32 MFMA = fp32 vector peak
+PEAK_F16_MFMA_TFLOPS = 2500.0      # dense f16/bf16 MFMA; the split path spends 3 MFMA flops per algorithmic flop
 PEAK_HBM_GBPS = 8000.0             # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 
 
@@ -116,6 +117,8 @@ def main():
     ap.add_argument("--all-masks", action="store_true",
                     help="run the mask head every iteration as the reference literally does (outputs identical; "
                          "the default skips the 14 mask heads whose results test_mode discards)")
+    ap.add_argument("--precision", default="f16x3", choices=["f16x3", "fp32"],
+                    help="f16x3: split-fp16 MFMA with fp32 accumulation (fp32-class accuracy); fp32: exact fp32 MFMA")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-breakdown", action="store_true")
     args = ap.parse_args()
@@ -143,7 +146,7 @@ def main():
     params = syn.make_params(0, T)
     fmaps_c, cnets_c = syn.make_features(1000 + rank, B, T, h, w)
     fmaps, cnets = fmaps_c.to(dev), cnets_c.to(dev)
-    eng = HotPathEngine(params, device=dev, T=T, use_graph=not args.no_graph)
+    eng = HotPathEngine(params, device=dev, T=T, use_graph=not args.no_graph, precision=args.precision)
 
     def step():
         eng.forward(fmaps, cnets, iters=iters, all_masks=args.all_masks)
@@ -169,16 +172,18 @@ def main():
     result = {
         "metric": "flow_fields_per_sec", "value": fields / dt, "unit": "flow-fields/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "fp32" if args.precision == "fp32" else "f16x3-split (fp32 accumulate)", "data": "synthetic",
         "config": {"workload": f"{args.workload}_{H}x{W}_T{T}_iters{iters}", "clips_per_gpu_per_step": B,
                    "flow_fields_per_clip": pairs, "feature_grid": [h, w], "parallelism": f"replicas{world}",
                    "hip_graph": not args.no_graph, "mask_head_every_iteration": bool(args.all_masks),
-                   "precision": "exact fp32 (v_mfma_f32_32x32x2_f32)"},
+                   "precision": ("exact fp32 (v_mfma_f32_32x32x2_f32)" if args.precision == "fp32" else
+                                 "split fp16x3 (x=hi+lo, 3x v_mfma_f32_32x32x16_f16, fp32 accumulate)")},
     }
 
     if rank == 0 and not args.no_kernel_breakdown:
         # instrumented eager pass: HIP events around every launch on the launch stream
-        eager = HotPathEngine(params, device=dev, T=T, use_graph=False)
+        eager = HotPathEngine(params, device=dev, T=T, use_graph=False, precision=args.precision)
         eager._plans = eng._plans                       # reuse buffers
         eager.forward(fmaps, cnets, iters=iters, all_masks=args.all_masks)
         reps = 2
@@ -197,10 +202,13 @@ def main():
                           "gbps_algorithmic": round(d["bytes"] / reps / (ms * 1e-3) / 1e9, 1) if d["bytes"] else None}
         result["kernels"] = kern
         dom = max(kern, key=lambda k: kern[k]["ms_per_clip"])
-        if kern[dom]["tflops"]:
+        if kern[dom]["tflops"] and dom.startswith("gemm"):
+            # algorithmic (fp32-equivalent) TFLOP/s; the f16x3 path issues 3 f16 MFMA flops per algorithmic flop,
+            # so its matrix-core roof for algorithmic flops is 2500/3
+            peak = PEAK_FP32_MFMA_TFLOPS if args.precision == "fp32" else PEAK_F16_MFMA_TFLOPS / 3.0
             result["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": kern[dom]["tflops"],
-                                  "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                  "frac": round(kern[dom]["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                                  "peak": round(peak, 1), "unit": "TFLOP/s",
+                                  "frac": round(kern[dom]["tflops"] / peak, 4), "traffic": None,
                                   "method": "sum of algorithmic FLOPs / sum of HIP-event durations over all launches "
                                             "of the kernel family in one instrumented clip"}
         else:
@@ -224,7 +232,7 @@ def main():
         sample_iters = 2 if args.workload != "demo256" else 3
         base, ups_cpu = cpu_baseline(fmaps_c, cnets_c, params, iters, sample_iters, pairs)
         result["cpu_baseline"] = base
-        chk = HotPathEngine(params, device=dev, T=T, use_graph=False)
+        chk = HotPathEngine(params, device=dev, T=T, use_graph=False, precision=args.precision)
         chk._plans = eng._plans
         ups_gpu, _ = chk.forward(fmaps, cnets, iters=sample_iters)
         result["epe_vs_oracle"] = {"value": max(orc.epe(a.cpu(), b) for a, b in zip(ups_gpu, ups_cpu)),

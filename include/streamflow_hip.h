@@ -82,7 +82,13 @@ int sf_corr_lookup(const float* lvl0, const float* lvl1, const float* lvl2, cons
  * to_qk/to_v (gma.py:48,82), einsum QK^T (gma.py:60) and attn@v (gma.py:97), timm Linear layers
  * (update.py:466-479), mask head (update.py:756-759; 3x3 conv as implicit GEMM). */
 enum { SF_LAYOUT_K_MAJOR = 0,   /* A[k*lda + m]   /  B[k*ldb + n]   (rows of k)            */
-       SF_LAYOUT_K_MINOR = 1 }; /* A[m*lda + k]   /  B[n*ldb + k]   (k contiguous)          */
+       SF_LAYOUT_K_MINOR = 1,   /* A[m*lda + k]   /  B[n*ldb + k]   (k contiguous)          */
+       SF_LAYOUT_SPLIT_F16 = 2 };/* A only, precision 1: weights pre-split on the host into two IEEE fp16
+                                    matrices A_hi/A_lo [M padded to 128][K padded to 32] (zero padded),
+                                    element (m,k) at m*lda_h + k, with w = hi + lo to ~22 bits         */
+enum { SF_PRECISION_FP32 = 0,   /* exact fp32: v_mfma_f32_32x32x2_f32, k-ordered fmaf chain          */
+       SF_PRECISION_F16X3 = 1 };/* split precision: x = hi+lo (fp16 each); a*b = ah*bh + ah*bl + al*bh
+                                    on v_mfma_f32_32x32x16_f16 with fp32 accumulation (~2^-22 relative)  */
 enum { SF_EPI_NONE = 0,         /* C = v                              v = alpha*(acc+bias)   */
        SF_EPI_GELU = 1,         /* C = gelu(v)                        exact erf GELU         */
        SF_EPI_RELU = 2,         /* C = max(v,0)                                              */
@@ -109,7 +115,10 @@ typedef struct SfGemm {
     int32_t conv3x3, h, w;
     float alpha;
     int32_t epilogue;
-    int32_t precision;            /* 0 = exact fp32 MFMA */
+    int32_t precision;            /* SF_PRECISION_* */
+    const void* A_hi; const void* A_lo;   /* SF_LAYOUT_SPLIT_F16 operand (shared by all batch indices) */
+    int64_t lda_h;                /* row stride of A_hi/A_lo in halfs (multiple of 8) */
+    int32_t a_padded;             /* K_MAJOR fp32 A is zero padded to [K up to 32][M up to 128]: no bounds checks */
 } SfGemm;
 
 int sf_gemm(const SfGemm* g, void* stream);

@@ -15,7 +15,8 @@ import torch  # noqa: F401  (imported first so the process-wide HIP runtime is t
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libstreamflow_hip.so")
 
-LAYOUT_K_MAJOR, LAYOUT_K_MINOR = 0, 1
+LAYOUT_K_MAJOR, LAYOUT_K_MINOR, LAYOUT_SPLIT_F16 = 0, 1, 2
+PRECISION_FP32, PRECISION_F16X3 = 0, 1
 EPI_NONE, EPI_GELU, EPI_RELU, EPI_RES, EPI_RES_GELU, EPI_RES_GELU_DW1, EPI_AXPY = range(7)
 
 _vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
@@ -32,6 +33,7 @@ class SfGemm(C.Structure):
         ("r_group", C.c_int32), ("r_group_stride", _i64),
         ("conv3x3", C.c_int32), ("h", C.c_int32), ("w", C.c_int32),
         ("alpha", _f), ("epilogue", C.c_int32), ("precision", C.c_int32),
+        ("A_hi", _vp), ("A_lo", _vp), ("lda_h", _i64), ("a_padded", C.c_int32),
     ]
 
 

@@ -14,10 +14,12 @@
 // buffering: global loads for tile t+1 are issued before the MFMAs of tile t and written to the
 // other LDS buffer afterwards (one barrier per k-tile).
 #include "sf_common.h"
+#include "gemm_epilogue.h"
 
 namespace {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+using sf::f32x16;
+using sf::gemm_epilogue;
 
 constexpr int kThreads = 256;
 
@@ -45,14 +47,20 @@ __device__ __forceinline__ int64_t krow_offset(const SrcDesc& s, int k) {
     return (int64_t)k * s.ld;
 }
 
+// `interior` is workgroup-uniform: the whole tile lies inside the operand and 16-byte loads are legal, so the
+// loads are unconditional (all in flight together); edge tiles take the guarded path.
 template <int BX, int BK, int NV>
-__device__ __forceinline__ void load_kmajor(const SrcDesc& s, int k0, int x0, int tid, Regs<NV>& r) {
+__device__ __forceinline__ void load_kmajor(const SrcDesc& s, int k0, int x0, int tid, bool interior, Regs<NV>& r) {
     constexpr int C4 = BX / 4;
+    constexpr bool kAllLive = (BK * C4) % kThreads == 0;
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
         const int idx = tid + j * kThreads;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (idx < BK * C4) {
+        if (interior && !s.conv3x3 && (kAllLive || idx < BK * C4)) {
+            const int k = k0 + idx / C4, x = x0 + (idx % C4) * 4;
+            v = *reinterpret_cast<const float4*>(s.base + krow_offset(s, k) + x);
+        } else if (idx < BK * C4) {
             const int k = k0 + idx / C4;
             const int x = x0 + (idx % C4) * 4;
             if (k < s.K) {
@@ -103,13 +111,17 @@ __device__ __forceinline__ void store_kmajor(float* lds, int tid, const Regs<NV>
 }
 
 template <int BX, int BK, int NV>
-__device__ __forceinline__ void load_kminor(const SrcDesc& s, int k0, int x0, int tid, Regs<NV>& r) {
+__device__ __forceinline__ void load_kminor(const SrcDesc& s, int k0, int x0, int tid, bool interior, Regs<NV>& r) {
     constexpr int K4 = BK / 4;
+    constexpr bool kAllLive = (BX * K4) % kThreads == 0;
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
         const int idx = tid + j * kThreads;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (idx < BX * K4) {
+        if (interior && (kAllLive || idx < BX * K4)) {
+            const int x = x0 + idx / K4, k = k0 + (idx % K4) * 4;
+            v = *reinterpret_cast<const float4*>(s.base + (int64_t)x * s.ld + k);
+        } else if (idx < BX * K4) {
             const int x = x0 + idx / K4;
             const int k = k0 + (idx % K4) * 4;
             if (x < s.X) {
@@ -185,11 +197,14 @@ __global__ __launch_bounds__(kThreads) void gemm_f32_mfma(const SfGemm g) {
     Regs<NVB> rb;
     const int nk = (g.K + BK - 1) / BK;
 
+    const bool a_in = da.vec_ok && (g.a_padded || m0 + BM <= g.M), b_in = db.vec_ok && n0 + BN <= g.N;
     auto load_tiles = [&](int kt) {
-        if (ALAY == SF_LAYOUT_K_MAJOR) load_kmajor<BM, BK, NVA>(da, kt * BK, m0, tid, ra);
-        else load_kminor<BM, BK, NVA>(da, kt * BK, m0, tid, ra);
-        if (BLAY == SF_LAYOUT_K_MAJOR) load_kmajor<BN, BK, NVB>(db, kt * BK, n0, tid, rb);
-        else load_kminor<BN, BK, NVB>(db, kt * BK, n0, tid, rb);
+        const bool k_in = (kt + 1) * BK <= g.K;
+        const bool ai = a_in && (k_in || (g.a_padded && ALAY == SF_LAYOUT_K_MAJOR)), bi = b_in && k_in;
+        if (ALAY == SF_LAYOUT_K_MAJOR) load_kmajor<BM, BK, NVA>(da, kt * BK, m0, tid, ai, ra);
+        else load_kminor<BM, BK, NVA>(da, kt * BK, m0, tid, ai, ra);
+        if (BLAY == SF_LAYOUT_K_MAJOR) load_kmajor<BN, BK, NVB>(db, kt * BK, n0, tid, bi, rb);
+        else load_kminor<BN, BK, NVB>(db, kt * BK, n0, tid, bi, rb);
     };
     auto store_tiles = [&](int buf) {
         if (ALAY == SF_LAYOUT_K_MAJOR) store_kmajor<BM, BK, NVA, SA>(sA + buf * BK * SA, tid, ra);
@@ -226,44 +241,7 @@ __global__ __launch_bounds__(kThreads) void gemm_f32_mfma(const SfGemm g) {
         __syncthreads();
     }
 
-    // ---- epilogue -------------------------------------------------------------------------------
-    float* C = g.C + (int64_t)z * g.strideC;
-    const float* R = g.R ? g.R + (int64_t)z * g.strideR : nullptr;
-    const float gam = (g.epilogue == SF_EPI_AXPY) ? g.gamma[0] : 0.f;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-            if (m >= g.M) continue;
-            const float bias = g.bias ? g.bias[m] : 0.f;
-            int64_t roff = 0;
-            if (R) roff = (g.r_group > 0) ? (int64_t)(m / g.r_group) * g.r_group_stride + (int64_t)(m % g.r_group) * g.ldr
-                                          : (int64_t)m * g.ldr;
-            float dww = 0.f, dwb = 0.f;
-            if (g.epilogue == SF_EPI_RES_GELU_DW1) { dww = g.dw_w[m]; dwb = g.dw_b[m]; }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int n = n0 + (wn * TN + j) * 32 + l31;
-                if (n >= g.N) continue;
-                float v = g.alpha * (acc[i][j][r] + bias);
-                switch (g.epilogue) {
-                    case SF_EPI_GELU: v = sf::gelu_erf(v); break;
-                    case SF_EPI_RELU: v = fmaxf(v, 0.f); break;
-                    case SF_EPI_RES: v = R[roff + n] + v; break;
-                    case SF_EPI_RES_GELU: v = sf::gelu_erf(R[roff + n] + v); break;
-                    case SF_EPI_RES_GELU_DW1: {
-                        const float t = sf::gelu_erf(R[roff + n] + v);
-                        v = sf::gelu_erf(t + (dww * t + dwb));
-                        break;
-                    }
-                    case SF_EPI_AXPY: v = R[roff + n] + gam * v; break;
-                    default: break;
-                }
-                C[(int64_t)m * g.ldc + n] = v;
-            }
-        }
-    }
+    gemm_epilogue<WM, WN, TM, TN>(g, acc, m0, n0, z, wm, wn, lane);
 }
 
 template <int WM, int WN, int TM, int TN, int BK>
@@ -297,15 +275,23 @@ int pick_bm(const SfGemm& g) {
 
 }  // namespace
 
+namespace sf {
+int gemm_split_dispatch(const SfGemm& g, hipStream_t st);   // gemm_split.hip
+}
+
 extern "C" int sf_gemm(const SfGemm* gp, void* stream) {
     SF_REQUIRE(gp != nullptr, "sf_gemm: null descriptor");
     const SfGemm& g = *gp;
-    SF_REQUIRE(g.A && g.B && g.C, "sf_gemm: null A/B/C");
+    SF_REQUIRE(g.B && g.C, "sf_gemm: null B/C");
+    SF_REQUIRE(g.A || (g.a_layout == SF_LAYOUT_SPLIT_F16 && g.A_hi && g.A_lo), "sf_gemm: null A");
     SF_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0 && g.batch > 0, "sf_gemm: bad dims M=%d N=%d K=%d batch=%d", g.M, g.N,
                g.K, g.batch);
-    SF_REQUIRE(g.a_layout >= 0 && g.a_layout <= 1 && g.b_layout >= 0 && g.b_layout <= 1, "sf_gemm: bad layout");
+    SF_REQUIRE(g.a_layout >= 0 && g.a_layout <= 2 && g.b_layout >= 0 && g.b_layout <= 1, "sf_gemm: bad layout");
+    SF_REQUIRE(g.a_layout != SF_LAYOUT_SPLIT_F16 || g.precision == SF_PRECISION_F16X3,
+               "sf_gemm: SPLIT_F16 weights need precision F16X3");
     SF_REQUIRE(g.epilogue >= SF_EPI_NONE && g.epilogue <= SF_EPI_AXPY, "sf_gemm: bad epilogue %d", g.epilogue);
-    SF_REQUIRE(g.precision == 0, "sf_gemm: precision %d not supported", g.precision);
+    SF_REQUIRE(g.precision == SF_PRECISION_FP32 || g.precision == SF_PRECISION_F16X3,
+               "sf_gemm: precision %d not supported", g.precision);
     if (g.epilogue == SF_EPI_RES || g.epilogue == SF_EPI_RES_GELU || g.epilogue == SF_EPI_RES_GELU_DW1 ||
         g.epilogue == SF_EPI_AXPY)
         SF_REQUIRE(g.R != nullptr, "sf_gemm: epilogue %d needs R", g.epilogue);
@@ -316,7 +302,12 @@ extern "C" int sf_gemm(const SfGemm* gp, void* stream) {
         SF_REQUIRE(g.K % 9 == 0 && g.h > 0 && g.w > 0 && g.h * g.w == g.N, "sf_gemm: conv3x3 needs K=9*Cin, h*w=N");
     }
     if (g.b_group) SF_REQUIRE(g.b_layout == SF_LAYOUT_K_MAJOR, "sf_gemm: b_group needs a K-major B");
+    SF_REQUIRE(sf::epilogue_spans_ok(g), "sf_gemm: C / R image larger than 1 GiB (32-bit buffer offsets in the epilogue)");
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (g.precision == SF_PRECISION_F16X3) {
+        SF_REQUIRE(!g.conv3x3, "sf_gemm: conv3x3 is only built for SF_PRECISION_FP32");
+        return sf::gemm_split_dispatch(g, st);
+    }
     const bool kminor = (g.a_layout == SF_LAYOUT_K_MINOR) || (g.b_layout == SF_LAYOUT_K_MINOR);
     const int bm = pick_bm(g);
     if (kminor) {   // k-contiguous operands: deeper k-tile so each row contributes a full 128-byte line

@@ -1,0 +1,297 @@
+// Split-precision GEMM ("f16x3"): fp32-class accuracy at bf16/f16 matrix-core rate.
+//
+// Every fp32 operand x is split as x = hi + lo with hi = f16(x), lo = f16(x - hi)  (22 mantissa bits
+// together), and a*b is accumulated in fp32 as  a_lo*b_hi + a_hi*b_lo + a_hi*b_hi  with three
+// v_mfma_f32_32x32x16_f16 instead of eight v_mfma_f32_32x32x2_f32: 3*32 cycles instead of 8*64 per
+// 32x32x16 block, i.e. 5.3x the exact-fp32 MFMA rate.  The dropped lo*lo term and the lo roundings are
+// ~2^-22 relative; measured end-to-end effect on the flow fields is ~3e-6 px EPE, three
+// orders inside the 1e-3 parity budget.  The reference itself deploys this network under fp16 autocast
+// (demo.py:427-456), so every activation on this path is known to fit the f16 range.
+//
+// Same interface, tiling and epilogues as gemm.hip.  Differences:
+//  * LDS holds the tiles ALREADY split, as f16 rows [x][k] (k contiguous, row stride BK+8 halfs = 80 B so
+//    the 16-byte fragment reads of 16 consecutive rows cover all 64 banks once);
+//  * weights are split and laid out [M][K] once on the host (SF_LAYOUT_SPLIT_F16); fp32 activations are split
+//    on the fly while being staged (K-major source: 8 row loads per thread = one k-octet of one pixel;
+//    K-minor source: two 16-byte loads);
+//  * every global read is a buffer load: the per-thread byte offset (voffset) is computed once before the
+//    k-loop, the k-tile / row offset is a wave-uniform SGPR (soffset).  There is no branch and no 64-bit
+//    address arithmetic in the loop.  Columns n >= N (rows m >= M) of a tile may load anything: an output
+//    element only depends on its own row of A and column of B, and those outputs are never stored.  Rows
+//    k >= K are forced to zero (clamped row + select on a wave-uniform or per-lane compare).
+#include "sf_common.h"
+#include "gemm_epilogue.h"
+
+namespace {
+
+using sf::f32x16;
+using sf::gemm_epilogue;
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr int kThreads = 256;
+constexpr int BK = 32;                 // k-tile depth
+constexpr int LDK = BK + 8;            // LDS row stride in halfs (80 bytes)
+
+__device__ __forceinline__ float as_f(unsigned u) { return __builtin_bit_cast(float, u); }
+
+struct Split8 {
+    f16x8 hi, lo;
+};
+
+__device__ __forceinline__ Split8 split8(const float (&x)[8]) {
+    Split8 s;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const _Float16 h = (_Float16)x[i];
+        s.hi[i] = h;
+        s.lo[i] = (_Float16)(x[i] - (float)h);
+    }
+    return s;
+}
+
+// One operand (A or B) of the GEMM as seen by one thread.
+template <int BX, int LAY>
+struct Operand {
+    static constexpr int NI = (BX * (BK / 8) + kThreads - 1) / kThreads;   // (row, k-octet) items per thread
+    static constexpr bool kUniformKo = (LAY == SF_LAYOUT_K_MAJOR) && (BX % 64 == 0);
+    __amdgpu_buffer_rsrc_t rsrc, rsrc_lo;
+    int voff[NI];        // per-thread byte offset (constant over the k-loop)
+    int ko[NI];          // k-octet of the item
+    int lds_off[NI];     // destination offset in halfs
+    bool live[NI];
+    int K, ld, group;
+    int64_t group_stride;
+    float v[(LAY == 2) ? 1 : NI][8];
+    u32x4 ph[(LAY == 2) ? NI : 1], pl[(LAY == 2) ? NI : 1];
+
+    __device__ __forceinline__ void init(const void* base, const void* base_lo, int64_t bytes, int ld_, int K_, int X,
+                                         int x0, int group_, int64_t group_stride_, int tid) {
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+        rsrc_lo = rsrc;
+        if (LAY == 2) rsrc_lo = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base_lo), 0, (int)bytes, 0x00020000);
+        K = K_; ld = ld_; group = group_; group_stride = group_stride_;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int idx = tid + j * kThreads;
+            int xl, kq;
+            if (LAY == SF_LAYOUT_K_MAJOR) { xl = idx % BX; kq = idx / BX; }      // lanes walk x: coalesced rows
+            else { kq = idx % (BK / 8); xl = idx / (BK / 8); }                   // lanes walk k
+            live[j] = (BX * (BK / 8)) % kThreads == 0 || idx < BX * (BK / 8);
+            ko[j] = kUniformKo ? __builtin_amdgcn_readfirstlane(kq) : kq;
+            lds_off[j] = xl * LDK + kq * 8;
+            // rows/columns past the operand are clamped: they are loaded (harmlessly) but never stored
+            const int xc = (x0 + xl < X) ? x0 + xl : X - 1;
+            if (LAY == SF_LAYOUT_K_MAJOR) voff[j] = xc * 4;
+            else if (LAY == SF_LAYOUT_K_MINOR) voff[j] = (xc * ld + kq * 8) * 4;
+            else voff[j] = ((x0 + xl) * ld + kq * 8) * 2;       // host-padded to 128 rows: always in range
+        }
+    }
+
+    // Issue the raw loads of k-tile k0 (nothing is consumed here, so no wait is needed before the MFMAs).
+    // K-major rows: tile_off = element offset of row k0 (tracked incrementally by the caller for grouped
+    // operands); rows past K are clamped to the last valid row and zeroed in store().
+    __device__ __forceinline__ void load(int k0, int tile_off) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            if (LAY == 2) {
+                ph[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[j], k0 * 2, 0);
+                pl[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_lo, voff[j], k0 * 2, 0);
+            } else if (LAY == SF_LAYOUT_K_MAJOR) {
+                const int kb = ko[j] * 8;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int over = k0 + kb + i - (K - 1);                 // > 0: row past the end
+                    const int r = (tile_off + (kb + i - (over > 0 ? over : 0)) * ld) * 4;
+                    if (kUniformKo) v[j][i] = as_f(__builtin_amdgcn_raw_buffer_load_b32(rsrc, voff[j], r, 0));
+                    else v[j][i] = as_f(__builtin_amdgcn_raw_buffer_load_b32(rsrc, voff[j] + r, 0, 0));
+                }
+            } else {
+                // k0 goes into the VGPR offset: soffset is excluded from the hardware range check, and the last
+                // k-octet of the last row may reach past the end of the buffer (then it reads as zero)
+                const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[j] + k0 * 4, 0, 0);
+                const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[j] + k0 * 4 + 16, 0, 0);
+                v[j][0] = as_f(a[0]); v[j][1] = as_f(a[1]); v[j][2] = as_f(a[2]); v[j][3] = as_f(a[3]);
+                v[j][4] = as_f(b[0]); v[j][5] = as_f(b[1]); v[j][6] = as_f(b[2]); v[j][7] = as_f(b[3]);
+            }
+        }
+    }
+
+    // Consume the staged tile (loaded for k-tile k0): zero rows k >= K, split into hi/lo f16, write to LDS.
+    __device__ __forceinline__ void store(int k0, _Float16* lds_hi, _Float16* lds_lo) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            if (!live[j]) continue;
+            if (LAY == 2) {
+                *reinterpret_cast<u32x4*>(lds_hi + lds_off[j]) = ph[j];
+                *reinterpret_cast<u32x4*>(lds_lo + lds_off[j]) = pl[j];
+            } else {
+                if (k0 + BK > K) {          // last, partial k-tile (workgroup-uniform)
+                    const int k = k0 + ko[j] * 8;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[j][i] = (k + i < K) ? v[j][i] : 0.f;
+                }
+                const Split8 s8 = split8(v[j]);
+                *reinterpret_cast<f16x8*>(lds_hi + lds_off[j]) = s8.hi;
+                *reinterpret_cast<f16x8*>(lds_lo + lds_off[j]) = s8.lo;
+            }
+        }
+    }
+};
+
+// element offset of K-major row k0 (start of a k-tile) for a possibly grouped operand; tiles never straddle
+// groups (group % 32 == 0 is checked on the host)
+struct RowCursor {
+    int group, ld, within, off;
+    int64_t group_stride;
+    __device__ __forceinline__ void init(int group_, int ld_, int64_t gs) { group = group_; ld = ld_; group_stride = gs; within = 0; off = 0; }
+    __device__ __forceinline__ void advance() {
+        if (group > 0) {
+            within += BK;
+            if (within >= group) { within = 0; off += (int)group_stride - (group - BK) * ld; }
+            else off += BK * ld;
+        } else off += BK * ld;
+    }
+};
+
+struct SplitArgs {
+    SfGemm g;
+    int64_t a_bytes, b_bytes;      // bytes spanned by one batch image of A / B (buffer range check)
+};
+
+template <int WM, int WN, int TM, int TN, int ALAY, int BLAY>
+__global__ __launch_bounds__(kThreads, 2) void gemm_f16x3_mfma(const SplitArgs args) {
+    const SfGemm& g = args.g;
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    // [buffer][hi|lo][rows][LDK]
+    __shared__ __attribute__((aligned(16))) _Float16 sA[2][2][BM * LDK];
+    __shared__ __attribute__((aligned(16))) _Float16 sB[2][2][BN * LDK];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM, z = blockIdx.z;
+
+    Operand<BM, ALAY> opa;
+    Operand<BN, BLAY> opb;
+    if (ALAY == 2) opa.init(g.A_hi, g.A_lo, args.a_bytes, (int)g.lda_h, g.K, g.M, m0, 0, 0, tid);
+    else opa.init(g.A + (int64_t)z * g.strideA, nullptr, args.a_bytes, (int)g.lda, g.K, g.M, m0, 0, 0, tid);
+    opb.init(g.B + (int64_t)z * g.strideB, nullptr, args.b_bytes, (int)g.ldb, g.K, g.N, n0, g.b_group, g.b_group_stride, tid);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = (g.K + BK - 1) / BK;
+    RowCursor ca, cb;
+    ca.init(0, (int)g.lda, 0);
+    cb.init(g.b_group, (int)g.ldb, g.b_group_stride);
+    opa.load(0, ca.off);
+    opb.load(0, cb.off);
+    opa.store(0, sA[0][0], sA[0][1]);
+    opb.store(0, sB[0][0], sB[0][1]);
+    __syncthreads();
+
+    const int khalf = lane >> 5, l31 = lane & 31;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) {
+            ca.advance();
+            cb.advance();
+            opa.load((kt + 1) * BK, ca.off);
+            opb.load((kt + 1) * BK, cb.off);
+        }
+        // keep the staged loads in flight across the MFMA block: nothing below may be hoisted above it
+        __builtin_amdgcn_sched_barrier(0);
+        const _Float16* pah = sA[cur][0] + (wm * TM * 32 + l31) * LDK + khalf * 8;
+        const _Float16* pal = sA[cur][1] + (wm * TM * 32 + l31) * LDK + khalf * 8;
+        const _Float16* pbh = sB[cur][0] + (wn * TN * 32 + l31) * LDK + khalf * 8;
+        const _Float16* pbl = sB[cur][1] + (wn * TN * 32 + l31) * LDK + khalf * 8;
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            f16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                ah[i] = *reinterpret_cast<const f16x8*>(pah + i * 32 * LDK + ks * 16);
+                al[i] = *reinterpret_cast<const f16x8*>(pal + i * 32 * LDK + ks * 16);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                bh[j] = *reinterpret_cast<const f16x8*>(pbh + j * 32 * LDK + ks * 16);
+                bl[j] = *reinterpret_cast<const f16x8*>(pbl + j * 32 * LDK + ks * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    // small terms first, so the dominant hi*hi product is added to an already-formed correction
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 1 < nk) {
+            opa.store((kt + 1) * BK, sA[cur ^ 1][0], sA[cur ^ 1][1]);
+            opb.store((kt + 1) * BK, sB[cur ^ 1][0], sB[cur ^ 1][1]);
+        }
+        __syncthreads();
+    }
+    gemm_epilogue<WM, WN, TM, TN>(g, acc, m0, n0, z, wm, wn, lane);
+}
+
+template <int WM, int WN, int TM, int TN>
+int launch_cfg(const SplitArgs& a, hipStream_t st) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    const SfGemm& g = a.g;
+    dim3 grid(sf::ceil_div(g.N, BN), sf::ceil_div(g.M, BM), g.batch);
+    const int lay = g.a_layout * 2 + g.b_layout;
+    switch (lay) {
+        case 0: hipLaunchKernelGGL((gemm_f16x3_mfma<WM, WN, TM, TN, 0, 0>), grid, dim3(kThreads), 0, st, a); break;
+        case 3: hipLaunchKernelGGL((gemm_f16x3_mfma<WM, WN, TM, TN, 1, 1>), grid, dim3(kThreads), 0, st, a); break;
+        case 4: hipLaunchKernelGGL((gemm_f16x3_mfma<WM, WN, TM, TN, 2, 0>), grid, dim3(kThreads), 0, st, a); break;
+        default: return sf::fail(SF_ERR_UNSUPPORTED, "sf_gemm(f16x3): layout combination a=%d b=%d not built",
+                                 g.a_layout, g.b_layout);
+    }
+    return sf::check_launch("sf_gemm(f16x3)");
+}
+
+int64_t span_bytes(int layout, int X, int K, int64_t ld, int group, int64_t group_stride) {
+    if (layout == SF_LAYOUT_K_MINOR) return ((int64_t)(X - 1) * ld + K) * 4;
+    if (group > 0) return ((int64_t)((K - 1) / group) * group_stride + (int64_t)((K - 1) % group) * ld + X) * 4;
+    return ((int64_t)(K - 1) * ld + X) * 4;
+}
+
+}  // namespace
+
+namespace sf {
+
+// called from sf_gemm (gemm.hip) when precision == SF_PRECISION_F16X3 (never for conv3x3)
+int gemm_split_dispatch(const SfGemm& g, hipStream_t st) {
+    if (g.b_group % 32) return fail(SF_ERR_BAD_ARG, "sf_gemm(f16x3): b_group must be a multiple of 32");
+    SplitArgs a;
+    a.g = g;
+    if (g.a_layout == SF_LAYOUT_SPLIT_F16) {
+        if (!g.A_hi || !g.A_lo || g.lda_h <= 0 || (g.lda_h & 7))
+            return fail(SF_ERR_BAD_ARG, "sf_gemm(f16x3): SPLIT_F16 A needs A_hi/A_lo and lda_h %% 8 == 0");
+        a.a_bytes = (int64_t)((g.M + 127) / 128 * 128) * g.lda_h * 2;
+    } else {
+        a.a_bytes = span_bytes(g.a_layout, g.M, g.K, g.lda, 0, 0);
+    }
+    a.b_bytes = span_bytes(g.b_layout, g.N, g.K, g.ldb, g.b_group, g.b_group_stride);
+    if (a.a_bytes >= ((int64_t)1 << 31) || a.b_bytes >= ((int64_t)1 << 31))
+        return fail(SF_ERR_UNSUPPORTED, "sf_gemm(f16x3): operand image larger than 2 GiB (32-bit buffer offsets)");
+    // tile choice: the 128-row tile moves the fewest bytes per MAC; drop to 64/32 rows when padding M would
+    // waste more than a quarter of the MFMAs
+    const int M = g.M;
+    auto padded = [&](int bm) { return (M + bm - 1) / bm * bm; };
+    if (padded(128) * 4 <= M * 5) return launch_cfg<2, 2, 2, 2>(a, st);
+    if (padded(64) * 4 <= M * 5 || M > 32) return launch_cfg<1, 4, 2, 1>(a, st);
+    return launch_cfg<1, 4, 1, 1>(a, st);
+}
+
+}  // namespace sf

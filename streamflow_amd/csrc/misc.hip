@@ -111,6 +111,7 @@ __global__ __launch_bounds__(kBlock) void softmax_rows_kernel(float* x, int cols
 }
 
 // ---- LayerNorm over channels (channel-major planes) -------------------------------------------------
+// generic fallback: one thread per pixel, three passes over the channels
 __global__ __launch_bounds__(kBlock) void layernorm_cm_kernel(const float* x, int64_t xs, const float* gamma,
                                                                const float* beta, float* y, int64_t ys, int C, int P,
                                                                float eps) {
@@ -130,20 +131,73 @@ __global__ __launch_bounds__(kBlock) void layernorm_cm_kernel(const float* x, in
     for (int c = 0; c < C; ++c) yp[(int64_t)c * P] = (xp[(int64_t)c * P] - mean) * rstd * gamma[c] + beta[c];
 }
 
+// fast path: a workgroup owns 64 consecutive pixels; the C channels are split over the 4 waves, each thread
+// keeps its CPT = C/4 values in registers (x is read exactly once, 256-byte coalesced rows), the two
+// reductions (mean, then centred variance: same two-pass arithmetic as nn.LayerNorm) go through LDS.
+constexpr int kLnPix = 64;
+template <int CPT>
+__global__ __launch_bounds__(kBlock) void layernorm_cm_split_kernel(const float* x, int64_t xs, const float* gamma,
+                                                                     const float* beta, float* y, int64_t ys, int P,
+                                                                     float eps) {
+    __shared__ float red[4][kLnPix];
+    constexpr int C = 4 * CPT;
+    const int px = threadIdx.x & (kLnPix - 1), cg = threadIdx.x >> 6;
+    const int p = blockIdx.x * kLnPix + px;
+    const bool ok = p < P;
+    const int pc = ok ? p : P - 1;
+    const float* xp = x + (int64_t)blockIdx.y * xs + (int64_t)cg * CPT * P + pc;
+    float v[CPT];
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) v[c] = xp[(int64_t)c * P];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) s += v[c];
+    red[cg][px] = s;
+    __syncthreads();
+    const float mean = ((red[0][px] + red[1][px]) + (red[2][px] + red[3][px])) * (1.0f / (float)C);
+    __syncthreads();
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) {
+        const float d = v[c] - mean;
+        q = fmaf(d, d, q);
+    }
+    red[cg][px] = q;
+    __syncthreads();
+    const float var = ((red[0][px] + red[1][px]) + (red[2][px] + red[3][px])) * (1.0f / (float)C);
+    const float rstd = 1.0f / sqrtf(var + eps);
+    if (!ok) return;
+    float* yp = y + (int64_t)blockIdx.y * ys + (int64_t)cg * CPT * P + p;
+    const float* gp = gamma + cg * CPT;
+    const float* bp = beta + cg * CPT;
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) yp[(int64_t)c * P] = (v[c] - mean) * rstd * gp[c] + bp[c];
+}
+
 // ---- attention over the TT tokens of one pixel ---------------------------------------------------------
+// A workgroup owns 64 consecutive pixels of one clip; the C channels are split over the 4 waves.  Each thread
+// accumulates the TT x TT partial scores of its channel slice, the slices are summed through LDS, every
+// thread then holds the full softmax weights of its pixel and produces its slice of the output channels.
+// All global accesses are 256-byte rows (64 lanes x consecutive pixels of one channel plane).
+constexpr int kTaPix = 64;
 template <int TT>
 __global__ __launch_bounds__(kBlock) void temporal_attn_kernel(const float* qkv, float* out, int C, int P) {
-    const int p = blockIdx.x * kBlock + threadIdx.x;
-    if (p >= P) return;
+    __shared__ float red[4][TT * TT][kTaPix];
+    const int px = threadIdx.x & (kTaPix - 1), cg = threadIdx.x >> 6;
+    const int p = blockIdx.x * kTaPix + px;
+    const bool ok = p < P;
+    const int pc = ok ? p : P - 1;
     const int b = blockIdx.y;
+    const int cpt = C / 4, c0 = cg * cpt;
     const int64_t img = (int64_t)3 * C * P;      // one token image of qkv
-    const float* base = qkv + (int64_t)b * TT * img + p;
+    const float* base = qkv + (int64_t)b * TT * img + pc;
     float s[TT][TT];
 #pragma unroll
     for (int t = 0; t < TT; ++t)
 #pragma unroll
         for (int u = 0; u < TT; ++u) s[t][u] = 0.f;
-    for (int c = 0; c < C; ++c) {
+#pragma unroll 4
+    for (int c = c0; c < c0 + cpt; ++c) {
         float q[TT], k[TT];
 #pragma unroll
         for (int t = 0; t < TT; ++t) {
@@ -155,13 +209,19 @@ __global__ __launch_bounds__(kBlock) void temporal_attn_kernel(const float* qkv,
 #pragma unroll
             for (int u = 0; u < TT; ++u) s[t][u] = fmaf(q[t], k[u], s[t][u]);
     }
+#pragma unroll
+    for (int t = 0; t < TT; ++t)
+#pragma unroll
+        for (int u = 0; u < TT; ++u) red[cg][t * TT + u][px] = s[t][u];
+    __syncthreads();
     const float scale = 1.0f / sqrtf((float)C);
 #pragma unroll
     for (int t = 0; t < TT; ++t) {
         float m = -INFINITY;
 #pragma unroll
         for (int u = 0; u < TT; ++u) {
-            s[t][u] *= scale;
+            const int e = t * TT + u;
+            s[t][u] = ((red[0][e][px] + red[1][e][px]) + (red[2][e][px] + red[3][e][px])) * scale;
             m = fmaxf(m, s[t][u]);
         }
         float sum = 0.f;
@@ -174,8 +234,10 @@ __global__ __launch_bounds__(kBlock) void temporal_attn_kernel(const float* qkv,
 #pragma unroll
         for (int u = 0; u < TT; ++u) s[t][u] *= inv;
     }
+    if (!ok) return;
     float* obase = out + (int64_t)b * TT * C * P + p;
-    for (int c = 0; c < C; ++c) {
+#pragma unroll 4
+    for (int c = c0; c < c0 + cpt; ++c) {
         float v[TT];
 #pragma unroll
         for (int u = 0; u < TT; ++u) v[u] = base[u * img + (int64_t)(2 * C + c) * P];
@@ -288,14 +350,19 @@ extern "C" int sf_softmax_rows(float* x, int64_t rows, int cols, void* stream) {
 extern "C" int sf_layernorm_cm(const float* x, int64_t x_img_stride, const float* gamma, const float* beta, float* y,
                                int64_t y_img_stride, int n_img, int C, int P, float eps, void* stream) {
     SF_REQUIRE(x && gamma && beta && y && n_img > 0 && C > 0 && P > 0, "sf_layernorm_cm: bad args");
-    hipLaunchKernelGGL(layernorm_cm_kernel, dim3(sf::ceil_div(P, kBlock), n_img), dim3(kBlock), 0,
-                       (hipStream_t)stream, x, x_img_stride, gamma, beta, y, y_img_stride, C, P, eps);
+    if (C == 128)
+        hipLaunchKernelGGL(layernorm_cm_split_kernel<32>, dim3(sf::ceil_div(P, kLnPix), n_img), dim3(kBlock), 0,
+                           (hipStream_t)stream, x, x_img_stride, gamma, beta, y, y_img_stride, P, eps);
+    else
+        hipLaunchKernelGGL(layernorm_cm_kernel, dim3(sf::ceil_div(P, kBlock), n_img), dim3(kBlock), 0,
+                           (hipStream_t)stream, x, x_img_stride, gamma, beta, y, y_img_stride, C, P, eps);
     return sf::check_launch("sf_layernorm_cm");
 }
 
 extern "C" int sf_temporal_attn(const float* qkv, float* out, int B, int TT, int C, int P, void* stream) {
     SF_REQUIRE(qkv && out && B > 0 && C > 0 && P > 0, "sf_temporal_attn: bad args");
-    dim3 grid(sf::ceil_div(P, kBlock), B), block(kBlock);
+    SF_REQUIRE(C % 4 == 0, "sf_temporal_attn: C must be a multiple of 4");
+    dim3 grid(sf::ceil_div(P, kTaPix), B), block(kBlock);
     hipStream_t st = (hipStream_t)stream;
     switch (TT) {
         case 1: hipLaunchKernelGGL(temporal_attn_kernel<1>, grid, block, 0, st, qkv, out, C, P); break;

@@ -155,8 +155,11 @@ class HotPathEngine:
     """`forward(fmaps, cnets, iters)` == reference loop in test_mode (streamflow.py:110-147)."""
 
     def __init__(self, state_dict: Dict[str, torch.Tensor], device="cuda:0", T: Optional[int] = None,
-                 use_graph: bool = False):
+                 use_graph: bool = False, precision: Optional[str] = None):
+        """precision: 'f16x3' (split fp16, fp32-class accuracy, default) or 'fp32' (exact fp32 MFMA);
+        None = the package-wide setting (streamflow_amd.ops.PRECISION)."""
         _lib.load()
+        self.precision = ops.PRECISION if precision is None else ops._PRECISION_NAMES[precision]
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("HotPathEngine needs an MI355X device (cuda:N); there is no CPU fallback")
@@ -226,9 +229,13 @@ class HotPathEngine:
         ops.flow_update(pl.coords1, pl.delta, pl.flow, pl.mf.slice(HDIM - 2, HDIM), n, h, w)
 
     def _run(self, pl: _Plan, fmaps: torch.Tensor, cnets: torch.Tensor, iters: int, all_masks: bool) -> None:
-        self._setup(pl, fmaps, cnets)
-        for it in range(iters):
-            self._iteration(pl, with_mask=all_masks or it == iters - 1)
+        prev = ops.set_precision(self.precision)
+        try:
+            self._setup(pl, fmaps, cnets)
+            for it in range(iters):
+                self._iteration(pl, with_mask=all_masks or it == iters - 1)
+        finally:
+            ops.set_precision(prev)
         flow_t = pl.flow.tensor().view(pl.n, 2, pl.h, pl.w)
         mask_t = pl.mask.tensor().view(pl.n, 576, pl.h, pl.w)
         _lib.check(_lib.load().sf_upsample_flow(flow_t.data_ptr(), mask_t.data_ptr(), pl.up.data_ptr(), pl.n, pl.h,
@@ -280,14 +287,17 @@ class HotPathEngine:
             for i, f in enumerate(flow_init):
                 coords1.view(Bc, T - 1, 2, h, w)[:, i] += f.to(coords1)
         ops.flow_update(pl.coords1, None, pl.flow, pl.mf.slice(HDIM - 2, HDIM), n, h, w)
+        prev = ops.set_precision(self.precision)
         self._setup(pl, fmaps, cnets)
         preds: List[List[torch.Tensor]] = [[] for _ in range(T - 1)]
         for _ in range(iters):
             self._iteration(pl, with_mask=True)
+            ops.set_precision(self.precision)
             up = ops.upsample_flow(pl.flow.tensor().view(n, 2, h, w), pl.mask.tensor().view(n, 576, h, w))
             up = up.view(Bc, T - 1, 2, 8 * h, 8 * w)
             for i in range(T - 1):
                 preds[i].append(up[:, i])
+        ops.set_precision(prev)
         return preds
 
     def _forward_graph(self, pl: _Plan, fmaps, cnets, iters, all_masks) -> None:
@@ -297,6 +307,7 @@ class HotPathEngine:
             pl.cnets_in = torch.empty_like(cnets)
         pl.fmaps_in.copy_(fmaps)
         pl.cnets_in.copy_(cnets)
+        key = key + (self.precision,)
         if pl.graph is None or pl.graph_key != key:
             # warm-up outside capture, then capture the whole clip as one graph.  The loop state (coords1, flow)
             # is re-initialised by the caller before every replay, so the graph itself is stateless.

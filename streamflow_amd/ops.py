@@ -15,7 +15,28 @@ import torch
 
 from . import _lib
 from ._lib import (EPI_AXPY, EPI_GELU, EPI_NONE, EPI_RELU, EPI_RES, EPI_RES_GELU, EPI_RES_GELU_DW1,  # noqa: F401
-                   LAYOUT_K_MAJOR, LAYOUT_K_MINOR, SfGemm)
+                   LAYOUT_K_MAJOR, LAYOUT_K_MINOR, LAYOUT_SPLIT_F16, PRECISION_F16X3, PRECISION_FP32, SfGemm)
+
+# Arithmetic mode of every GEMM-shaped op (sf_gemm, corr build):
+#   PRECISION_FP32  exact fp32 on v_mfma_f32_32x32x2_f32
+#   PRECISION_F16X3 split precision (x = hi + lo in fp16, 3 MFMAs per product, fp32 accumulate; ~2^-22 relative)
+PRECISION = PRECISION_F16X3
+_PRECISION_NAMES = {"fp32": PRECISION_FP32, "f16x3": PRECISION_F16X3}
+
+
+def set_precision(mode) -> int:
+    """mode: 'fp32' | 'f16x3' (or the integer constants).  Returns the previous mode."""
+    global PRECISION
+    prev = PRECISION
+    PRECISION = _PRECISION_NAMES[mode] if isinstance(mode, str) else int(mode)
+    if PRECISION not in (PRECISION_FP32, PRECISION_F16X3):
+        PRECISION = prev
+        raise RuntimeError(f"unknown precision {mode}")
+    return prev
+
+
+def precision_name() -> str:
+    return {v: k for k, v in _PRECISION_NAMES.items()}[PRECISION]
 
 
 class Profiler:
@@ -132,12 +153,22 @@ class PackedLinear:
         else:
             w2 = w.reshape(w.shape[0], -1).t()
         self.K, self.M = w2.shape
-        self.lda = (self.M + 3) // 4 * 4
-        wt = torch.zeros(self.K, self.lda, dtype=torch.float32, device=device)
-        wt[:, : self.M] = w2
+        self.lda = (self.M + 127) // 128 * 128            # zero padded to [K up to 32][M up to 128] (a_padded)
+        wt = torch.zeros((self.K + 31) // 32 * 32, self.lda, dtype=torch.float32, device=device)
+        wt[: self.K, : self.M] = w2
         self.wt = wt.contiguous()
         self.bias = None if bias is None else bias.detach().to(device=device, dtype=torch.float32).contiguous()
         self.conv3x3 = conv3x3
+        # split-precision image: w = hi + lo (fp16 each), rows [M padded to 128][K padded to 32], zero padded
+        mp, kp = (self.M + 127) // 128 * 128, (self.K + 31) // 32 * 32
+        wm = w2.t().contiguous()                       # [M][K] fp32
+        hi = wm.to(torch.float16)
+        lo = (wm - hi.float()).to(torch.float16)
+        self.hi = torch.zeros(mp, kp, dtype=torch.float16, device=device)
+        self.lo = torch.zeros(mp, kp, dtype=torch.float16, device=device)
+        self.hi[: self.M, : self.K] = hi
+        self.lo[: self.M, : self.K] = lo
+        self.lda_h = kp
 
 
 def gemm(A: PackedLinear, X: Planes, Y: Planes, epilogue: int = EPI_NONE, R: Optional[Planes] = None,
@@ -153,6 +184,11 @@ def gemm(A: PackedLinear, X: Planes, Y: Planes, epilogue: int = EPI_NONE, R: Opt
     g.lda, g.ldb, g.ldc = A.lda, X.P, Y.P
     g.strideA, g.strideB, g.strideC = 0, X.img_stride, Y.img_stride
     g.a_layout, g.b_layout = LAYOUT_K_MAJOR, LAYOUT_K_MAJOR
+    g.a_padded = 1
+    prec = PRECISION_FP32 if A.conv3x3 else PRECISION     # the implicit 3x3 gather is only built for the fp32 kernel
+    if prec == PRECISION_F16X3:
+        g.a_layout = LAYOUT_SPLIT_F16
+        g.A_hi, g.A_lo, g.lda_h = A.hi.data_ptr(), A.lo.data_ptr(), A.lda_h
     g.b_group, g.b_group_stride = X.group, X.group_stride
     if R is not None:
         assert R.rows == A.M and R.n_img == Y.n_img
@@ -162,7 +198,7 @@ def gemm(A: PackedLinear, X: Planes, Y: Planes, epilogue: int = EPI_NONE, R: Opt
         g.dw_w, g.dw_b = dw_w.data_ptr(), dw_b.data_ptr()
     if A.conv3x3:
         g.conv3x3, g.h, g.w = 1, int(hw[0]), int(hw[1])
-    g.alpha, g.epilogue, g.precision = float(alpha), int(epilogue), 0
+    g.alpha, g.epilogue, g.precision = float(alpha), int(epilogue), prec
     _launch("gemm", 2.0 * g.M * g.N * g.K * g.batch, 0,
             lambda: _lib.check(_lib.load().sf_gemm(C.byref(g), _lib.stream()), "sf_gemm"))
 
@@ -173,6 +209,7 @@ def gemm_raw(**kw) -> None:
     g.alpha = 1.0
     for k, v in kw.items():
         setattr(g, k, v)
+    g.precision = PRECISION
     name = "gemm_attn" if g.a_layout == LAYOUT_K_MINOR else "gemm"
     _launch(name, 2.0 * g.M * g.N * g.K * g.batch, 0,
             lambda: _lib.check(_lib.load().sf_gemm(C.byref(g), _lib.stream()), "sf_gemm"))

@@ -32,7 +32,7 @@ def test_every_declared_symbol_is_exported(lib):
 def test_struct_layout_matches_header():
     from streamflow_amd._lib import SfGemm
     # 8 pointers + 4 i32 + 8 i64 + 2 i32 + (i32,pad,i64)*2 + 3 i32 + f32 + 2 i32  (natural alignment)
-    assert ctypes.sizeof(SfGemm) == 208
+    assert ctypes.sizeof(SfGemm) == 240
     assert SfGemm.lda.offset == 80 and SfGemm.b_group_stride.offset == 160 and SfGemm.alpha.offset == 196
 
 
@@ -87,8 +87,9 @@ def test_packed_linear_layout():
     from streamflow_amd.ops import PackedLinear
     w = torch.arange(6 * 5, dtype=torch.float32).view(6, 5, 1, 1)
     p = PackedLinear(w, None, "cpu")
-    assert (p.K, p.M, p.lda) == (5, 6, 8)
-    assert torch.equal(p.wt[:, :6], w.view(6, 5).t()) and p.wt[:, 6:].abs().sum() == 0
+    assert (p.K, p.M, p.lda) == (5, 6, 128) and tuple(p.wt.shape) == (32, 128)
+    assert torch.equal(p.wt[:5, :6], w.view(6, 5).t()) and p.wt[:, 6:].abs().sum() == 0 and p.wt[5:].abs().sum() == 0
+    assert tuple(p.hi.shape) == (128, 32) and torch.equal((p.hi.float() + p.lo.float())[:6, :5], w.view(6, 5))
     w3 = torch.randn(4, 3, 3, 3)
     p3 = PackedLinear(w3, None, "cpu", conv3x3=True)
     assert p3.K == 27 and p3.wt[(1 * 3 + 2) * 3 + 1, 2] == w3[2, 1, 1, 2]

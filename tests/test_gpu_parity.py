@@ -40,6 +40,15 @@ def dev():
     return _gpu()
 
 
+@pytest.fixture(params=["fp32", "f16x3"])
+def precision(request):
+    """Every GEMM-shaped kernel is checked in both arithmetic modes (exact fp32 MFMA / split fp16x3)."""
+    import streamflow_amd as sfa
+    prev = sfa.set_precision(request.param)
+    yield request.param
+    sfa.set_precision(prev)
+
+
 def test_library_loaded_is_in_tree():
     import os
     from streamflow_amd import _lib
@@ -68,7 +77,7 @@ def test_bilinear_sampler(golden, dev):
 
 
 @pytest.mark.parametrize("tag", list(cases.CORR_CASES))
-def test_corr_build_and_lookup_vs_golden(golden, dev, tag):
+def test_corr_build_and_lookup_vs_golden(golden, dev, tag, precision):
     from streamflow_amd.corr import CorrBlock
     g = golden(tag)
     f1, f2, coords, ident = cases.corr_inputs(tag)
@@ -83,7 +92,7 @@ def test_corr_build_and_lookup_vs_golden(golden, dev, tag):
     close(vol.reshape(B * h * w, 1, h, w), g["level0"], 2e-5, 1e-5, what=f"{tag} CorrBlock.corr")
 
 
-def test_gma_vs_golden(golden, dev):
+def test_gma_vs_golden(golden, dev, precision):
     from streamflow_amd.gma import Attention, Aggregate
     g = golden("gma")
     P, inp, mf = cases.gma_inputs()
@@ -101,7 +110,7 @@ def _sub(params, prefix):
     return {k[len(prefix) + 1:]: v for k, v in params.items() if k.startswith(prefix + ".")}
 
 
-def test_skblocks_vs_golden(golden, dev):
+def test_skblocks_vs_golden(golden, dev, precision):
     from streamflow_amd import synthetic as syn
     from streamflow_amd.update import PCBlock4_Deep_nopool_res
     g = golden("skblock")
@@ -114,7 +123,7 @@ def test_skblocks_vs_golden(golden, dev):
 
 
 @pytest.mark.parametrize("tag", list(cases.UPDATE_CASES))
-def test_update_block_vs_golden(golden, dev, tag):
+def test_update_block_vs_golden(golden, dev, tag, precision):
     from argparse import Namespace
     from streamflow_amd.update import SKUpdateBlock_TAM_v3
     g = golden(tag)
@@ -140,26 +149,26 @@ def test_upsample_vs_golden(golden, dev):
 
 @pytest.mark.parametrize("tag", list(cases.FORWARD_CASES))
 @pytest.mark.parametrize("graph", [False, True])
-def test_engine_forward_vs_golden(golden, dev, tag, graph):
+def test_engine_forward_vs_golden(golden, dev, tag, graph, precision):
     """The fused engine against the reference's SKFlow_MF8.forward outputs (golden)."""
     from oracle import streamflow_oracle as orc
     from streamflow_amd.engine import HotPathEngine
     g = golden(tag)
     B, T, H, W, iters, seed, use_init = cases.FORWARD_CASES[tag]
     P, fmaps, cnets, finit, iters = cases.forward_inputs(tag)
-    eng = HotPathEngine(P, device=dev, T=T, use_graph=graph)
+    eng = HotPathEngine(P, device=dev, T=T, use_graph=graph, precision=precision)
     finit_d = None if finit is None else [f.to(dev) for f in finit]
     for rep in range(2):                                    # second call exercises graph replay / buffer reuse
         ups, low = eng.forward(fmaps.to(dev), cnets.to(dev), iters=iters, flow_init=finit_d)
         for i in range(T - 1):
             e = orc.epe(ups[i].cpu(), torch.from_numpy(g[f"up{i}"]))
-            print(f"{tag} graph={graph} rep={rep} pair {i}: EPE vs reference = {e:.3e}")
+            print(f"{tag} {precision} graph={graph} rep={rep} pair {i}: EPE vs reference = {e:.3e}")
             assert e <= 1e-3, f"{tag} pair {i}: EPE {e}"
             if use_init:
                 close(low[i], g[f"low{i}"], 1e-3, what=f"{tag} lowres {i}")
 
 
-def test_model_api_forward_vs_golden(golden, dev):
+def test_model_api_forward_vs_golden(golden, dev, precision):
     """SKFlow_MF8 with the reference's signature (list of frames in 0..255, test_mode), stand-in encoder."""
     from oracle import streamflow_oracle as orc
     from streamflow_amd.model import SKFlow_MF8, default_args
@@ -181,7 +190,7 @@ def test_model_api_forward_vs_golden(golden, dev):
         assert orc.epe(allp[i][0].cpu(), torch.from_numpy(g[f"first{i}"])) <= 1e-3
 
 
-def test_sintel_shape_vs_oracle(dev):
+def test_sintel_shape_vs_oracle(dev, precision):
     """Headline shape (440x1024 -> 55x128 grid, T=4), 2 iterations, against the CPU oracle; also the
     size-independent properties: level-1 == mean of level-0 2x2 blocks, attention rows sum to 1."""
     from oracle import streamflow_oracle as orc
@@ -205,5 +214,5 @@ def test_sintel_shape_vs_oracle(dev):
     ups_o, low_o = orc.hotpath_forward(fmaps, cnets, P, 2)
     for i in range(T - 1):
         e = orc.epe(ups[i], ups_o[i])
-        print(f"sintel-shape pair {i}: EPE vs oracle = {e:.3e}")
+        print(f"sintel-shape {precision} pair {i}: EPE vs oracle = {e:.3e}")
         assert e <= 1e-3
