@@ -21,6 +21,7 @@
 //    k >= K are forced to zero (clamped row + select on a wave-uniform or per-lane compare).
 #include "sf_common.h"
 #include "gemm_epilogue.h"
+#include <cstdlib>
 
 namespace {
 
@@ -160,13 +161,13 @@ struct SplitArgs {
 };
 
 template <int WM, int WN, int TM, int TN, int ALAY, int BLAY>
-__global__ __launch_bounds__(kThreads, 2) void gemm_f16x3_mfma(const SplitArgs args) {
+__global__ __launch_bounds__(kThreads, 3) void gemm_f16x3_mfma(const SplitArgs args) {
     const SfGemm& g = args.g;
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     static_assert(WM * WN == 4, "4 waves per workgroup");
-    // [buffer][hi|lo][rows][LDK]
-    __shared__ __attribute__((aligned(16))) _Float16 sA[2][2][BM * LDK];
-    __shared__ __attribute__((aligned(16))) _Float16 sB[2][2][BN * LDK];
+    // [hi|lo][rows][LDK]; ONE LDS stage (the next tile waits in registers), so 3 workgroups fit per CU
+    __shared__ __attribute__((aligned(16))) _Float16 sA[2][BM * LDK];
+    __shared__ __attribute__((aligned(16))) _Float16 sB[2][BN * LDK];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -192,13 +193,12 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_f16x3_mfma(const SplitArgs a
     cb.init(g.b_group, (int)g.ldb, g.b_group_stride);
     opa.load(0, ca.off);
     opb.load(0, cb.off);
-    opa.store(0, sA[0][0], sA[0][1]);
-    opb.store(0, sB[0][0], sB[0][1]);
+    opa.store(0, sA[0], sA[1]);
+    opb.store(0, sB[0], sB[1]);
     __syncthreads();
 
     const int khalf = lane >> 5, l31 = lane & 31;
     for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
         if (kt + 1 < nk) {
             ca.advance();
             cb.advance();
@@ -207,10 +207,10 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_f16x3_mfma(const SplitArgs a
         }
         // keep the staged loads in flight across the MFMA block: nothing below may be hoisted above it
         __builtin_amdgcn_sched_barrier(0);
-        const _Float16* pah = sA[cur][0] + (wm * TM * 32 + l31) * LDK + khalf * 8;
-        const _Float16* pal = sA[cur][1] + (wm * TM * 32 + l31) * LDK + khalf * 8;
-        const _Float16* pbh = sB[cur][0] + (wn * TN * 32 + l31) * LDK + khalf * 8;
-        const _Float16* pbl = sB[cur][1] + (wn * TN * 32 + l31) * LDK + khalf * 8;
+        const _Float16* pah = sA[0] + (wm * TM * 32 + l31) * LDK + khalf * 8;
+        const _Float16* pal = sA[1] + (wm * TM * 32 + l31) * LDK + khalf * 8;
+        const _Float16* pbh = sB[0] + (wn * TN * 32 + l31) * LDK + khalf * 8;
+        const _Float16* pbl = sB[1] + (wn * TN * 32 + l31) * LDK + khalf * 8;
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
             f16x8 ah[TM], al[TM], bh[TN], bl[TN];
@@ -236,10 +236,11 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_f16x3_mfma(const SplitArgs a
         }
         __builtin_amdgcn_sched_barrier(0);
         if (kt + 1 < nk) {
-            opa.store((kt + 1) * BK, sA[cur ^ 1][0], sA[cur ^ 1][1]);
-            opb.store((kt + 1) * BK, sB[cur ^ 1][0], sB[cur ^ 1][1]);
+            __syncthreads();                       // every wave is done reading tile kt
+            opa.store((kt + 1) * BK, sA[0], sA[1]);
+            opb.store((kt + 1) * BK, sB[0], sB[1]);
+            __syncthreads();
         }
-        __syncthreads();
     }
     gemm_epilogue<WM, WN, TM, TN>(g, acc, m0, n0, z, wm, wn, lane);
 }
@@ -289,6 +290,12 @@ int gemm_split_dispatch(const SfGemm& g, hipStream_t st) {
     // waste more than a quarter of the MFMAs
     const int M = g.M;
     auto padded = [&](int bm) { return (M + bm - 1) / bm * bm; };
+    if (const char* e = getenv("SF_GEMM_BM")) {          // experiment knob
+        const int bm = atoi(e);
+        if (bm == 128) return launch_cfg<2, 2, 2, 2>(a, st);
+        if (bm == 64) return launch_cfg<1, 4, 2, 1>(a, st);
+        if (bm == 32) return launch_cfg<1, 4, 1, 1>(a, st);
+    }
     if (padded(128) * 4 <= M * 5) return launch_cfg<2, 2, 2, 2>(a, st);
     if (padded(64) * 4 <= M * 5 || M > 32) return launch_cfg<1, 4, 2, 1>(a, st);
     return launch_cfg<1, 4, 1, 1>(a, st);

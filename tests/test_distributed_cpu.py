@@ -1,0 +1,62 @@
+"""CPU, world_size 2 on gloo: the multi-GPU harness logic of bench.py (clip sharding, barrier-bracketed
+timing with max over ranks, whole-job aggregation).  The hot path itself has no collective: ranks are
+independent replicas over clips."""
+import os
+import socket
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, REPO)
+    import bench
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    clips = bench.shard(7, world, rank)
+    done = []
+
+    def step():                       # rank 1 is slower: the reported time must be the max over ranks
+        time.sleep(0.01 * (1 + rank))
+        done.append(1)
+
+    def allreduce_max(x):
+        t = torch.tensor([x], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    dt = bench.timed_steps(step, steps=5, warmup=2, world=world, sync_fn=lambda: None, barrier_fn=dist.barrier,
+                           allreduce_max_fn=allreduce_max)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (clips, len(done), dt))
+    if rank == 0:
+        torch.save(gathered, out)
+    dist.destroy_process_group()
+
+
+def test_two_rank_harness(tmp_path):
+    out = str(tmp_path / "res.pt")
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    res = torch.load(out)
+    (c0, n0, t0), (c1, n1, t1) = res
+    assert sorted(c0 + c1) == list(range(7)) and not set(c0) & set(c1)      # disjoint cover of the clips
+    assert n0 == n1 == 7                                                      # 2 warm-up + exactly 5 timed steps
+    assert t0 == t1                                                           # every rank reports the max
+    assert t0 >= 5 * 0.02 * 0.9                                               # ... which is the slow rank's time
+
+
+def test_usable_cores_positive():
+    sys.path.insert(0, REPO)
+    import bench
+    assert 1 <= bench.usable_cores() <= (os.cpu_count() or 1)
