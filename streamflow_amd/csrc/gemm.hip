@@ -172,7 +172,9 @@ __global__ __launch_bounds__(kThreads) void gemm_f32_mfma(const SfGemm g) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM, z = blockIdx.z;
+    const int mt = (g.M + BM - 1) / BM, nt = (g.N + BN - 1) / BN;
+    const sf::TileCoord tc = sf::xcd_tile(blockIdx.x, gridDim.x, mt, nt);
+    const int n0 = tc.n_tile * BN, m0 = tc.m_tile * BM, z = tc.z;
 
     SrcDesc da, db;
     da.base = g.A + (int64_t)z * g.strideA;
@@ -247,7 +249,7 @@ __global__ __launch_bounds__(kThreads) void gemm_f32_mfma(const SfGemm g) {
 template <int WM, int WN, int TM, int TN, int BK>
 int launch_cfg(const SfGemm& g, hipStream_t st) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    dim3 grid(sf::ceil_div(g.N, BN), sf::ceil_div(g.M, BM), g.batch);
+    dim3 grid(sf::ceil_div(g.N, BN) * sf::ceil_div(g.M, BM) * g.batch);      // 1-D: see sf::xcd_tile
     const int lay = g.a_layout * 2 + g.b_layout;
     switch (lay) {
         case 0: hipLaunchKernelGGL((gemm_f32_mfma<WM, WN, TM, TN, BK, 0, 0>), grid, dim3(kThreads), 0, st, g); break;

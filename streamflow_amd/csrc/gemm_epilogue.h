@@ -17,6 +17,26 @@
 namespace sf {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// XCD-aware workgroup -> tile mapping.  MI355X dispatches workgroup b to XCD b % 8 (8 XCDs, private 4 MiB L2s).
+// Each XCD gets one CONTIGUOUS range of tile ids (bijective also when the grid is not a multiple of 8), and
+// tile ids run m-tile fastest: the m-tiles that share one B (activation) tile are consecutive ids on the
+// same XCD, so the tile is fetched into that L2 once; and because the id -> (image, pixel tile) mapping is
+// the same for every GEMM over the same pixels, the XCD that wrote a pixel range in one GEMM's epilogue is
+// the one that reads it as the next GEMM's B operand.  Placement only affects speed, never results.
+struct TileCoord { int m_tile, n_tile, z; };
+__device__ __forceinline__ TileCoord xcd_tile(int b, int nwg, int mt, int nt) {
+    constexpr int kXcd = 8;
+    const int xcd = b % kXcd, local = b / kXcd;
+    const int q = nwg / kXcd, r = nwg % kXcd;
+    const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+    TileCoord t;
+    t.m_tile = id % mt;
+    t.n_tile = (id / mt) % nt;
+    t.z = id / (mt * nt);
+    return t;
+}
+
 constexpr int kOobTerm = 1 << 30;      // > any legal byte offset (host checks spans < 2^30)
 
 template <int EPI>

@@ -171,7 +171,9 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_f16x3_mfma(const SplitArgs a
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM, z = blockIdx.z;
+    const int mt = (g.M + BM - 1) / BM, nt = (g.N + BN - 1) / BN;
+    const sf::TileCoord tc = sf::xcd_tile(blockIdx.x, gridDim.x, mt, nt);
+    const int n0 = tc.n_tile * BN, m0 = tc.m_tile * BM, z = tc.z;
 
     Operand<BM, ALAY> opa;
     Operand<BN, BLAY> opb;
@@ -249,7 +251,7 @@ template <int WM, int WN, int TM, int TN>
 int launch_cfg(const SplitArgs& a, hipStream_t st) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     const SfGemm& g = a.g;
-    dim3 grid(sf::ceil_div(g.N, BN), sf::ceil_div(g.M, BM), g.batch);
+    dim3 grid(sf::ceil_div(g.N, BN) * sf::ceil_div(g.M, BM) * g.batch);      // 1-D: see sf::xcd_tile
     const int lay = g.a_layout * 2 + g.b_layout;
     switch (lay) {
         case 0: hipLaunchKernelGGL((gemm_f16x3_mfma<WM, WN, TM, TN, 0, 0>), grid, dim3(kThreads), 0, st, a); break;

@@ -129,7 +129,8 @@ class _Plan:
                 ("concat", 640),                       # [nets | inps | mf | mf_global | mf_temporal]
                 ("v128", 128), ("ln128", 128), ("qkv", 384), ("att128", 128), ("tx128", 128), ("h256", 256),
                 ("delta", 2),                          # == [Bc][2*Pn][P]
-                ("m256", 256), ("mask", 576), ("coords1", 2)]
+                ("m256", 256), ("mask", 576), ("coords1", 2),
+                ("hid2", 192), ("xa2", 128), ("xb2", 128)]        # scratch of the flow branch (runs concurrently)
         ws = Workspace(sum(n * r * P + 64 for _, r in spec), device)
         self.ws = ws
         for name, r in spec:
@@ -163,6 +164,11 @@ class HotPathEngine:
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("HotPathEngine needs an MI355X device (cuda:N); there is no CPU fallback")
+        # independent chains of one iteration (flow branch || corr branch of the motion encoder; temporal block ||
+        # global aggregation) are enqueued on a second stream, so the tails of one chain's small kernels are
+        # filled by the other; inside a captured graph these become parallel branches.
+        self.parallel_branches = True
+        self._side = torch.cuda.Stream(device=self.device)
         self.W = HotPathWeights(state_dict, self.device, T)
         self.use_graph = use_graph
         self._plans: Dict[Tuple[int, int, int, int], _Plan] = {}
@@ -196,28 +202,45 @@ class HotPathEngine:
         W = self.W
         Bc, Pn, h, w, P, n = pl.Bc, pl.Pn, pl.h, pl.w, pl.P, pl.n
         sk = lambda Wt, X, Y, fg=False: run_skblock(Wt, X, Y, pl.hid, pl.xa, pl.xb, h, w, fg)
-        # a3: correlation features for all pairs (streamflow.py:132)
+        main = torch.cuda.current_stream()
+        side = self._side if self.parallel_branches else main
+
+        def fork():
+            if side is not main:
+                side.wait_stream(main)
+
+        def join():
+            if side is not main:
+                main.wait_stream(side)
+
+        # a9: motion encoder (update.py:329-339).  flow branch (convf1 -> convf2) on the side stream ...
+        fork()
+        with torch.cuda.stream(side):
+            ops.gemm(W.convf1, pl.flow, pl.f128, EPI_NONE)
+            run_skblock(W.convf2, pl.f128, pl.cat256.slice(192, 256), pl.hid2, pl.xa2, pl.xb2, h, w)
+        # ... while the main stream does a3 (correlation lookup for all pairs, streamflow.py:132) and the corr branch
         ops.corr_lookup(pl.lvls, pl.lvl_pair_stride, pl.coords1, pl.corr, Bc, Pn, h, w)
-        # a9: motion encoder (update.py:329-339)
         sk(W.convc1, pl.corr, pl.cor256, True)                     # cor = gelu(convc1(corr))
         sk(W.convc2, pl.cor256, pl.cat256.slice(0, 192))
-        ops.gemm(W.convf1, pl.flow, pl.f128, EPI_NONE)
-        sk(W.convf2, pl.f128, pl.cat256.slice(192, 256))
+        join()
         sk(W.conv, pl.cat256, pl.mf.slice(0, HDIM - 2))            # mf = cat(out, flow); flow rows kept by flow_update
-        # a7: global aggregation  mfg = mf + gamma * attn @ to_v(mf)   (gma.py:91-104)
+        # a10: temporal transformer block over the T-1 tokens of each pixel (update.py:481-484,770), side stream
+        fork()
+        with torch.cuda.stream(side):
+            ops.layernorm_cm(pl.mf, W.ln1_w, W.ln1_b, pl.ln128)
+            ops.gemm(W.qkv, pl.ln128, pl.qkv, EPI_NONE)
+            ops.temporal_attn(pl.qkv, pl.att128, Bc, Pn, HDIM)
+            ops.gemm(W.proj, pl.att128, pl.tx128, EPI_RES, R=pl.mf)
+            ops.layernorm_cm(pl.tx128, W.ln2_w, W.ln2_b, pl.ln128)
+            ops.gemm(W.fc1, pl.ln128, pl.h256, EPI_GELU)
+            ops.gemm(W.fc2, pl.h256, pl.mft, EPI_RES, R=pl.tx128)
+        # a7: global aggregation  mfg = mf + gamma * attn @ to_v(mf)   (gma.py:91-104), main stream
         ops.gemm(W.to_v, pl.mf, pl.v128, EPI_NONE)
         ops.gemm_raw(A=pl.v128.ptr, B=pl.attn.data_ptr(), C=pl.mfg.ptr, R=pl.mf.ptr, gamma=W.gamma.data_ptr(),
                      M=HDIM, N=P, K=P, batch=n, lda=P, ldb=P, ldc=P, ldr=P, strideA=pl.v128.img_stride,
                      strideB=P * P, strideC=pl.mfg.img_stride, strideR=pl.mf.img_stride,
                      a_layout=LAYOUT_K_MINOR, b_layout=LAYOUT_K_MINOR, alpha=1.0, epilogue=EPI_AXPY)
-        # a10: temporal transformer block over the T-1 tokens of each pixel (update.py:481-484,770)
-        ops.layernorm_cm(pl.mf, W.ln1_w, W.ln1_b, pl.ln128)
-        ops.gemm(W.qkv, pl.ln128, pl.qkv, EPI_NONE)
-        ops.temporal_attn(pl.qkv, pl.att128, Bc, Pn, HDIM)
-        ops.gemm(W.proj, pl.att128, pl.tx128, EPI_RES, R=pl.mf)
-        ops.layernorm_cm(pl.tx128, W.ln2_w, W.ln2_b, pl.ln128)
-        ops.gemm(W.fc1, pl.ln128, pl.h256, EPI_GELU)
-        ops.gemm(W.fc2, pl.h256, pl.mft, EPI_RES, R=pl.tx128)
+        join()
         # "gru": SKBlock(640 -> 128) over cat[nets, inps, mf, mfg, mft]; new nets overwrite the nets slice
         sk(W.gru, pl.concat, pl.nets)
         # flow head sees all T-1 hidden states of a clip jointly (update.py:774)
