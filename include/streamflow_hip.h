@@ -119,9 +119,18 @@ typedef struct SfGemm {
     const void* A_hi; const void* A_lo;   /* SF_LAYOUT_SPLIT_F16 operand (shared by all batch indices) */
     int64_t lda_h;                /* row stride of A_hi/A_lo in halfs (multiple of 8) */
     int32_t a_padded;             /* K_MAJOR fp32 A is zero padded to [K up to 32][M up to 128]: no bounds checks */
+    /* split-K (precision F16X3 only): the K range is cut into k_splits slices, slice s writes its partial
+       product (epilogue must be SF_EPI_NONE, no bias) to C + s*split_stride; combine with sf_splitk_combine. */
+    int32_t k_splits; int64_t split_stride;
 } SfGemm;
 
 int sf_gemm(const SfGemm* g, void* stream);
+
+/* out[i] = R[i] + gamma[0] * sum_s partial[s*split_stride + i]  for n_img images of rows*P floats each
+ * (image strides in floats): the AXPY epilogue of gma.py:102 applied after a split-K attn @ v. */
+int sf_splitk_combine(const float* partial, int64_t split_stride, int k_splits, int64_t part_img_stride,
+                      const float* R, int64_t r_img_stride, const float* gamma, float* out,
+                      int64_t out_img_stride, int n_img, int64_t floats_per_img, void* stream);
 
 /* ---- row softmax in place (gma.py:63): x [rows][cols] ------------------------------------------ */
 int sf_softmax_rows(float* x, int64_t rows, int cols, void* stream);

@@ -304,6 +304,7 @@ extern "C" int sf_gemm(const SfGemm* gp, void* stream) {
         SF_REQUIRE(g.K % 9 == 0 && g.h > 0 && g.w > 0 && g.h * g.w == g.N, "sf_gemm: conv3x3 needs K=9*Cin, h*w=N");
     }
     if (g.b_group) SF_REQUIRE(g.b_layout == SF_LAYOUT_K_MAJOR, "sf_gemm: b_group needs a K-major B");
+    SF_REQUIRE(g.k_splits <= 1 || g.precision == SF_PRECISION_F16X3, "sf_gemm: split-K is only built for SF_PRECISION_F16X3");
     SF_REQUIRE(sf::epilogue_spans_ok(g), "sf_gemm: C / R image larger than 1 GiB (32-bit buffer offsets in the epilogue)");
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (g.precision == SF_PRECISION_F16X3) {

@@ -173,7 +173,8 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_f16x3_mfma(const SplitArgs a
     const int wm = wave / WN, wn = wave % WN;
     const int mt = (g.M + BM - 1) / BM, nt = (g.N + BN - 1) / BN;
     const sf::TileCoord tc = sf::xcd_tile(blockIdx.x, gridDim.x, mt, nt);
-    const int n0 = tc.n_tile * BN, m0 = tc.m_tile * BM, z = tc.z;
+    const int ksp = g.k_splits > 1 ? g.k_splits : 1;
+    const int n0 = tc.n_tile * BN, m0 = tc.m_tile * BM, z = tc.z / ksp, split = tc.z % ksp;
 
     Operand<BM, ALAY> opa;
     Operand<BN, BLAY> opb;
@@ -189,19 +190,21 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_f16x3_mfma(const SplitArgs a
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nk = (g.K + BK - 1) / BK;
+    const int nk_all = (g.K + BK - 1) / BK;
+    const int kt_beg = (int)((int64_t)nk_all * split / ksp), kt_end = (int)((int64_t)nk_all * (split + 1) / ksp);
     RowCursor ca, cb;
     ca.init(0, (int)g.lda, 0);
     cb.init(g.b_group, (int)g.ldb, g.b_group_stride);
-    opa.load(0, ca.off);
-    opb.load(0, cb.off);
-    opa.store(0, sA[0], sA[1]);
-    opb.store(0, sB[0], sB[1]);
+    for (int t = 0; t < kt_beg; ++t) { ca.advance(); cb.advance(); }       // split-K: start of this slice
+    opa.load(kt_beg * BK, ca.off);
+    opb.load(kt_beg * BK, cb.off);
+    opa.store(kt_beg * BK, sA[0], sA[1]);
+    opb.store(kt_beg * BK, sB[0], sB[1]);
     __syncthreads();
 
     const int khalf = lane >> 5, l31 = lane & 31;
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) {
+    for (int kt = kt_beg; kt < kt_end; ++kt) {
+        if (kt + 1 < kt_end) {
             ca.advance();
             cb.advance();
             opa.load((kt + 1) * BK, ca.off);
@@ -237,21 +240,27 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_f16x3_mfma(const SplitArgs a
                 }
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (kt + 1 < nk) {
+        if (kt + 1 < kt_end) {
             __syncthreads();                       // every wave is done reading tile kt
             opa.store((kt + 1) * BK, sA[0], sA[1]);
             opb.store((kt + 1) * BK, sB[0], sB[1]);
             __syncthreads();
         }
     }
-    gemm_epilogue<WM, WN, TM, TN>(g, acc, m0, n0, z, wm, wn, lane);
+    if (ksp > 1) {             // partial product of this K slice: plain store to its own slab
+        SfGemm gs = g;
+        gs.C = g.C + (int64_t)split * g.split_stride;
+        gemm_epilogue<WM, WN, TM, TN>(gs, acc, m0, n0, z, wm, wn, lane);
+    } else {
+        gemm_epilogue<WM, WN, TM, TN>(g, acc, m0, n0, z, wm, wn, lane);
+    }
 }
 
 template <int WM, int WN, int TM, int TN>
 int launch_cfg(const SplitArgs& a, hipStream_t st) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     const SfGemm& g = a.g;
-    dim3 grid(sf::ceil_div(g.N, BN) * sf::ceil_div(g.M, BM) * g.batch);      // 1-D: see sf::xcd_tile
+    dim3 grid(sf::ceil_div(g.N, BN) * sf::ceil_div(g.M, BM) * g.batch * (g.k_splits > 1 ? g.k_splits : 1));   // 1-D: see sf::xcd_tile
     const int lay = g.a_layout * 2 + g.b_layout;
     switch (lay) {
         case 0: hipLaunchKernelGGL((gemm_f16x3_mfma<WM, WN, TM, TN, 0, 0>), grid, dim3(kThreads), 0, st, a); break;
@@ -275,6 +284,8 @@ namespace sf {
 
 // called from sf_gemm (gemm.hip) when precision == SF_PRECISION_F16X3 (never for conv3x3)
 int gemm_split_dispatch(const SfGemm& g, hipStream_t st) {
+    if (g.k_splits > 1 && (g.epilogue != SF_EPI_NONE || g.bias || g.b_group || g.k_splits > 16))
+        return fail(SF_ERR_BAD_ARG, "sf_gemm(f16x3): split-K needs SF_EPI_NONE, no bias, no grouping, k_splits <= 16");
     if (g.b_group % 32) return fail(SF_ERR_BAD_ARG, "sf_gemm(f16x3): b_group must be a multiple of 32");
     SplitArgs a;
     a.g = g;

@@ -309,6 +309,27 @@ __global__ __launch_bounds__(kBlock) void upsample_kernel(const float* flow, con
     }
 }
 
+// ---- split-K combine: out = R + gamma * sum_s partial_s ------------------------------------------------
+__global__ __launch_bounds__(kBlock) void splitk_combine_kernel(const float* partial, int64_t split_stride, int ks,
+                                                                 int64_t part_img_stride, const float* R,
+                                                                 int64_t r_img_stride, const float* gamma, float* out,
+                                                                 int64_t out_img_stride, int64_t per_img4) {
+    const int img = blockIdx.y;
+    const float g = gamma[0];
+    const float4* p4 = reinterpret_cast<const float4*>(partial + img * part_img_stride);
+    const float4* r4 = reinterpret_cast<const float4*>(R + img * r_img_stride);
+    float4* o4 = reinterpret_cast<float4*>(out + img * out_img_stride);
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < per_img4; i += (int64_t)gridDim.x * kBlock) {
+        float4 a = p4[i];
+        for (int s = 1; s < ks; ++s) {
+            const float4 b = p4[i + s * (split_stride / 4)];
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        const float4 r = r4[i];
+        o4[i] = make_float4(r.x + g * a.x, r.y + g * a.y, r.z + g * a.z, r.w + g * a.w);
+    }
+}
+
 inline int grid_for(int64_t total) {
     int64_t b = (total + kBlock - 1) / kBlock;
     return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
@@ -382,4 +403,19 @@ extern "C" int sf_upsample_flow(const float* flow, const float* mask, float* out
     hipLaunchKernelGGL(upsample_kernel, dim3(sf::ceil_div(w, kUpSeg), h, n), dim3(kBlock), 0, (hipStream_t)stream,
                        flow, mask, out, h, w);
     return sf::check_launch("sf_upsample_flow");
+}
+
+extern "C" int sf_splitk_combine(const float* partial, int64_t split_stride, int k_splits, int64_t part_img_stride,
+                                 const float* R, int64_t r_img_stride, const float* gamma, float* out,
+                                 int64_t out_img_stride, int n_img, int64_t floats_per_img, void* stream) {
+    SF_REQUIRE(partial && R && gamma && out && k_splits >= 1 && n_img > 0 && floats_per_img > 0, "sf_splitk_combine: bad args");
+    SF_REQUIRE(((floats_per_img | split_stride | part_img_stride | r_img_stride | out_img_stride) & 3) == 0 &&
+               ((reinterpret_cast<uintptr_t>(partial) | reinterpret_cast<uintptr_t>(R) | reinterpret_cast<uintptr_t>(out)) & 15) == 0,
+               "sf_splitk_combine: pointers/strides must be 16-byte aligned");
+    const int64_t per4 = floats_per_img / 4;
+    int64_t bx = (per4 + kBlock - 1) / kBlock;
+    if (bx > 1024) bx = 1024;
+    hipLaunchKernelGGL(splitk_combine_kernel, dim3((unsigned)bx, n_img), dim3(kBlock), 0, (hipStream_t)stream, partial,
+                       split_stride, k_splits, part_img_stride, R, r_img_stride, gamma, out, out_img_stride, per4);
+    return sf::check_launch("sf_splitk_combine");
 }

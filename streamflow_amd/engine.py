@@ -12,6 +12,7 @@ Image index convention everywhere: img = clip * (T-1) + pair   (the reference's 
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -130,7 +131,8 @@ class _Plan:
                 ("v128", 128), ("ln128", 128), ("qkv", 384), ("att128", 128), ("tx128", 128), ("h256", 256),
                 ("delta", 2),                          # == [Bc][2*Pn][P]
                 ("m256", 256), ("mask", 576), ("coords1", 2),
-                ("hid2", 192), ("xa2", 128), ("xb2", 128)]        # scratch of the flow branch (runs concurrently)
+                ("hid2", 192), ("xa2", 128), ("xb2", 128),       # scratch of the flow branch (runs concurrently)
+                ("part", 128 * 4)]                                # split-K slabs of attn @ v: [4][n][128][P]
         ws = Workspace(sum(n * r * P + 64 for _, r in spec), device)
         self.ws = ws
         for name, r in spec:
@@ -168,6 +170,7 @@ class HotPathEngine:
         # global aggregation) are enqueued on a second stream, so the tails of one chain's small kernels are
         # filled by the other; inside a captured graph these become parallel branches.
         self.parallel_branches = True
+        self.attn_k_splits = min(4, int(os.environ.get("SF_ATTN_KSPLITS", "3")))     # 1 = no split-K (<= 4)
         self._side = torch.cuda.Stream(device=self.device)
         self.W = HotPathWeights(state_dict, self.device, T)
         self.use_graph = use_graph
@@ -236,10 +239,20 @@ class HotPathEngine:
             ops.gemm(W.fc2, pl.h256, pl.mft, EPI_RES, R=pl.tx128)
         # a7: global aggregation  mfg = mf + gamma * attn @ to_v(mf)   (gma.py:91-104), main stream
         ops.gemm(W.to_v, pl.mf, pl.v128, EPI_NONE)
-        ops.gemm_raw(A=pl.v128.ptr, B=pl.attn.data_ptr(), C=pl.mfg.ptr, R=pl.mf.ptr, gamma=W.gamma.data_ptr(),
-                     M=HDIM, N=P, K=P, batch=n, lda=P, ldb=P, ldc=P, ldr=P, strideA=pl.v128.img_stride,
-                     strideB=P * P, strideC=pl.mfg.img_stride, strideR=pl.mf.img_stride,
-                     a_layout=LAYOUT_K_MINOR, b_layout=LAYOUT_K_MINOR, alpha=1.0, epilogue=EPI_AXPY)
+        ks = self.attn_k_splits if self.precision == ops.PRECISION_F16X3 else 1
+        if ks > 1 and P % 4 == 0:
+            # attn @ v streams the N x N matrix (HBM-bound) but has only N/128 * images workgroups: split K so that
+            # enough bytes are in flight; partial products go to slabs, combined with the AXPY of gma.py:102
+            ops.gemm_raw(A=pl.v128.ptr, B=pl.attn.data_ptr(), C=pl.part.ptr, M=HDIM, N=P, K=P, batch=n, lda=P, ldb=P,
+                         ldc=P, strideA=pl.v128.img_stride, strideB=P * P, strideC=HDIM * P,       # slabs: [split][img][128][P]
+                         a_layout=LAYOUT_K_MINOR, b_layout=LAYOUT_K_MINOR, alpha=1.0, epilogue=EPI_NONE,
+                         k_splits=ks, split_stride=n * HDIM * P)
+            ops.splitk_combine(pl.part.base[pl.part.off:], n * HDIM * P, ks, HDIM * P, pl.mf, W.gamma, pl.mfg)
+        else:
+            ops.gemm_raw(A=pl.v128.ptr, B=pl.attn.data_ptr(), C=pl.mfg.ptr, R=pl.mf.ptr, gamma=W.gamma.data_ptr(),
+                         M=HDIM, N=P, K=P, batch=n, lda=P, ldb=P, ldc=P, ldr=P, strideA=pl.v128.img_stride,
+                         strideB=P * P, strideC=pl.mfg.img_stride, strideR=pl.mf.img_stride,
+                         a_layout=LAYOUT_K_MINOR, b_layout=LAYOUT_K_MINOR, alpha=1.0, epilogue=EPI_AXPY)
         join()
         # "gru": SKBlock(640 -> 128) over cat[nets, inps, mf, mfg, mft]; new nets overwrite the nets slice
         sk(W.gru, pl.concat, pl.nets)

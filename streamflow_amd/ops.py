@@ -215,6 +215,15 @@ def gemm_raw(**kw) -> None:
             lambda: _lib.check(_lib.load().sf_gemm(C.byref(g), _lib.stream()), "sf_gemm"))
 
 
+def splitk_combine(partial: torch.Tensor, split_stride: int, k_splits: int, part_img_stride: int, R: Planes,
+                   gamma: torch.Tensor, out: Planes) -> None:
+    assert R.rows == out.rows and R.n_img == out.n_img
+    _launch("splitk_combine", 0, 4.0 * (k_splits + 2) * R.n_img * R.rows * R.P,
+            lambda: _lib.check(_lib.load().sf_splitk_combine(
+                partial.data_ptr(), split_stride, k_splits, part_img_stride, R.ptr, R.img_stride, gamma.data_ptr(),
+                out.ptr, out.img_stride, R.n_img, R.rows * R.P, _lib.stream()), "sf_splitk_combine"))
+
+
 def dwconv_res_gelu(X: Planes, wgt: torch.Tensor, bias: torch.Tensor, Y: Planes, h: int, w: int, k: int) -> None:
     assert X.rows == Y.rows == wgt.shape[0] and X.P == h * w
     _launch("dwconv%d" % k, 2.0 * k * k * X.n_img * X.rows * h * w, 8.0 * X.n_img * X.rows * h * w,
