@@ -119,6 +119,7 @@ def main():
                          "the default skips the 14 mask heads whose results test_mode discards)")
     ap.add_argument("--precision", default="f16x3", choices=["f16x3", "fp32"],
                     help="f16x3: split-fp16 MFMA with fp32 accumulation (fp32-class accuracy); fp32: exact fp32 MFMA")
+    ap.add_argument("--gemm-shapes", action="store_true", help="per-shape GEMM rows in the kernel table")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-breakdown", action="store_true")
     args = ap.parse_args()
@@ -185,6 +186,8 @@ def main():
         # instrumented eager pass: HIP events around every launch on the launch stream
         eager = HotPathEngine(params, device=dev, T=T, use_graph=False, precision=args.precision)
         eager._plans = eng._plans                       # reuse buffers
+        eager.parallel_branches = False                 # serial launches: clean per-kernel durations
+        ops.PROFILE_SHAPES = args.gemm_shapes
         eager.forward(fmaps, cnets, iters=iters, all_masks=args.all_masks)
         reps = 2
         ops.PROFILER = ops.Profiler()
@@ -201,7 +204,13 @@ def main():
                           "tflops": round(d["flops"] / reps / (ms * 1e-3) / 1e12, 2) if d["flops"] else None,
                           "gbps_algorithmic": round(d["bytes"] / reps / (ms * 1e-3) / 1e9, 1) if d["bytes"] else None}
         result["kernels"] = kern
-        dom = max(kern, key=lambda k: kern[k]["ms_per_clip"])
+        if args.gemm_shapes:            # fold the per-shape rows back into one family row for the roofline
+            fam = [k for k in kern if k.startswith("gemm M")]
+            ms = sum(kern[k]["ms_per_clip"] for k in fam)
+            fl = sum(summ[k]["flops"] for k in fam) / reps
+            kern["gemm"] = {"launches_per_clip": sum(kern[k]["launches_per_clip"] for k in fam), "ms_per_clip": round(ms, 4),
+                            "avg_us": None, "tflops": round(fl / (ms * 1e-3) / 1e12, 2), "gbps_algorithmic": None}
+        dom = max((k for k in kern if not k.startswith("gemm M")), key=lambda k: kern[k]["ms_per_clip"])
         if kern[dom]["tflops"] and dom.startswith("gemm"):
             # algorithmic (fp32-equivalent) TFLOP/s; the f16x3 path issues 3 f16 MFMA flops per algorithmic flop,
             # so its matrix-core roof for algorithmic flops is 2500/3

@@ -63,8 +63,10 @@ struct Operand {
     bool live[NI];
     int K, ld, group;
     int64_t group_stride;
-    float v[(LAY == 2) ? 1 : NI][8];
-    u32x4 ph[(LAY == 2) ? NI : 1], pl[(LAY == 2) ? NI : 1];
+    struct Regs {                                  // one staged k-tile of this thread
+        float v[(LAY == 2) ? 1 : NI][8];
+        u32x4 ph[(LAY == 2) ? NI : 1], pl[(LAY == 2) ? NI : 1];
+    };
 
     __device__ __forceinline__ void init(const void* base, const void* base_lo, int64_t bytes, int ld_, int K_, int X,
                                          int x0, int group_, int64_t group_stride_, int tid) {
@@ -92,47 +94,47 @@ struct Operand {
     // Issue the raw loads of k-tile k0 (nothing is consumed here, so no wait is needed before the MFMAs).
     // K-major rows: tile_off = element offset of row k0 (tracked incrementally by the caller for grouped
     // operands); rows past K are clamped to the last valid row and zeroed in store().
-    __device__ __forceinline__ void load(int k0, int tile_off) {
+    __device__ __forceinline__ void load(int k0, int tile_off, Regs& rg) const {
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
             if (LAY == 2) {
-                ph[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[j], k0 * 2, 0);
-                pl[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_lo, voff[j], k0 * 2, 0);
+                rg.ph[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[j], k0 * 2, 0);
+                rg.pl[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_lo, voff[j], k0 * 2, 0);
             } else if (LAY == SF_LAYOUT_K_MAJOR) {
                 const int kb = ko[j] * 8;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const int over = k0 + kb + i - (K - 1);                 // > 0: row past the end
                     const int r = (tile_off + (kb + i - (over > 0 ? over : 0)) * ld) * 4;
-                    if (kUniformKo) v[j][i] = as_f(__builtin_amdgcn_raw_buffer_load_b32(rsrc, voff[j], r, 0));
-                    else v[j][i] = as_f(__builtin_amdgcn_raw_buffer_load_b32(rsrc, voff[j] + r, 0, 0));
+                    if (kUniformKo) rg.v[j][i] = as_f(__builtin_amdgcn_raw_buffer_load_b32(rsrc, voff[j], r, 0));
+                    else rg.v[j][i] = as_f(__builtin_amdgcn_raw_buffer_load_b32(rsrc, voff[j] + r, 0, 0));
                 }
             } else {
                 // k0 goes into the VGPR offset: soffset is excluded from the hardware range check, and the last
                 // k-octet of the last row may reach past the end of the buffer (then it reads as zero)
                 const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[j] + k0 * 4, 0, 0);
                 const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[j] + k0 * 4 + 16, 0, 0);
-                v[j][0] = as_f(a[0]); v[j][1] = as_f(a[1]); v[j][2] = as_f(a[2]); v[j][3] = as_f(a[3]);
-                v[j][4] = as_f(b[0]); v[j][5] = as_f(b[1]); v[j][6] = as_f(b[2]); v[j][7] = as_f(b[3]);
+                rg.v[j][0] = as_f(a[0]); rg.v[j][1] = as_f(a[1]); rg.v[j][2] = as_f(a[2]); rg.v[j][3] = as_f(a[3]);
+                rg.v[j][4] = as_f(b[0]); rg.v[j][5] = as_f(b[1]); rg.v[j][6] = as_f(b[2]); rg.v[j][7] = as_f(b[3]);
             }
         }
     }
 
     // Consume the staged tile (loaded for k-tile k0): zero rows k >= K, split into hi/lo f16, write to LDS.
-    __device__ __forceinline__ void store(int k0, _Float16* lds_hi, _Float16* lds_lo) {
+    __device__ __forceinline__ void store(int k0, _Float16* lds_hi, _Float16* lds_lo, Regs& rg) const {
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
             if (!live[j]) continue;
             if (LAY == 2) {
-                *reinterpret_cast<u32x4*>(lds_hi + lds_off[j]) = ph[j];
-                *reinterpret_cast<u32x4*>(lds_lo + lds_off[j]) = pl[j];
+                *reinterpret_cast<u32x4*>(lds_hi + lds_off[j]) = rg.ph[j];
+                *reinterpret_cast<u32x4*>(lds_lo + lds_off[j]) = rg.pl[j];
             } else {
                 if (k0 + BK > K) {          // last, partial k-tile (workgroup-uniform)
                     const int k = k0 + ko[j] * 8;
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) v[j][i] = (k + i < K) ? v[j][i] : 0.f;
+                    for (int i = 0; i < 8; ++i) rg.v[j][i] = (k + i < K) ? rg.v[j][i] : 0.f;
                 }
-                const Split8 s8 = split8(v[j]);
+                const Split8 s8 = split8(rg.v[j]);
                 *reinterpret_cast<f16x8*>(lds_hi + lds_off[j]) = s8.hi;
                 *reinterpret_cast<f16x8*>(lds_lo + lds_off[j]) = s8.lo;
             }
@@ -158,6 +160,8 @@ struct RowCursor {
 struct SplitArgs {
     SfGemm g;
     int64_t a_bytes, b_bytes;      // bytes spanned by one batch image of A / B (buffer range check)
+    int dbg;                       // ablation bits (SF_GEMM_DBG, experiments only): 1 no global loads in the loop,
+                                   // 2 no MFMAs, 4 no convert/LDS stores in the loop
 };
 
 template <int WM, int WN, int TM, int TN, int ALAY, int BLAY>
@@ -178,6 +182,8 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_f16x3_mfma(const SplitArgs a
 
     Operand<BM, ALAY> opa;
     Operand<BN, BLAY> opb;
+    typename Operand<BM, ALAY>::Regs ra;
+    typename Operand<BN, BLAY>::Regs rb;
     if (ALAY == 2) opa.init(g.A_hi, g.A_lo, args.a_bytes, (int)g.lda_h, g.K, g.M, m0, 0, 0, tid);
     else opa.init(g.A + (int64_t)z * g.strideA, nullptr, args.a_bytes, (int)g.lda, g.K, g.M, m0, 0, 0, tid);
     opb.init(g.B + (int64_t)z * g.strideB, nullptr, args.b_bytes, (int)g.ldb, g.K, g.N, n0, g.b_group, g.b_group_stride, tid);
@@ -196,10 +202,10 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_f16x3_mfma(const SplitArgs a
     ca.init(0, (int)g.lda, 0);
     cb.init(g.b_group, (int)g.ldb, g.b_group_stride);
     for (int t = 0; t < kt_beg; ++t) { ca.advance(); cb.advance(); }       // split-K: start of this slice
-    opa.load(kt_beg * BK, ca.off);
-    opb.load(kt_beg * BK, cb.off);
-    opa.store(kt_beg * BK, sA[0], sA[1]);
-    opb.store(kt_beg * BK, sB[0], sB[1]);
+    opa.load(kt_beg * BK, ca.off, ra);
+    opb.load(kt_beg * BK, cb.off, rb);
+    opa.store(kt_beg * BK, sA[0], sA[1], ra);
+    opb.store(kt_beg * BK, sB[0], sB[1], rb);
     __syncthreads();
 
     const int khalf = lane >> 5, l31 = lane & 31;
@@ -207,8 +213,8 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_f16x3_mfma(const SplitArgs a
         if (kt + 1 < kt_end) {
             ca.advance();
             cb.advance();
-            opa.load((kt + 1) * BK, ca.off);
-            opb.load((kt + 1) * BK, cb.off);
+            opa.load((kt + 1) * BK, ca.off, ra);
+            opb.load((kt + 1) * BK, cb.off, rb);
         }
         // keep the staged loads in flight across the MFMA block: nothing below may be hoisted above it
         __builtin_amdgcn_sched_barrier(0);
@@ -242,8 +248,8 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_f16x3_mfma(const SplitArgs a
         __builtin_amdgcn_sched_barrier(0);
         if (kt + 1 < kt_end) {
             __syncthreads();                       // every wave is done reading tile kt
-            opa.store((kt + 1) * BK, sA[0], sA[1]);
-            opb.store((kt + 1) * BK, sB[0], sB[1]);
+            opa.store((kt + 1) * BK, sA[0], sA[1], ra);
+            opb.store((kt + 1) * BK, sB[0], sB[1], rb);
             __syncthreads();
         }
     }
@@ -254,6 +260,155 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_f16x3_mfma(const SplitArgs a
     } else {
         gemm_epilogue<WM, WN, TM, TN>(g, acc, m0, n0, z, wm, wn, lane);
     }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------
+// Wave-specialised 128x128 kernel: 8 waves per workgroup.
+//   waves 0-3 (consumers): LDS fragment reads + MFMAs only, each a 64x64 sub-tile -- nothing in their loop
+//                          ever waits on global memory;
+//   waves 4-7 (producers): global loads kept kDepth k-tiles ahead in their own registers (they hold no
+//                          accumulators, so they can afford it), fp32 -> hi/lo f16 split, LDS writes.
+// One workgroup barrier per k-tile hands LDS stage (t+1)&1 to the consumers.  In the single-role kernel above every
+// wave serialises load-issue -> MFMA -> wait -> convert -> LDS write, and all units idle ~70 % of the time.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int kWsThreads = 512;
+constexpr int kDepth = 3;
+
+template <int ALAY, int BLAY>
+__global__ __launch_bounds__(kWsThreads, 4) void gemm_f16x3_ws(const SplitArgs args) {
+    const SfGemm& g = args.g;
+    constexpr int BM = 128, BN = 128, TM = 2, TN = 2, WN = 2;
+    __shared__ __attribute__((aligned(16))) _Float16 sA[2][2][BM * LDK];     // [stage][hi|lo][rows][LDK]
+    __shared__ __attribute__((aligned(16))) _Float16 sB[2][2][BN * LDK];
+
+    const int tid = threadIdx.x;
+    const bool producer = tid >= kThreads;              // wave-uniform (waves 4..7)
+    const int ptid = tid & (kThreads - 1);
+    const int lane = tid & 63, wave = (tid >> 6) & 3;
+    const int wm = wave / WN, wn = wave % WN;
+    const int mt = (g.M + BM - 1) / BM, nt = (g.N + BN - 1) / BN;
+    const sf::TileCoord tc = sf::xcd_tile(blockIdx.x, gridDim.x, mt, nt);
+    const int ksp = g.k_splits > 1 ? g.k_splits : 1;
+    const int n0 = tc.n_tile * BN, m0 = tc.m_tile * BM, z = tc.z / ksp, split = tc.z % ksp;
+    const int nk_all = (g.K + BK - 1) / BK;
+    const int kt_beg = (int)((int64_t)nk_all * split / ksp), kt_end = (int)((int64_t)nk_all * (split + 1) / ksp);
+    const int nk = kt_end - kt_beg;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (producer) {
+        Operand<BM, ALAY> opa;
+        Operand<BN, BLAY> opb;
+        typename Operand<BM, ALAY>::Regs ra[kDepth];
+        typename Operand<BN, BLAY>::Regs rb[kDepth];
+        if (ALAY == 2) opa.init(g.A_hi, g.A_lo, args.a_bytes, (int)g.lda_h, g.K, g.M, m0, 0, 0, ptid);
+        else opa.init(g.A + (int64_t)z * g.strideA, nullptr, args.a_bytes, (int)g.lda, g.K, g.M, m0, 0, 0, ptid);
+        opb.init(g.B + (int64_t)z * g.strideB, nullptr, args.b_bytes, (int)g.ldb, g.K, g.N, n0, g.b_group,
+                 g.b_group_stride, ptid);
+        RowCursor ca, cb;                     // row offset of the NEXT tile to be loaded
+        ca.init(0, (int)g.lda, 0);
+        cb.init(g.b_group, (int)g.ldb, g.b_group_stride);
+        for (int t = 0; t < kt_beg; ++t) { ca.advance(); cb.advance(); }
+#pragma unroll
+        for (int u = 0; u < kDepth; ++u) {
+            if (u < nk) {
+                opa.load((kt_beg + u) * BK, ca.off, ra[u]);
+                opb.load((kt_beg + u) * BK, cb.off, rb[u]);
+                ca.advance();
+                cb.advance();
+            }
+        }
+        opa.store(kt_beg * BK, sA[0][0], sA[0][1], ra[0]);
+        opb.store(kt_beg * BK, sB[0][0], sB[0][1], rb[0]);
+        __syncthreads();
+        for (int base = 0; base < nk; base += kDepth) {
+#pragma unroll
+            for (int u = 0; u < kDepth; ++u) {
+                const int t = base + u;                 // tile the consumers work on in this step
+                if (t < nk) {
+                    // register set u held tile t (already in LDS): refill it with tile t + kDepth ...
+                    if (t + kDepth < nk && !(args.dbg & 1)) {
+                        opa.load((kt_beg + t + kDepth) * BK, ca.off, ra[u]);
+                        opb.load((kt_beg + t + kDepth) * BK, cb.off, rb[u]);
+                        ca.advance();
+                        cb.advance();
+                    }
+                    // ... and hand tile t + 1 (loaded kDepth - 1 steps ago) to LDS stage (t + 1) & 1
+                    if (t + 1 < nk && !(args.dbg & 4)) {
+                        constexpr int kNextSet[3] = {1, 2, 0};
+                        const int st = (t + 1) & 1;
+                        opa.store((kt_beg + t + 1) * BK, sA[st][0], sA[st][1], ra[kNextSet[u]]);
+                        opb.store((kt_beg + t + 1) * BK, sB[st][0], sB[st][1], rb[kNextSet[u]]);
+                    }
+                    __syncthreads();
+                }
+            }
+        }
+        return;                                          // producers take no part in the epilogue
+    }
+
+    // ---------------- consumers ----------------
+    __syncthreads();                                     // stage 0 filled
+    const int khalf = lane >> 5, l31 = lane & 31;
+    for (int t = 0; t < nk; ++t) {
+        const int st = t & 1;
+        if (args.dbg & 2) { __syncthreads(); continue; }
+        const _Float16* pah = sA[st][0] + (wm * TM * 32 + l31) * LDK + khalf * 8;
+        const _Float16* pal = sA[st][1] + (wm * TM * 32 + l31) * LDK + khalf * 8;
+        const _Float16* pbh = sB[st][0] + (wn * TN * 32 + l31) * LDK + khalf * 8;
+        const _Float16* pbl = sB[st][1] + (wn * TN * 32 + l31) * LDK + khalf * 8;
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            f16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                ah[i] = *reinterpret_cast<const f16x8*>(pah + i * 32 * LDK + ks * 16);
+                al[i] = *reinterpret_cast<const f16x8*>(pal + i * 32 * LDK + ks * 16);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                bh[j] = *reinterpret_cast<const f16x8*>(pbh + j * 32 * LDK + ks * 16);
+                bl[j] = *reinterpret_cast<const f16x8*>(pbl + j * 32 * LDK + ks * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    }
+    if (ksp > 1) {
+        SfGemm gs = g;
+        gs.C = g.C + (int64_t)split * g.split_stride;
+        gemm_epilogue<2, 2, TM, TN>(gs, acc, m0, n0, z, wm, wn, lane);
+    } else {
+        gemm_epilogue<2, 2, TM, TN>(g, acc, m0, n0, z, wm, wn, lane);
+    }
+}
+
+int launch_ws(const SplitArgs& a, hipStream_t st) {
+    const SfGemm& g = a.g;
+    dim3 grid(sf::ceil_div(g.N, 128) * sf::ceil_div(g.M, 128) * g.batch * (g.k_splits > 1 ? g.k_splits : 1));
+    const int lay = g.a_layout * 2 + g.b_layout;
+    switch (lay) {
+        case 0: hipLaunchKernelGGL((gemm_f16x3_ws<0, 0>), grid, dim3(kWsThreads), 0, st, a); break;
+        case 3: hipLaunchKernelGGL((gemm_f16x3_ws<1, 1>), grid, dim3(kWsThreads), 0, st, a); break;
+        case 4: hipLaunchKernelGGL((gemm_f16x3_ws<2, 0>), grid, dim3(kWsThreads), 0, st, a); break;
+        default: return sf::fail(SF_ERR_UNSUPPORTED, "sf_gemm(f16x3): layout combination a=%d b=%d not built",
+                                 g.a_layout, g.b_layout);
+    }
+    return sf::check_launch("sf_gemm(f16x3, wave-specialised)");
 }
 
 template <int WM, int WN, int TM, int TN>
@@ -289,6 +444,7 @@ int gemm_split_dispatch(const SfGemm& g, hipStream_t st) {
     if (g.b_group % 32) return fail(SF_ERR_BAD_ARG, "sf_gemm(f16x3): b_group must be a multiple of 32");
     SplitArgs a;
     a.g = g;
+    a.dbg = getenv("SF_GEMM_DBG") ? atoi(getenv("SF_GEMM_DBG")) : 0;
     if (g.a_layout == SF_LAYOUT_SPLIT_F16) {
         if (!g.A_hi || !g.A_lo || g.lda_h <= 0 || (g.lda_h & 7))
             return fail(SF_ERR_BAD_ARG, "sf_gemm(f16x3): SPLIT_F16 A needs A_hi/A_lo and lda_h %% 8 == 0");
@@ -306,10 +462,13 @@ int gemm_split_dispatch(const SfGemm& g, hipStream_t st) {
     if (const char* e = getenv("SF_GEMM_BM")) {          // experiment knob
         const int bm = atoi(e);
         if (bm == 128) return launch_cfg<2, 2, 2, 2>(a, st);
+        if (bm == 129) return launch_ws(a, st);
         if (bm == 64) return launch_cfg<1, 4, 2, 1>(a, st);
         if (bm == 32) return launch_cfg<1, 4, 1, 1>(a, st);
     }
-    if (padded(128) * 4 <= M * 5) return launch_cfg<2, 2, 2, 2>(a, st);
+    // deep-K problems gain from the wave-specialised kernel's 3-tile prefetch; shallow ones are dominated by
+    // prologue/epilogue, where the single-role kernel (all waves store) is a little faster
+    if (padded(128) * 4 <= M * 5) return (g.K / (g.k_splits > 1 ? g.k_splits : 1) >= 768) ? launch_ws(a, st) : launch_cfg<2, 2, 2, 2>(a, st);
     if (padded(64) * 4 <= M * 5 || M > 32) return launch_cfg<1, 4, 2, 1>(a, st);
     return launch_cfg<1, 4, 1, 1>(a, st);
 }

@@ -68,6 +68,7 @@ class Profiler:
 
 
 PROFILER: Optional[Profiler] = None
+PROFILE_SHAPES = False      # tag GEMM launches with their shape in the profiler (bench.py --gemm-shapes)
 
 
 def _launch(name: str, flops: float, nbytes: float, fn) -> None:
@@ -199,7 +200,8 @@ def gemm(A: PackedLinear, X: Planes, Y: Planes, epilogue: int = EPI_NONE, R: Opt
     if A.conv3x3:
         g.conv3x3, g.h, g.w = 1, int(hw[0]), int(hw[1])
     g.alpha, g.epilogue, g.precision = float(alpha), int(epilogue), prec
-    _launch("gemm", 2.0 * g.M * g.N * g.K * g.batch, 0,
+    name = "gemm" if not PROFILE_SHAPES else f"gemm M{g.M} K{g.K} b{g.batch} e{g.epilogue}"
+    _launch(name, 2.0 * g.M * g.N * g.K * g.batch, 0,
             lambda: _lib.check(_lib.load().sf_gemm(C.byref(g), _lib.stream()), "sf_gemm"))
 
 
