@@ -58,7 +58,8 @@ int sf_bilinear_sampler(const float* img, const float* coords, float* out, float
  * Level 0 = f1^T f2 / sqrt(D); levels 1..3 are pooled in the GEMM epilogue while the tile is still in
  * registers, so every pyramid cell is written once and level 0 is never re-read.
  * lvl_pair_stride: HOST array of 4 strides in floats (ignored when pairs == 1; may be NULL then).
- * num_levels must be 4 (streamflow.py:38).  precision: 0 = exact fp32 MFMA (k-ordered fmaf chain). */
+ * num_levels must be 4 (streamflow.py:38).  precision: SF_PRECISION_FP32 (exact fp32 MFMA, k-ordered fmaf
+ * chain) or SF_PRECISION_F16X3 (split fp16, fp32 accumulate; see sf_gemm). */
 int sf_corr_build_pyramid(const float* f1, const float* f2, int64_t f_clip_stride, int64_t f_pair_stride,
                           float* lvl0, float* lvl1, float* lvl2, float* lvl3,
                           const int64_t* lvl_pair_stride, int B, int pairs, int D, int h, int w,

@@ -4,9 +4,11 @@
 // VALU-bound stencil (225 or 49 FMAs per output).  One workgroup owns one (image, channel) plane
 // strip: the strip plus its K/2 halo is staged once in LDS (zero padded, so the inner loop has no
 // bounds checks), each thread produces a 4x4 output tile from a sliding window held in registers
-// (one ds_read_b128 row segment feeds 4 output rows x 4 output columns x K taps), and the K*K
-// weights of the channel are wave-uniform, so they are fetched through the scalar cache and used as
-// SGPR operands of v_fmac_f32 -- no LDS or VGPR traffic for weights at all.
+// (one ds_read_b128 row segment feeds 4 output columns x K taps).  The K*K weights of the channel sit in LDS
+// behind the tile and are read one kernel row at a time with broadcast reads into VGPRs.  (Measured: fetching
+// them through the scalar cache as SGPR operands of v_fmac_f32 was 18 % slower -- every weight row costs an
+// lgkmcnt(0) drain -- and a register sliding window that cuts the LDS row reads 4x changed nothing: the
+// kernel is bound by VALU issue, 47 TFLOP/s of fp32 FMA.)
 #include "sf_common.h"
 
 namespace {
@@ -46,6 +48,9 @@ __global__ __launch_bounds__(kMaxThreads) void dwconv_res_gelu_kernel(const DwAr
         if (gy >= 0 && gy < g.h && gx >= 0 && gx < g.w) v = xp[gy * g.w + gx];
         tile[idx] = v;
     }
+    // the channel's K*K weights go to LDS behind the tile
+    float* wl = tile + rows * wp + 8;
+    for (int i = threadIdx.x; i < KS * KS; i += blockDim.x) wl[i] = wc[i];
     __syncthreads();
 
     const int tiles_y = g.strip_h / TY;
@@ -59,14 +64,13 @@ __global__ __launch_bounds__(kMaxThreads) void dwconv_res_gelu_kernel(const DwAr
         for (int j = 0; j < TX; ++j) acc[i][j] = 0.f;
 
     const float4* base = reinterpret_cast<const float4*>(tile) + (ty * TY) * g.wp4 + tx;
-    // ky is a rolled loop on purpose: only KY_UNROLL weight rows (wave-uniform SGPRs) are live at a time;
-    // fully unrolled, the compiler hoists all K*K scalar loads and spills.  Each (ky, oy) pair re-reads its
-    // window row from LDS (4x redundant ds_read_b128, ~20% of the VALU time, no register shifting).
+    // ky is a rolled loop on purpose: only KY_UNROLL weight rows are live at a time.  Each (ky, oy) pair re-reads
+    // its window row from LDS (4x redundant ds_read_b128; measured not to matter, see the header).
 #pragma unroll KY_UNROLL
     for (int ky = 0; ky < KS; ++ky) {
         float wrow[KS];
 #pragma unroll
-        for (int kx = 0; kx < KS; ++kx) wrow[kx] = wc[ky * KS + kx];          // wave-uniform -> scalar loads
+        for (int kx = 0; kx < KS; ++kx) wrow[kx] = wl[ky * KS + kx];          // uniform address: LDS broadcast
 #pragma unroll
         for (int oy = 0; oy < TY; ++oy) {
             float in[IN_V * 4];
@@ -121,7 +125,7 @@ extern "C" int sf_dwconv_res_gelu(const float* x, int64_t x_img_stride, const fl
     g.wp4 = (g.tiles_x * TX + ksize - 1 + 3) / 4;
     g.vec_store = ((w & 3) == 0) && ((y_img_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
     const int rows = g.strip_h + ksize - 1;
-    const size_t lds = ((size_t)rows * g.wp4 * 4 + 8) * sizeof(float);
+    const size_t lds = ((size_t)rows * g.wp4 * 4 + 8 + ksize * ksize + 8) * sizeof(float);
     SF_REQUIRE(lds <= 64 * 1024, "sf_dwconv_res_gelu: strip needs %zu bytes of LDS", lds);
     const int threads = ((tiles_y * g.tiles_x + 63) / 64) * 64;
     dim3 grid(n_img * C, sf::ceil_div(h, g.strip_h));

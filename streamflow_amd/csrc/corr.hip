@@ -16,6 +16,7 @@
 // emits the 81 taps per pixel with lanes running over PIXELS, so every output store is a 256-byte
 // run inside one of the 324 channel planes (NCHW output, no transposing copy as in the reference).
 #include "sf_common.h"
+#include "split_operand.h"
 
 namespace {
 
@@ -43,7 +44,65 @@ struct BuildArgs {
     int vec_a, vec_b;
 };
 
-__global__ __launch_bounds__(kThreads) void corr_build_kernel(const BuildArgs g) {
+// Epilogue shared by both arithmetic modes: scale, write level 0, pool levels 1..3 in registers.
+// acc[t][r]: target patch row t (0..7), MFMA C/D register r -> source pixel (r&3)+8*(r>>2)+4*(lane>>5) of the
+// wave's 32-pixel block, lane&31 = target patch column.
+__device__ __forceinline__ void pyramid_epilogue(const BuildArgs& g, f32x16 (&acc)[PR], int b, int pair, int m0, int wave,
+                                                 int py0, int px0, int lane) {
+    const int khalf = lane >> 5, l31 = lane & 31;
+    const int x = px0 + l31;
+    const int64_t P0 = (int64_t)g.hl[0] * g.wl[0], P1 = (int64_t)g.hl[1] * g.wl[1];
+    const int64_t P2 = (int64_t)g.hl[2] * g.wl[2], P3 = (int64_t)g.hl[3] * g.wl[3];
+    float* const L0 = g.lvl[0] + pair * g.lvl_pair_stride[0];
+    float* const L1 = g.lvl[1] + pair * g.lvl_pair_stride[1];
+    float* const L2 = g.lvl[2] + pair * g.lvl_pair_stride[2];
+    float* const L3 = g.lvl[3] + pair * g.lvl_pair_stride[3];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int i = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;     // source pixel (wave-half uniform)
+        const bool iok = i < g.N;
+        const int64_t row = (int64_t)b * g.N + i;
+        float v0[PR];
+#pragma unroll
+        for (int t = 0; t < PR; ++t) v0[t] = acc[t][r] * g.scale;
+        if (iok && x < g.wl[0]) {
+#pragma unroll
+            for (int t = 0; t < PR; ++t)
+                if (py0 + t < g.hl[0]) L0[row * P0 + (int64_t)(py0 + t) * g.wl[0] + x] = v0[t];
+        }
+        float v1[PR / 2];
+#pragma unroll
+        for (int t = 0; t < PR / 2; ++t) {
+            float s = v0[2 * t] + v0[2 * t + 1];
+            s += __shfl_xor(s, 1);
+            v1[t] = 0.25f * s;
+        }
+        if (iok && (l31 & 1) == 0 && (x >> 1) < g.wl[1]) {
+#pragma unroll
+            for (int t = 0; t < PR / 2; ++t)
+                if ((py0 >> 1) + t < g.hl[1]) L1[row * P1 + (int64_t)((py0 >> 1) + t) * g.wl[1] + (x >> 1)] = v1[t];
+        }
+        float v2[PR / 4];
+#pragma unroll
+        for (int t = 0; t < PR / 4; ++t) {
+            float s = v1[2 * t] + v1[2 * t + 1];
+            s += __shfl_xor(s, 2);
+            v2[t] = 0.25f * s;
+        }
+        if (iok && (l31 & 3) == 0 && (x >> 2) < g.wl[2]) {
+#pragma unroll
+            for (int t = 0; t < PR / 4; ++t)
+                if ((py0 >> 2) + t < g.hl[2]) L2[row * P2 + (int64_t)((py0 >> 2) + t) * g.wl[2] + (x >> 2)] = v2[t];
+        }
+        float s3 = v2[0] + v2[1];
+        s3 += __shfl_xor(s3, 4);
+        s3 *= 0.25f;
+        if (iok && (l31 & 7) == 0 && (x >> 3) < g.wl[3] && (py0 >> 3) < g.hl[3])
+            L3[row * P3 + (int64_t)(py0 >> 3) * g.wl[3] + (x >> 3)] = s3;
+    }
+}
+
+__global__ __launch_bounds__(kThreads, 2) void corr_build_kernel(const BuildArgs g) {
     __shared__ __attribute__((aligned(16))) float smem[2 * BK * (SA + SB)];
     float* sA = smem;
     float* sB = smem + 2 * BK * SA;
@@ -135,57 +194,84 @@ __global__ __launch_bounds__(kThreads) void corr_build_kernel(const BuildArgs g)
         __syncthreads();
     }
 
-    // ---- epilogue: scale, write level 0, pool levels 1..3 in registers ------------------------------
-    const int x = px0 + l31;
-    const int64_t P0 = (int64_t)g.hl[0] * g.wl[0], P1 = (int64_t)g.hl[1] * g.wl[1];
-    const int64_t P2 = (int64_t)g.hl[2] * g.wl[2], P3 = (int64_t)g.hl[3] * g.wl[3];
-    float* const L0 = g.lvl[0] + pair * g.lvl_pair_stride[0];
-    float* const L1 = g.lvl[1] + pair * g.lvl_pair_stride[1];
-    float* const L2 = g.lvl[2] + pair * g.lvl_pair_stride[2];
-    float* const L3 = g.lvl[3] + pair * g.lvl_pair_stride[3];
+    pyramid_epilogue(g, acc, b, pair, m0, wave, py0, px0, lane);
+}
+
+// ---- split-precision (f16x3) build: same tiling, operands staged as (hi, lo) f16 (see gemm_split.hip) -----
+// A = f1 [D][N] (rows of k, source pixels contiguous), B = f2 gathered as an 8x32 target patch.  Both are fp32
+// K-major sources split on the fly; rows k >= D are zeroed, source pixels / patch cells outside the image are
+// clamped (their products are never stored).  3 MFMAs of 32x32x16 per product instead of 8 of 32x32x2: the
+// kernel goes from fp32-MFMA-bound to (nearly) bound by the single write of the pyramid.
+__global__ __launch_bounds__(kThreads, 2) void corr_build_split_kernel(const BuildArgs g) {
+    using namespace sf_split;
+    __shared__ __attribute__((aligned(16))) _Float16 sA[2][BM * LDK];
+    __shared__ __attribute__((aligned(16))) _Float16 sB[2][BN * LDK];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int khalf = lane >> 5, l31 = lane & 31;
+    const int b = blockIdx.z / g.pairs, pair = blockIdx.z % g.pairs;
+    const int m0 = blockIdx.y * BM;
+    const int py0 = (blockIdx.x / g.pcols) * PR, px0 = (blockIdx.x % g.pcols) * PC;
+    const float* A = g.f1 + (int64_t)b * g.f_clip_stride + (int64_t)pair * g.f_pair_stride;
+    const float* Bm = g.f2 + (int64_t)b * g.f_clip_stride + (int64_t)pair * g.f_pair_stride;
+    const int64_t bytes = (int64_t)g.D * g.N * 4;
+
+    Operand<BM, SF_LAYOUT_K_MAJOR> opa;
+    Operand<BN, SF_LAYOUT_K_MAJOR> opb;
+    typename Operand<BM, SF_LAYOUT_K_MAJOR>::Regs ra;
+    typename Operand<BN, SF_LAYOUT_K_MAJOR>::Regs rb;
+    opa.init(A, nullptr, bytes, g.N, g.D, g.N, m0, 0, 0, tid);
+    opb.init(Bm, nullptr, bytes, g.N, g.D, g.N, 0, 0, 0, tid);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int i = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;     // source pixel (wave-half uniform)
-        const bool iok = i < g.N;
-        const int64_t row = (int64_t)b * g.N + i;
-        float v0[PR];
-#pragma unroll
-        for (int t = 0; t < PR; ++t) v0[t] = acc[t][r] * g.scale;
-        if (iok && x < g.wl[0]) {
-#pragma unroll
-            for (int t = 0; t < PR; ++t)
-                if (py0 + t < g.hl[0]) L0[row * P0 + (int64_t)(py0 + t) * g.wl[0] + x] = v0[t];
-        }
-        float v1[PR / 2];
-#pragma unroll
-        for (int t = 0; t < PR / 2; ++t) {
-            float s = v0[2 * t] + v0[2 * t + 1];
-            s += __shfl_xor(s, 1);
-            v1[t] = 0.25f * s;
-        }
-        if (iok && (l31 & 1) == 0 && (x >> 1) < g.wl[1]) {
-#pragma unroll
-            for (int t = 0; t < PR / 2; ++t)
-                if ((py0 >> 1) + t < g.hl[1]) L1[row * P1 + (int64_t)((py0 >> 1) + t) * g.wl[1] + (x >> 1)] = v1[t];
-        }
-        float v2[PR / 4];
-#pragma unroll
-        for (int t = 0; t < PR / 4; ++t) {
-            float s = v1[2 * t] + v1[2 * t + 1];
-            s += __shfl_xor(s, 2);
-            v2[t] = 0.25f * s;
-        }
-        if (iok && (l31 & 3) == 0 && (x >> 2) < g.wl[2]) {
-#pragma unroll
-            for (int t = 0; t < PR / 4; ++t)
-                if ((py0 >> 2) + t < g.hl[2]) L2[row * P2 + (int64_t)((py0 >> 2) + t) * g.wl[2] + (x >> 2)] = v2[t];
-        }
-        float s3 = v2[0] + v2[1];
-        s3 += __shfl_xor(s3, 4);
-        s3 *= 0.25f;
-        if (iok && (l31 & 7) == 0 && (x >> 3) < g.wl[3] && (py0 >> 3) < g.hl[3])
-            L3[row * P3 + (int64_t)(py0 >> 3) * g.wl[3] + (x >> 3)] = s3;
+    for (int j = 0; j < Operand<BN, SF_LAYOUT_K_MAJOR>::NI; ++j) {      // column n of the B tile = cell (n/32, n%32) of the patch
+        const int n = (tid + j * kThreads) % BN;
+        const int y = min(py0 + n / PC, g.h - 1), x = min(px0 + n % PC, g.w - 1);
+        opb.voff[j] = (y * g.w + x) * 4;
     }
+
+    f32x16 acc[PR];
+#pragma unroll
+    for (int t = 0; t < PR; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    const int nk = (g.D + BK - 1) / BK;
+    opa.load(0, 0, ra);
+    opb.load(0, 0, rb);
+    opa.store(0, sA[0], sA[1], ra);
+    opb.store(0, sB[0], sB[1], rb);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) {
+            opa.load((kt + 1) * BK, (kt + 1) * BK * g.N, ra);
+            opb.load((kt + 1) * BK, (kt + 1) * BK * g.N, rb);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const _Float16* pah = sA[0] + (wave * 32 + l31) * LDK + khalf * 8;
+        const _Float16* pal = sA[1] + (wave * 32 + l31) * LDK + khalf * 8;
+        const _Float16* pbh = sB[0] + l31 * LDK + khalf * 8;
+        const _Float16* pbl = sB[1] + l31 * LDK + khalf * 8;
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            const f16x8 ah = *reinterpret_cast<const f16x8*>(pah + ks * 16);
+            const f16x8 al = *reinterpret_cast<const f16x8*>(pal + ks * 16);
+#pragma unroll
+            for (int t = 0; t < PR; ++t) {
+                const f16x8 bh = *reinterpret_cast<const f16x8*>(pbh + t * PC * LDK + ks * 16);
+                const f16x8 bl = *reinterpret_cast<const f16x8*>(pbl + t * PC * LDK + ks * 16);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 1 < nk) {
+            __syncthreads();
+            opa.store((kt + 1) * BK, sA[0], sA[1], ra);
+            opb.store((kt + 1) * BK, sB[0], sB[1], rb);
+            __syncthreads();
+        }
+    }
+    pyramid_epilogue(g, acc, b, pair, m0, wave, py0, px0, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -296,7 +382,10 @@ extern "C" int sf_corr_build_pyramid(const float* f1, const float* f2, int64_t f
     SF_REQUIRE(B > 0 && pairs > 0 && D > 0 && h > 0 && w > 0, "sf_corr_build_pyramid: bad dims");
     SF_REQUIRE(pairs == 1 || lvl_pair_stride, "sf_corr_build_pyramid: pairs > 1 needs lvl_pair_stride");
     SF_REQUIRE(num_levels == 4, "sf_corr_build_pyramid: num_levels must be 4 (got %d)", num_levels);
-    SF_REQUIRE(precision == 0, "sf_corr_build_pyramid: precision %d not supported", precision);
+    SF_REQUIRE(precision == SF_PRECISION_FP32 || precision == SF_PRECISION_F16X3,
+               "sf_corr_build_pyramid: precision %d not supported", precision);
+    SF_REQUIRE(precision == SF_PRECISION_FP32 || (int64_t)D * h * w * 4 < ((int64_t)1 << 31),
+               "sf_corr_build_pyramid: feature image larger than 2 GiB");
     SF_REQUIRE((h >> 3) >= 1 && (w >> 3) >= 1, "sf_corr_build_pyramid: feature grid %dx%d too small for 4 levels", h, w);
     SF_REQUIRE((int64_t)B * pairs <= 65535, "sf_corr_build_pyramid: B*pairs too large");
     BuildArgs g;
@@ -315,7 +404,10 @@ extern "C" int sf_corr_build_pyramid(const float* f1, const float* f2, int64_t f
     g.vec_b = ((w & 3) == 0) && ((f_clip_stride & 3) == 0) && ((f_pair_stride & 3) == 0) &&
               ((reinterpret_cast<uintptr_t>(f2) & 15) == 0);
     dim3 grid(g.pcols * sf::ceil_div(h, PR), sf::ceil_div(g.N, BM), B * pairs);
-    hipLaunchKernelGGL(corr_build_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, g);
+    if (precision == SF_PRECISION_F16X3)
+        hipLaunchKernelGGL(corr_build_split_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, g);
+    else
+        hipLaunchKernelGGL(corr_build_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, g);
     return sf::check_launch("sf_corr_build_pyramid");
 }
 

@@ -1,0 +1,137 @@
+// Operand staging for the split-precision (f16x3) matrix-core kernels: buffer-load descriptors, the
+// fp32 -> (hi, lo) f16 split, and the LDS image layout.  Shared by gemm_split.hip and corr.hip.
+#pragma once
+#include "sf_common.h"
+
+namespace sf_split {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr int kThreads = 256;
+constexpr int BK = 32;                 // k-tile depth
+constexpr int LDK = BK + 8;            // LDS row stride in halfs (80 bytes)
+
+__device__ __forceinline__ float as_f(unsigned u) { return __builtin_bit_cast(float, u); }
+
+struct Split8 {
+    f16x8 hi, lo;
+};
+
+__device__ __forceinline__ Split8 split8(const float (&x)[8]) {
+    Split8 s;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const _Float16 h = (_Float16)x[i];
+        s.hi[i] = h;
+        s.lo[i] = (_Float16)(x[i] - (float)h);
+    }
+    return s;
+}
+
+// One operand (A or B) of the GEMM as seen by one thread.
+template <int BX, int LAY>
+struct Operand {
+    static constexpr int NI = (BX * (BK / 8) + kThreads - 1) / kThreads;   // (row, k-octet) items per thread
+    static constexpr bool kUniformKo = (LAY == SF_LAYOUT_K_MAJOR) && (BX % 64 == 0);
+    __amdgpu_buffer_rsrc_t rsrc, rsrc_lo;
+    int voff[NI];        // per-thread byte offset (constant over the k-loop)
+    int ko[NI];          // k-octet of the item
+    int lds_off[NI];     // destination offset in halfs
+    bool live[NI];
+    int K, ld, group;
+    int64_t group_stride;
+    struct Regs {                                  // one staged k-tile of this thread
+        float v[(LAY == 2) ? 1 : NI][8];
+        u32x4 ph[(LAY == 2) ? NI : 1], pl[(LAY == 2) ? NI : 1];
+    };
+
+    __device__ __forceinline__ void init(const void* base, const void* base_lo, int64_t bytes, int ld_, int K_, int X,
+                                         int x0, int group_, int64_t group_stride_, int tid) {
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+        rsrc_lo = rsrc;
+        if (LAY == 2) rsrc_lo = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base_lo), 0, (int)bytes, 0x00020000);
+        K = K_; ld = ld_; group = group_; group_stride = group_stride_;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int idx = tid + j * kThreads;
+            int xl, kq;
+            if (LAY == SF_LAYOUT_K_MAJOR) { xl = idx % BX; kq = idx / BX; }      // lanes walk x: coalesced rows
+            else { kq = idx % (BK / 8); xl = idx / (BK / 8); }                   // lanes walk k
+            live[j] = (BX * (BK / 8)) % kThreads == 0 || idx < BX * (BK / 8);
+            ko[j] = kUniformKo ? __builtin_amdgcn_readfirstlane(kq) : kq;
+            lds_off[j] = xl * LDK + kq * 8;
+            // rows/columns past the operand are clamped: they are loaded (harmlessly) but never stored
+            const int xc = (x0 + xl < X) ? x0 + xl : X - 1;
+            if (LAY == SF_LAYOUT_K_MAJOR) voff[j] = xc * 4;
+            else if (LAY == SF_LAYOUT_K_MINOR) voff[j] = (xc * ld + kq * 8) * 4;
+            else voff[j] = ((x0 + xl) * ld + kq * 8) * 2;       // host-padded to 128 rows: always in range
+        }
+    }
+
+    // Issue the raw loads of k-tile k0 (nothing is consumed here, so no wait is needed before the MFMAs).
+    // K-major rows: tile_off = element offset of row k0 (tracked incrementally by the caller for grouped
+    // operands); rows past K are clamped to the last valid row and zeroed in store().
+    __device__ __forceinline__ void load(int k0, int tile_off, Regs& rg) const {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            if (LAY == 2) {
+                rg.ph[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[j], k0 * 2, 0);
+                rg.pl[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_lo, voff[j], k0 * 2, 0);
+            } else if (LAY == SF_LAYOUT_K_MAJOR) {
+                const int kb = ko[j] * 8;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int over = k0 + kb + i - (K - 1);                 // > 0: row past the end
+                    const int r = (tile_off + (kb + i - (over > 0 ? over : 0)) * ld) * 4;
+                    if (kUniformKo) rg.v[j][i] = as_f(__builtin_amdgcn_raw_buffer_load_b32(rsrc, voff[j], r, 0));
+                    else rg.v[j][i] = as_f(__builtin_amdgcn_raw_buffer_load_b32(rsrc, voff[j] + r, 0, 0));
+                }
+            } else {
+                // k0 goes into the VGPR offset: soffset is excluded from the hardware range check, and the last
+                // k-octet of the last row may reach past the end of the buffer (then it reads as zero)
+                const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[j] + k0 * 4, 0, 0);
+                const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[j] + k0 * 4 + 16, 0, 0);
+                rg.v[j][0] = as_f(a[0]); rg.v[j][1] = as_f(a[1]); rg.v[j][2] = as_f(a[2]); rg.v[j][3] = as_f(a[3]);
+                rg.v[j][4] = as_f(b[0]); rg.v[j][5] = as_f(b[1]); rg.v[j][6] = as_f(b[2]); rg.v[j][7] = as_f(b[3]);
+            }
+        }
+    }
+
+    // Consume the staged tile (loaded for k-tile k0): zero rows k >= K, split into hi/lo f16, write to LDS.
+    __device__ __forceinline__ void store(int k0, _Float16* lds_hi, _Float16* lds_lo, Regs& rg) const {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            if (!live[j]) continue;
+            if (LAY == 2) {
+                *reinterpret_cast<u32x4*>(lds_hi + lds_off[j]) = rg.ph[j];
+                *reinterpret_cast<u32x4*>(lds_lo + lds_off[j]) = rg.pl[j];
+            } else {
+                if (k0 + BK > K) {          // last, partial k-tile (workgroup-uniform)
+                    const int k = k0 + ko[j] * 8;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) rg.v[j][i] = (k + i < K) ? rg.v[j][i] : 0.f;
+                }
+                const Split8 s8 = split8(rg.v[j]);
+                *reinterpret_cast<f16x8*>(lds_hi + lds_off[j]) = s8.hi;
+                *reinterpret_cast<f16x8*>(lds_lo + lds_off[j]) = s8.lo;
+            }
+        }
+    }
+};
+
+// element offset of K-major row k0 (start of a k-tile) for a possibly grouped operand; tiles never straddle
+// groups (group % 32 == 0 is checked on the host)
+struct RowCursor {
+    int group, ld, within, off;
+    int64_t group_stride;
+    __device__ __forceinline__ void init(int group_, int ld_, int64_t gs) { group = group_; ld = ld_; group_stride = gs; within = 0; off = 0; }
+    __device__ __forceinline__ void advance() {
+        if (group > 0) {
+            within += BK;
+            if (within >= group) { within = 0; off += (int)group_stride - (group - BK) * ld; }
+            else off += BK * ld;
+        } else off += BK * ld;
+    }
+};
+
+}  // namespace sf_split

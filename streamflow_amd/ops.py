@@ -303,7 +303,7 @@ def corr_build(f1_ptr: int, f2_ptr: int, clip_stride: int, pair_stride: int, lvl
     _launch("corr_build", 2.0 * N * N * D * B * pairs, nbytes, lambda: _lib.check(
         _lib.load().sf_corr_build_pyramid(
             f1_ptr, f2_ptr, clip_stride, pair_stride, lvls[0].data_ptr(), lvls[1].data_ptr(), lvls[2].data_ptr(),
-            lvls[3].data_ptr(), pair_strides(lvl_pair_stride), B, pairs, D, h, w, 4, 0, _lib.stream()),
+            lvls[3].data_ptr(), pair_strides(lvl_pair_stride), B, pairs, D, h, w, 4, PRECISION, _lib.stream()),
         "sf_corr_build_pyramid"))
 
 
