@@ -113,6 +113,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="sintel", choices=list(WORKLOADS))
+    ap.add_argument("--clips", type=int, default=1, help="clips per GPU per step (batched through every launch)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
     ap.add_argument("--all-masks", action="store_true",
                     help="run the mask head every iteration as the reference literally does (outputs identical; "
@@ -142,7 +143,7 @@ def main():
     from streamflow_amd.engine import HotPathEngine
 
     H, W, T, iters = WORKLOADS[args.workload]
-    h, w, B = H // 8, W // 8, 1
+    h, w, B = H // 8, W // 8, args.clips
     pairs = T - 1
     params = syn.make_params(0, T)
     fmaps_c, cnets_c = syn.make_features(1000 + rank, B, T, h, w)

@@ -123,7 +123,14 @@ typedef struct SfGemm {
     /* split-K (precision F16X3 only): the K range is cut into k_splits slices, slice s writes its partial
        product (epilogue must be SF_EPI_NONE, no bias) to C + s*split_stride; combine with sf_splitk_combine. */
     int32_t k_splits; int64_t split_stride;
+    /* optional scratch (caller-owned).  If given (>= auto_split_max * batch * M * N floats... see sf_gemm_split_ws_floats)
+       and k_splits == 0, the library may split K on its own for small grids with deep K (F16X3 only): partial
+       products go to the scratch and a second kernel applies bias / epilogue.  Results are deterministic. */
+    float* split_ws; int64_t split_ws_floats;
 } SfGemm;
+
+/* floats of scratch that let sf_gemm auto-split a problem of this size (0 if it never would) */
+int64_t sf_gemm_split_ws_floats(int M, int N, int K, int batch);
 
 int sf_gemm(const SfGemm* g, void* stream);
 

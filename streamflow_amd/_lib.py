@@ -35,6 +35,7 @@ class SfGemm(C.Structure):
         ("alpha", _f), ("epilogue", C.c_int32), ("precision", C.c_int32),
         ("A_hi", _vp), ("A_lo", _vp), ("lda_h", _i64), ("a_padded", C.c_int32),
         ("k_splits", C.c_int32), ("split_stride", _i64),
+        ("split_ws", _vp), ("split_ws_floats", _i64),
     ]
 
 
@@ -47,6 +48,7 @@ SIGNATURES = {
     "sf_corr_build_pyramid": (_i, [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, C.POINTER(_i64), _i, _i, _i, _i, _i, _i, _i, _vp]),
     "sf_corr_lookup": (_i, [_vp, _vp, _vp, _vp, C.POINTER(_i64), _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _vp]),
     "sf_gemm": (_i, [C.POINTER(SfGemm), _vp]),
+    "sf_gemm_split_ws_floats": (_i64, [_i, _i, _i, _i]),
     "sf_softmax_rows": (_i, [_vp, _i64, _i, _vp]),
     "sf_splitk_combine": (_i, [_vp, _i64, _i, _i64, _vp, _i64, _vp, _vp, _i64, _i, _i64, _vp]),
     "sf_dwconv_res_gelu": (_i, [_vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _vp]),

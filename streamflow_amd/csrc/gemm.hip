@@ -279,6 +279,11 @@ int pick_bm(const SfGemm& g) {
 
 namespace sf {
 int gemm_split_dispatch(const SfGemm& g, hipStream_t st);   // gemm_split.hip
+int64_t gemm_split_ws_floats(int M, int N, int K, int batch);
+}
+
+extern "C" int64_t sf_gemm_split_ws_floats(int M, int N, int K, int batch) {
+    return sf::gemm_split_ws_floats(M, N, K, batch);
 }
 
 extern "C" int sf_gemm(const SfGemm* gp, void* stream) {

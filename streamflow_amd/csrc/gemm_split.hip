@@ -307,14 +307,101 @@ int64_t span_bytes(int layout, int X, int K, int64_t ld, int group, int64_t grou
     return ((int64_t)(K - 1) * ld + X) * 4;
 }
 
+
+// ---- split-K combine with the full epilogue: C = epi(alpha * (sum_s partial_s + bias)) -----------------------------
+// partial slabs: [split][batch][M][N] (N contiguous).  One thread = 4 consecutive columns of one row.
+template <int EPI>
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const SfGemm g, const float* part, int ks, int64_t slab) {
+    constexpr bool kNeedsR = (EPI == SF_EPI_RES || EPI == SF_EPI_RES_GELU || EPI == SF_EPI_RES_GELU_DW1 ||
+                              EPI == SF_EPI_AXPY);
+    const int m = blockIdx.y, z = blockIdx.z;
+    const int n = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (n >= g.N) return;
+    const float* p = part + ((int64_t)z * g.M + m) * g.N + n;
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < ks; ++s) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (n + i < g.N) a[i] += p[(int64_t)s * slab + i];
+    }
+    const float bias = g.bias ? g.bias[m] : 0.f;
+    const float gam = (EPI == SF_EPI_AXPY) ? g.gamma[0] : 0.f;
+    const float dww = (EPI == SF_EPI_RES_GELU_DW1) ? g.dw_w[m] : 0.f, dwb = (EPI == SF_EPI_RES_GELU_DW1) ? g.dw_b[m] : 0.f;
+    const float* R = nullptr;
+    if (kNeedsR) {
+        const int64_t roff = (g.r_group > 0) ? (int64_t)(m / g.r_group) * g.r_group_stride + (int64_t)(m % g.r_group) * g.ldr
+                                             : (int64_t)m * g.ldr;
+        R = g.R + (int64_t)z * g.strideR + roff + n;
+    }
+    float* C = g.C + (int64_t)z * g.strideC + (int64_t)m * g.ldc + n;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (n + i < g.N) {
+            const float v = g.alpha * (a[i] + bias);
+            C[i] = sf::epi_apply<EPI>(v, kNeedsR ? R[i] : 0.f, dww, dwb, gam);
+        }
+    }
+}
+
+int launch_splitk_epilogue(const SfGemm& g, const float* part, int ks, int64_t slab, hipStream_t st) {
+    dim3 grid(sf::ceil_div(sf::ceil_div(g.N, 4), 256), g.M, g.batch), block(256);
+    switch (g.epilogue) {
+        case SF_EPI_GELU: hipLaunchKernelGGL(splitk_epilogue_kernel<SF_EPI_GELU>, grid, block, 0, st, g, part, ks, slab); break;
+        case SF_EPI_RELU: hipLaunchKernelGGL(splitk_epilogue_kernel<SF_EPI_RELU>, grid, block, 0, st, g, part, ks, slab); break;
+        case SF_EPI_RES: hipLaunchKernelGGL(splitk_epilogue_kernel<SF_EPI_RES>, grid, block, 0, st, g, part, ks, slab); break;
+        case SF_EPI_RES_GELU: hipLaunchKernelGGL(splitk_epilogue_kernel<SF_EPI_RES_GELU>, grid, block, 0, st, g, part, ks, slab); break;
+        case SF_EPI_RES_GELU_DW1: hipLaunchKernelGGL(splitk_epilogue_kernel<SF_EPI_RES_GELU_DW1>, grid, block, 0, st, g, part, ks, slab); break;
+        case SF_EPI_AXPY: hipLaunchKernelGGL(splitk_epilogue_kernel<SF_EPI_AXPY>, grid, block, 0, st, g, part, ks, slab); break;
+        default: hipLaunchKernelGGL(splitk_epilogue_kernel<SF_EPI_NONE>, grid, block, 0, st, g, part, ks, slab); break;
+    }
+    return sf::check_launch("sf_gemm(split-K epilogue)");
+}
+
+// automatic split-K policy: grids that cannot fill the 256 CUs while each workgroup walks a long K chain
+int auto_splits(int M, int N, int K, int batch) {
+    const int bm = (M > 64) ? 128 : (M > 32 ? 64 : 32);
+    const long wgs = (long)((M + bm - 1) / bm) * ((N + 127) / 128) * batch;
+    const int nk = (K + BK - 1) / BK;
+    if (wgs >= 96 || nk < 8) return 1;       // measured: for 165-workgroup grids the slab round trip eats the gain
+    int ks = (int)((512 + wgs - 1) / wgs);
+    if (ks > nk / 3) ks = nk / 3;
+    if (ks > 8) ks = 8;
+    return ks < 2 ? 1 : ks;
+}
+
 }  // namespace
 
 namespace sf {
 
 // called from sf_gemm (gemm.hip) when precision == SF_PRECISION_F16X3 (never for conv3x3)
+int64_t gemm_split_ws_floats(int M, int N, int K, int batch) {
+    const int ks = auto_splits(M, N, K, batch);
+    return ks > 1 ? (int64_t)ks * batch * M * N : 0;
+}
+
+int gemm_split_dispatch_inner(const SfGemm& g, hipStream_t st);
+
 int gemm_split_dispatch(const SfGemm& g, hipStream_t st) {
-    if (g.k_splits > 1 && (g.epilogue != SF_EPI_NONE || g.bias || g.b_group || g.k_splits > 16))
-        return fail(SF_ERR_BAD_ARG, "sf_gemm(f16x3): split-K needs SF_EPI_NONE, no bias, no grouping, k_splits <= 16");
+    // automatic split-K through caller-provided scratch
+    if (g.k_splits == 0 && g.split_ws) {
+        const int ks = auto_splits(g.M, g.N, g.K, g.batch);
+        const int64_t slab = (int64_t)g.batch * g.M * g.N;
+        if (ks > 1 && g.split_ws_floats >= ks * slab) {
+            SfGemm p = g;
+            p.C = g.split_ws; p.ldc = g.N; p.strideC = (int64_t)g.M * g.N;
+            p.bias = nullptr; p.R = nullptr; p.epilogue = SF_EPI_NONE; p.alpha = 1.0f;
+            p.k_splits = ks; p.split_stride = slab;
+            const int rc = gemm_split_dispatch_inner(p, st);
+            if (rc != SF_OK) return rc;
+            return launch_splitk_epilogue(g, g.split_ws, ks, slab, st);
+        }
+    }
+    return gemm_split_dispatch_inner(g, st);
+}
+
+int gemm_split_dispatch_inner(const SfGemm& g, hipStream_t st) {
+    if (g.k_splits > 1 && (g.epilogue != SF_EPI_NONE || g.bias || g.k_splits > 16))
+        return fail(SF_ERR_BAD_ARG, "sf_gemm(f16x3): split-K needs SF_EPI_NONE, no bias, k_splits <= 16");
     if (g.b_group % 32) return fail(SF_ERR_BAD_ARG, "sf_gemm(f16x3): b_group must be a multiple of 32");
     SplitArgs a;
     a.g = g;
@@ -342,7 +429,8 @@ int gemm_split_dispatch(const SfGemm& g, hipStream_t st) {
     }
     // deep-K problems gain from the wave-specialised kernel's 3-tile prefetch; shallow ones are dominated by
     // prologue/epilogue, where the single-role kernel (all waves store) is a little faster
-    if (padded(128) * 4 <= M * 5) return (g.K / (g.k_splits > 1 ? g.k_splits : 1) >= 768) ? launch_ws(a, st) : launch_cfg<2, 2, 2, 2>(a, st);
+    static const int ws_min_k = getenv("SF_WS_MINK") ? atoi(getenv("SF_WS_MINK")) : 768;
+    if (padded(128) * 4 <= M * 5) return (g.K / (g.k_splits > 1 ? g.k_splits : 1) >= ws_min_k) ? launch_ws(a, st) : launch_cfg<2, 2, 2, 2>(a, st);
     if (padded(64) * 4 <= M * 5 || M > 32) return launch_cfg<1, 4, 2, 1>(a, st);
     return launch_cfg<1, 4, 1, 1>(a, st);
 }

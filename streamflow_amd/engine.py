@@ -132,7 +132,8 @@ class _Plan:
                 ("delta", 2),                          # == [Bc][2*Pn][P]
                 ("m256", 256), ("mask", 576), ("coords1", 2),
                 ("hid2", 192), ("xa2", 128), ("xb2", 128),       # scratch of the flow branch (runs concurrently)
-                ("part", 128 * 4)]                                # split-K slabs of attn @ v: [4][n][128][P]
+                ("part", 128 * 4),                               # split-K slabs of attn @ v: [4][n][128][P]
+                ("splitws", 1024)]                                # scratch for sf_gemm's automatic split-K
         ws = Workspace(sum(n * r * P + 64 for _, r in spec), device)
         self.ws = ws
         for name, r in spec:
@@ -170,6 +171,7 @@ class HotPathEngine:
         # global aggregation) are enqueued on a second stream, so the tails of one chain's small kernels are
         # filled by the other; inside a captured graph these become parallel branches.
         self.parallel_branches = True
+        self.auto_split_k = os.environ.get("SF_AUTO_SPLITK", "1") != "0"
         self.attn_k_splits = min(4, int(os.environ.get("SF_ATTN_KSPLITS", "3")))     # 1 = no split-K (<= 4)
         self._side = torch.cuda.Stream(device=self.device)
         self.W = HotPathWeights(state_dict, self.device, T)
@@ -266,12 +268,14 @@ class HotPathEngine:
 
     def _run(self, pl: _Plan, fmaps: torch.Tensor, cnets: torch.Tensor, iters: int, all_masks: bool) -> None:
         prev = ops.set_precision(self.precision)
+        ops.SPLIT_WS = pl.splitws.tensor().view(-1) if self.auto_split_k else None
         try:
             self._setup(pl, fmaps, cnets)
             for it in range(iters):
                 self._iteration(pl, with_mask=all_masks or it == iters - 1)
         finally:
             ops.set_precision(prev)
+            ops.SPLIT_WS = None
         flow_t = pl.flow.tensor().view(pl.n, 2, pl.h, pl.w)
         mask_t = pl.mask.tensor().view(pl.n, 576, pl.h, pl.w)
         _lib.check(_lib.load().sf_upsample_flow(flow_t.data_ptr(), mask_t.data_ptr(), pl.up.data_ptr(), pl.n, pl.h,

@@ -67,6 +67,8 @@ class Profiler:
         return out
 
 
+SPLIT_WS: Optional[torch.Tensor] = None     # scratch that lets sf_gemm split K for small grids (set by the engine)
+
 PROFILER: Optional[Profiler] = None
 PROFILE_SHAPES = False      # tag GEMM launches with their shape in the profiler (bench.py --gemm-shapes)
 
@@ -200,6 +202,8 @@ def gemm(A: PackedLinear, X: Planes, Y: Planes, epilogue: int = EPI_NONE, R: Opt
     if A.conv3x3:
         g.conv3x3, g.h, g.w = 1, int(hw[0]), int(hw[1])
     g.alpha, g.epilogue, g.precision = float(alpha), int(epilogue), prec
+    if SPLIT_WS is not None and prec == PRECISION_F16X3:
+        g.split_ws, g.split_ws_floats = SPLIT_WS.data_ptr(), SPLIT_WS.numel()
     name = "gemm" if not PROFILE_SHAPES else f"gemm M{g.M} K{g.K} b{g.batch} e{g.epilogue}"
     _launch(name, 2.0 * g.M * g.N * g.K * g.batch, 0,
             lambda: _lib.check(_lib.load().sf_gemm(C.byref(g), _lib.stream()), "sf_gemm"))

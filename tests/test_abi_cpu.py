@@ -21,8 +21,8 @@ def lib():
 def test_every_declared_symbol_is_exported(lib):
     from streamflow_amd import _lib
     hdr = open(os.path.join(REPO, "include", "streamflow_hip.h")).read()
-    declared = set(re.findall(r"^\s*(?:int|const char\*)\s+(sf_\w+)\s*\(", hdr, flags=re.M))
-    assert len(declared) >= 15
+    declared = set(re.findall(r"^\s*(?:int|int64_t|const char\*)\s+(sf_\w+)\s*\(", hdr, flags=re.M))
+    assert len(declared) >= 16
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
     assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
@@ -32,7 +32,7 @@ def test_every_declared_symbol_is_exported(lib):
 def test_struct_layout_matches_header():
     from streamflow_amd._lib import SfGemm
     # 8 pointers + 4 i32 + 8 i64 + 2 i32 + (i32,pad,i64)*2 + 3 i32 + f32 + 2 i32  (natural alignment)
-    assert ctypes.sizeof(SfGemm) == 248
+    assert ctypes.sizeof(SfGemm) == 264
     assert SfGemm.lda.offset == 80 and SfGemm.b_group_stride.offset == 160 and SfGemm.alpha.offset == 196
 
 
