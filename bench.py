@@ -226,6 +226,17 @@ def main():
                                   "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                                   "frac": round((kern[dom]["gbps_algorithmic"] or 0) / PEAK_HBM_GBPS, 4),
                                   "traffic": None}
+        # HBM traffic of the dominant family from the committed rocprofv3 PMC pass (bench.py cannot run the profiler)
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+                tr = json.load(f)
+            fam = tr.get(result["roofline"]["kernel"])
+            if fam:
+                result["roofline"]["traffic"] = int((fam["fetch_kib_per_launch"] + fam["write_kib_per_launch"]) * 1024)
+                result["roofline"]["traffic_note"] = ("mean FETCH_SIZE+WRITE_SIZE per launch, rocprofv3 --pmc, "
+                                                      "profiles/r01_b_pmc_hbm_traffic.md (FETCH_SIZE uncorrected)")
+        except (OSError, KeyError, ValueError):
+            pass
         # north-star sub-metric: corr build + lookup against the HBM roofline (algorithmic bytes)
         cb, cl = kern.get("corr_build"), kern.get("corr_lookup")
         if cb and cl:
@@ -248,6 +259,25 @@ def main():
         result["epe_vs_oracle"] = {"value": max(orc.epe(a.cpu(), b) for a, b in zip(ups_gpu, ups_cpu)),
                                    "unit": "px", "iters": sample_iters,
                                    "note": "max over the 3 pairs of mean EPE, HIP path vs CPU oracle, full shape"}
+
+    if rank == 0 and world == 1 and args.clips == 1 and not args.no_kernel_breakdown:
+        # throughput with 4 clips batched through every launch (fills the GPU better; same kernels, same results)
+        try:
+            B4 = 4
+            f4, c4 = syn.make_features(2000, B4, T, h, w)
+            f4, c4 = f4.to(dev), c4.to(dev)
+            for _ in range(2):
+                eng.forward(f4, c4, iters=iters, all_masks=args.all_masks)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                eng.forward(f4, c4, iters=iters, all_masks=args.all_masks)
+            torch.cuda.synchronize()
+            dt4 = (time.perf_counter() - t0) / 5
+            result["batched"] = {"clips_per_step": B4, "value": B4 * pairs / dt4, "unit": "flow-fields/s",
+                                 "ms_per_step": 1e3 * dt4}
+        except RuntimeError as e:                      # e.g. out of memory on a smaller part
+            result["batched"] = {"error": str(e)[:200]}
 
     if rank == 0:
         print(json.dumps(result))
