@@ -118,7 +118,7 @@ def main():
     ap.add_argument("--all-masks", action="store_true",
                     help="run the mask head every iteration as the reference literally does (outputs identical; "
                          "the default skips the 14 mask heads whose results test_mode discards)")
-    ap.add_argument("--precision", default="f16x3", choices=["f16x3", "fp32"],
+    ap.add_argument("--precision", default="f16x3", choices=["f16x3", "fp32", "f16x2"],
                     help="f16x3: split-fp16 MFMA with fp32 accumulation (fp32-class accuracy); fp32: exact fp32 MFMA")
     ap.add_argument("--gemm-shapes", action="store_true", help="per-shape GEMM rows in the kernel table")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -175,12 +175,14 @@ def main():
         "metric": "flow_fields_per_sec", "value": fields / dt, "unit": "flow-fields/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "fp32" if args.precision == "fp32" else "f16x3-split (fp32 accumulate)", "data": "synthetic",
+        "dtype": {"fp32": "fp32", "f16x3": "f16x3-split (fp32 accumulate)",
+                  "f16x2": "f16x2 (weights hi+lo, activations fp16; fp32 accumulate)"}[args.precision], "data": "synthetic",
         "config": {"workload": f"{args.workload}_{H}x{W}_T{T}_iters{iters}", "clips_per_gpu_per_step": B,
                    "flow_fields_per_clip": pairs, "feature_grid": [h, w], "parallelism": f"replicas{world}",
                    "hip_graph": not args.no_graph, "mask_head_every_iteration": bool(args.all_masks),
-                   "precision": ("exact fp32 (v_mfma_f32_32x32x2_f32)" if args.precision == "fp32" else
-                                 "split fp16x3 (x=hi+lo, 3x v_mfma_f32_32x32x16_f16, fp32 accumulate)")},
+                   "precision": {"fp32": "exact fp32 (v_mfma_f32_32x32x2_f32)",
+                                 "f16x3": "split fp16x3 (x=hi+lo, 3x v_mfma_f32_32x32x16_f16, fp32 accumulate)",
+                                 "f16x2": "weights hi+lo fp16, activations fp16 (2x v_mfma_f32_32x32x16_f16)"}[args.precision]},
     }
 
     if rank == 0 and not args.no_kernel_breakdown:
@@ -215,7 +217,8 @@ def main():
         if kern[dom]["tflops"] and dom.startswith("gemm"):
             # algorithmic (fp32-equivalent) TFLOP/s; the f16x3 path issues 3 f16 MFMA flops per algorithmic flop,
             # so its matrix-core roof for algorithmic flops is 2500/3
-            peak = PEAK_FP32_MFMA_TFLOPS if args.precision == "fp32" else PEAK_F16_MFMA_TFLOPS / 3.0
+            peak = {"fp32": PEAK_FP32_MFMA_TFLOPS, "f16x3": PEAK_F16_MFMA_TFLOPS / 3.0,
+                    "f16x2": PEAK_F16_MFMA_TFLOPS / 2.0}[args.precision]
             result["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": kern[dom]["tflops"],
                                   "peak": round(peak, 1), "unit": "TFLOP/s",
                                   "frac": round(kern[dom]["tflops"] / peak, 4), "traffic": None,

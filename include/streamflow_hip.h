@@ -88,8 +88,10 @@ enum { SF_LAYOUT_K_MAJOR = 0,   /* A[k*lda + m]   /  B[k*ldb + n]   (rows of k) 
                                     matrices A_hi/A_lo [M padded to 128][K padded to 32] (zero padded),
                                     element (m,k) at m*lda_h + k, with w = hi + lo to ~22 bits         */
 enum { SF_PRECISION_FP32 = 0,   /* exact fp32: v_mfma_f32_32x32x2_f32, k-ordered fmaf chain          */
-       SF_PRECISION_F16X3 = 1 };/* split precision: x = hi+lo (fp16 each); a*b = ah*bh + ah*bl + al*bh
+       SF_PRECISION_F16X3 = 1,  /* split precision: x = hi+lo (fp16 each); a*b = ah*bh + ah*bl + al*bh
                                     on v_mfma_f32_32x32x16_f16 with fp32 accumulation (~2^-22 relative)  */
+       SF_PRECISION_F16X2 = 2 };/* A (weights) split hi+lo, B (activations) rounded once to fp16:
+                                    a*b = ah*b + al*b, 2 MFMAs; error = the fp16 rounding of B (2^-11 rel.) */
 enum { SF_EPI_NONE = 0,         /* C = v                              v = alpha*(acc+bias)   */
        SF_EPI_GELU = 1,         /* C = gelu(v)                        exact erf GELU         */
        SF_EPI_RELU = 2,         /* C = max(v,0)                                              */

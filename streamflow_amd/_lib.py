@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libstreamflow_hip.so")
 
 LAYOUT_K_MAJOR, LAYOUT_K_MINOR, LAYOUT_SPLIT_F16 = 0, 1, 2
-PRECISION_FP32, PRECISION_F16X3 = 0, 1
+PRECISION_FP32, PRECISION_F16X3, PRECISION_F16X2 = 0, 1, 2
 EPI_NONE, EPI_GELU, EPI_RELU, EPI_RES, EPI_RES_GELU, EPI_RES_GELU_DW1, EPI_AXPY = range(7)
 
 _vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float

@@ -294,10 +294,10 @@ extern "C" int sf_gemm(const SfGemm* gp, void* stream) {
     SF_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0 && g.batch > 0, "sf_gemm: bad dims M=%d N=%d K=%d batch=%d", g.M, g.N,
                g.K, g.batch);
     SF_REQUIRE(g.a_layout >= 0 && g.a_layout <= 2 && g.b_layout >= 0 && g.b_layout <= 1, "sf_gemm: bad layout");
-    SF_REQUIRE(g.a_layout != SF_LAYOUT_SPLIT_F16 || g.precision == SF_PRECISION_F16X3,
+    SF_REQUIRE(g.a_layout != SF_LAYOUT_SPLIT_F16 || g.precision != SF_PRECISION_FP32,
                "sf_gemm: SPLIT_F16 weights need precision F16X3");
     SF_REQUIRE(g.epilogue >= SF_EPI_NONE && g.epilogue <= SF_EPI_AXPY, "sf_gemm: bad epilogue %d", g.epilogue);
-    SF_REQUIRE(g.precision == SF_PRECISION_FP32 || g.precision == SF_PRECISION_F16X3,
+    SF_REQUIRE(g.precision >= SF_PRECISION_FP32 && g.precision <= SF_PRECISION_F16X2,
                "sf_gemm: precision %d not supported", g.precision);
     if (g.epilogue == SF_EPI_RES || g.epilogue == SF_EPI_RES_GELU || g.epilogue == SF_EPI_RES_GELU_DW1 ||
         g.epilogue == SF_EPI_AXPY)
@@ -309,10 +309,10 @@ extern "C" int sf_gemm(const SfGemm* gp, void* stream) {
         SF_REQUIRE(g.K % 9 == 0 && g.h > 0 && g.w > 0 && g.h * g.w == g.N, "sf_gemm: conv3x3 needs K=9*Cin, h*w=N");
     }
     if (g.b_group) SF_REQUIRE(g.b_layout == SF_LAYOUT_K_MAJOR, "sf_gemm: b_group needs a K-major B");
-    SF_REQUIRE(g.k_splits <= 1 || g.precision == SF_PRECISION_F16X3, "sf_gemm: split-K is only built for SF_PRECISION_F16X3");
+    SF_REQUIRE(g.k_splits <= 1 || g.precision != SF_PRECISION_FP32, "sf_gemm: split-K is only built for the split-precision modes");
     SF_REQUIRE(sf::epilogue_spans_ok(g), "sf_gemm: C / R image larger than 1 GiB (32-bit buffer offsets in the epilogue)");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (g.precision == SF_PRECISION_F16X3) {
+    if (g.precision != SF_PRECISION_FP32) {
         SF_REQUIRE(!g.conv3x3, "sf_gemm: conv3x3 is only built for SF_PRECISION_FP32");
         return sf::gemm_split_dispatch(g, st);
     }

@@ -38,14 +38,14 @@ struct SplitArgs {
                                    // 2 no MFMAs, 4 no convert/LDS stores in the loop
 };
 
-template <int WM, int WN, int TM, int TN, int ALAY, int BLAY>
+template <int WM, int WN, int TM, int TN, int ALAY, int BLAY, bool SB>
 __global__ __launch_bounds__(kThreads, 3) void gemm_f16x3_mfma(const SplitArgs args) {
     const SfGemm& g = args.g;
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     static_assert(WM * WN == 4, "4 waves per workgroup");
     // [hi|lo][rows][LDK]; ONE LDS stage (the next tile waits in registers), so 3 workgroups fit per CU
     __shared__ __attribute__((aligned(16))) _Float16 sA[2][BM * LDK];
-    __shared__ __attribute__((aligned(16))) _Float16 sB[2][BN * LDK];
+    __shared__ __attribute__((aligned(16))) _Float16 sB[SB ? 2 : 1][BN * LDK];       // SB = false: B has no lo part
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_f16x3_mfma(const SplitArgs a
     opa.load(kt_beg * BK, ca.off, ra);
     opb.load(kt_beg * BK, cb.off, rb);
     opa.store(kt_beg * BK, sA[0], sA[1], ra);
-    opb.store(kt_beg * BK, sB[0], sB[1], rb);
+    opb.template store<SB>(kt_beg * BK, sB[0], sB[SB ? 1 : 0], rb);
     __syncthreads();
 
     const int khalf = lane >> 5, l31 = lane & 31;
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_f16x3_mfma(const SplitArgs a
         const _Float16* pah = sA[0] + (wm * TM * 32 + l31) * LDK + khalf * 8;
         const _Float16* pal = sA[1] + (wm * TM * 32 + l31) * LDK + khalf * 8;
         const _Float16* pbh = sB[0] + (wn * TN * 32 + l31) * LDK + khalf * 8;
-        const _Float16* pbl = sB[1] + (wn * TN * 32 + l31) * LDK + khalf * 8;
+        const _Float16* pbl = sB[SB ? 1 : 0] + (wn * TN * 32 + l31) * LDK + khalf * 8;
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
             f16x8 ah[TM], al[TM], bh[TN], bl[TN];
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_f16x3_mfma(const SplitArgs a
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 bh[j] = *reinterpret_cast<const f16x8*>(pbh + j * 32 * LDK + ks * 16);
-                bl[j] = *reinterpret_cast<const f16x8*>(pbl + j * 32 * LDK + ks * 16);
+                if (SB) bl[j] = *reinterpret_cast<const f16x8*>(pbl + j * 32 * LDK + ks * 16);
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_f16x3_mfma(const SplitArgs a
                 for (int j = 0; j < TN; ++j) {
                     // small terms first, so the dominant hi*hi product is added to an already-formed correction
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    if (SB) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                 }
         }
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_f16x3_mfma(const SplitArgs a
         if (kt + 1 < kt_end) {
             __syncthreads();                       // every wave is done reading tile kt
             opa.store((kt + 1) * BK, sA[0], sA[1], ra);
-            opb.store((kt + 1) * BK, sB[0], sB[1], rb);
+            opb.template store<SB>((kt + 1) * BK, sB[0], sB[SB ? 1 : 0], rb);
             __syncthreads();
         }
     }
@@ -149,12 +149,12 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_f16x3_mfma(const SplitArgs a
 constexpr int kWsThreads = 512;
 constexpr int kDepth = 3;
 
-template <int ALAY, int BLAY>
+template <int ALAY, int BLAY, bool SB>
 __global__ __launch_bounds__(kWsThreads, 4) void gemm_f16x3_ws(const SplitArgs args) {
     const SfGemm& g = args.g;
     constexpr int BM = 128, BN = 128, TM = 2, TN = 2, WN = 2;
     __shared__ __attribute__((aligned(16))) _Float16 sA[2][2][BM * LDK];     // [stage][hi|lo][rows][LDK]
-    __shared__ __attribute__((aligned(16))) _Float16 sB[2][2][BN * LDK];
+    __shared__ __attribute__((aligned(16))) _Float16 sB[2][SB ? 2 : 1][BN * LDK];
 
     const int tid = threadIdx.x;
     const bool producer = tid >= kThreads;              // wave-uniform (waves 4..7)
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(kWsThreads, 4) void gemm_f16x3_ws(const SplitArgs a
             }
         }
         opa.store(kt_beg * BK, sA[0][0], sA[0][1], ra[0]);
-        opb.store(kt_beg * BK, sB[0][0], sB[0][1], rb[0]);
+        opb.template store<SB>(kt_beg * BK, sB[0][0], sB[0][SB ? 1 : 0], rb[0]);
         __syncthreads();
         for (int base = 0; base < nk; base += kDepth) {
 #pragma unroll
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(kWsThreads, 4) void gemm_f16x3_ws(const SplitArgs a
                         constexpr int kNextSet[3] = {1, 2, 0};
                         const int st = (t + 1) & 1;
                         opa.store((kt_beg + t + 1) * BK, sA[st][0], sA[st][1], ra[kNextSet[u]]);
-                        opb.store((kt_beg + t + 1) * BK, sB[st][0], sB[st][1], rb[kNextSet[u]]);
+                        opb.template store<SB>((kt_beg + t + 1) * BK, sB[st][0], sB[st][SB ? 1 : 0], rb[kNextSet[u]]);
                     }
                     __syncthreads();
                 }
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(kWsThreads, 4) void gemm_f16x3_ws(const SplitArgs a
         const _Float16* pah = sA[st][0] + (wm * TM * 32 + l31) * LDK + khalf * 8;
         const _Float16* pal = sA[st][1] + (wm * TM * 32 + l31) * LDK + khalf * 8;
         const _Float16* pbh = sB[st][0] + (wn * TN * 32 + l31) * LDK + khalf * 8;
-        const _Float16* pbl = sB[st][1] + (wn * TN * 32 + l31) * LDK + khalf * 8;
+        const _Float16* pbl = sB[st][SB ? 1 : 0] + (wn * TN * 32 + l31) * LDK + khalf * 8;
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
             f16x8 ah[TM], al[TM], bh[TN], bl[TN];
@@ -249,14 +249,14 @@ __global__ __launch_bounds__(kWsThreads, 4) void gemm_f16x3_ws(const SplitArgs a
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 bh[j] = *reinterpret_cast<const f16x8*>(pbh + j * 32 * LDK + ks * 16);
-                bl[j] = *reinterpret_cast<const f16x8*>(pbl + j * 32 * LDK + ks * 16);
+                if (SB) bl[j] = *reinterpret_cast<const f16x8*>(pbl + j * 32 * LDK + ks * 16);
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    if (SB) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                 }
         }
@@ -271,34 +271,59 @@ __global__ __launch_bounds__(kWsThreads, 4) void gemm_f16x3_ws(const SplitArgs a
     }
 }
 
+template <bool SB>
 int launch_ws(const SplitArgs& a, hipStream_t st) {
     const SfGemm& g = a.g;
     dim3 grid(sf::ceil_div(g.N, 128) * sf::ceil_div(g.M, 128) * g.batch * (g.k_splits > 1 ? g.k_splits : 1));
     const int lay = g.a_layout * 2 + g.b_layout;
     switch (lay) {
-        case 0: hipLaunchKernelGGL((gemm_f16x3_ws<0, 0>), grid, dim3(kWsThreads), 0, st, a); break;
-        case 3: hipLaunchKernelGGL((gemm_f16x3_ws<1, 1>), grid, dim3(kWsThreads), 0, st, a); break;
-        case 4: hipLaunchKernelGGL((gemm_f16x3_ws<2, 0>), grid, dim3(kWsThreads), 0, st, a); break;
+        case 0: hipLaunchKernelGGL((gemm_f16x3_ws<0, 0, SB>), grid, dim3(kWsThreads), 0, st, a); break;
+        case 3: hipLaunchKernelGGL((gemm_f16x3_ws<1, 1, SB>), grid, dim3(kWsThreads), 0, st, a); break;
+        case 4: hipLaunchKernelGGL((gemm_f16x3_ws<2, 0, SB>), grid, dim3(kWsThreads), 0, st, a); break;
         default: return sf::fail(SF_ERR_UNSUPPORTED, "sf_gemm(f16x3): layout combination a=%d b=%d not built",
                                  g.a_layout, g.b_layout);
     }
     return sf::check_launch("sf_gemm(f16x3, wave-specialised)");
 }
 
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, bool SB>
 int launch_cfg(const SplitArgs& a, hipStream_t st) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     const SfGemm& g = a.g;
     dim3 grid(sf::ceil_div(g.N, BN) * sf::ceil_div(g.M, BM) * g.batch * (g.k_splits > 1 ? g.k_splits : 1));   // 1-D: see sf::xcd_tile
     const int lay = g.a_layout * 2 + g.b_layout;
     switch (lay) {
-        case 0: hipLaunchKernelGGL((gemm_f16x3_mfma<WM, WN, TM, TN, 0, 0>), grid, dim3(kThreads), 0, st, a); break;
-        case 3: hipLaunchKernelGGL((gemm_f16x3_mfma<WM, WN, TM, TN, 1, 1>), grid, dim3(kThreads), 0, st, a); break;
-        case 4: hipLaunchKernelGGL((gemm_f16x3_mfma<WM, WN, TM, TN, 2, 0>), grid, dim3(kThreads), 0, st, a); break;
+        case 0: hipLaunchKernelGGL((gemm_f16x3_mfma<WM, WN, TM, TN, 0, 0, SB>), grid, dim3(kThreads), 0, st, a); break;
+        case 3: hipLaunchKernelGGL((gemm_f16x3_mfma<WM, WN, TM, TN, 1, 1, SB>), grid, dim3(kThreads), 0, st, a); break;
+        case 4: hipLaunchKernelGGL((gemm_f16x3_mfma<WM, WN, TM, TN, 2, 0, SB>), grid, dim3(kThreads), 0, st, a); break;
         default: return sf::fail(SF_ERR_UNSUPPORTED, "sf_gemm(f16x3): layout combination a=%d b=%d not built",
                                  g.a_layout, g.b_layout);
     }
     return sf::check_launch("sf_gemm(f16x3)");
+}
+
+
+template <bool SB>
+int pick_tile(const SplitArgs& a, hipStream_t st) {
+    const SfGemm& g = a.g;
+    // tile choice: the 128-row tile moves the fewest bytes per MAC; drop to 64/32 rows when padding M would
+    // waste more than a quarter of the MFMAs
+    const int M = g.M;
+    auto padded = [&](int bm) { return (M + bm - 1) / bm * bm; };
+    if (const char* e = getenv("SF_GEMM_BM")) {          // experiment knob
+        const int bm = atoi(e);
+        if (bm == 128) return launch_cfg<2, 2, 2, 2, SB>(a, st);
+        if (bm == 129) return launch_ws<SB>(a, st);
+        if (bm == 64) return launch_cfg<1, 4, 2, 1, SB>(a, st);
+        if (bm == 32) return launch_cfg<1, 4, 1, 1, SB>(a, st);
+    }
+    // deep-K problems gain from the wave-specialised kernel's 3-tile prefetch; shallow ones are dominated by
+    // prologue/epilogue, where the single-role kernel (all waves store) is a little faster
+    static const int ws_min_k = getenv("SF_WS_MINK") ? atoi(getenv("SF_WS_MINK")) : 768;
+    if (padded(128) * 4 <= M * 5)
+        return (g.K / (g.k_splits > 1 ? g.k_splits : 1) >= ws_min_k) ? launch_ws<SB>(a, st) : launch_cfg<2, 2, 2, 2, SB>(a, st);
+    if (padded(64) * 4 <= M * 5 || M > 32) return launch_cfg<1, 4, 2, 1, SB>(a, st);
+    return launch_cfg<1, 4, 1, 1, SB>(a, st);
 }
 
 int64_t span_bytes(int layout, int X, int K, int64_t ld, int group, int64_t group_stride) {
@@ -418,21 +443,7 @@ int gemm_split_dispatch_inner(const SfGemm& g, hipStream_t st) {
         return fail(SF_ERR_UNSUPPORTED, "sf_gemm(f16x3): operand image larger than 2 GiB (32-bit buffer offsets)");
     // tile choice: the 128-row tile moves the fewest bytes per MAC; drop to 64/32 rows when padding M would
     // waste more than a quarter of the MFMAs
-    const int M = g.M;
-    auto padded = [&](int bm) { return (M + bm - 1) / bm * bm; };
-    if (const char* e = getenv("SF_GEMM_BM")) {          // experiment knob
-        const int bm = atoi(e);
-        if (bm == 128) return launch_cfg<2, 2, 2, 2>(a, st);
-        if (bm == 129) return launch_ws(a, st);
-        if (bm == 64) return launch_cfg<1, 4, 2, 1>(a, st);
-        if (bm == 32) return launch_cfg<1, 4, 1, 1>(a, st);
-    }
-    // deep-K problems gain from the wave-specialised kernel's 3-tile prefetch; shallow ones are dominated by
-    // prologue/epilogue, where the single-role kernel (all waves store) is a little faster
-    static const int ws_min_k = getenv("SF_WS_MINK") ? atoi(getenv("SF_WS_MINK")) : 768;
-    if (padded(128) * 4 <= M * 5) return (g.K / (g.k_splits > 1 ? g.k_splits : 1) >= ws_min_k) ? launch_ws(a, st) : launch_cfg<2, 2, 2, 2>(a, st);
-    if (padded(64) * 4 <= M * 5 || M > 32) return launch_cfg<1, 4, 2, 1>(a, st);
-    return launch_cfg<1, 4, 1, 1>(a, st);
+    return (g.precision == SF_PRECISION_F16X2) ? pick_tile<false>(a, st) : pick_tile<true>(a, st);
 }
 
 }  // namespace sf

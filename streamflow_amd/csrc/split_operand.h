@@ -98,22 +98,31 @@ struct Operand {
     }
 
     // Consume the staged tile (loaded for k-tile k0): zero rows k >= K, split into hi/lo f16, write to LDS.
+    // kLo = false: keep only the fp16 rounding of the values (SF_PRECISION_F16X2's B operand)
+    template <bool kLo = true>
     __device__ __forceinline__ void store(int k0, _Float16* lds_hi, _Float16* lds_lo, Regs& rg) const {
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
             if (!live[j]) continue;
             if (LAY == 2) {
                 *reinterpret_cast<u32x4*>(lds_hi + lds_off[j]) = rg.ph[j];
-                *reinterpret_cast<u32x4*>(lds_lo + lds_off[j]) = rg.pl[j];
+                if (kLo) *reinterpret_cast<u32x4*>(lds_lo + lds_off[j]) = rg.pl[j];
             } else {
                 if (k0 + BK > K) {          // last, partial k-tile (workgroup-uniform)
                     const int k = k0 + ko[j] * 8;
 #pragma unroll
                     for (int i = 0; i < 8; ++i) rg.v[j][i] = (k + i < K) ? rg.v[j][i] : 0.f;
                 }
-                const Split8 s8 = split8(rg.v[j]);
-                *reinterpret_cast<f16x8*>(lds_hi + lds_off[j]) = s8.hi;
-                *reinterpret_cast<f16x8*>(lds_lo + lds_off[j]) = s8.lo;
+                if (kLo) {
+                    const Split8 s8 = split8(rg.v[j]);
+                    *reinterpret_cast<f16x8*>(lds_hi + lds_off[j]) = s8.hi;
+                    *reinterpret_cast<f16x8*>(lds_lo + lds_off[j]) = s8.lo;
+                } else {
+                    f16x8 h;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) h[i] = (_Float16)rg.v[j][i];
+                    *reinterpret_cast<f16x8*>(lds_hi + lds_off[j]) = h;
+                }
             }
         }
     }

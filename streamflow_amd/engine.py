@@ -160,7 +160,8 @@ class HotPathEngine:
 
     def __init__(self, state_dict: Dict[str, torch.Tensor], device="cuda:0", T: Optional[int] = None,
                  use_graph: bool = False, precision: Optional[str] = None):
-        """precision: 'f16x3' (split fp16, fp32-class accuracy, default) or 'fp32' (exact fp32 MFMA);
+        """precision: 'f16x3' (split fp16, fp32-class accuracy, default), 'fp32' (exact fp32 MFMA) or 'f16x2'
+        (weights split, activations rounded to fp16: ~1e-4 px EPE, faster);
         None = the package-wide setting (streamflow_amd.ops.PRECISION)."""
         _lib.load()
         self.precision = ops.PRECISION if precision is None else ops._PRECISION_NAMES[precision]
@@ -241,7 +242,7 @@ class HotPathEngine:
             ops.gemm(W.fc2, pl.h256, pl.mft, EPI_RES, R=pl.tx128)
         # a7: global aggregation  mfg = mf + gamma * attn @ to_v(mf)   (gma.py:91-104), main stream
         ops.gemm(W.to_v, pl.mf, pl.v128, EPI_NONE)
-        ks = self.attn_k_splits if self.precision == ops.PRECISION_F16X3 else 1
+        ks = self.attn_k_splits if self.precision != ops.PRECISION_FP32 else 1
         if ks > 1 and P % 4 == 0:
             # attn @ v streams the N x N matrix (HBM-bound) but has only N/128 * images workgroups: split K so that
             # enough bytes are in flight; partial products go to slabs, combined with the AXPY of gma.py:102

@@ -15,21 +15,24 @@ import torch
 
 from . import _lib
 from ._lib import (EPI_AXPY, EPI_GELU, EPI_NONE, EPI_RELU, EPI_RES, EPI_RES_GELU, EPI_RES_GELU_DW1,  # noqa: F401
-                   LAYOUT_K_MAJOR, LAYOUT_K_MINOR, LAYOUT_SPLIT_F16, PRECISION_F16X3, PRECISION_FP32, SfGemm)
+                   LAYOUT_K_MAJOR, LAYOUT_K_MINOR, LAYOUT_SPLIT_F16, PRECISION_F16X2, PRECISION_F16X3, PRECISION_FP32,
+                   SfGemm)
 
 # Arithmetic mode of every GEMM-shaped op (sf_gemm, corr build):
 #   PRECISION_FP32  exact fp32 on v_mfma_f32_32x32x2_f32
 #   PRECISION_F16X3 split precision (x = hi + lo in fp16, 3 MFMAs per product, fp32 accumulate; ~2^-22 relative)
+#   PRECISION_F16X2 weights split hi + lo, activations rounded once to fp16 (2 MFMAs per product; 2^-11 relative on
+#                   the activations: ~1e-4 px EPE on the flows, opt-in)
 PRECISION = PRECISION_F16X3
-_PRECISION_NAMES = {"fp32": PRECISION_FP32, "f16x3": PRECISION_F16X3}
+_PRECISION_NAMES = {"fp32": PRECISION_FP32, "f16x3": PRECISION_F16X3, "f16x2": PRECISION_F16X2}
 
 
 def set_precision(mode) -> int:
-    """mode: 'fp32' | 'f16x3' (or the integer constants).  Returns the previous mode."""
+    """mode: 'fp32' | 'f16x3' | 'f16x2' (or the integer constants).  Returns the previous mode."""
     global PRECISION
     prev = PRECISION
     PRECISION = _PRECISION_NAMES[mode] if isinstance(mode, str) else int(mode)
-    if PRECISION not in (PRECISION_FP32, PRECISION_F16X3):
+    if PRECISION not in (PRECISION_FP32, PRECISION_F16X3, PRECISION_F16X2):
         PRECISION = prev
         raise RuntimeError(f"unknown precision {mode}")
     return prev
@@ -189,7 +192,7 @@ def gemm(A: PackedLinear, X: Planes, Y: Planes, epilogue: int = EPI_NONE, R: Opt
     g.a_layout, g.b_layout = LAYOUT_K_MAJOR, LAYOUT_K_MAJOR
     g.a_padded = 1
     prec = PRECISION_FP32 if A.conv3x3 else PRECISION     # the implicit 3x3 gather is only built for the fp32 kernel
-    if prec == PRECISION_F16X3:
+    if prec != PRECISION_FP32:
         g.a_layout = LAYOUT_SPLIT_F16
         g.A_hi, g.A_lo, g.lda_h = A.hi.data_ptr(), A.lo.data_ptr(), A.lda_h
     g.b_group, g.b_group_stride = X.group, X.group_stride
@@ -202,7 +205,7 @@ def gemm(A: PackedLinear, X: Planes, Y: Planes, epilogue: int = EPI_NONE, R: Opt
     if A.conv3x3:
         g.conv3x3, g.h, g.w = 1, int(hw[0]), int(hw[1])
     g.alpha, g.epilogue, g.precision = float(alpha), int(epilogue), prec
-    if SPLIT_WS is not None and prec == PRECISION_F16X3:
+    if SPLIT_WS is not None and prec != PRECISION_FP32:
         g.split_ws, g.split_ws_floats = SPLIT_WS.data_ptr(), SPLIT_WS.numel()
     name = "gemm" if not PROFILE_SHAPES else f"gemm M{g.M} K{g.K} b{g.batch} e{g.epilogue}"
     _launch(name, 2.0 * g.M * g.N * g.K * g.batch, 0,
@@ -307,7 +310,8 @@ def corr_build(f1_ptr: int, f2_ptr: int, clip_stride: int, pair_stride: int, lvl
     _launch("corr_build", 2.0 * N * N * D * B * pairs, nbytes, lambda: _lib.check(
         _lib.load().sf_corr_build_pyramid(
             f1_ptr, f2_ptr, clip_stride, pair_stride, lvls[0].data_ptr(), lvls[1].data_ptr(), lvls[2].data_ptr(),
-            lvls[3].data_ptr(), pair_strides(lvl_pair_stride), B, pairs, D, h, w, 4, PRECISION, _lib.stream()),
+            lvls[3].data_ptr(), pair_strides(lvl_pair_stride), B, pairs, D, h, w, 4, min(PRECISION, PRECISION_F16X3),
+            _lib.stream()),
         "sf_corr_build_pyramid"))
 
 

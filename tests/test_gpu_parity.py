@@ -190,6 +190,24 @@ def test_model_api_forward_vs_golden(golden, dev, precision):
         assert orc.epe(allp[i][0].cpu(), torch.from_numpy(g[f"first{i}"])) <= 1e-3
 
 
+def test_f16x2_mode_within_parity_budget(dev):
+    """Opt-in f16x2 mode (activations rounded once to fp16): looser than f16x3 but must stay inside the 1e-3 px
+    EPE budget of the north star; 15 iterations at a small shape, against the CPU oracle."""
+    from oracle import streamflow_oracle as orc
+    from streamflow_amd import synthetic as syn
+    from streamflow_amd.engine import HotPathEngine
+    B, T, h, w = 1, 4, 16, 24
+    P = syn.make_params(5, T)
+    fmaps, cnets = syn.make_features(5, B, T, h, w)
+    ups_o, _ = orc.hotpath_forward(fmaps, cnets, P, 15)
+    for prec, bound in (("f16x2", 1e-3), ("f16x3", 5e-5)):
+        eng = HotPathEngine(P, device=dev, T=T, precision=prec)
+        ups, _ = eng.forward(fmaps.to(dev), cnets.to(dev), iters=15)
+        e = max(orc.epe(u.cpu(), o) for u, o in zip(ups, ups_o))
+        print(f"{prec}: 15-iteration EPE vs oracle = {e:.3e}")
+        assert e <= bound, (prec, e)
+
+
 def test_sintel_shape_vs_oracle(dev, precision):
     """Headline shape (440x1024 -> 55x128 grid, T=4), 2 iterations, against the CPU oracle; also the
     size-independent properties: level-1 == mean of level-0 2x2 blocks, attention rows sum to 1."""
