@@ -108,10 +108,13 @@ class HotPathWeights:
         self.fc2 = PackedLinear(sd[tb + ".mlp.fc2.weight"], sd[tb + ".mlp.fc2.bias"], device)
 
 
+ATTN_ROW_LIMIT = 1 << 28          # floats per image the GEMM epilogue can address with 32-bit offsets (1 GiB)
+
+
 class _Plan:
     """Buffers for one (clips, pairs, h, w) shape."""
 
-    def __init__(self, W: HotPathWeights, Bc: int, h: int, w: int, D: int, device):
+    def __init__(self, W: HotPathWeights, Bc: int, h: int, w: int, D: int, device, attn_chunk_rows: int = 0):
         Pn = W.pairs
         n, P = Bc * Pn, h * w
         self.Bc, self.Pn, self.h, self.w, self.n, self.P, self.D = Bc, Pn, h, w, n, P, D
@@ -124,7 +127,16 @@ class _Plan:
         dims = [(h >> l, w >> l) for l in range(4)]
         self.lvl_pair_stride = [Bc * P * hl * wl for hl, wl in dims]
         self.lvls = [torch.empty(Pn * s, dtype=torch.float32, device=device) for s in self.lvl_pair_stride]
-        self.attn = torch.empty(n, P, P, dtype=torch.float32, device=device)
+        # GMA attention: materialise the N x N matrix once (reference core/gma.py) when an image's matrix fits the
+        # kernels' 32-bit offsets; otherwise (high resolution, e.g. 1080p: N = 32400 -> 4.2 GB per image) recompute
+        # softmax(q k^T) v in row chunks every iteration, which is what the reference's demo does through
+        # flash-attn (demo.py:235-258): same mathematics, no N^2 tensor kept.
+        if attn_chunk_rows <= 0 and P * P < ATTN_ROW_LIMIT:
+            self.attn_rows = P
+        else:
+            lim = max(1, (ATTN_ROW_LIMIT - 1) // P)
+            self.attn_rows = min(P, lim if attn_chunk_rows <= 0 else min(attn_chunk_rows, lim))
+        self.attn = torch.empty(n, self.attn_rows, P, dtype=torch.float32, device=device)
         spec = [("qk", 2 * HDIM), ("corr", COR_PLANES), ("flow", 2), ("hid", 960), ("xa", 640), ("xb", 640),
                 ("cor256", 256), ("cat256", 256), ("f128", 128),
                 ("concat", 640),                       # [nets | inps | mf | mf_global | mf_temporal]
@@ -173,6 +185,7 @@ class HotPathEngine:
         # filled by the other; inside a captured graph these become parallel branches.
         self.parallel_branches = True
         self.auto_split_k = os.environ.get("SF_AUTO_SPLITK", "1") != "0"
+        self.attn_chunk_rows = int(os.environ.get("SF_ATTN_CHUNK_ROWS", "0"))  # > 0 forces the recompute path
         self.attn_k_splits = min(4, int(os.environ.get("SF_ATTN_KSPLITS", "3")))     # 1 = no split-K (<= 4)
         self._side = torch.cuda.Stream(device=self.device)
         self.W = HotPathWeights(state_dict, self.device, T)
@@ -183,8 +196,22 @@ class HotPathEngine:
     def plan(self, Bc: int, h: int, w: int, D: int) -> _Plan:
         key = (Bc, h, w, D)
         if key not in self._plans:
-            self._plans[key] = _Plan(self.W, Bc, h, w, D, self.device)
+            self._plans[key] = _Plan(self.W, Bc, h, w, D, self.device, self.attn_chunk_rows)
         return self._plans[key]
+
+    # ---------------------------------------------------------------------------------------------
+    def _attention_rows(self, pl: _Plan, i0: int, rows: int) -> None:
+        """attn[:, :rows, :] = softmax(scale * q[:, i0:i0+rows]^T k)   (gma.py:53-65) for every image."""
+        P, n = pl.P, pl.n
+        ops.gemm_raw(A=pl.qk.ptr + 4 * i0, B=pl.qk.ptr + 4 * HDIM * P, C=pl.attn.data_ptr(), M=rows, N=P, K=HDIM,
+                     batch=n, lda=P, ldb=P, ldc=P, strideA=pl.qk.img_stride, strideB=pl.qk.img_stride,
+                     strideC=pl.attn_rows * P, a_layout=LAYOUT_K_MAJOR, b_layout=LAYOUT_K_MAJOR,
+                     alpha=float(HDIM) ** -0.5, epilogue=EPI_NONE)
+        if rows == pl.attn_rows:
+            ops.softmax_rows(pl.attn, n * rows, P)
+        else:                                     # last, shorter chunk: rows of each image are not contiguous
+            for img in range(n):
+                ops.softmax_rows(pl.attn[img], rows, P)
 
     # ---------------------------------------------------------------------------------------------
     def _setup(self, pl: _Plan, fmaps: torch.Tensor, cnets: torch.Tensor) -> None:
@@ -199,10 +226,8 @@ class HotPathEngine:
         ops.context_split(cnets, pl.nets, pl.inps, HDIM)
         # a6: attn = softmax(scale * q k^T) over the context features (gma.py:53-65), computed once
         ops.gemm(W.to_qk, pl.inps, pl.qk, EPI_NONE)
-        ops.gemm_raw(A=pl.qk.ptr, B=pl.qk.ptr + 4 * HDIM * P, C=pl.attn.data_ptr(), M=P, N=P, K=HDIM, batch=n,
-                     lda=P, ldb=P, ldc=P, strideA=pl.qk.img_stride, strideB=pl.qk.img_stride, strideC=P * P,
-                     a_layout=LAYOUT_K_MAJOR, b_layout=LAYOUT_K_MAJOR, alpha=float(HDIM) ** -0.5, epilogue=EPI_NONE)
-        ops.softmax_rows(pl.attn, n * P, P)
+        if pl.attn_rows == P:
+            self._attention_rows(pl, 0, P)
 
     def _iteration(self, pl: _Plan, with_mask: bool) -> None:
         W = self.W
@@ -243,7 +268,17 @@ class HotPathEngine:
         # a7: global aggregation  mfg = mf + gamma * attn @ to_v(mf)   (gma.py:91-104), main stream
         ops.gemm(W.to_v, pl.mf, pl.v128, EPI_NONE)
         ks = self.attn_k_splits if self.precision != ops.PRECISION_FP32 else 1
-        if ks > 1 and P % 4 == 0:
+        if pl.attn_rows < P:
+            # high-resolution path: recompute the attention rows chunk by chunk (K6' of SURVEY.md)
+            for i0 in range(0, P, pl.attn_rows):
+                rows = min(pl.attn_rows, P - i0)
+                self._attention_rows(pl, i0, rows)
+                ops.gemm_raw(A=pl.v128.ptr, B=pl.attn.data_ptr(), C=pl.mfg.ptr + 4 * i0, R=pl.mf.ptr + 4 * i0,
+                             gamma=W.gamma.data_ptr(), M=HDIM, N=rows, K=P, batch=n, lda=P, ldb=P, ldc=P, ldr=P,
+                             strideA=pl.v128.img_stride, strideB=pl.attn_rows * P, strideC=pl.mfg.img_stride,
+                             strideR=pl.mf.img_stride, a_layout=LAYOUT_K_MINOR, b_layout=LAYOUT_K_MINOR, alpha=1.0,
+                             epilogue=EPI_AXPY)
+        elif ks > 1 and P % 4 == 0:
             # attn @ v streams the N x N matrix (HBM-bound) but has only N/128 * images workgroups: split K so that
             # enough bytes are in flight; partial products go to slabs, combined with the AXPY of gma.py:102
             ops.gemm_raw(A=pl.v128.ptr, B=pl.attn.data_ptr(), C=pl.part.ptr, M=HDIM, N=P, K=P, batch=n, lda=P, ldb=P,

@@ -234,3 +234,67 @@ def test_sintel_shape_vs_oracle(dev, precision):
         e = orc.epe(ups[i], ups_o[i])
         print(f"sintel-shape {precision} pair {i}: EPE vs oracle = {e:.3e}")
         assert e <= 1e-3
+
+
+def test_kitti_shape_T2_vs_oracle(dev):
+    """BASELINE config 3: KITTI shape 376x1248 -> 47x156 grid (odd height, width not a multiple of 32), T=2
+    (one pair, single-token temporal block, 128->2 flow head), corr build + lookup + 2 iterations vs the oracle."""
+    from oracle import streamflow_oracle as orc
+    from streamflow_amd import synthetic as syn
+    from streamflow_amd.engine import HotPathEngine
+    B, T, h, w = 1, 2, 47, 156
+    P = syn.make_params(13, T)
+    fmaps, cnets = syn.make_features(13, B, T, h, w)
+    eng = HotPathEngine(P, device=dev, T=T)
+    ups, low = eng.forward(fmaps.to(dev), cnets.to(dev), iters=2)
+    pl = eng.plan(B, h, w, 256)
+    pyr = orc.corr_pyramid(fmaps[:, 0], fmaps[:, 1])
+    for l in range(4):
+        got = pl.lvls[l].view(pyr[l].shape).cpu()
+        assert (got - pyr[l]).abs().max().item() < 5e-5, f"level {l}"
+    ups_o, _ = orc.hotpath_forward(fmaps, cnets, P, 2)
+    e = orc.epe(ups[0].cpu(), ups_o[0])
+    print(f"kitti-shape T=2: EPE vs oracle = {e:.3e}")
+    assert ups[0].shape == (1, 2, 376, 1248) and e <= 1e-3
+
+
+def test_chunked_attention_path_vs_golden(golden, dev):
+    """The high-resolution attention path (rows recomputed chunk by chunk every iteration, never an N x N tensor;
+    SURVEY K6') forced at a small shape: must agree with the reference forward like the materialised path."""
+    from oracle import streamflow_oracle as orc
+    from streamflow_amd.engine import HotPathEngine
+    tag = "forward_T4"
+    g = golden(tag)
+    B, T, H, W, iters, seed, use_init = cases.FORWARD_CASES[tag]
+    P, fmaps, cnets, finit, iters = cases.forward_inputs(tag)
+    eng = HotPathEngine(P, device=dev, T=T)
+    eng.attn_chunk_rows = 100                      # 384 pixels -> chunks of 100, 100, 100, 84 rows
+    ups, _ = eng.forward(fmaps.to(dev), cnets.to(dev), iters=iters)
+    assert eng.plan(B, H // 8, W // 8, 256).attn_rows == 100
+    for i in range(T - 1):
+        e = orc.epe(ups[i].cpu(), torch.from_numpy(g[f"up{i}"]))
+        assert e <= 1e-3, e
+
+
+def test_spring_shape_smoke(dev):
+    """BASELINE config 5 shape (1080x1920 -> 1088x1920 padded -> 136x240 grid, N = 32640): the 4-GB-per-pair
+    volumes and the chunked attention path run; outputs finite; pyramid pooling property holds on a sample."""
+    from streamflow_amd import synthetic as syn
+    from streamflow_amd.engine import HotPathEngine
+    B, T, h, w = 1, 4, 136, 240
+    P = syn.make_params(17, T)
+    fmaps, cnets = syn.make_features(17, B, T, h, w)
+    eng = HotPathEngine(P, device=dev, T=T)
+    ups, low = eng.forward(fmaps.to(dev), cnets.to(dev), iters=1)
+    pl = eng.plan(B, h, w, 256)
+    assert pl.attn_rows < h * w
+    assert ups[0].shape == (1, 2, 1088, 1920)
+    for u in ups:
+        assert torch.isfinite(u).all()
+    N = h * w
+    i = 12345                                           # one source pixel of pair 0
+    l0 = pl.lvls[0][i * N:(i + 1) * N].view(h, w)
+    l1 = pl.lvls[1][i * (N // 4):(i + 1) * (N // 4)].view(h // 2, w // 2)
+    assert (l0.view(h // 2, 2, w // 2, 2).mean(dim=(1, 3)) - l1).abs().max().item() < 1e-5
+    ref = (fmaps[0, 0].reshape(256, N)[:, i].to(dev) @ fmaps[0, 1].reshape(256, N).to(dev)) / 16.0
+    assert (l0.reshape(-1) - ref).abs().max().item() < 1e-3
