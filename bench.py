@@ -121,6 +121,10 @@ def main():
     ap.add_argument("--precision", default="f16x3", choices=["f16x3", "fp32", "f16x2"],
                     help="f16x3: split-fp16 MFMA with fp32 accumulation (fp32-class accuracy); fp32: exact fp32 MFMA")
     ap.add_argument("--gemm-shapes", action="store_true", help="per-shape GEMM rows in the kernel table")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for the barrier / max-over-ranks (nccl = RCCL; gloo for dry runs)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="dry-run aid: map every rank to cuda:LOCAL_RANK %% device_count (use with --dist-backend gloo)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-breakdown", action="store_true")
     args = ap.parse_args()
@@ -134,10 +138,15 @@ def main():
         raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 "
                          "--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    if args.share_device:
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     from streamflow_amd import ops, synthetic as syn
     from streamflow_amd.engine import HotPathEngine
@@ -160,7 +169,7 @@ def main():
     def allreduce_max(x: float) -> float:
         if world == 1:
             return x
-        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        t = torch.tensor([x], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
