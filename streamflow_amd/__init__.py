@@ -15,3 +15,4 @@ from .update import (PCBlock4_Deep_nopool_res, SKBlock, SKMotionEncoder6_Deep_no
 from .utils import InputPadder, bilinear_sampler, coords_grid  # noqa: F401
 from .engine import HotPathEngine  # noqa: F401
 from .ops import set_precision, precision_name  # noqa: F401
+from .demo import group_clips, predict_frames  # noqa: F401
