@@ -243,7 +243,12 @@ __global__ __launch_bounds__(kThreads) void gemm_f32_mfma(const SfGemm g) {
         __syncthreads();
     }
 
-    gemm_epilogue<WM, WN, TM, TN>(g, acc, m0, n0, z, wm, wn, lane);
+    if (sizeof(smem) >= 4 * sf::kEpiScratchFloats * sizeof(float) && sf::epilogue_vec_ok(g, z)) {
+        __syncthreads();                                         // the main-loop LDS becomes the transpose scratch
+        sf::gemm_epilogue_vec<WM, WN, TM, TN>(g, acc, m0, n0, z, wm, wn, lane, smem + wave * sf::kEpiScratchFloats);
+    } else {
+        gemm_epilogue<WM, WN, TM, TN>(g, acc, m0, n0, z, wm, wn, lane);
+    }
 }
 
 template <int WM, int WN, int TM, int TN, int BK>

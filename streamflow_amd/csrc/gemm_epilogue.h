@@ -138,6 +138,117 @@ __device__ __forceinline__ void gemm_epilogue(const SfGemm& g, f32x16 (&acc)[TM]
     }
 }
 
+
+// ---- vector epilogue: 16-byte residual loads and result stores ------------------------------------------------
+// The MFMA C/D layout gives a lane ONE column of 16 rows, so the natural store is 64 dword stores per thread (and as
+// many dword residual loads): the epilogue is bound by memory-instruction issue, not bandwidth.  Here every 32x32
+// accumulator tile goes through a per-wave LDS scratch (row stride 36 floats: conflict-free dword writes, 16-byte
+// aligned rows) and comes back as 4 x float4 per lane (row = lane/8 + 8q, 4 consecutive columns), i.e. 4x fewer
+// memory instructions with the same 128-byte segments.  Needs N % 4 == 0, ld % 4 == 0 and 16-byte aligned bases
+// (checked by the caller, which falls back to the dword epilogue otherwise).
+constexpr int kEpiStride = 36;
+constexpr int kEpiScratchFloats = 32 * kEpiStride;          // per wave
+
+typedef unsigned int epi_u32x4 __attribute__((ext_vector_type(4)));
+
+template <int EPI, int WM, int WN, int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue_vec_impl(const SfGemm& g, f32x16 (&acc)[TM][TN], int m0, int n0, int z,
+                                                       int wm, int wn, int lane, float* scratch) {
+    constexpr bool kNeedsR = (EPI == SF_EPI_RES || EPI == SF_EPI_RES_GELU || EPI == SF_EPI_RES_GELU_DW1 ||
+                              EPI == SF_EPI_AXPY);
+    const int khalf = lane >> 5, l31 = lane & 31;
+    const int rrow = lane >> 3, rcol = (lane & 7) * 4;       // read-back coordinates inside a 32x32 tile
+    const int c_bytes = (int)(((int64_t)(g.M - 1) * g.ldc + g.N) * 4);
+    __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(g.C + (int64_t)z * g.strideC, 0, c_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rr = rc;
+    if (kNeedsR) {
+        const int mr = g.M - 1;
+        const int64_t last = (g.r_group > 0) ? (int64_t)(mr / g.r_group) * g.r_group_stride + (int64_t)(mr % g.r_group) * g.ldr
+                                             : (int64_t)mr * g.ldr;
+        rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.R) + (int64_t)z * g.strideR, 0,
+                                               (int)((last + g.N) * 4), 0x00020000);
+    }
+    const float gam = (EPI == SF_EPI_AXPY) ? g.gamma[0] : 0.f;
+    const bool has_bias = g.bias != nullptr;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int mt0 = m0 + (wm * TM + i) * 32;
+        // per-row parameters and residuals of this row of tiles (all loads issued before any arithmetic)
+        float bias[4], dww[4], dwb[4];
+        int crow[4];
+        epi_u32x4 rv[TN][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int m = mt0 + rrow + 8 * q;
+            const int mc = m < g.M ? m : g.M - 1;
+            crow[q] = m < g.M ? m * (int)g.ldc * 4 : kOobTerm;
+            bias[q] = has_bias ? g.bias[mc] : 0.f;
+            if (EPI == SF_EPI_RES_GELU_DW1) { dww[q] = g.dw_w[mc]; dwb[q] = g.dw_b[mc]; }
+            else { dww[q] = dwb[q] = 0.f; }
+            if (kNeedsR) {
+                const int rro = (g.r_group > 0)
+                    ? (int)(((int64_t)(mc / g.r_group) * g.r_group_stride + (int64_t)(mc % g.r_group) * g.ldr) * 4)
+                    : mc * (int)g.ldr * 4;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int n = n0 + (wn * TN + j) * 32 + rcol;
+                    const int nc = n < g.N ? n : g.N - 4;         // N % 4 == 0: a column quad is all in or all out
+                    rv[j][q] = __builtin_amdgcn_raw_buffer_load_b128(rr, rro + nc * 4, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            // transpose the tile through LDS (a wave's DS operations execute in order, no barrier needed)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                scratch[((r & 3) + 8 * (r >> 2) + 4 * khalf) * kEpiStride + l31] = acc[i][j][r];
+            const int n = n0 + (wn * TN + j) * 32 + rcol;
+            const int ccol = n < g.N ? n * 4 : kOobTerm;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 a = *reinterpret_cast<const float4*>(scratch + (rrow + 8 * q) * kEpiStride + rcol);
+                const float av[4] = {a.x, a.y, a.z, a.w};
+                epi_u32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = g.alpha * (av[e] + bias[q]);
+                    // copy the element to a scalar first: __builtin_bit_cast applied directly to an ext-vector element
+                    // lvalue reads the vector's FIRST element (clang quirk seen with ROCm 7.2)
+                    const unsigned ru = kNeedsR ? rv[j][q][e] : 0u;
+                    const float r = __builtin_bit_cast(float, ru);
+                    o[e] = __builtin_bit_cast(unsigned, epi_apply<EPI>(v, r, dww[q], dwb[q], gam));
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(o, rc, crow[q] + ccol, 0, 0);
+            }
+        }
+    }
+}
+
+template <int WM, int WN, int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue_vec(const SfGemm& g, f32x16 (&acc)[TM][TN], int m0, int n0, int z, int wm,
+                                                  int wn, int lane, float* scratch) {
+    switch (g.epilogue) {     // wave-uniform
+        case SF_EPI_GELU: gemm_epilogue_vec_impl<SF_EPI_GELU, WM, WN, TM, TN>(g, acc, m0, n0, z, wm, wn, lane, scratch); break;
+        case SF_EPI_RELU: gemm_epilogue_vec_impl<SF_EPI_RELU, WM, WN, TM, TN>(g, acc, m0, n0, z, wm, wn, lane, scratch); break;
+        case SF_EPI_RES: gemm_epilogue_vec_impl<SF_EPI_RES, WM, WN, TM, TN>(g, acc, m0, n0, z, wm, wn, lane, scratch); break;
+        case SF_EPI_RES_GELU: gemm_epilogue_vec_impl<SF_EPI_RES_GELU, WM, WN, TM, TN>(g, acc, m0, n0, z, wm, wn, lane, scratch); break;
+        case SF_EPI_RES_GELU_DW1:
+            gemm_epilogue_vec_impl<SF_EPI_RES_GELU_DW1, WM, WN, TM, TN>(g, acc, m0, n0, z, wm, wn, lane, scratch); break;
+        case SF_EPI_AXPY: gemm_epilogue_vec_impl<SF_EPI_AXPY, WM, WN, TM, TN>(g, acc, m0, n0, z, wm, wn, lane, scratch); break;
+        default: gemm_epilogue_vec_impl<SF_EPI_NONE, WM, WN, TM, TN>(g, acc, m0, n0, z, wm, wn, lane, scratch); break;
+    }
+}
+
+// wave-uniform: may the vector epilogue be used for this problem?
+__device__ __forceinline__ bool epilogue_vec_ok(const SfGemm& g, int z) {
+    bool ok = (g.N & 3) == 0 && (g.ldc & 3) == 0 && (g.strideC & 3) == 0 &&
+              ((reinterpret_cast<uintptr_t>(g.C) & 15) == 0);
+    if (g.R) ok = ok && (g.ldr & 3) == 0 && (g.strideR & 3) == 0 && (g.r_group_stride & 3) == 0 &&
+                  ((reinterpret_cast<uintptr_t>(g.R) & 15) == 0);
+    return ok;
+}
+
 // host-side guard for the 32-bit buffer offsets used above
 inline bool epilogue_spans_ok(const SfGemm& g) {
     const int64_t c = ((int64_t)(g.M - 1) * g.ldc + g.N) * 4;

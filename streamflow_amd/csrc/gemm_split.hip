@@ -44,8 +44,11 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_f16x3_mfma(const SplitArgs a
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     static_assert(WM * WN == 4, "4 waves per workgroup");
     // [hi|lo][rows][LDK]; ONE LDS stage (the next tile waits in registers), so 3 workgroups fit per CU
-    __shared__ __attribute__((aligned(16))) _Float16 sA[2][BM * LDK];
-    __shared__ __attribute__((aligned(16))) _Float16 sB[SB ? 2 : 1][BN * LDK];       // SB = false: B has no lo part
+    constexpr int kMainHalfs = 2 * BM * LDK + (SB ? 2 : 1) * BN * LDK;          // SB = false: B has no lo part
+    constexpr int kEpiHalfs = 4 * sf::kEpiScratchFloats * 2;
+    __shared__ __attribute__((aligned(16))) _Float16 smem[kMainHalfs > kEpiHalfs ? kMainHalfs : kEpiHalfs];
+    _Float16 (*sA)[BM * LDK] = reinterpret_cast<_Float16 (*)[BM * LDK]>(smem);
+    _Float16 (*sB)[BN * LDK] = reinterpret_cast<_Float16 (*)[BN * LDK]>(smem + 2 * BM * LDK);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -127,12 +130,14 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_f16x3_mfma(const SplitArgs a
             __syncthreads();
         }
     }
-    if (ksp > 1) {             // partial product of this K slice: plain store to its own slab
-        SfGemm gs = g;
-        gs.C = g.C + (int64_t)split * g.split_stride;
-        gemm_epilogue<WM, WN, TM, TN>(gs, acc, m0, n0, z, wm, wn, lane);
+    SfGemm gs = g;
+    if (ksp > 1) gs.C = g.C + (int64_t)split * g.split_stride;   // partial product of this K slice: its own slab
+    if (sf::epilogue_vec_ok(gs, z)) {
+        __syncthreads();                                         // the main-loop LDS becomes the transpose scratch
+        sf::gemm_epilogue_vec<WM, WN, TM, TN>(gs, acc, m0, n0, z, wm, wn, lane,
+                                              reinterpret_cast<float*>(smem) + wave * sf::kEpiScratchFloats);
     } else {
-        gemm_epilogue<WM, WN, TM, TN>(g, acc, m0, n0, z, wm, wn, lane);
+        gemm_epilogue<WM, WN, TM, TN>(gs, acc, m0, n0, z, wm, wn, lane);
     }
 }
 
@@ -262,12 +267,14 @@ __global__ __launch_bounds__(kWsThreads, 4) void gemm_f16x3_ws(const SplitArgs a
         }
         __syncthreads();
     }
-    if (ksp > 1) {
-        SfGemm gs = g;
-        gs.C = g.C + (int64_t)split * g.split_stride;
-        gemm_epilogue<2, 2, TM, TN>(gs, acc, m0, n0, z, wm, wn, lane);
+    SfGemm gs = g;
+    if (ksp > 1) gs.C = g.C + (int64_t)split * g.split_stride;
+    if (sf::epilogue_vec_ok(gs, z)) {
+        // every consumer wave passed the last barrier of the loop, i.e. all LDS reads are done: stage 0 of A is free
+        sf::gemm_epilogue_vec<2, 2, TM, TN>(gs, acc, m0, n0, z, wm, wn, lane,
+                                            reinterpret_cast<float*>(&sA[0][0][0]) + wave * sf::kEpiScratchFloats);
     } else {
-        gemm_epilogue<2, 2, TM, TN>(g, acc, m0, n0, z, wm, wn, lane);
+        gemm_epilogue<2, 2, TM, TN>(gs, acc, m0, n0, z, wm, wn, lane);
     }
 }
 
