@@ -246,7 +246,7 @@ def main():
             if fam:
                 result["roofline"]["traffic"] = int((fam["fetch_kib_per_launch"] + fam["write_kib_per_launch"]) * 1024)
                 result["roofline"]["traffic_note"] = ("mean FETCH_SIZE+WRITE_SIZE per launch, rocprofv3 --pmc, "
-                                                      "profiles/r01_b_pmc_hbm_traffic.md (FETCH_SIZE uncorrected)")
+                                                      "profiles/r01_c_pmc_hbm_traffic.md (FETCH_SIZE uncorrected)")
         except (OSError, KeyError, ValueError):
             pass
         # north-star sub-metric: corr build + lookup against the HBM roofline (algorithmic bytes)
