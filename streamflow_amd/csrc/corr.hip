@@ -277,7 +277,7 @@ __global__ __launch_bounds__(kThreads, 2) void corr_build_split_kernel(const Bui
 // ------------------------------------------------------------------------------------------------
 // lookup
 // ------------------------------------------------------------------------------------------------
-constexpr int LP = 64;             // source pixels per workgroup
+constexpr int LP = 32;             // source pixels per workgroup (2640 workgroups at Sintel shape: one full round at 11 per CU)
 constexpr int RAD = 4, WIN = 2 * RAD + 1, FP = WIN + 1;   // 9 taps, 10-cell footprint
 constexpr int WSTRIDE = FP * FP + 1;                       // 101: consecutive pixels -> consecutive banks
 

@@ -17,14 +17,25 @@ struct Split8 {
     f16x8 hi, lo;
 };
 
+// x = hi + lo with 3 VALU instructions per element instead of 5+: hi is x with its mantissa truncated to the 10
+// explicit bits of fp16 (one v_and, exactly representable in fp16 for normal-range values), lo = x - hi is exact in
+// fp32, and both are narrowed two at a time with v_cvt_pkrtz_f16_f32.  |x - (hi + lo)| <= 2^-20 |x| (round-to-zero
+// twice; the round-to-nearest variant reaches 2^-22 but costs a convert, a convert back, a subtract, a convert and a
+// pack per element -- the GEMM is bound by instruction issue, not by MFMA, so the cheaper split is the faster one).
+typedef __fp16 pk_half2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ Split8 split8(const float (&x)[8]) {
-    Split8 s;
+    union { f16x8 v; pk_half2 h[4]; } hi, lo;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const _Float16 h = (_Float16)x[i];
-        s.hi[i] = h;
-        s.lo[i] = (_Float16)(x[i] - (float)h);
+    for (int i = 0; i < 4; ++i) {
+        const float a = x[2 * i], b = x[2 * i + 1];
+        const float ah = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, a) & 0xFFFFE000u);
+        const float bh = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, b) & 0xFFFFE000u);
+        hi.h[i] = __builtin_amdgcn_cvt_pkrtz(ah, bh);
+        lo.h[i] = __builtin_amdgcn_cvt_pkrtz(a - ah, b - bh);
     }
+    Split8 s;
+    s.hi = hi.v;
+    s.lo = lo.v;
     return s;
 }
 
@@ -40,6 +51,7 @@ struct Operand {
     bool live[NI];
     int K, ld, group;
     int64_t group_stride;
+    int rowc[NI][8];     // K-major: byte offset of row (ko*8 + i) inside a k-tile -- loop invariant, wave uniform
     struct Regs {                                  // one staged k-tile of this thread
         float v[(LAY == 2) ? 1 : NI][8];
         u32x4 ph[(LAY == 2) ? NI : 1], pl[(LAY == 2) ? NI : 1];
@@ -62,7 +74,11 @@ struct Operand {
             lds_off[j] = xl * LDK + kq * 8;
             // rows/columns past the operand are clamped: they are loaded (harmlessly) but never stored
             const int xc = (x0 + xl < X) ? x0 + xl : X - 1;
-            if (LAY == SF_LAYOUT_K_MAJOR) voff[j] = xc * 4;
+            if (LAY == SF_LAYOUT_K_MAJOR) {
+                voff[j] = xc * 4;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) rowc[j][i] = (ko[j] * 8 + i) * ld * 4;
+            }
             else if (LAY == SF_LAYOUT_K_MINOR) voff[j] = (xc * ld + kq * 8) * 4;
             else voff[j] = ((x0 + xl) * ld + kq * 8) * 2;       // host-padded to 128 rows: always in range
         }
@@ -78,13 +94,23 @@ struct Operand {
                 rg.ph[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[j], k0 * 2, 0);
                 rg.pl[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_lo, voff[j], k0 * 2, 0);
             } else if (LAY == SF_LAYOUT_K_MAJOR) {
-                const int kb = ko[j] * 8;
+                if (k0 + BK <= K) {
+                    // interior k-tile (workgroup-uniform): one v_add per item, the row offsets are SGPR constants
+                    const int vo = voff[j] + tile_off * 4;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int over = k0 + kb + i - (K - 1);                 // > 0: row past the end
-                    const int r = (tile_off + (kb + i - (over > 0 ? over : 0)) * ld) * 4;
-                    if (kUniformKo) rg.v[j][i] = as_f(__builtin_amdgcn_raw_buffer_load_b32(rsrc, voff[j], r, 0));
-                    else rg.v[j][i] = as_f(__builtin_amdgcn_raw_buffer_load_b32(rsrc, voff[j] + r, 0, 0));
+                    for (int i = 0; i < 8; ++i) {
+                        if (kUniformKo) rg.v[j][i] = as_f(__builtin_amdgcn_raw_buffer_load_b32(rsrc, vo, rowc[j][i], 0));
+                        else rg.v[j][i] = as_f(__builtin_amdgcn_raw_buffer_load_b32(rsrc, vo + rowc[j][i], 0, 0));
+                    }
+                } else {
+                    const int kb = ko[j] * 8;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int over = k0 + kb + i - (K - 1);                 // > 0: row past the end
+                        const int r = (tile_off + (kb + i - (over > 0 ? over : 0)) * ld) * 4;
+                        if (kUniformKo) rg.v[j][i] = as_f(__builtin_amdgcn_raw_buffer_load_b32(rsrc, voff[j], r, 0));
+                        else rg.v[j][i] = as_f(__builtin_amdgcn_raw_buffer_load_b32(rsrc, voff[j] + r, 0, 0));
+                    }
                 }
             } else {
                 // k0 goes into the VGPR offset: soffset is excluded from the hardware range check, and the last
