@@ -317,10 +317,7 @@ extern "C" int sf_gemm(const SfGemm* gp, void* stream) {
     SF_REQUIRE(g.k_splits <= 1 || g.precision != SF_PRECISION_FP32, "sf_gemm: split-K is only built for the split-precision modes");
     SF_REQUIRE(sf::epilogue_spans_ok(g), "sf_gemm: C / R image larger than 1 GiB (32-bit buffer offsets in the epilogue)");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (g.precision != SF_PRECISION_FP32) {
-        SF_REQUIRE(!g.conv3x3, "sf_gemm: conv3x3 is only built for SF_PRECISION_FP32");
-        return sf::gemm_split_dispatch(g, st);
-    }
+    if (g.precision != SF_PRECISION_FP32) return sf::gemm_split_dispatch(g, st);
     const bool kminor = (g.a_layout == SF_LAYOUT_K_MINOR) || (g.b_layout == SF_LAYOUT_K_MINOR);
     const int bm = pick_bm(g);
     if (kminor) {   // k-contiguous operands: deeper k-tile so each row contributes a full 128-byte line

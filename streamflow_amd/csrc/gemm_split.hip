@@ -64,6 +64,13 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_f16x3_mfma(const SplitArgs a
     if (ALAY == 2) opa.init(g.A_hi, g.A_lo, args.a_bytes, (int)g.lda_h, g.K, g.M, m0, 0, 0, tid);
     else opa.init(g.A + (int64_t)z * g.strideA, nullptr, args.a_bytes, (int)g.lda, g.K, g.M, m0, 0, 0, tid);
     opb.init(g.B + (int64_t)z * g.strideB, nullptr, args.b_bytes, (int)g.ldb, g.K, g.N, n0, g.b_group, g.b_group_stride, tid);
+    const bool conv = (BLAY == SF_LAYOUT_K_MAJOR) && g.conv3x3;
+    const int cin = conv ? g.K / 9 : 1;
+    if (BLAY == SF_LAYOUT_K_MAJOR && conv) opb.set_conv3x3(n0, g.h, g.w, tid);
+    // per k-tile of an implicit 3x3 conv: tap, row offset of channel c0 = k0 % cin, byte shift of the tap
+    auto conv_tap = [&](int k0) { return k0 / cin; };
+    auto conv_off = [&](int k0) { return (k0 % cin) * (int)g.ldb; };
+    auto conv_shift = [&](int k0) { const int t = k0 / cin; return ((t / 3 - 1) * g.w + (t % 3 - 1)) * 4; };
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -80,9 +87,10 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_f16x3_mfma(const SplitArgs a
     cb.init(g.b_group, (int)g.ldb, g.b_group_stride);
     for (int t = 0; t < kt_beg; ++t) { ca.advance(); cb.advance(); }       // split-K: start of this slice
     opa.load(kt_beg * BK, ca.off, ra);
-    opb.load(kt_beg * BK, cb.off, rb);
+    if (conv) opb.load(kt_beg * BK, conv_off(kt_beg * BK), rb, conv_shift(kt_beg * BK));
+    else opb.load(kt_beg * BK, cb.off, rb);
     opa.store(kt_beg * BK, sA[0], sA[1], ra);
-    opb.template store<SB>(kt_beg * BK, sB[0], sB[SB ? 1 : 0], rb);
+    opb.template store<SB>(kt_beg * BK, sB[0], sB[SB ? 1 : 0], rb, conv ? conv_tap(kt_beg * BK) : -1);
     __syncthreads();
 
     const int khalf = lane >> 5, l31 = lane & 31;
@@ -91,7 +99,8 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_f16x3_mfma(const SplitArgs a
             ca.advance();
             cb.advance();
             opa.load((kt + 1) * BK, ca.off, ra);
-            opb.load((kt + 1) * BK, cb.off, rb);
+            if (conv) opb.load((kt + 1) * BK, conv_off((kt + 1) * BK), rb, conv_shift((kt + 1) * BK));
+            else opb.load((kt + 1) * BK, cb.off, rb);
         }
         // keep the staged loads in flight across the MFMA block: nothing below may be hoisted above it
         __builtin_amdgcn_sched_barrier(0);
@@ -126,7 +135,7 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_f16x3_mfma(const SplitArgs a
         if (kt + 1 < kt_end) {
             __syncthreads();                       // every wave is done reading tile kt
             opa.store((kt + 1) * BK, sA[0], sA[1], ra);
-            opb.template store<SB>((kt + 1) * BK, sB[0], sB[SB ? 1 : 0], rb);
+            opb.template store<SB>((kt + 1) * BK, sB[0], sB[SB ? 1 : 0], rb, conv ? conv_tap((kt + 1) * BK) : -1);
             __syncthreads();
         }
     }
@@ -328,7 +337,8 @@ int pick_tile(const SplitArgs& a, hipStream_t st) {
     // prologue/epilogue, where the single-role kernel (all waves store) is a little faster
     static const int ws_min_k = getenv("SF_WS_MINK") ? atoi(getenv("SF_WS_MINK")) : 768;
     if (padded(128) * 4 <= M * 5)
-        return (g.K / (g.k_splits > 1 ? g.k_splits : 1) >= ws_min_k) ? launch_ws<SB>(a, st) : launch_cfg<2, 2, 2, 2, SB>(a, st);
+        return (!g.conv3x3 && g.K / (g.k_splits > 1 ? g.k_splits : 1) >= ws_min_k) ? launch_ws<SB>(a, st)
+                                                                                      : launch_cfg<2, 2, 2, 2, SB>(a, st);
     if (padded(64) * 4 <= M * 5 || M > 32) return launch_cfg<1, 4, 2, 1, SB>(a, st);
     return launch_cfg<1, 4, 1, 1, SB>(a, st);
 }
@@ -434,6 +444,8 @@ int gemm_split_dispatch(const SfGemm& g, hipStream_t st) {
 int gemm_split_dispatch_inner(const SfGemm& g, hipStream_t st) {
     if (g.k_splits > 1 && (g.epilogue != SF_EPI_NONE || g.bias || g.k_splits > 16))
         return fail(SF_ERR_BAD_ARG, "sf_gemm(f16x3): split-K needs SF_EPI_NONE, no bias, k_splits <= 16");
+    if (g.conv3x3 && (g.b_layout != SF_LAYOUT_K_MAJOR || (g.K / 9) % 32 || g.b_group || g.k_splits > 1))
+        return fail(SF_ERR_UNSUPPORTED, "sf_gemm(split): conv3x3 needs a plain K-major B with Cin %% 32 == 0");
     if (g.b_group % 32) return fail(SF_ERR_BAD_ARG, "sf_gemm(f16x3): b_group must be a multiple of 32");
     SplitArgs a;
     a.g = g;

@@ -52,6 +52,7 @@ struct Operand {
     int K, ld, group;
     int64_t group_stride;
     int rowc[NI][8];     // K-major: byte offset of row (ko*8 + i) inside a k-tile -- loop invariant, wave uniform
+    unsigned tapmask[NI];   // implicit 3x3 conv: bit t set = tap t of this thread's pixel lies inside the image
     struct Regs {                                  // one staged k-tile of this thread
         float v[(LAY == 2) ? 1 : NI][8];
         u32x4 ph[(LAY == 2) ? NI : 1], pl[(LAY == 2) ? NI : 1];
@@ -74,6 +75,7 @@ struct Operand {
             lds_off[j] = xl * LDK + kq * 8;
             // rows/columns past the operand are clamped: they are loaded (harmlessly) but never stored
             const int xc = (x0 + xl < X) ? x0 + xl : X - 1;
+            tapmask[j] = 0x1ffu;
             if (LAY == SF_LAYOUT_K_MAJOR) {
                 voff[j] = xc * 4;
 #pragma unroll
@@ -84,10 +86,30 @@ struct Operand {
         }
     }
 
+    // implicit 3x3 convolution (pad 1) over an h x w image: K = 9 * cin, k = tap * cin + c.  A k-tile never straddles
+    // taps (cin % 32 == 0, checked on the host), so a tile is a plain K-major tile of the input shifted by the tap's
+    // (dy, dx); pixels whose tap falls outside the image are zeroed in store() through tapmask.
+    __device__ __forceinline__ void set_conv3x3(int x0, int h, int w, int tid) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int idx = tid + j * kThreads;
+            const int x = x0 + idx % BX;                       // K-major item mapping: lanes walk x
+            const int yy = x / w, xx = x % w;
+            unsigned m = 0;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int y2 = yy + t / 3 - 1, x2 = xx + t % 3 - 1;
+                if (y2 >= 0 && y2 < h && x2 >= 0 && x2 < w) m |= 1u << t;
+            }
+            tapmask[j] = m;
+            voff[j] = x * 4;                                    // no clamping: out-of-range taps are masked / range-checked
+        }
+    }
+
     // Issue the raw loads of k-tile k0 (nothing is consumed here, so no wait is needed before the MFMAs).
     // K-major rows: tile_off = element offset of row k0 (tracked incrementally by the caller for grouped
     // operands); rows past K are clamped to the last valid row and zeroed in store().
-    __device__ __forceinline__ void load(int k0, int tile_off, Regs& rg) const {
+    __device__ __forceinline__ void load(int k0, int tile_off, Regs& rg, int shift_bytes = 0) const {
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
             if (LAY == 2) {
@@ -96,7 +118,7 @@ struct Operand {
             } else if (LAY == SF_LAYOUT_K_MAJOR) {
                 if (k0 + BK <= K) {
                     // interior k-tile (workgroup-uniform): one v_add per item, the row offsets are SGPR constants
-                    const int vo = voff[j] + tile_off * 4;
+                    const int vo = voff[j] + tile_off * 4 + shift_bytes;
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
                         if (kUniformKo) rg.v[j][i] = as_f(__builtin_amdgcn_raw_buffer_load_b32(rsrc, vo, rowc[j][i], 0));
@@ -126,7 +148,7 @@ struct Operand {
     // Consume the staged tile (loaded for k-tile k0): zero rows k >= K, split into hi/lo f16, write to LDS.
     // kLo = false: keep only the fp16 rounding of the values (SF_PRECISION_F16X2's B operand)
     template <bool kLo = true>
-    __device__ __forceinline__ void store(int k0, _Float16* lds_hi, _Float16* lds_lo, Regs& rg) const {
+    __device__ __forceinline__ void store(int k0, _Float16* lds_hi, _Float16* lds_lo, Regs& rg, int tap = -1) const {
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
             if (!live[j]) continue;
@@ -138,6 +160,11 @@ struct Operand {
                     const int k = k0 + ko[j] * 8;
 #pragma unroll
                     for (int i = 0; i < 8; ++i) rg.v[j][i] = (k + i < K) ? rg.v[j][i] : 0.f;
+                }
+                if (tap >= 0) {             // implicit 3x3 conv: zero padding
+                    const bool in = (tapmask[j] >> tap) & 1u;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) rg.v[j][i] = in ? rg.v[j][i] : 0.f;
                 }
                 if (kLo) {
                     const Split8 s8 = split8(rg.v[j]);

@@ -191,7 +191,7 @@ def gemm(A: PackedLinear, X: Planes, Y: Planes, epilogue: int = EPI_NONE, R: Opt
     g.strideA, g.strideB, g.strideC = 0, X.img_stride, Y.img_stride
     g.a_layout, g.b_layout = LAYOUT_K_MAJOR, LAYOUT_K_MAJOR
     g.a_padded = 1
-    prec = PRECISION_FP32 if A.conv3x3 else PRECISION     # the implicit 3x3 gather is only built for the fp32 kernel
+    prec = PRECISION
     if prec != PRECISION_FP32:
         g.a_layout = LAYOUT_SPLIT_F16
         g.A_hi, g.A_lo, g.lda_h = A.hi.data_ptr(), A.lo.data_ptr(), A.lda_h
