@@ -63,7 +63,11 @@ int sf_bilinear_sampler(const float* img, const float* coords, float* out, float
 int sf_corr_build_pyramid(const float* f1, const float* f2, int64_t f_clip_stride, int64_t f_pair_stride,
                           float* lvl0, float* lvl1, float* lvl2, float* lvl3,
                           const int64_t* lvl_pair_stride, int B, int pairs, int D, int h, int w,
-                          int num_levels, int precision, void* stream);
+                          int num_levels, int precision, void* split_ws, int64_t split_ws_bytes, void* stream);
+/* Workspace of the SF_PRECISION_F16X3 build: the (hi, lo) fp16 split of every f1 / f2 image, packed in k-octets
+ * per pixel so that the build kernel can DMA operand tiles straight into LDS.  Not needed (may be NULL / 0) for
+ * SF_PRECISION_FP32.  Contents are scratch: dead once the call's kernels have run. */
+int64_t sf_corr_build_ws_bytes(int B, int pairs, int D, int h, int w);
 
 /* ---- a3: CorrBlock.__call__  (core/corr.py:23-44) ----------------------------------------------
  * Image index img = b*pairs + t.  coords [B*pairs][2][h][w] (ch0 = x, ch1 = y)  ->

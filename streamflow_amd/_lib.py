@@ -13,7 +13,8 @@ from typing import Optional
 import torch  # noqa: F401  (imported first so the process-wide HIP runtime is torch's libamdhip64)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libstreamflow_hip.so")
+# SF_HIP_LIB: load an alternative build of the same library (A/B timing of kernel variants)
+LIB_PATH = os.environ.get("SF_HIP_LIB") or os.path.join(_HERE, "libstreamflow_hip.so")
 
 LAYOUT_K_MAJOR, LAYOUT_K_MINOR, LAYOUT_SPLIT_F16 = 0, 1, 2
 PRECISION_FP32, PRECISION_F16X3, PRECISION_F16X2 = 0, 1, 2
@@ -45,7 +46,9 @@ SIGNATURES = {
     "sf_last_error": (C.c_char_p, []),
     "sf_coords_grid": (_i, [_vp, _i, _i, _i, _vp]),
     "sf_bilinear_sampler": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
-    "sf_corr_build_pyramid": (_i, [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, C.POINTER(_i64), _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "sf_corr_build_pyramid": (_i, [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, C.POINTER(_i64), _i, _i, _i, _i, _i, _i, _i,
+                                   _vp, _i64, _vp]),
+    "sf_corr_build_ws_bytes": (_i64, [_i, _i, _i, _i, _i]),
     "sf_corr_lookup": (_i, [_vp, _vp, _vp, _vp, C.POINTER(_i64), _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _vp]),
     "sf_gemm": (_i, [C.POINTER(SfGemm), _vp]),
     "sf_gemm_split_ws_floats": (_i64, [_i, _i, _i, _i]),

@@ -44,62 +44,119 @@ struct BuildArgs {
     int vec_a, vec_b;
 };
 
+// Store side of the epilogue.  One v_mul + one buffer_store per level-0 cell: the wave's 32 source rows are addressed
+// from a per-wave buffer resource (32-bit offsets; the row / patch-row part rides in the scalar offset), horizontal
+// pooling partners come over DPP instead of ds_bpermute, and each pooled level is stored under one exec-mask region
+// per 4-register group.  kGuard = false: interior tile, nothing to check.  kGuard = true (tile touches the image
+// border or the end of the source pixels): a cell that must not be written gets an out-of-range offset and the
+// buffer unit drops the store -- one v_cndmask per store instead of a branch.  (A branchy, 64-bit-addressed version
+// of this epilogue cost ~33k cycles per tile, more than the tile's whole MFMA loop.)
+__device__ __forceinline__ float dpp_xor1(float v) {     // lane ^ 1 (quad_perm [1,0,3,2])
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float dpp_xor2(float v) {     // lane ^ 2 (quad_perm [2,3,0,1])
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float dpp_shl4(float v) {     // lane + 4 inside a row of 16 (row_shl:4)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x104, 0xF, 0xF, true));
+}
+
+template <bool kGuard>
+__device__ __forceinline__ void pyramid_store(const BuildArgs& g, f32x16 (&acc)[PR], int b, int pair, int m0, int wave,
+                                              int py0, int px0, int lane) {
+    const int khalf = lane >> 5, l31 = lane & 31;
+    const int P0 = g.hl[0] * g.wl[0], P1 = g.hl[1] * g.wl[1], P2 = g.hl[2] * g.wl[2], P3 = g.hl[3] * g.wl[3];
+    const int i0 = m0 + wave * 32;                          // first source pixel of the wave
+    const int64_t row0 = (int64_t)b * g.N + i0;
+    constexpr int kSpan = 0x7ffffff0, kDrop = (int)0x80000000u;
+    const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(
+        g.lvl[0] + pair * g.lvl_pair_stride[0] + row0 * P0 + py0 * g.wl[0] + px0, 0, kSpan, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(
+        g.lvl[1] + pair * g.lvl_pair_stride[1] + row0 * P1 + (py0 >> 1) * g.wl[1] + (px0 >> 1), 0, kSpan, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(
+        g.lvl[2] + pair * g.lvl_pair_stride[2] + row0 * P2 + (py0 >> 2) * g.wl[2] + (px0 >> 2), 0, kSpan, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r3 = __builtin_amdgcn_make_buffer_rsrc(
+        g.lvl[3] + pair * g.lvl_pair_stride[3] + row0 * P3 + (py0 >> 3) * g.wl[3] + (px0 >> 3), 0, kSpan, 0x00020000);
+    const int x = px0 + l31;
+    // per-lane offsets; a lane whose column lies outside the level is dropped for good
+    const int vo0 = (!kGuard || x < g.wl[0]) ? (4 * khalf * P0 + l31) * 4 : kDrop;
+    const int vo1 = (!kGuard || (x >> 1) < g.wl[1]) ? (4 * khalf * P1 + (l31 >> 1)) * 4 : kDrop;
+    const int vo2 = (!kGuard || (x >> 2) < g.wl[2]) ? (4 * khalf * P2 + (l31 >> 2)) * 4 : kDrop;
+    const int vo3 = (!kGuard || (x >> 3) < g.wl[3]) ? (4 * khalf * P3 + (l31 >> 3)) * 4 : kDrop;
+    // level 0 (3/4 of the bytes) is streamed past the caches: it would only displace the operand tiles in L2 and the
+    // pooled levels, which are small enough (a quarter of level 0 together) to stay in the 256 MB Infinity Cache
+    // for the lookups that follow
+    constexpr int kNt = 2;
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {                        // register group: source pixels 8*rq + 4*khalf + (0..3)
+        float v1[4][PR / 2], v2[4][PR / 4], v3[4];
+        bool iok[4];
+#pragma unroll
+        for (int ri = 0; ri < 4; ++ri) {
+            const int r = rq * 4 + ri, rr = ri + 8 * rq;
+            iok[ri] = !kGuard || (i0 + rr + 4 * khalf < g.N);
+            float v0[PR];
+#pragma unroll
+            for (int t = 0; t < PR; ++t) {
+                v0[t] = acc[t][r] * g.scale;
+                const bool ok = !kGuard || (iok[ri] && py0 + t < g.hl[0]);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v0[t]), r0, ok ? vo0 : kDrop,
+                                                      (rr * P0 + t * g.wl[0]) * 4, kNt);
+            }
+#pragma unroll
+            for (int t = 0; t < PR / 2; ++t) {
+                const float s = v0[2 * t] + v0[2 * t + 1];
+                v1[ri][t] = 0.25f * (s + dpp_xor1(s));
+            }
+#pragma unroll
+            for (int t = 0; t < PR / 4; ++t) {
+                const float s = v1[ri][2 * t] + v1[ri][2 * t + 1];
+                v2[ri][t] = 0.25f * (s + dpp_xor2(s));
+            }
+            const float s = v2[ri][0] + v2[ri][1];
+            v3[ri] = 0.25f * (s + dpp_shl4(s));
+        }
+        if ((l31 & 1) == 0) {
+#pragma unroll
+            for (int ri = 0; ri < 4; ++ri)
+#pragma unroll
+                for (int t = 0; t < PR / 2; ++t) {
+                    const bool ok = !kGuard || (iok[ri] && (py0 >> 1) + t < g.hl[1]);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v1[ri][t]), r1, ok ? vo1 : kDrop,
+                                                          ((ri + 8 * rq) * P1 + t * g.wl[1]) * 4, 0);
+                }
+        }
+        if ((l31 & 3) == 0) {
+#pragma unroll
+            for (int ri = 0; ri < 4; ++ri)
+#pragma unroll
+                for (int t = 0; t < PR / 4; ++t) {
+                    const bool ok = !kGuard || (iok[ri] && (py0 >> 2) + t < g.hl[2]);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v2[ri][t]), r2, ok ? vo2 : kDrop,
+                                                          ((ri + 8 * rq) * P2 + t * g.wl[2]) * 4, 0);
+                }
+        }
+        if ((l31 & 7) == 0) {
+#pragma unroll
+            for (int ri = 0; ri < 4; ++ri) {
+                const bool ok = !kGuard || (iok[ri] && (py0 >> 3) < g.hl[3]);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v3[ri]), r3, ok ? vo3 : kDrop,
+                                                      ((ri + 8 * rq) * P3) * 4, 0);
+            }
+        }
+    }
+}
+
 // Epilogue shared by both arithmetic modes: scale, write level 0, pool levels 1..3 in registers.
 // acc[t][r]: target patch row t (0..7), MFMA C/D register r -> source pixel (r&3)+8*(r>>2)+4*(lane>>5) of the
 // wave's 32-pixel block, lane&31 = target patch column.
 __device__ __forceinline__ void pyramid_epilogue(const BuildArgs& g, f32x16 (&acc)[PR], int b, int pair, int m0, int wave,
                                                  int py0, int px0, int lane) {
-    const int khalf = lane >> 5, l31 = lane & 31;
-    const int x = px0 + l31;
-    const int64_t P0 = (int64_t)g.hl[0] * g.wl[0], P1 = (int64_t)g.hl[1] * g.wl[1];
-    const int64_t P2 = (int64_t)g.hl[2] * g.wl[2], P3 = (int64_t)g.hl[3] * g.wl[3];
-    float* const L0 = g.lvl[0] + pair * g.lvl_pair_stride[0];
-    float* const L1 = g.lvl[1] + pair * g.lvl_pair_stride[1];
-    float* const L2 = g.lvl[2] + pair * g.lvl_pair_stride[2];
-    float* const L3 = g.lvl[3] + pair * g.lvl_pair_stride[3];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int i = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;     // source pixel (wave-half uniform)
-        const bool iok = i < g.N;
-        const int64_t row = (int64_t)b * g.N + i;
-        float v0[PR];
-#pragma unroll
-        for (int t = 0; t < PR; ++t) v0[t] = acc[t][r] * g.scale;
-        if (iok && x < g.wl[0]) {
-#pragma unroll
-            for (int t = 0; t < PR; ++t)
-                if (py0 + t < g.hl[0]) L0[row * P0 + (int64_t)(py0 + t) * g.wl[0] + x] = v0[t];
-        }
-        float v1[PR / 2];
-#pragma unroll
-        for (int t = 0; t < PR / 2; ++t) {
-            float s = v0[2 * t] + v0[2 * t + 1];
-            s += __shfl_xor(s, 1);
-            v1[t] = 0.25f * s;
-        }
-        if (iok && (l31 & 1) == 0 && (x >> 1) < g.wl[1]) {
-#pragma unroll
-            for (int t = 0; t < PR / 2; ++t)
-                if ((py0 >> 1) + t < g.hl[1]) L1[row * P1 + (int64_t)((py0 >> 1) + t) * g.wl[1] + (x >> 1)] = v1[t];
-        }
-        float v2[PR / 4];
-#pragma unroll
-        for (int t = 0; t < PR / 4; ++t) {
-            float s = v1[2 * t] + v1[2 * t + 1];
-            s += __shfl_xor(s, 2);
-            v2[t] = 0.25f * s;
-        }
-        if (iok && (l31 & 3) == 0 && (x >> 2) < g.wl[2]) {
-#pragma unroll
-            for (int t = 0; t < PR / 4; ++t)
-                if ((py0 >> 2) + t < g.hl[2]) L2[row * P2 + (int64_t)((py0 >> 2) + t) * g.wl[2] + (x >> 2)] = v2[t];
-        }
-        float s3 = v2[0] + v2[1];
-        s3 += __shfl_xor(s3, 4);
-        s3 *= 0.25f;
-        if (iok && (l31 & 7) == 0 && (x >> 3) < g.wl[3] && (py0 >> 3) < g.hl[3])
-            L3[row * P3 + (int64_t)(py0 >> 3) * g.wl[3] + (x >> 3)] = s3;
-    }
+    const bool interior = m0 + BM <= g.N && py0 + PR <= g.hl[0] && px0 + PC <= g.wl[0] &&
+                          (py0 >> 1) + PR / 2 <= g.hl[1] && (py0 >> 2) + PR / 4 <= g.hl[2] && (py0 >> 3) < g.hl[3] &&
+                          ((px0 + PC) >> 1) <= g.wl[1] && ((px0 + PC) >> 2) <= g.wl[2] && ((px0 + PC) >> 3) <= g.wl[3];
+    if (interior) pyramid_store<false>(g, acc, b, pair, m0, wave, py0, px0, lane);
+    else pyramid_store<true>(g, acc, b, pair, m0, wave, py0, px0, lane);
 }
 
 __global__ __launch_bounds__(kThreads, 2) void corr_build_kernel(const BuildArgs g) {
@@ -197,36 +254,74 @@ __global__ __launch_bounds__(kThreads, 2) void corr_build_kernel(const BuildArgs
     pyramid_epilogue(g, acc, b, pair, m0, wave, py0, px0, lane);
 }
 
-// ---- split-precision (f16x3) build: same tiling, operands staged as (hi, lo) f16 (see gemm_split.hip) -----
-// A = f1 [D][N] (rows of k, source pixels contiguous), B = f2 gathered as an 8x32 target patch.  Both are fp32
-// K-major sources split on the fly; rows k >= D are zeroed, source pixels / patch cells outside the image are
-// clamped (their products are never stored).  3 MFMAs of 32x32x16 per product instead of 8 of 32x32x2: the
-// kernel goes from fp32-MFMA-bound to (nearly) bound by the single write of the pyramid.
-__global__ __launch_bounds__(kThreads, 2) void corr_build_split_kernel(const BuildArgs g) {
+// ---- split-precision (f16x3) build --------------------------------------------------------------------------
+// Operands: f = hi + lo, two IEEE fp16 planes, products ah*bh + ah*bl + al*bh on v_mfma_f32_32x32x16_f16 with
+// fp32 accumulation (~2^-22 relative, see gemm_split.hip).  Splitting costs ~5 VALU per element, so it is done
+// ONCE per feature image by split_pack_kernel into a workspace laid out for the matrix cores:
+//     ws image = [hi | lo],   plane[(k/8)*N + pixel][k%8]      (16 bytes = one MFMA operand k-octet of one pixel)
+// The build kernel then moves operand tiles HBM/L2 -> LDS with buffer_load_dwordx4 ... lds (no VGPR staging, no
+// conversion, no ds_write): 6 DMA instructions per thread per 16-deep k-step against 24 MFMAs, and the LDS image is
+// lane-linear in exactly the order ds_read_b128 wants it (consecutive lanes = consecutive pixels = consecutive
+// 16-byte slots, conflict-free).  Two 24 KB stages; two workgroups per CU so that one workgroup's pyramid
+// epilogue (170 stores per wave) overlaps the other's MFMA loop.
+constexpr int DK = 16;                              // k per stage
+constexpr int ST_A = (DK / 8) * BM * 16;            // bytes of the A_hi (= A_lo) part of a stage
+constexpr int ST_B = (DK / 8) * BN * 16;            // bytes of B_hi (= B_lo)
+constexpr int STAGE = 2 * ST_A + 2 * ST_B;          // 24576
+#ifndef SF_CORR_NSTAGE
+#define SF_CORR_NSTAGE 2
+#endif
+constexpr int NSTAGE = SF_CORR_NSTAGE;                           // two stages in flight behind the one being consumed
+
+__global__ __launch_bounds__(256) void split_pack_kernel(const float* f1, const float* f2, int64_t f_clip_stride,
+                                                         int64_t f_pair_stride, char* ws, int pairs, int D, int Dp,
+                                                         int N) {
     using namespace sf_split;
-    __shared__ __attribute__((aligned(16))) _Float16 sA[2][BM * LDK];
-    __shared__ __attribute__((aligned(16))) _Float16 sB[2][BN * LDK];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int px = blockIdx.x * 256 + threadIdx.x, kq = blockIdx.y;
+    const int side = blockIdx.z & 1, img = blockIdx.z >> 1;             // img = b * pairs + pair
+    if (px >= N) return;
+    const float* f = (side ? f2 : f1) + (int64_t)(img / pairs) * f_clip_stride + (int64_t)(img % pairs) * f_pair_stride;
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (kq * 8 + i < D) ? f[(int64_t)(kq * 8 + i) * N + px] : 0.f;
+    const Split8 s8 = split8(v);
+    const int64_t half = (int64_t)(Dp / 8) * N * 16;
+    char* dst = ws + (int64_t)blockIdx.z * 2 * half + ((int64_t)kq * N + px) * 16;
+    *reinterpret_cast<f16x8*>(dst) = s8.hi;
+    *reinterpret_cast<f16x8*>(dst + half) = s8.lo;
+}
+
+typedef __attribute__((address_space(3))) void* lds_ptr;
+
+__global__ __launch_bounds__(kThreads, NSTAGE == 2 ? 3 : 2) void corr_build_dma_kernel(const BuildArgs g, const char* ws, int Dp) {
+    using namespace sf_split;
+    __shared__ __attribute__((aligned(1024))) char smem[NSTAGE * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int khalf = lane >> 5, l31 = lane & 31;
     const int b = blockIdx.z / g.pairs, pair = blockIdx.z % g.pairs;
     const int m0 = blockIdx.y * BM;
     const int py0 = (blockIdx.x / g.pcols) * PR, px0 = (blockIdx.x % g.pcols) * PC;
-    const float* A = g.f1 + (int64_t)b * g.f_clip_stride + (int64_t)pair * g.f_pair_stride;
-    const float* Bm = g.f2 + (int64_t)b * g.f_clip_stride + (int64_t)pair * g.f_pair_stride;
-    const int64_t bytes = (int64_t)g.D * g.N * 4;
+    const int half = (Dp / 8) * g.N * 16;                       // bytes of one hi (or lo) plane (< 2 GiB, host-checked)
+    const char* imgA = ws + (int64_t)(blockIdx.z * 2 + 0) * 2 * half;
+    const char* imgB = ws + (int64_t)(blockIdx.z * 2 + 1) * 2 * half;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(imgA), 0, 2 * half, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(imgB), 0, 2 * half, 0x00020000);
+    // per-thread source offsets (pixels / patch cells past the image are clamped: their products are never stored)
+    const int voa = ((tid >> 7) * g.N + min(m0 + (tid & 127), g.N - 1)) * 16;          // slot = kq*128 + px = tid
+    const int vob = (min(py0 + tid / PC, g.h - 1) * g.w + min(px0 + tid % PC, g.w - 1)) * 16;   // slot = kq*256 + cell
+    const int kq_step = g.N * 16;
 
-    Operand<BM, SF_LAYOUT_K_MAJOR> opa;
-    Operand<BN, SF_LAYOUT_K_MAJOR> opb;
-    typename Operand<BM, SF_LAYOUT_K_MAJOR>::Regs ra;
-    typename Operand<BN, SF_LAYOUT_K_MAJOR>::Regs rb;
-    opa.init(A, nullptr, bytes, g.N, g.D, g.N, m0, 0, 0, tid);
-    opb.init(Bm, nullptr, bytes, g.N, g.D, g.N, 0, 0, 0, tid);
-#pragma unroll
-    for (int j = 0; j < Operand<BN, SF_LAYOUT_K_MAJOR>::NI; ++j) {      // column n of the B tile = cell (n/32, n%32) of the patch
-        const int n = (tid + j * kThreads) % BN;
-        const int y = min(py0 + n / PC, g.h - 1), x = min(px0 + n % PC, g.w - 1);
-        opb.voff[j] = (y * g.w + x) * 4;
-    }
+    auto issue = [&](int kt, int buf) {
+        char* sb = smem + buf * STAGE + wave * 1024;
+        const int so = kt * (DK / 8) * kq_step;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)(sb), 16, voa, so, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)(sb + ST_A), 16, voa + half, so, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr)(sb + 2 * ST_A), 16, vob, so, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr)(sb + 2 * ST_A + 4096), 16, vob, so + kq_step, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr)(sb + 2 * ST_A + ST_B), 16, vob + half, so, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr)(sb + 2 * ST_A + ST_B + 4096), 16, vob + half, so + kq_step, 0, 0);
+    };
 
     f32x16 acc[PR];
 #pragma unroll
@@ -234,41 +329,30 @@ __global__ __launch_bounds__(kThreads, 2) void corr_build_split_kernel(const Bui
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-    const int nk = (g.D + BK - 1) / BK;
-    opa.load(0, 0, ra);
-    opb.load(0, 0, rb);
-    opa.store(0, sA[0], sA[1], ra);
-    opb.store(0, sB[0], sB[1], rb);
-    __syncthreads();
+    const int nk = Dp / DK;
+    const int offa = (khalf * BM + wave * 32 + l31) * 16;
+    const int offb = 2 * ST_A + (khalf * BN + l31) * 16;
+    issue(0, 0);
+    if (NSTAGE > 2 && nk > 1) issue(1, 1);
+    int cur = 0, nxt = NSTAGE - 1;                                        // ring slots of stage kt and stage kt + 2
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) {
-            opa.load((kt + 1) * BK, (kt + 1) * BK * g.N, ra);
-            opb.load((kt + 1) * BK, (kt + 1) * BK * g.N, rb);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        const _Float16* pah = sA[0] + (wave * 32 + l31) * LDK + khalf * 8;
-        const _Float16* pal = sA[1] + (wave * 32 + l31) * LDK + khalf * 8;
-        const _Float16* pbh = sB[0] + l31 * LDK + khalf * 8;
-        const _Float16* pbl = sB[1] + l31 * LDK + khalf * 8;
+        // this wave's 6 pieces of stage kt have landed (the 6 of stage kt+1 may still be in flight) ...
+        if (NSTAGE > 2 && kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                           // ... everyone's; and slot nxt (stage kt-1) is no longer read
+        if (kt + NSTAGE - 1 < nk) issue(kt + NSTAGE - 1, nxt);
+        const char* sb = smem + cur * STAGE;
+        cur = (cur == NSTAGE - 1) ? 0 : cur + 1;
+        nxt = (nxt == NSTAGE - 1) ? 0 : nxt + 1;
+        const f16x8 ah = *reinterpret_cast<const f16x8*>(sb + offa);
+        const f16x8 al = *reinterpret_cast<const f16x8*>(sb + offa + ST_A);
 #pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {
-            const f16x8 ah = *reinterpret_cast<const f16x8*>(pah + ks * 16);
-            const f16x8 al = *reinterpret_cast<const f16x8*>(pal + ks * 16);
-#pragma unroll
-            for (int t = 0; t < PR; ++t) {
-                const f16x8 bh = *reinterpret_cast<const f16x8*>(pbh + t * PC * LDK + ks * 16);
-                const f16x8 bl = *reinterpret_cast<const f16x8*>(pbl + t * PC * LDK + ks * 16);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t], 0, 0, 0);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (kt + 1 < nk) {
-            __syncthreads();
-            opa.store((kt + 1) * BK, sA[0], sA[1], ra);
-            opb.store((kt + 1) * BK, sB[0], sB[1], rb);
-            __syncthreads();
+        for (int t = 0; t < PR; ++t) {
+            const f16x8 bh = *reinterpret_cast<const f16x8*>(sb + offb + t * PC * 16);
+            const f16x8 bl = *reinterpret_cast<const f16x8*>(sb + offb + ST_B + t * PC * 16);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t], 0, 0, 0);
         }
     }
     pyramid_epilogue(g, acc, b, pair, m0, wave, py0, px0, lane);
@@ -374,18 +458,31 @@ __global__ void bilinear_sampler_kernel(const float* img, const float* coords, f
 
 }  // namespace
 
+extern "C" int64_t sf_corr_build_ws_bytes(int B, int pairs, int D, int h, int w) {
+    if (B <= 0 || pairs <= 0 || D <= 0 || h <= 0 || w <= 0) return 0;
+    return (int64_t)2 * B * pairs * (sf::ceil_div(D, DK) * DK) * h * w * 4;      // (f1, f2) x images x (hi + lo) planes
+}
+
 extern "C" int sf_corr_build_pyramid(const float* f1, const float* f2, int64_t f_clip_stride, int64_t f_pair_stride,
                                      float* lvl0, float* lvl1, float* lvl2, float* lvl3,
                                      const int64_t* lvl_pair_stride, int B, int pairs, int D, int h, int w,
-                                     int num_levels, int precision, void* stream) {
+                                     int num_levels, int precision, void* split_ws, int64_t split_ws_bytes,
+                                     void* stream) {
     SF_REQUIRE(f1 && f2 && lvl0 && lvl1 && lvl2 && lvl3, "sf_corr_build_pyramid: null pointer");
     SF_REQUIRE(B > 0 && pairs > 0 && D > 0 && h > 0 && w > 0, "sf_corr_build_pyramid: bad dims");
     SF_REQUIRE(pairs == 1 || lvl_pair_stride, "sf_corr_build_pyramid: pairs > 1 needs lvl_pair_stride");
     SF_REQUIRE(num_levels == 4, "sf_corr_build_pyramid: num_levels must be 4 (got %d)", num_levels);
     SF_REQUIRE(precision == SF_PRECISION_FP32 || precision == SF_PRECISION_F16X3,
                "sf_corr_build_pyramid: precision %d not supported", precision);
-    SF_REQUIRE(precision == SF_PRECISION_FP32 || (int64_t)D * h * w * 4 < ((int64_t)1 << 31),
+    const int Dp = sf::ceil_div(D, DK) * DK;
+    SF_REQUIRE(precision == SF_PRECISION_FP32 || (int64_t)Dp * h * w * 4 < ((int64_t)1 << 31),
                "sf_corr_build_pyramid: feature image larger than 2 GiB");
+    SF_REQUIRE(precision == SF_PRECISION_FP32 ||
+                   (split_ws && split_ws_bytes >= sf_corr_build_ws_bytes(B, pairs, D, h, w) &&
+                    (reinterpret_cast<uintptr_t>(split_ws) & 15) == 0),
+               "sf_corr_build_pyramid: SF_PRECISION_F16X3 needs a 16-byte aligned workspace of "
+               "sf_corr_build_ws_bytes() bytes");
+    SF_REQUIRE((int64_t)48 * h * w * 4 < ((int64_t)1 << 31), "sf_corr_build_pyramid: feature grid %dx%d too large", h, w);
     SF_REQUIRE((h >> 3) >= 1 && (w >> 3) >= 1, "sf_corr_build_pyramid: feature grid %dx%d too small for 4 levels", h, w);
     SF_REQUIRE((int64_t)B * pairs <= 65535, "sf_corr_build_pyramid: B*pairs too large");
     BuildArgs g;
@@ -404,9 +501,12 @@ extern "C" int sf_corr_build_pyramid(const float* f1, const float* f2, int64_t f
     g.vec_b = ((w & 3) == 0) && ((f_clip_stride & 3) == 0) && ((f_pair_stride & 3) == 0) &&
               ((reinterpret_cast<uintptr_t>(f2) & 15) == 0);
     dim3 grid(g.pcols * sf::ceil_div(h, PR), sf::ceil_div(g.N, BM), B * pairs);
-    if (precision == SF_PRECISION_F16X3)
-        hipLaunchKernelGGL(corr_build_split_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, g);
-    else
+    if (precision == SF_PRECISION_F16X3) {
+        hipLaunchKernelGGL(split_pack_kernel, dim3(sf::ceil_div(g.N, 256), Dp / 8, 2 * B * pairs), dim3(256), 0,
+                           (hipStream_t)stream, f1, f2, f_clip_stride, f_pair_stride, (char*)split_ws, pairs, D, Dp, g.N);
+        hipLaunchKernelGGL(corr_build_dma_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, g,
+                           (const char*)split_ws, Dp);
+    } else
         hipLaunchKernelGGL(corr_build_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, g);
     return sf::check_launch("sf_corr_build_pyramid");
 }

@@ -127,6 +127,8 @@ class _Plan:
         dims = [(h >> l, w >> l) for l in range(4)]
         self.lvl_pair_stride = [Bc * P * hl * wl for hl, wl in dims]
         self.lvls = [torch.empty(Pn * s, dtype=torch.float32, device=device) for s in self.lvl_pair_stride]
+        # scratch of the split-precision volume build: (hi, lo) fp16 planes of every f1 / f2 image
+        self.corr_ws = torch.empty(max(ops.corr_build_ws_bytes(Bc, Pn, D, h, w), 16), dtype=torch.uint8, device=device)
         # GMA attention: materialise the N x N matrix once (reference core/gma.py) when an image's matrix fits the
         # kernels' 32-bit offsets; otherwise (high resolution, e.g. 1080p: N = 32400 -> 4.2 GB per image) recompute
         # softmax(q k^T) v in row chunks every iteration, which is what the reference's demo does through
@@ -221,7 +223,7 @@ class HotPathEngine:
         T = Pn + 1
         # a1+a2: all pairs, one launch.  pair t = (frame t, frame t+1)
         ops.corr_build(fmaps.data_ptr(), fmaps.data_ptr() + 4 * D * P, T * D * P, D * P, pl.lvls, pl.lvl_pair_stride,
-                       Bc, Pn, D, h, w)
+                       Bc, Pn, D, h, w, ws=pl.corr_ws)
         # streamflow.py:119-122: nets = tanh(.), inps = relu(.)
         ops.context_split(cnets, pl.nets, pl.inps, HDIM)
         # a6: attn = softmax(scale * q k^T) over the context features (gma.py:53-65), computed once

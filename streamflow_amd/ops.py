@@ -301,17 +301,27 @@ def pair_strides(arr: Optional[Sequence[int]]):
     return (C.c_int64 * 4)(*[int(a) for a in arr])
 
 
+def corr_build_ws_bytes(B: int, pairs: int, D: int, h: int, w: int) -> int:
+    return int(_lib.load().sf_corr_build_ws_bytes(B, pairs, D, h, w))
+
+
 def corr_build(f1_ptr: int, f2_ptr: int, clip_stride: int, pair_stride: int, lvls: Sequence[torch.Tensor],
-               lvl_pair_stride: Optional[Sequence[int]], B: int, pairs: int, D: int, h: int, w: int) -> None:
+               lvl_pair_stride: Optional[Sequence[int]], B: int, pairs: int, D: int, h: int, w: int,
+               ws: Optional[torch.Tensor] = None) -> None:
+    """ws: scratch of corr_build_ws_bytes() bytes for the split-precision build (allocated here when omitted)."""
     N = h * w
+    prec = min(PRECISION, PRECISION_F16X3)
+    need = corr_build_ws_bytes(B, pairs, D, h, w) if prec != PRECISION_FP32 else 0
+    if need and (ws is None or ws.numel() * ws.element_size() < need):
+        ws = torch.empty(need, dtype=torch.uint8, device=lvls[0].device)
     cells = sum((h >> l) * (w >> l) for l in range(4))
     # algorithmic bytes per (clip, pair): both feature maps read once + every pyramid cell written once
     nbytes = B * pairs * (2.0 * N * D * 4 + 4.0 * N * cells)
     _launch("corr_build", 2.0 * N * N * D * B * pairs, nbytes, lambda: _lib.check(
         _lib.load().sf_corr_build_pyramid(
             f1_ptr, f2_ptr, clip_stride, pair_stride, lvls[0].data_ptr(), lvls[1].data_ptr(), lvls[2].data_ptr(),
-            lvls[3].data_ptr(), pair_strides(lvl_pair_stride), B, pairs, D, h, w, 4, min(PRECISION, PRECISION_F16X3),
-            _lib.stream()),
+            lvls[3].data_ptr(), pair_strides(lvl_pair_stride), B, pairs, D, h, w, 4, prec,
+            ws.data_ptr() if need else None, need, _lib.stream()),
         "sf_corr_build_pyramid"))
 
 
