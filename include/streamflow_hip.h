@@ -88,9 +88,12 @@ int sf_corr_lookup(const float* lvl0, const float* lvl1, const float* lvl2, cons
  * (update.py:466-479), mask head (update.py:756-759; 3x3 conv as implicit GEMM). */
 enum { SF_LAYOUT_K_MAJOR = 0,   /* A[k*lda + m]   /  B[k*ldb + n]   (rows of k)            */
        SF_LAYOUT_K_MINOR = 1,   /* A[m*lda + k]   /  B[n*ldb + k]   (k contiguous)          */
-       SF_LAYOUT_SPLIT_F16 = 2 };/* A only, precision 1: weights pre-split on the host into two IEEE fp16
+       SF_LAYOUT_SPLIT_F16 = 2,/* A only, precision 1: weights pre-split on the host into two IEEE fp16
                                     matrices A_hi/A_lo [M padded to 128][K padded to 32] (zero padded),
                                     element (m,k) at m*lda_h + k, with w = hi + lo to ~22 bits         */
+       SF_LAYOUT_F16_K_MINOR = 3 };/* B only, split precisions: B points to IEEE fp16 values B[n*ldb + k]
+                                    (ldb, strideB in halfs; ldb % 2 == 0); used as they are, no lo part:
+                                    a*b = ah*b + al*b.  The stored attention matrix (sf_softmax_rows).   */
 enum { SF_PRECISION_FP32 = 0,   /* exact fp32: v_mfma_f32_32x32x2_f32, k-ordered fmaf chain          */
        SF_PRECISION_F16X3 = 1,  /* split precision: x = hi+lo (fp16 each); a*b = ah*bh + ah*bl + al*bh
                                     on v_mfma_f32_32x32x16_f16 with fp32 accumulation (~2^-22 relative)  */
@@ -146,8 +149,11 @@ int sf_splitk_combine(const float* partial, int64_t split_stride, int k_splits, 
                       const float* R, int64_t r_img_stride, const float* gamma, float* out,
                       int64_t out_img_stride, int n_img, int64_t floats_per_img, void* stream);
 
-/* ---- row softmax in place (gma.py:63): x [rows][cols] ------------------------------------------ */
-int sf_softmax_rows(float* x, int64_t rows, int cols, void* stream);
+/* ---- row softmax (gma.py:63): x [rows][cols] ----------------------------------------------------
+ * out_f16 == NULL: in place.  Otherwise the weights are written as IEEE fp16 to out_f16 [rows][cols] (x is then
+ * scratch): the attention matrix is re-read by every refinement iteration's attn @ v and that read is HBM-bound,
+ * so the split-precision modes store it in half the bytes (SF_LAYOUT_F16_K_MINOR below). */
+int sf_softmax_rows(float* x, int64_t rows, int cols, void* out_f16, void* stream);
 
 /* ---- depthwise KxK conv + bias + residual + GELU  (update.py:33-34 with kernel in {7,15}) -------
  * y = gelu(x + dwconv(x) + b);  plane (img, c) of x is the [h][w] map at x + img*x_img_stride + c*h*w

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SF_HIP_LIB: load an alternative build of the same library (A/B timing of kernel variants)
 LIB_PATH = os.environ.get("SF_HIP_LIB") or os.path.join(_HERE, "libstreamflow_hip.so")
 
-LAYOUT_K_MAJOR, LAYOUT_K_MINOR, LAYOUT_SPLIT_F16 = 0, 1, 2
+LAYOUT_K_MAJOR, LAYOUT_K_MINOR, LAYOUT_SPLIT_F16, LAYOUT_F16_K_MINOR = 0, 1, 2, 3
 PRECISION_FP32, PRECISION_F16X3, PRECISION_F16X2 = 0, 1, 2
 EPI_NONE, EPI_GELU, EPI_RELU, EPI_RES, EPI_RES_GELU, EPI_RES_GELU_DW1, EPI_AXPY = range(7)
 
@@ -52,7 +52,7 @@ SIGNATURES = {
     "sf_corr_lookup": (_i, [_vp, _vp, _vp, _vp, C.POINTER(_i64), _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _vp]),
     "sf_gemm": (_i, [C.POINTER(SfGemm), _vp]),
     "sf_gemm_split_ws_floats": (_i64, [_i, _i, _i, _i]),
-    "sf_softmax_rows": (_i, [_vp, _i64, _i, _vp]),
+    "sf_softmax_rows": (_i, [_vp, _i64, _i, _vp, _vp]),
     "sf_splitk_combine": (_i, [_vp, _i64, _i, _i64, _vp, _i64, _vp, _vp, _i64, _i, _i64, _vp]),
     "sf_dwconv_res_gelu": (_i, [_vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _vp]),
     "sf_layernorm_cm": (_i, [_vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _i, _f, _vp]),

@@ -34,12 +34,13 @@ using namespace sf_split;
 struct SplitArgs {
     SfGemm g;
     int64_t a_bytes, b_bytes;      // bytes spanned by one batch image of A / B (buffer range check)
+    long long* ts;                 // SF_GEMM_TS_BUF: per-workgroup phase timestamps (experiments only)
     int dbg;                       // ablation bits (SF_GEMM_DBG, experiments only): 1 no global loads in the loop,
                                    // 2 no MFMAs, 4 no convert/LDS stores in the loop
 };
 
 template <int WM, int WN, int TM, int TN, int ALAY, int BLAY, bool SB>
-__global__ __launch_bounds__(kThreads, 3) void gemm_f16x3_mfma(const SplitArgs args) {
+__global__ __launch_bounds__(kThreads, (TM * TN >= 8) ? 2 : 3) void gemm_f16x3_mfma(const SplitArgs args) {
     const SfGemm& g = args.g;
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     static_assert(WM * WN == 4, "4 waves per workgroup");
@@ -57,13 +58,16 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_f16x3_mfma(const SplitArgs a
     const int ksp = g.k_splits > 1 ? g.k_splits : 1;
     const int n0 = tc.n_tile * BN, m0 = tc.m_tile * BM, z = tc.z / ksp, split = tc.z % ksp;
 
+    const long long ts0 = __builtin_readcyclecounter();
+    const long long rt0 = __builtin_amdgcn_s_memrealtime();
     Operand<BM, ALAY> opa;
     Operand<BN, BLAY> opb;
     typename Operand<BM, ALAY>::Regs ra;
     typename Operand<BN, BLAY>::Regs rb;
     if (ALAY == 2) opa.init(g.A_hi, g.A_lo, args.a_bytes, (int)g.lda_h, g.K, g.M, m0, 0, 0, tid);
     else opa.init(g.A + (int64_t)z * g.strideA, nullptr, args.a_bytes, (int)g.lda, g.K, g.M, m0, 0, 0, tid);
-    opb.init(g.B + (int64_t)z * g.strideB, nullptr, args.b_bytes, (int)g.ldb, g.K, g.N, n0, g.b_group, g.b_group_stride, tid);
+    opb.init(reinterpret_cast<const char*>(g.B) + (int64_t)z * g.strideB * (BLAY == SF_LAYOUT_F16_K_MINOR ? 2 : 4), nullptr,
+             args.b_bytes, (int)g.ldb, g.K, g.N, n0, g.b_group, g.b_group_stride, tid);
     const bool conv = (BLAY == SF_LAYOUT_K_MAJOR) && g.conv3x3;
     const int cin = conv ? g.K / 9 : 1;
     if (BLAY == SF_LAYOUT_K_MAJOR && conv) opb.set_conv3x3(n0, g.h, g.w, tid);
@@ -92,6 +96,7 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_f16x3_mfma(const SplitArgs a
     opa.store(kt_beg * BK, sA[0], sA[1], ra);
     opb.template store<SB>(kt_beg * BK, sB[0], sB[SB ? 1 : 0], rb, conv ? conv_tap(kt_beg * BK) : -1);
     __syncthreads();
+    const long long ts1 = __builtin_readcyclecounter();
 
     const int khalf = lane >> 5, l31 = lane & 31;
     for (int kt = kt_beg; kt < kt_end; ++kt) {
@@ -139,6 +144,7 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_f16x3_mfma(const SplitArgs a
             __syncthreads();
         }
     }
+    const long long ts2 = __builtin_readcyclecounter();
     SfGemm gs = g;
     if (ksp > 1) gs.C = g.C + (int64_t)split * g.split_stride;   // partial product of this K slice: its own slab
     if (sf::epilogue_vec_ok(gs, z)) {
@@ -147,6 +153,13 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_f16x3_mfma(const SplitArgs a
                                               reinterpret_cast<float*>(smem) + wave * sf::kEpiScratchFloats);
     } else {
         gemm_epilogue<WM, WN, TM, TN>(gs, acc, m0, n0, z, wm, wn, lane);
+    }
+    if (args.ts && tid == 0) {
+        long long* d = args.ts + (int64_t)blockIdx.x * 8;
+        d[0] = ts0; d[1] = ts1; d[2] = ts2; d[3] = __builtin_readcyclecounter();
+        d[4] = rt0; d[5] = __builtin_amdgcn_s_memrealtime();
+        d[6] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));      // XCC_ID[3:0]
+        d[7] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));      // HW_ID
     }
 }
 
@@ -198,8 +211,8 @@ __global__ __launch_bounds__(kWsThreads, 4) void gemm_f16x3_ws(const SplitArgs a
         typename Operand<BN, BLAY>::Regs rb[kDepth];
         if (ALAY == 2) opa.init(g.A_hi, g.A_lo, args.a_bytes, (int)g.lda_h, g.K, g.M, m0, 0, 0, ptid);
         else opa.init(g.A + (int64_t)z * g.strideA, nullptr, args.a_bytes, (int)g.lda, g.K, g.M, m0, 0, 0, ptid);
-        opb.init(g.B + (int64_t)z * g.strideB, nullptr, args.b_bytes, (int)g.ldb, g.K, g.N, n0, g.b_group,
-                 g.b_group_stride, ptid);
+        opb.init(reinterpret_cast<const char*>(g.B) + (int64_t)z * g.strideB * (BLAY == SF_LAYOUT_F16_K_MINOR ? 2 : 4), nullptr,
+                 args.b_bytes, (int)g.ldb, g.K, g.N, n0, g.b_group, g.b_group_stride, ptid);
         RowCursor ca, cb;                     // row offset of the NEXT tile to be loaded
         ca.init(0, (int)g.lda, 0);
         cb.init(g.b_group, (int)g.ldb, g.b_group_stride);
@@ -291,11 +304,15 @@ template <bool SB>
 int launch_ws(const SplitArgs& a, hipStream_t st) {
     const SfGemm& g = a.g;
     dim3 grid(sf::ceil_div(g.N, 128) * sf::ceil_div(g.M, 128) * g.batch * (g.k_splits > 1 ? g.k_splits : 1));
-    const int lay = g.a_layout * 2 + g.b_layout;
+    const int lay = g.a_layout * 4 + g.b_layout;
+    if (lay == 7) {                                     // K-minor fp32 A x stored fp16 B (attn @ v): B has no lo part
+        hipLaunchKernelGGL((gemm_f16x3_ws<1, 3, false>), grid, dim3(kWsThreads), 0, st, a);
+        return sf::check_launch("sf_gemm(f16x3, wave-specialised)");
+    }
     switch (lay) {
         case 0: hipLaunchKernelGGL((gemm_f16x3_ws<0, 0, SB>), grid, dim3(kWsThreads), 0, st, a); break;
-        case 3: hipLaunchKernelGGL((gemm_f16x3_ws<1, 1, SB>), grid, dim3(kWsThreads), 0, st, a); break;
-        case 4: hipLaunchKernelGGL((gemm_f16x3_ws<2, 0, SB>), grid, dim3(kWsThreads), 0, st, a); break;
+        case 5: hipLaunchKernelGGL((gemm_f16x3_ws<1, 1, SB>), grid, dim3(kWsThreads), 0, st, a); break;
+        case 8: hipLaunchKernelGGL((gemm_f16x3_ws<2, 0, SB>), grid, dim3(kWsThreads), 0, st, a); break;
         default: return sf::fail(SF_ERR_UNSUPPORTED, "sf_gemm(f16x3): layout combination a=%d b=%d not built",
                                  g.a_layout, g.b_layout);
     }
@@ -307,11 +324,18 @@ int launch_cfg(const SplitArgs& a, hipStream_t st) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     const SfGemm& g = a.g;
     dim3 grid(sf::ceil_div(g.N, BN) * sf::ceil_div(g.M, BM) * g.batch * (g.k_splits > 1 ? g.k_splits : 1));   // 1-D: see sf::xcd_tile
-    const int lay = g.a_layout * 2 + g.b_layout;
+    const int lay = g.a_layout * 4 + g.b_layout;
+    if (lay == 7) {
+        if constexpr (!SB && TM * TN == 4) {             // only the 128x128 tile is built for the stored-fp16 B
+            hipLaunchKernelGGL((gemm_f16x3_mfma<WM, WN, TM, TN, 1, 3, false>), grid, dim3(kThreads), 0, st, a);
+            return sf::check_launch("sf_gemm(f16x3)");
+        }
+        return sf::fail(SF_ERR_UNSUPPORTED, "sf_gemm(f16x3): SF_LAYOUT_F16_K_MINOR B not built for this tile");
+    }
     switch (lay) {
         case 0: hipLaunchKernelGGL((gemm_f16x3_mfma<WM, WN, TM, TN, 0, 0, SB>), grid, dim3(kThreads), 0, st, a); break;
-        case 3: hipLaunchKernelGGL((gemm_f16x3_mfma<WM, WN, TM, TN, 1, 1, SB>), grid, dim3(kThreads), 0, st, a); break;
-        case 4: hipLaunchKernelGGL((gemm_f16x3_mfma<WM, WN, TM, TN, 2, 0, SB>), grid, dim3(kThreads), 0, st, a); break;
+        case 5: hipLaunchKernelGGL((gemm_f16x3_mfma<WM, WN, TM, TN, 1, 1, SB>), grid, dim3(kThreads), 0, st, a); break;
+        case 8: hipLaunchKernelGGL((gemm_f16x3_mfma<WM, WN, TM, TN, 2, 0, SB>), grid, dim3(kThreads), 0, st, a); break;
         default: return sf::fail(SF_ERR_UNSUPPORTED, "sf_gemm(f16x3): layout combination a=%d b=%d not built",
                                  g.a_layout, g.b_layout);
     }
@@ -329,6 +353,8 @@ int pick_tile(const SplitArgs& a, hipStream_t st) {
     if (const char* e = getenv("SF_GEMM_BM")) {          // experiment knob
         const int bm = atoi(e);
         if (bm == 128) return launch_cfg<2, 2, 2, 2, SB>(a, st);
+        if (bm == 256) return launch_cfg<2, 2, 4, 2, SB>(a, st);
+        if (bm == 257) return launch_cfg<2, 2, 2, 4, SB>(a, st);
         if (bm == 129) return launch_ws<SB>(a, st);
         if (bm == 64) return launch_cfg<1, 4, 2, 1, SB>(a, st);
         if (bm == 32) return launch_cfg<1, 4, 1, 1, SB>(a, st);
@@ -344,6 +370,7 @@ int pick_tile(const SplitArgs& a, hipStream_t st) {
 }
 
 int64_t span_bytes(int layout, int X, int K, int64_t ld, int group, int64_t group_stride) {
+    if (layout == SF_LAYOUT_F16_K_MINOR) return ((int64_t)(X - 1) * ld + K) * 2;
     if (layout == SF_LAYOUT_K_MINOR) return ((int64_t)(X - 1) * ld + K) * 4;
     if (group > 0) return ((int64_t)((K - 1) / group) * group_stride + (int64_t)((K - 1) % group) * ld + X) * 4;
     return ((int64_t)(K - 1) * ld + X) * 4;
@@ -450,6 +477,7 @@ int gemm_split_dispatch_inner(const SfGemm& g, hipStream_t st) {
     SplitArgs a;
     a.g = g;
     a.dbg = getenv("SF_GEMM_DBG") ? atoi(getenv("SF_GEMM_DBG")) : 0;
+    a.ts = getenv("SF_GEMM_TS_BUF") ? (long long*)strtoull(getenv("SF_GEMM_TS_BUF"), nullptr, 0) : nullptr;
     if (g.a_layout == SF_LAYOUT_SPLIT_F16) {
         if (!g.A_hi || !g.A_lo || g.lda_h <= 0 || (g.lda_h & 7))
             return fail(SF_ERR_BAD_ARG, "sf_gemm(f16x3): SPLIT_F16 A needs A_hi/A_lo and lda_h %% 8 == 0");
@@ -462,6 +490,11 @@ int gemm_split_dispatch_inner(const SfGemm& g, hipStream_t st) {
         return fail(SF_ERR_UNSUPPORTED, "sf_gemm(f16x3): operand image larger than 2 GiB (32-bit buffer offsets)");
     // tile choice: the 128-row tile moves the fewest bytes per MAC; drop to 64/32 rows when padding M would
     // waste more than a quarter of the MFMAs
+    if (g.b_layout == SF_LAYOUT_F16_K_MINOR) {
+        if (g.a_layout != SF_LAYOUT_K_MINOR || (g.ldb & 1) || g.b_group || g.conv3x3 || (reinterpret_cast<uintptr_t>(g.B) & 3))
+            return fail(SF_ERR_UNSUPPORTED, "sf_gemm(f16x3): SF_LAYOUT_F16_K_MINOR B needs a K-minor A, even ldb, 4-byte aligned B");
+        return pick_tile<false>(a, st);
+    }
     return (g.precision == SF_PRECISION_F16X2) ? pick_tile<false>(a, st) : pick_tile<true>(a, st);
 }
 

@@ -88,9 +88,10 @@ __device__ __forceinline__ float wave_sum(float v) {
 // One workgroup per row; the row lives in registers (up to kSmMax values per thread), so it is read once and
 // written once (the first version made three passes over memory: 1.4x the reads and 2x the writes).
 constexpr int kSmMax = 32;              // 256 threads x 32 = rows up to 8192 columns in registers
-__global__ __launch_bounds__(kBlock) void softmax_rows_kernel(float* x, int cols) {
+__global__ __launch_bounds__(kBlock) void softmax_rows_kernel(float* x, int cols, _Float16* y16) {
     __shared__ float red[kBlock / 64];
     float* row = x + (int64_t)blockIdx.x * cols;
+    _Float16* row16 = y16 ? y16 + (int64_t)blockIdx.x * cols : nullptr;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float v[kSmMax];
     float m = -INFINITY;
@@ -119,14 +120,18 @@ __global__ __launch_bounds__(kBlock) void softmax_rows_kernel(float* x, int cols
 #pragma unroll
     for (int j = 0; j < kSmMax; ++j) {
         const int c = tid + j * kBlock;
-        if (c < cols) row[c] = v[j] * inv;
+        if (c < cols) {
+            if (row16) row16[c] = (_Float16)(v[j] * inv);
+            else row[c] = v[j] * inv;
+        }
     }
 }
 
 // fallback for very long rows: three passes over memory
-__global__ __launch_bounds__(kBlock) void softmax_rows_long_kernel(float* x, int cols) {
+__global__ __launch_bounds__(kBlock) void softmax_rows_long_kernel(float* x, int cols, _Float16* y16) {
     __shared__ float red[kBlock / 64];
     float* row = x + (int64_t)blockIdx.x * cols;
+    _Float16* row16 = y16 ? y16 + (int64_t)blockIdx.x * cols : nullptr;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float m = -INFINITY;
     for (int c = tid; c < cols; c += kBlock) m = fmaxf(m, row[c]);
@@ -146,7 +151,10 @@ __global__ __launch_bounds__(kBlock) void softmax_rows_long_kernel(float* x, int
     __syncthreads();
     s = (red[0] + red[1]) + (red[2] + red[3]);
     const float inv = 1.0f / s;
-    for (int c = tid; c < cols; c += kBlock) row[c] *= inv;
+    for (int c = tid; c < cols; c += kBlock) {
+        if (row16) row16[c] = (_Float16)(row[c] * inv);
+        else row[c] *= inv;
+    }
 }
 
 // ---- LayerNorm over channels (channel-major planes) -------------------------------------------------
@@ -400,13 +408,13 @@ extern "C" int sf_flow_update(float* coords1, const float* delta, float* flow_a,
     return sf::check_launch("sf_flow_update");
 }
 
-extern "C" int sf_softmax_rows(float* x, int64_t rows, int cols, void* stream) {
+extern "C" int sf_softmax_rows(float* x, int64_t rows, int cols, void* out_f16, void* stream) {
     SF_REQUIRE(x && rows > 0 && cols > 0, "sf_softmax_rows: bad args");
     SF_REQUIRE(rows <= 0x7fffffffLL, "sf_softmax_rows: too many rows");
     if (cols <= kSmMax * kBlock)
-        hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(kBlock), 0, (hipStream_t)stream, x, cols);
+        hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(kBlock), 0, (hipStream_t)stream, x, cols, (_Float16*)out_f16);
     else
-        hipLaunchKernelGGL(softmax_rows_long_kernel, dim3((unsigned)rows), dim3(kBlock), 0, (hipStream_t)stream, x, cols);
+        hipLaunchKernelGGL(softmax_rows_long_kernel, dim3((unsigned)rows), dim3(kBlock), 0, (hipStream_t)stream, x, cols, (_Float16*)out_f16);
     return sf::check_launch("sf_softmax_rows");
 }
 

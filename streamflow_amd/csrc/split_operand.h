@@ -54,8 +54,8 @@ struct Operand {
     int rowc[NI][8];     // K-major: byte offset of row (ko*8 + i) inside a k-tile -- loop invariant, wave uniform
     unsigned tapmask[NI];   // implicit 3x3 conv: bit t set = tap t of this thread's pixel lies inside the image
     struct Regs {                                  // one staged k-tile of this thread
-        float v[(LAY == 2) ? 1 : NI][8];
-        u32x4 ph[(LAY == 2) ? NI : 1], pl[(LAY == 2) ? NI : 1];
+        float v[(LAY >= 2) ? 1 : NI][8];
+        u32x4 ph[(LAY >= 2) ? NI : 1], pl[(LAY == 2) ? NI : 1];
     };
 
     __device__ __forceinline__ void init(const void* base, const void* base_lo, int64_t bytes, int ld_, int K_, int X,
@@ -82,6 +82,7 @@ struct Operand {
                 for (int i = 0; i < 8; ++i) rowc[j][i] = (ko[j] * 8 + i) * ld * 4;
             }
             else if (LAY == SF_LAYOUT_K_MINOR) voff[j] = (xc * ld + kq * 8) * 4;
+            else if (LAY == SF_LAYOUT_F16_K_MINOR) voff[j] = (xc * ld + kq * 8) * 2;
             else voff[j] = ((x0 + xl) * ld + kq * 8) * 2;       // host-padded to 128 rows: always in range
         }
     }
@@ -112,7 +113,11 @@ struct Operand {
     __device__ __forceinline__ void load(int k0, int tile_off, Regs& rg, int shift_bytes = 0) const {
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
-            if (LAY == 2) {
+            if (LAY == SF_LAYOUT_F16_K_MINOR) {
+                // already fp16: k0 rides in the VGPR offset so that the range check sees it (reads past the end give 0;
+                // the tail k >= K inside a row reads the next row's finite values against zeroed A columns)
+                rg.ph[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[j] + k0 * 2, 0, 0);
+            } else if (LAY == 2) {
                 rg.ph[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[j], k0 * 2, 0);
                 rg.pl[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_lo, voff[j], k0 * 2, 0);
             } else if (LAY == SF_LAYOUT_K_MAJOR) {
@@ -152,7 +157,9 @@ struct Operand {
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
             if (!live[j]) continue;
-            if (LAY == 2) {
+            if (LAY == SF_LAYOUT_F16_K_MINOR) {
+                *reinterpret_cast<u32x4*>(lds_hi + lds_off[j]) = rg.ph[j];
+            } else if (LAY == 2) {
                 *reinterpret_cast<u32x4*>(lds_hi + lds_off[j]) = rg.ph[j];
                 if (kLo) *reinterpret_cast<u32x4*>(lds_lo + lds_off[j]) = rg.pl[j];
             } else {

@@ -18,8 +18,8 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import torch
 
 from . import _lib, ops
-from .ops import (EPI_AXPY, EPI_GELU, EPI_NONE, EPI_RELU, EPI_RES, EPI_RES_GELU, EPI_RES_GELU_DW1, LAYOUT_K_MAJOR,
-                  LAYOUT_K_MINOR, PackedLinear, Planes, Workspace)
+from .ops import (EPI_AXPY, EPI_GELU, EPI_NONE, EPI_RELU, EPI_RES, EPI_RES_GELU, EPI_RES_GELU_DW1, LAYOUT_F16_K_MINOR,
+                  LAYOUT_K_MAJOR, LAYOUT_K_MINOR, PackedLinear, Planes, Workspace)
 
 HDIM = 128
 COR_PLANES = 324
@@ -114,7 +114,8 @@ ATTN_ROW_LIMIT = 1 << 28          # floats per image the GEMM epilogue can addre
 class _Plan:
     """Buffers for one (clips, pairs, h, w) shape."""
 
-    def __init__(self, W: HotPathWeights, Bc: int, h: int, w: int, D: int, device, attn_chunk_rows: int = 0):
+    def __init__(self, W: HotPathWeights, Bc: int, h: int, w: int, D: int, device, attn_chunk_rows: int = 0,
+                 attn_f16: bool = False):
         Pn = W.pairs
         n, P = Bc * Pn, h * w
         self.Bc, self.Pn, self.h, self.w, self.n, self.P, self.D = Bc, Pn, h, w, n, P, D
@@ -139,6 +140,11 @@ class _Plan:
             lim = max(1, (ATTN_ROW_LIMIT - 1) // P)
             self.attn_rows = min(P, lim if attn_chunk_rows <= 0 else min(attn_chunk_rows, lim))
         self.attn = torch.empty(n, self.attn_rows, P, dtype=torch.float32, device=device)
+        # split-precision modes keep the materialised matrix in fp16 (half the bytes of the HBM-bound attn @ v that
+        # every iteration repeats; measured effect on the final flow: 4e-6 px mean EPE); self.attn is then only the
+        # logits scratch of the one-time softmax
+        self.attn16 = (torch.empty(n, P, P, dtype=torch.float16, device=device)
+                       if attn_f16 and self.attn_rows == P and P % 2 == 0 else None)
         spec = [("qk", 2 * HDIM), ("corr", COR_PLANES), ("flow", 2), ("hid", 960), ("xa", 640), ("xb", 640),
                 ("cor256", 256), ("cat256", 256), ("f128", 128),
                 ("concat", 640),                       # [nets | inps | mf | mf_global | mf_temporal]
@@ -198,7 +204,8 @@ class HotPathEngine:
     def plan(self, Bc: int, h: int, w: int, D: int) -> _Plan:
         key = (Bc, h, w, D)
         if key not in self._plans:
-            self._plans[key] = _Plan(self.W, Bc, h, w, D, self.device, self.attn_chunk_rows)
+            self._plans[key] = _Plan(self.W, Bc, h, w, D, self.device, self.attn_chunk_rows,
+                                     attn_f16=self.precision != ops.PRECISION_FP32)
         return self._plans[key]
 
     # ---------------------------------------------------------------------------------------------
@@ -210,7 +217,7 @@ class HotPathEngine:
                      strideC=pl.attn_rows * P, a_layout=LAYOUT_K_MAJOR, b_layout=LAYOUT_K_MAJOR,
                      alpha=float(HDIM) ** -0.5, epilogue=EPI_NONE)
         if rows == pl.attn_rows:
-            ops.softmax_rows(pl.attn, n * rows, P)
+            ops.softmax_rows(pl.attn, n * rows, P, out16=pl.attn16)
         else:                                     # last, shorter chunk: rows of each image are not contiguous
             for img in range(n):
                 ops.softmax_rows(pl.attn[img], rows, P)
@@ -270,6 +277,8 @@ class HotPathEngine:
         # a7: global aggregation  mfg = mf + gamma * attn @ to_v(mf)   (gma.py:91-104), main stream
         ops.gemm(W.to_v, pl.mf, pl.v128, EPI_NONE)
         ks = self.attn_k_splits if self.precision != ops.PRECISION_FP32 else 1
+        attn_ptr, attn_lay = ((pl.attn16.data_ptr(), LAYOUT_F16_K_MINOR) if pl.attn16 is not None
+                              else (pl.attn.data_ptr(), LAYOUT_K_MINOR))
         if pl.attn_rows < P:
             # high-resolution path: recompute the attention rows chunk by chunk (K6' of SURVEY.md)
             for i0 in range(0, P, pl.attn_rows):
@@ -283,16 +292,16 @@ class HotPathEngine:
         elif ks > 1 and P % 4 == 0:
             # attn @ v streams the N x N matrix (HBM-bound) but has only N/128 * images workgroups: split K so that
             # enough bytes are in flight; partial products go to slabs, combined with the AXPY of gma.py:102
-            ops.gemm_raw(A=pl.v128.ptr, B=pl.attn.data_ptr(), C=pl.part.ptr, M=HDIM, N=P, K=P, batch=n, lda=P, ldb=P,
+            ops.gemm_raw(A=pl.v128.ptr, B=attn_ptr, C=pl.part.ptr, M=HDIM, N=P, K=P, batch=n, lda=P, ldb=P,
                          ldc=P, strideA=pl.v128.img_stride, strideB=P * P, strideC=HDIM * P,       # slabs: [split][img][128][P]
-                         a_layout=LAYOUT_K_MINOR, b_layout=LAYOUT_K_MINOR, alpha=1.0, epilogue=EPI_NONE,
+                         a_layout=LAYOUT_K_MINOR, b_layout=attn_lay, alpha=1.0, epilogue=EPI_NONE,
                          k_splits=ks, split_stride=n * HDIM * P)
             ops.splitk_combine(pl.part.base[pl.part.off:], n * HDIM * P, ks, HDIM * P, pl.mf, W.gamma, pl.mfg)
         else:
-            ops.gemm_raw(A=pl.v128.ptr, B=pl.attn.data_ptr(), C=pl.mfg.ptr, R=pl.mf.ptr, gamma=W.gamma.data_ptr(),
+            ops.gemm_raw(A=pl.v128.ptr, B=attn_ptr, C=pl.mfg.ptr, R=pl.mf.ptr, gamma=W.gamma.data_ptr(),
                          M=HDIM, N=P, K=P, batch=n, lda=P, ldb=P, ldc=P, ldr=P, strideA=pl.v128.img_stride,
                          strideB=P * P, strideC=pl.mfg.img_stride, strideR=pl.mf.img_stride,
-                         a_layout=LAYOUT_K_MINOR, b_layout=LAYOUT_K_MINOR, alpha=1.0, epilogue=EPI_AXPY)
+                         a_layout=LAYOUT_K_MINOR, b_layout=attn_lay, alpha=1.0, epilogue=EPI_AXPY)
         join()
         # "gru": SKBlock(640 -> 128) over cat[nets, inps, mf, mfg, mft]; new nets overwrite the nets slice
         sk(W.gru, pl.concat, pl.nets)

@@ -15,7 +15,7 @@ import torch
 
 from . import _lib
 from ._lib import (EPI_AXPY, EPI_GELU, EPI_NONE, EPI_RELU, EPI_RES, EPI_RES_GELU, EPI_RES_GELU_DW1,  # noqa: F401
-                   LAYOUT_K_MAJOR, LAYOUT_K_MINOR, LAYOUT_SPLIT_F16, PRECISION_F16X2, PRECISION_F16X3, PRECISION_FP32,
+                   LAYOUT_K_MAJOR, LAYOUT_K_MINOR, LAYOUT_SPLIT_F16, LAYOUT_F16_K_MINOR, PRECISION_F16X2, PRECISION_F16X3, PRECISION_FP32,
                    SfGemm)
 
 # Arithmetic mode of every GEMM-shaped op (sf_gemm, corr build):
@@ -255,9 +255,13 @@ def temporal_attn(QKV: Planes, OUT: Planes, B: int, TT: int, C_: int) -> None:
                                "sf_temporal_attn"))
 
 
-def softmax_rows(x: torch.Tensor, rows: int, cols: int) -> None:
-    _launch("softmax_rows", 0, 8.0 * rows * cols,
-            lambda: _lib.check(_lib.load().sf_softmax_rows(x.data_ptr(), rows, cols, _lib.stream()), "sf_softmax_rows"))
+def softmax_rows(x: torch.Tensor, rows: int, cols: int, out16: Optional[torch.Tensor] = None) -> None:
+    """In place, or (out16: fp16 [rows][cols]) written as half precision with x left as scratch."""
+    assert out16 is None or (out16.dtype == torch.float16 and out16.numel() >= rows * cols)
+    _launch("softmax_rows", 0, (8.0 if out16 is None else 6.0) * rows * cols,
+            lambda: _lib.check(_lib.load().sf_softmax_rows(x.data_ptr(), rows, cols,
+                                                           out16.data_ptr() if out16 is not None else None,
+                                                           _lib.stream()), "sf_softmax_rows"))
 
 
 def coords_grid(batch: int, ht: int, wd: int, device) -> torch.Tensor:
