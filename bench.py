@@ -92,6 +92,8 @@ def cpu_baseline(fmaps, cnets, params, iters_total: int, sample_iters: int, pair
     cores = min(usable_cores(), 64)
     torch.set_num_threads(cores)
     log(f"cpu baseline: oracle on {cores} host threads (os.cpu_count()={os.cpu_count()})")
+    orc.hotpath_forward(fmaps, cnets, params, 1)        # untimed: thread pool start-up and first-touch page faults
+    log("cpu baseline: warm-up pass done")
     t0 = time.perf_counter()
     ups1, _ = orc.hotpath_forward(fmaps, cnets, params, 1)
     t1 = time.perf_counter()
@@ -113,7 +115,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="sintel", choices=list(WORKLOADS))
-    ap.add_argument("--clips", type=int, default=1, help="clips per GPU per step (batched through every launch)")
+    ap.add_argument("--clips", type=int, default=8,
+                    help="clips per GPU per step, batched through every launch (default 8 = the per-GPU share of "
+                         "BASELINE.json's 8-GPU 'Sintel-shape batch=64' configuration; 1 = single-clip latency)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
     ap.add_argument("--all-masks", action="store_true",
                     help="run the mask head every iteration as the reference literally does (outputs identical; "
@@ -187,6 +191,7 @@ def main():
         "dtype": {"fp32": "fp32", "f16x3": "f16x3-split (fp32 accumulate)",
                   "f16x2": "f16x2 (weights hi+lo, activations fp16; fp32 accumulate)"}[args.precision], "data": "synthetic",
         "config": {"workload": f"{args.workload}_{H}x{W}_T{T}_iters{iters}", "clips_per_gpu_per_step": B,
+                   "clips_per_step_all_gpus": world * B,
                    "flow_fields_per_clip": pairs, "feature_grid": [h, w], "parallelism": f"replicas{world}",
                    "hip_graph": not args.no_graph, "mask_head_every_iteration": bool(args.all_masks),
                    "precision": {"fp32": "exact fp32 (v_mfma_f32_32x32x2_f32)",
@@ -211,18 +216,18 @@ def main():
         kern = {}
         for name, d in summ.items():
             ms = d["ms"] / reps
-            kern[name] = {"launches_per_clip": d["launches"] // reps, "ms_per_clip": round(ms, 4),
+            kern[name] = {"launches_per_step": d["launches"] // reps, "ms_per_step": round(ms, 4),
                           "avg_us": round(1e3 * ms / max(d["launches"] // reps, 1), 2),
                           "tflops": round(d["flops"] / reps / (ms * 1e-3) / 1e12, 2) if d["flops"] else None,
                           "gbps_algorithmic": round(d["bytes"] / reps / (ms * 1e-3) / 1e9, 1) if d["bytes"] else None}
         result["kernels"] = kern
         if args.gemm_shapes:            # fold the per-shape rows back into one family row for the roofline
             fam = [k for k in kern if k.startswith("gemm M")]
-            ms = sum(kern[k]["ms_per_clip"] for k in fam)
+            ms = sum(kern[k]["ms_per_step"] for k in fam)
             fl = sum(summ[k]["flops"] for k in fam) / reps
-            kern["gemm"] = {"launches_per_clip": sum(kern[k]["launches_per_clip"] for k in fam), "ms_per_clip": round(ms, 4),
+            kern["gemm"] = {"launches_per_step": sum(kern[k]["launches_per_step"] for k in fam), "ms_per_step": round(ms, 4),
                             "avg_us": None, "tflops": round(fl / (ms * 1e-3) / 1e12, 2), "gbps_algorithmic": None}
-        dom = max((k for k in kern if not k.startswith("gemm M")), key=lambda k: kern[k]["ms_per_clip"])
+        dom = max((k for k in kern if not k.startswith("gemm M")), key=lambda k: kern[k]["ms_per_step"])
         if kern[dom]["tflops"] and dom.startswith("gemm"):
             # algorithmic (fp32-equivalent) TFLOP/s; the f16x3 path issues 3 f16 MFMA flops per algorithmic flop,
             # so its matrix-core roof for algorithmic flops is 2500/3
@@ -232,7 +237,7 @@ def main():
                                   "peak": round(peak, 1), "unit": "TFLOP/s",
                                   "frac": round(kern[dom]["tflops"] / peak, 4), "traffic": None,
                                   "method": "sum of algorithmic FLOPs / sum of HIP-event durations over all launches "
-                                            "of the kernel family in one instrumented clip"}
+                                            "of the kernel family in one instrumented step"}
         else:
             result["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": kern[dom]["gbps_algorithmic"],
                                   "peak": PEAK_HBM_GBPS, "unit": "GB/s",
@@ -253,43 +258,42 @@ def main():
         cb, cl = kern.get("corr_build"), kern.get("corr_lookup")
         if cb and cl:
             tot_b = (summ["corr_build"]["bytes"] + summ["corr_lookup"]["bytes"]) / reps
-            tot_ms = cb["ms_per_clip"] + cl["ms_per_clip"]
+            tot_ms = cb["ms_per_step"] + cl["ms_per_step"]
             result["roofline_corr"] = {"bound": "hbm", "unit": "GB/s", "peak": PEAK_HBM_GBPS,
                                        "build_gbps": cb["gbps_algorithmic"], "lookup_gbps": cl["gbps_algorithmic"],
-                                       "build_tflops": cb["tflops"], "build_plus_lookup_ms_per_clip": round(tot_ms, 4),
+                                       "build_tflops": cb["tflops"], "build_plus_lookup_ms_per_step": round(tot_ms, 4),
                                        "achieved": round(tot_b / (tot_ms * 1e-3) / 1e9, 1),
                                        "frac": round(tot_b / (tot_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4)}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import streamflow_oracle as orc
         sample_iters = 2 if args.workload != "demo256" else 3
-        base, ups_cpu = cpu_baseline(fmaps_c, cnets_c, params, iters, sample_iters, pairs)
+        # bounded sample: the first clip of the step only
+        base, ups_cpu = cpu_baseline(fmaps_c[:1], cnets_c[:1], params, iters, sample_iters, pairs)
         result["cpu_baseline"] = base
         chk = HotPathEngine(params, device=dev, T=T, use_graph=False, precision=args.precision)
         chk._plans = eng._plans
-        ups_gpu, _ = chk.forward(fmaps, cnets, iters=sample_iters)
+        ups_gpu, _ = chk.forward(fmaps[:1].contiguous(), cnets[:1].contiguous(), iters=sample_iters)
         result["epe_vs_oracle"] = {"value": max(orc.epe(a.cpu(), b) for a, b in zip(ups_gpu, ups_cpu)),
                                    "unit": "px", "iters": sample_iters,
                                    "note": "max over the 3 pairs of mean EPE, HIP path vs CPU oracle, full shape"}
 
-    if rank == 0 and world == 1 and args.clips == 1 and not args.no_kernel_breakdown:
-        # throughput with 4 clips batched through every launch (fills the GPU better; same kernels, same results)
+    if rank == 0 and world == 1 and args.clips != 1 and not args.no_kernel_breakdown:
+        # single-clip latency: the same engine and kernels with one clip per launch (tails and launch gaps show)
         try:
-            B4 = 4
-            f4, c4 = syn.make_features(2000, B4, T, h, w)
-            f4, c4 = f4.to(dev), c4.to(dev)
-            for _ in range(2):
-                eng.forward(f4, c4, iters=iters, all_masks=args.all_masks)
+            f1, c1 = fmaps[:1].contiguous(), cnets[:1].contiguous()
+            for _ in range(3):
+                eng.forward(f1, c1, iters=iters, all_masks=args.all_masks)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            for _ in range(5):
-                eng.forward(f4, c4, iters=iters, all_masks=args.all_masks)
+            for _ in range(10):
+                eng.forward(f1, c1, iters=iters, all_masks=args.all_masks)
             torch.cuda.synchronize()
-            dt4 = (time.perf_counter() - t0) / 5
-            result["batched"] = {"clips_per_step": B4, "value": B4 * pairs / dt4, "unit": "flow-fields/s",
-                                 "ms_per_step": 1e3 * dt4}
-        except RuntimeError as e:                      # e.g. out of memory on a smaller part
-            result["batched"] = {"error": str(e)[:200]}
+            dt1 = (time.perf_counter() - t0) / 10
+            result["single_clip"] = {"clips_per_step": 1, "value": pairs / dt1, "unit": "flow-fields/s",
+                                     "ms_per_clip": 1e3 * dt1}
+        except RuntimeError as e:
+            result["single_clip"] = {"error": str(e)[:200]}
 
     if rank == 0:
         print(json.dumps(result))
