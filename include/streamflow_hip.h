@@ -157,9 +157,12 @@ int sf_softmax_rows(float* x, int64_t rows, int cols, void* out_f16, void* strea
 
 /* ---- depthwise KxK conv + bias + residual + GELU  (update.py:33-34 with kernel in {7,15}) -------
  * y = gelu(x + dwconv(x) + b);  plane (img, c) of x is the [h][w] map at x + img*x_img_stride + c*h*w
- * (same for y with y_img_stride); wgt [C][K][K], bias [C]. */
+ * (same for y with y_img_stride); wgt [C][K][K], bias [C].  x and y must not overlap.
+ * precision SF_PRECISION_FP32: fp32 FMA stencil on the VALU.  Split precisions: every kernel row is a banded
+ * Toeplitz GEMM on the matrix cores with (hi, lo) fp16 operands and fp32 accumulation (same arithmetic as sf_gemm's
+ * SF_PRECISION_F16X3; F16X2 is treated as F16X3 here). */
 int sf_dwconv_res_gelu(const float* x, int64_t x_img_stride, const float* wgt, const float* bias, float* y,
-                       int64_t y_img_stride, int n_img, int C, int h, int w, int ksize, void* stream);
+                       int64_t y_img_stride, int n_img, int C, int h, int w, int ksize, int precision, void* stream);
 
 /* ---- LayerNorm over channels of channel-major planes (update.py:462-463,481-483) --------------
  * x,y [n_img][C][P] (image strides given in floats), normalises each (img,p) column over C. */

@@ -10,6 +10,7 @@
 // lgkmcnt(0) drain -- and a register sliding window that cuts the LDS row reads 4x changed nothing: the
 // kernel is bound by VALU issue, 47 TFLOP/s of fp32 FMA.)
 #include "sf_common.h"
+#include "split_operand.h"
 
 namespace {
 
@@ -107,13 +108,218 @@ __global__ __launch_bounds__(kMaxThreads) void dwconv_res_gelu_kernel(const DwAr
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// The same convolution on the matrix cores (split precisions).
+//
+// For one kernel row ky, a run of 16 outputs along x is a small GEMM over the 32 input columns that can reach them:
+//     out[y][x0 + n] += sum_k  in[y + ky - R][x0 - 8 + k] * T_ky[k][n],     T_ky[k][n] = w[ky][k - n - 8 + R]  (0 outside)
+// i.e. A = a 16-row x 32-column window of the (zero padded) input plane, B = a banded Toeplitz matrix that depends
+// only on (channel, ky).  One v_mfma_f32_16x16x32_f16 does the 16x16 outputs of one ky; with x = hi + lo fp16 halves of
+// both operands (products al*bh + ah*bl + ah*bh, fp32 accumulation: the GEMMs' split precision) that is 3 MFMAs per
+// ky and 16x16 tile = 48 cycles against 15 x 256 FMAs / 32 lanes = 120 cycles on the VALU, and the matrix cores run
+// closer to their peak than the stencil did to the VALU's (47-58 TFLOP/s = ~40 %).  K = 15: 15/32 of the multiplied
+// entries are structural zeros -- the price of having no fp32 FMA faster than 1 per lane per 2 cycles.
+//  * the plane strip is split ONCE while it is staged (hi and lo fp16 planes in LDS, 8-column octets = one A
+//    fragment per lane, row stride = 2 mod 4 sixteen-byte units: conflict-free ds_read_b128 for the 16 rows of a
+//    fragment);
+//  * the 2 x KS Toeplitz fragments of the channel live in REGISTERS for the whole workgroup (8 VGPRs per ky), built
+//    once from a zero-padded copy of the channel's weights; a workgroup walks several images of the same channel;
+//  * a wave works on 2 horizontally adjacent tiles at a time (consecutive MFMAs alternate accumulators) and requests
+//    the A fragments of kernel row ky+1 before the MFMAs of row ky.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct DwmArgs {
+    const float* x; const float* wgt; const float* bias; float* y;
+    int64_t x_img_stride, y_img_stride;
+    int n_img, C, h, w;
+    int imgs_per_wg;
+    int strip_h;      // output rows per strip (multiple of 16)
+    int w16;          // w rounded up to 16
+    int stride16;     // LDS row stride in 16-byte units (= 8 halfs)
+    int vec_ok;       // rows are 16-byte aligned: float4 staging loads
+};
+
+template <int KS>
+__global__ __launch_bounds__(256, 2) void dwconv_mfma_kernel(const DwmArgs g) {
+    using namespace sf_split;
+    constexpr int R = KS / 2;
+    constexpr int WZ = 64;                                      // zero-padded weight row: w[ky][j - 24]
+    constexpr int TG = 2;                                       // adjacent column tiles a wave works on together
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, kg = lane >> 4;
+    const int c = blockIdx.x, ys = blockIdx.y * g.strip_h;
+    const int rows_in = g.strip_h + KS - 1;
+    const int noct = (g.w16 + 16) / 8;                          // octets per staged row: columns -8 .. w16 + 7
+    const int plane_bytes = rows_in * g.stride16 * 16;
+    char* hi = lds;
+    char* lo = lds + plane_bytes;
+    float* wz = reinterpret_cast<float*>(lds + 2 * plane_bytes);
+
+    // ---- the channel's Toeplitz fragments -> registers --------------------------------------------------
+    for (int i = tid; i < KS * WZ; i += 256) {
+        const int ky = i / WZ, j = i % WZ - 24;
+        wz[i] = (j >= 0 && j < KS) ? g.wgt[(int64_t)c * KS * KS + ky * KS + j] : 0.f;
+    }
+    __syncthreads();
+    f16x8 bh[KS], bl[KS];
+#pragma unroll
+    for (int ky = 0; ky < KS; ++ky) {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = wz[ky * WZ + (kg * 8 + i) - n - 8 + R + 24];
+        const Split8 s8 = split8(v);
+        bh[ky] = s8.hi;
+        bl[ky] = s8.lo;
+    }
+    const float bv = g.bias[c];
+    const int ntx = g.w16 / 16, nty = g.strip_h / 16;
+    const int ngroups = nty * ((ntx + TG - 1) / TG);            // groups of up to TG adjacent column tiles
+
+    const int img0 = blockIdx.z * g.imgs_per_wg;
+    const int img_end = min(img0 + g.imgs_per_wg, g.n_img);
+    for (int img = img0; img < img_end; ++img) {
+        const float* __restrict__ xp = g.x + img * g.x_img_stride + (int64_t)c * g.h * g.w;
+        float* __restrict__ yp = g.y + img * g.y_img_stride + (int64_t)c * g.h * g.w;
+        const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(yp, 0, g.h * g.w * 4, 0x00020000);
+        // LDS-only barriers: the previous image's output stores stay in flight (a __syncthreads would drain them)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                           // previous image's tiles are done with the LDS planes
+        // ---- stage + split the strip (rows ys-R .., columns -8 ..), zero padded: one octet = 8 consecutive columns
+        // of one row = one A-fragment slot; FU octets per thread at a time, all their loads issued before any is used
+        constexpr int FU = 4;
+        for (int base = tid; base < rows_in * noct; base += 256 * FU) {
+            float v[FU][8];
+            int off[FU];
+#pragma unroll
+            for (int u = 0; u < FU; ++u) {
+                const int idx = base + u * 256;
+                const int ry_ = idx / noct, co = idx - ry_ * noct;
+                const int gy = ys - R + ry_, gx = co * 8 - 8;
+                const bool live = idx < rows_in * noct;
+                const bool rowok = live && gy >= 0 && gy < g.h;
+                off[u] = live ? (ry_ * g.stride16 + co) * 16 : -1;
+                if (rowok && g.vec_ok && gx >= 0 && gx + 8 <= g.w) {
+                    const float4 q0 = *reinterpret_cast<const float4*>(xp + gy * g.w + gx);
+                    const float4 q1 = *reinterpret_cast<const float4*>(xp + gy * g.w + gx + 4);
+                    v[u][0] = q0.x; v[u][1] = q0.y; v[u][2] = q0.z; v[u][3] = q0.w;
+                    v[u][4] = q1.x; v[u][5] = q1.y; v[u][6] = q1.z; v[u][7] = q1.w;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        v[u][i] = (rowok && gx + i >= 0 && gx + i < g.w) ? xp[gy * g.w + gx + i] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < FU; ++u) {
+                if (off[u] < 0) continue;
+                const Split8 s8 = split8(v[u]);
+                *reinterpret_cast<f16x8*>(hi + off[u]) = s8.hi;
+                *reinterpret_cast<f16x8*>(lo + off[u]) = s8.lo;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+
+        for (int grp = wave; grp < ngroups; grp += 4) {
+            const int ty = grp % nty, tx0 = (grp / nty) * TG;
+            f32x4 acc[TG];
+#pragma unroll
+            for (int j = 0; j < TG; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            // fragment of tile j, kernel row ky: rows ty*16 + ky + n, octets (tx0 + j)*2 + kg.  Tiles past the right
+            // edge (ntx not a multiple of TG) read the last valid tile again and are not stored.
+            int offj[TG];
+#pragma unroll
+            for (int j = 0; j < TG; ++j)
+                offj[j] = ((ty * 16 + n) * g.stride16 + min(tx0 + j, ntx - 1) * 2 + kg) * 16;
+            const int row_step = g.stride16 * 16;
+            // output cell (j, r) of this lane: row gy0 + r, column gx0 + 16 j.  Stores are buffer ops with 32-bit offsets;
+            // a cell outside the plane gets an out-of-range offset that the buffer unit drops (no branches).
+            const int gy0 = ys + ty * 16 + 4 * kg, gx0 = tx0 * 16 + n;
+            const int off0 = (gy0 * g.w + gx0) * 4;
+            // software pipeline: the fragments of kernel row ky + 1 are requested before the MFMAs of row ky
+            f16x8 ah[2][TG], al[2][TG];
+#pragma unroll
+            for (int j = 0; j < TG; ++j) {
+                ah[0][j] = *reinterpret_cast<const f16x8*>(hi + offj[j]);
+                al[0][j] = *reinterpret_cast<const f16x8*>(lo + offj[j]);
+            }
+#pragma unroll
+            for (int ky = 0; ky < KS; ++ky) {
+                const int cur = ky & 1, nxt = cur ^ 1;
+                if (ky + 1 < KS) {
+#pragma unroll
+                    for (int j = 0; j < TG; ++j) {
+                        ah[nxt][j] = *reinterpret_cast<const f16x8*>(hi + offj[j] + (ky + 1) * row_step);
+                        al[nxt][j] = *reinterpret_cast<const f16x8*>(lo + offj[j] + (ky + 1) * row_step);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < TG; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[cur][j], bh[ky], acc[j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < TG; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[cur][j], bl[ky], acc[j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < TG; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[cur][j], bh[ky], acc[j], 0, 0, 0);
+            }
+            // C/D layout of the 16x16 MFMA: column = lane & 15, row = 4 * (lane >> 4) + reg.  The residual x comes back
+            // from the staged planes as hi + lo (|x - (hi + lo)| <= 2^-20 |x|, the split's own precision): no
+            // global load in the tile loop.
+            const int xoff0 = ((ty * 16 + 4 * kg + R) * g.stride16) * 16 + (gx0 + 8) * 2;
+#pragma unroll
+            for (int j = 0; j < TG; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool ok = (gx0 + j * 16 < g.w) && (gy0 + r < g.h);
+                    const int xo = xoff0 + r * row_step + min(j, ntx - 1 - tx0) * 32;
+                    const float xv = (float)*reinterpret_cast<const _Float16*>(hi + xo) +
+                                     (float)*reinterpret_cast<const _Float16*>(lo + xo);
+                    const float o = sf::gelu_erf(xv + (acc[j][r] + bv));
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), ry,
+                                                          ok ? off0 + (r * g.w + j * 16) * 4 : (int)0x80000000u, 0, 0);
+                }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int sf_dwconv_res_gelu(const float* x, int64_t x_img_stride, const float* wgt, const float* bias, float* y,
-                                  int64_t y_img_stride, int n_img, int C, int h, int w, int ksize, void* stream) {
+                                  int64_t y_img_stride, int n_img, int C, int h, int w, int ksize, int precision,
+                                  void* stream) {
     SF_REQUIRE(x && wgt && bias && y, "sf_dwconv_res_gelu: null pointer");
     SF_REQUIRE(n_img > 0 && C > 0 && h > 0 && w > 0, "sf_dwconv_res_gelu: bad dims");
     SF_REQUIRE(ksize == 15 || ksize == 7, "sf_dwconv_res_gelu: kernel size %d not built (7, 15)", ksize);
+    SF_REQUIRE(precision >= SF_PRECISION_FP32 && precision <= SF_PRECISION_F16X2, "sf_dwconv_res_gelu: bad precision");
+    SF_REQUIRE((int64_t)h * w < (1 << 30), "sf_dwconv_res_gelu: plane too large");
+    // K = 7: only 7/32 of the Toeplitz entries are non-zero and the stencil is the faster kernel (65 vs 87 us at
+    // 128 channels x 24 images); K = 15 runs 1.45x faster on the matrix cores
+    if (precision != SF_PRECISION_FP32 && ksize == 15) {
+        DwmArgs m;
+        m.x = x; m.wgt = wgt; m.bias = bias; m.y = y; m.x_img_stride = x_img_stride; m.y_img_stride = y_img_stride;
+        m.n_img = n_img; m.C = C; m.h = h; m.w = w;
+        m.w16 = sf::ceil_div(w, 16) * 16;
+        const int base16 = (m.w16 + 16) / 8;
+        m.stride16 = (base16 % 4 == 2) ? base16 : base16 + (2 - base16 % 4 + 4) % 4;
+        // rows per strip: as many 16-row tiles as fit ~60 KB of LDS (two fp16 planes)
+        const int h16 = sf::ceil_div(h, 16) * 16;
+        int strip = h16;
+        while (strip > 16 && (size_t)2 * (strip + ksize - 1) * m.stride16 * 16 > 60 * 1024) strip -= 16;
+        m.strip_h = strip;
+        const size_t lds = (size_t)2 * (strip + ksize - 1) * m.stride16 * 16 + (size_t)ksize * 64 * sizeof(float);
+        SF_REQUIRE(lds <= 64 * 1024, "sf_dwconv_res_gelu: width %d too large for the matrix-core kernel", w);
+        m.vec_ok = ((w & 3) == 0) && ((x_img_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+        // several images of a channel per workgroup (the Toeplitz fragments are built once), but keep >= ~2048 workgroups
+        const int strips = sf::ceil_div(h, strip);
+        int groups = sf::ceil_div(2048, C * strips);
+        if (groups > n_img) groups = n_img;
+        if (groups < 1) groups = 1;
+        m.imgs_per_wg = sf::ceil_div(n_img, groups);
+        dim3 grid(C, strips, sf::ceil_div(n_img, m.imgs_per_wg));
+        SF_REQUIRE(strips <= 65535 && grid.z <= 65535, "sf_dwconv_res_gelu: grid too large");
+        hipLaunchKernelGGL(dwconv_mfma_kernel<15>, grid, dim3(256), lds, (hipStream_t)stream, m);
+        return sf::check_launch("sf_dwconv_res_gelu(mfma)");
+    }
     DwArgs g;
     g.x = x; g.wgt = wgt; g.bias = bias; g.y = y; g.C = C; g.h = h; g.w = w;
     g.x_img_stride = x_img_stride; g.y_img_stride = y_img_stride;

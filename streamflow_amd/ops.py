@@ -238,7 +238,8 @@ def dwconv_res_gelu(X: Planes, wgt: torch.Tensor, bias: torch.Tensor, Y: Planes,
     _launch("dwconv%d" % k, 2.0 * k * k * X.n_img * X.rows * h * w, 8.0 * X.n_img * X.rows * h * w,
             lambda: _lib.check(_lib.load().sf_dwconv_res_gelu(X.ptr, X.img_stride, wgt.data_ptr(), bias.data_ptr(),
                                                               Y.ptr, Y.img_stride, X.n_img, X.rows, h, w, k,
-                                                              _lib.stream()), "sf_dwconv_res_gelu"))
+                                                              min(PRECISION, PRECISION_F16X3), _lib.stream()),
+                               "sf_dwconv_res_gelu"))
 
 
 def layernorm_cm(X: Planes, gamma: torch.Tensor, beta: torch.Tensor, Y: Planes, eps: float = 1e-5) -> None:

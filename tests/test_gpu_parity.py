@@ -332,3 +332,28 @@ def test_gemm_stored_fp16_operand(dev, K):
         assert err < 2e-6, err
     finally:
         ops.PRECISION = prev
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [15, 7])
+@pytest.mark.parametrize("hw", [(55, 128), (23, 37), (16, 24), (70, 52)])
+def test_dwconv_vs_torch(dev, precision, k, hw):
+    """y = gelu(x + dwconv_kxk(x) + b) (update.py:33-34) against torch in float64: the fp32 stencil and, in the split
+    precisions, the Toeplitz-on-MFMA kernel (ragged widths / heights exercise the zero padding and the tile tails)."""
+    import torch.nn.functional as F
+    from streamflow_amd import ops
+    from streamflow_amd.ops import Planes
+    h, w = hw
+    g = torch.Generator().manual_seed(k * 1000 + h)
+    n_img, C = 3, 5
+    x = torch.randn(n_img, C, h * w, generator=g)
+    wgt = torch.randn(C, k, k, generator=g) / k
+    b = torch.randn(C, generator=g) * 0.1
+    X, Y = Planes.of(x.to(dev)), Planes.of(torch.empty(n_img, C, h * w, device=dev))
+    ops.dwconv_res_gelu(X, wgt.to(dev).contiguous(), b.to(dev), Y, h, w, k)
+    torch.cuda.synchronize()
+    xd = x.double().view(n_img, C, h, w)
+    ref = F.gelu(xd + F.conv2d(xd, wgt.double().view(C, 1, k, k), b.double(), padding=k // 2, groups=C))
+    got = Y.tensor().view(n_img, C, h, w).double().cpu()
+    err = (got - ref).abs().max().item()
+    assert err < (2e-5 if precision != "fp32" else 2e-5), (precision, err)

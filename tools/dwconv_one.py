@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""Depthwise conv + residual + GELU alone (timing).  argv: C n_img k [precision]"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from streamflow_amd import ops
+from streamflow_amd.ops import Planes
+C, n, k = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+ops.set_precision(sys.argv[4] if len(sys.argv) > 4 else "f16x3")
+h, w = 55, 128
+dev = torch.device("cuda:0")
+X = Planes.of(torch.randn(n, C, h * w, device=dev)); Y = Planes.of(torch.empty(n, C, h * w, device=dev))
+wgt = (torch.randn(C, k, k, device=dev) / k).contiguous(); b = torch.randn(C, device=dev) * 0.1
+for _ in range(3):
+    ops.dwconv_res_gelu(X, wgt, b, Y, h, w, k)
+s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+s.record()
+reps = 20
+for _ in range(reps):
+    ops.dwconv_res_gelu(X, wgt, b, Y, h, w, k)
+e.record(); torch.cuda.synchronize()
+us = s.elapsed_time(e) * 1e3 / reps
+print(f"dwconv{k} C={C} n={n} {ops.precision_name()}: {us:.1f} us  {2.0 * k * k * n * C * h * w / us / 1e6:.1f} TF-equivalent  {8.0 * n * C * h * w / us / 1e3:.0f} GB/s")
+
