@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""HBM traffic per launch and kernel family from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE), corrected as
+MI355X_MICROARCH.md prescribes for gfx950: FETCH_SIZE counts 128-byte requests at 64 B, so it is doubled; WRITE_SIZE
+is used as reported.  Both factors are calibrated on softmax_rows, whose traffic is known exactly (reads rows*cols*4
+bytes once).  usage: traffic_json.py <fetch_counter_collection.csv> <write_counter_collection.csv> > traffic.json"""
+import collections, csv, json, re, sys
+
+FAMILY = [(r"corr_build|split_pack", "corr_build"), (r"corr_lookup", "corr_lookup"),
+          (r"gemm_f16x3_\w+<1, 3", "gemm_attn"), (r"gemm_f16x3_ws<1, 1", "gemm_attn"), (r"gemm_f", "gemm"),
+          (r"splitk_epilogue", "gemm"), (r"splitk_combine", "splitk_combine"), (r"dwconv_mfma", "dwconv15"),
+          (r"dwconv_res_gelu_kernel<15>", "dwconv15"), (r"dwconv_res_gelu_kernel<7>", "dwconv7"),
+          (r"softmax_rows", "softmax_rows"), (r"layernorm", "layernorm"), (r"temporal_attn", "temporal_attn"),
+          (r"upsample", "upsample_flow"), (r"flow_update", "flow_update"), (r"context_split", "context_split")]
+
+def family(name):
+    for pat, fam in FAMILY:
+        if re.search(pat, name):
+            return fam
+    return None
+
+def collect(path, counter):
+    tot, cnt = collections.Counter(), collections.Counter()
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter:
+            continue
+        f = family(r["Kernel_Name"])
+        if f:
+            tot[f] += float(r["Counter_Value"])
+            cnt[f] += 1
+    return tot, cnt
+
+ft, fc = collect(sys.argv[1], "FETCH_SIZE")
+wt, wc = collect(sys.argv[2], "WRITE_SIZE")
+# split_pack + corr_build_dma are two launches of one sf_corr_build_pyramid call: count calls, not launches
+out = {"_note": "KiB per launch (mean). fetch = 2 x FETCH_SIZE (gfx950 correction, MI355X_MICROARCH.md HBM section), "
+                "write = WRITE_SIZE; calibrated on softmax_rows (known bytes)."}
+for f in sorted(set(ft) | set(wt)):
+    nf, nw = max(fc[f], 1), max(wc[f], 1)
+    if f == "corr_build":
+        nf, nw = max(nf // 2, 1), max(nw // 2, 1)
+    out[f] = {"fetch_kib_per_launch": round(2.0 * ft[f] / nf, 1), "write_kib_per_launch": round(wt[f] / nw, 1),
+              "fetch_size_raw_kib": round(ft[f] / nf, 1), "launches_profiled": nf}
+print(json.dumps(out, indent=1))
