@@ -187,6 +187,13 @@ int sf_flow_update(float* coords1, const float* delta, float* flow_a, int64_t fl
  * flow [n][2][h][w], mask [n][9*64][h][w] -> out [n][2][8h][8w]. */
 int sf_upsample_flow(const float* flow, const float* mask, float* out, int n, int h, int w, void* stream);
 
+/* ---- f4: forward_interpolate  (core/utils/utils.py:34-62; warm start, evaluate_mf.py:305,362) ----
+ * flow, out [n_img][2][h][w] (ch0 = dx, ch1 = dy).  Each source pixel is pushed along its flow; points landing
+ * outside the open rectangle (0, w) x (0, h) are dropped; every grid pixel receives the flow of the nearest
+ * remaining point (exact Euclidean nearest neighbour in float64, lowest source index on ties), zero if none is left.
+ * Replaces scipy.interpolate.griddata(method='nearest') on the host. */
+int sf_forward_interpolate(const float* flow, float* out, int n_img, int h, int w, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -306,3 +306,25 @@ def hotpath_forward(fmaps: Tensor, cnets: Tensor, p: Params, iters: int,
 def epe(a: Tensor, b: Tensor) -> float:
     """Mean end-point error between two [.,2,H,W] flow fields (evaluate_mf.py:146-147)."""
     return torch.sqrt(((a - b) ** 2).sum(dim=-3)).mean().item()
+
+
+def forward_interpolate(flow: torch.Tensor) -> torch.Tensor:
+    """core/utils/utils.py:34-62 (warm start of the next clip, evaluate_mf.py:305): every source pixel is pushed
+    along its flow (float64 position = integer grid + float32 flow, numpy promotion), points landing outside
+    (0, w) x (0, h) are dropped, and each grid pixel takes the flow of the NEAREST remaining point
+    (scipy.interpolate.griddata(method='nearest') = exact nearest neighbour in the Euclidean metric).
+    Restated as a brute-force argmin over squared float64 distances; ties (measure zero) go to the lowest
+    source index.  With no valid point the result is zero (scipy raises there)."""
+    f = flow.detach().cpu().double()
+    ht, wd = f.shape[-2:]
+    y0, x0 = torch.meshgrid(torch.arange(ht, dtype=torch.float64), torch.arange(wd, dtype=torch.float64), indexing="ij")
+    x1, y1 = (x0 + f[0]).reshape(-1), (y0 + f[1]).reshape(-1)
+    dx, dy = f[0].reshape(-1), f[1].reshape(-1)
+    valid = (x1 > 0) & (x1 < wd) & (y1 > 0) & (y1 < ht)
+    if not bool(valid.any()):
+        return torch.zeros(2, ht, wd)
+    x1, y1, dx, dy = x1[valid], y1[valid], dx[valid], dy[valid]
+    gx, gy = x0.reshape(-1, 1), y0.reshape(-1, 1)
+    d2 = (x1[None, :] - gx) ** 2 + (y1[None, :] - gy) ** 2          # [targets, points]
+    idx = d2.argmin(dim=1)
+    return torch.stack([dx[idx].reshape(ht, wd), dy[idx].reshape(ht, wd)]).float()

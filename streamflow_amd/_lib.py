@@ -60,6 +60,7 @@ SIGNATURES = {
     "sf_context_split": (_i, [_vp, _vp, _i64, _vp, _i64, _i, _i, _i, _vp]),
     "sf_flow_update": (_i, [_vp, _vp, _vp, _i64, _vp, _i64, _i, _i, _i, _vp]),
     "sf_upsample_flow": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "sf_forward_interpolate": (_i, [_vp, _vp, _i, _i, _i, _vp]),
 }
 
 _lib: Optional[C.CDLL] = None

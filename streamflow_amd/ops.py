@@ -300,6 +300,16 @@ def upsample_flow(flow: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def forward_interpolate(flow: torch.Tensor) -> torch.Tensor:
+    """flow [n,2,h,w] -> [n,2,h,w] (reference utils.py:34-62, on the device)."""
+    _dev_check(flow)
+    n, _, h, w = flow.shape
+    out = torch.empty_like(flow)
+    _lib.check(_lib.load().sf_forward_interpolate(flow.data_ptr(), out.data_ptr(), n, h, w, _lib.stream()),
+               "sf_forward_interpolate")
+    return out
+
+
 def pair_strides(arr: Optional[Sequence[int]]):
     if arr is None:
         return None

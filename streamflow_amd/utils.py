@@ -25,6 +25,17 @@ def bilinear_sampler(img: torch.Tensor, coords: torch.Tensor, mode: str = "bilin
     return res
 
 
+def forward_interpolate(flow: torch.Tensor) -> torch.Tensor:
+    """Reference `forward_interpolate(flow)` (core/utils/utils.py:34-62): flow [2, H, W] -> [2, H, W] float32, the
+    warm start for the next clip.  Runs on the GPU and returns a device tensor (the reference goes through numpy /
+    scipy on the host and returns a CPU tensor that the caller moves back with `.cuda()`).  A leading batch
+    dimension [B, 2, H, W] is accepted as an extension."""
+    f = flow.detach().float().contiguous()
+    if f.dim() == 3:
+        return ops.forward_interpolate(f[None])[0]
+    return ops.forward_interpolate(f)
+
+
 class InputPadder:
     """Pads images so H and W are divisible by 8 (reference utils.py:7-31; host-side plumbing)."""
 

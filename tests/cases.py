@@ -16,6 +16,7 @@ FORWARD_CASES = {"forward_T4": (1, 4, 128, 192, 4, 71, False),
                  "forward_demo256": (1, 4, 256, 256, 4, 73, False)}                   # B,T,H,W,iters,seed,init
 GMA_CASE = (31, 2, 12, 16)                                                           # seed, BT, h, w
 UPSAMPLE_SEED = 61
+INTERP_CASES = {"interp_a": (81, 23, 31, 4.0), "interp_b": (82, 16, 40, 12.0), "interp_c": (83, 9, 7, 1.0)}   # seed, h, w, flow scale
 
 
 def _grid(B, h, w):
@@ -83,3 +84,10 @@ def forward_inputs(tag):
     fmaps, cnets = syn.make_features(seed, B, T, h, w)
     finit = [syn.randn(seed, f"flow_init{i}", (B, 2, h, w), 1.5) for i in range(T - 1)] if use_init else None
     return P, fmaps, cnets, finit, iters
+
+
+def interp_inputs(tag):
+    """Low-resolution flow [2, h, w] for forward_interpolate (utils.py:34-62); the larger scales push many source
+    points outside the image (dropped by the reference's `valid` mask)."""
+    seed, h, w, scale = INTERP_CASES[tag]
+    return syn.randn(seed, "interp.flow", (2, h, w), scale)

@@ -116,7 +116,12 @@ def ref_args(T):
                      mixed_precision=False, dropout=0)
 
 
+ONLY = set(sys.argv[1:])          # optional: fixture names to (re)write; default all
+
+
 def save(name, **arrays):
+    if ONLY and name not in ONLY:
+        return
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **{k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v))
                                  for k, v in arrays.items()})
@@ -190,6 +195,10 @@ def main():
         flow, mask = cases.upsample_inputs()
         model = ref_model.SKFlow_MF8(ref_args(4))
         save("upsample", out=model.upsample_flow(flow, mask))
+
+        # ---- f4 forward_interpolate (scipy griddata nearest; warm start of the next clip) -------------
+        for tag in cases.INTERP_CASES:
+            save(tag, out=ref_utils.forward_interpolate(cases.interp_inputs(tag)))
 
         # ---- a12 full forward through SKFlow_MF8.forward (config-1 style plumbing) -----------
         for tag, (B, T, H, W, iters, seed, use_init) in cases.FORWARD_CASES.items():

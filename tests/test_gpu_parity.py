@@ -357,3 +357,30 @@ def test_dwconv_vs_torch(dev, precision, k, hw):
     got = Y.tensor().view(n_img, C, h, w).double().cpu()
     err = (got - ref).abs().max().item()
     assert err < (2e-5 if precision != "fp32" else 2e-5), (precision, err)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", list(cases.INTERP_CASES))
+def test_forward_interpolate_vs_reference(golden, dev, tag):
+    """f4: the GPU nearest-neighbour kernel returns exactly the reference's scipy griddata result."""
+    import streamflow_amd as sfa
+    out = sfa.forward_interpolate(cases.interp_inputs(tag).to(dev))
+    assert out.is_cuda and torch.equal(out.cpu(), torch.from_numpy(golden(tag)["out"]))
+
+
+@pytest.mark.gpu
+def test_forward_interpolate_full_size_vs_oracle(dev):
+    """Sintel-size low-resolution flows (55x128, batch of 3) against the CPU restatement, plus the properties that hold
+    at any size: every output vector is one of the input vectors whose warped position is valid, and a zero flow maps
+    to itself except on the excluded border row / column (x1 > 0, y1 > 0 are strict in the reference)."""
+    from oracle import streamflow_oracle as orc
+    import streamflow_amd as sfa
+    from streamflow_amd import synthetic as syn
+    flow = syn.randn(91, "interp.full", (3, 2, 55, 128), 6.0)
+    out = sfa.forward_interpolate(flow.to(dev)).cpu()
+    for i in range(3):
+        assert torch.equal(out[i], orc.forward_interpolate(flow[i]))
+    pairs_in = {tuple(v) for v in flow[0].reshape(2, -1).t().tolist()}
+    assert all(tuple(v) in pairs_in for v in out[0].reshape(2, -1).t().tolist())
+    z = sfa.forward_interpolate(torch.zeros(1, 2, 16, 24, device=dev))
+    assert torch.count_nonzero(z).item() == 0

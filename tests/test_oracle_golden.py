@@ -109,3 +109,10 @@ def test_full_forward(golden, tag):
         preds, _ = orc.hotpath_forward(fmaps, cnets, P, 1, all_iters=True)
         for i in range(T - 1):
             assert orc.epe(preds[i][0], torch.from_numpy(g[f"first{i}"])) < 1e-4
+
+
+@pytest.mark.parametrize("tag", list(cases.INTERP_CASES))
+def test_forward_interpolate(golden, tag):
+    """f4: bit-exact against the reference's scipy griddata result (values are copies of input flow entries)."""
+    out = orc.forward_interpolate(cases.interp_inputs(tag))
+    assert torch.equal(out, torch.from_numpy(golden(tag)["out"]))
