@@ -35,8 +35,6 @@ struct SplitArgs {
     SfGemm g;
     int64_t a_bytes, b_bytes;      // bytes spanned by one batch image of A / B (buffer range check)
     long long* ts;                 // SF_GEMM_TS_BUF: per-workgroup phase timestamps (experiments only)
-    int dbg;                       // ablation bits (SF_GEMM_DBG, experiments only): 1 no global loads in the loop,
-                                   // 2 no MFMAs, 4 no convert/LDS stores in the loop
 };
 
 template <int WM, int WN, int TM, int TN, int ALAY, int BLAY, bool SB>
@@ -164,161 +162,6 @@ __global__ __launch_bounds__(kThreads, (TM * TN >= 8) ? 2 : 3) void gemm_f16x3_m
 }
 
 
-// ------------------------------------------------------------------------------------------------------------
-// Wave-specialised 128x128 kernel: 8 waves per workgroup.
-//   waves 0-3 (consumers): LDS fragment reads + MFMAs only, each a 64x64 sub-tile -- nothing in their loop
-//                          ever waits on global memory;
-//   waves 4-7 (producers): global loads kept kDepth k-tiles ahead in their own registers (they hold no
-//                          accumulators, so they can afford it), fp32 -> hi/lo f16 split, LDS writes.
-// One workgroup barrier per k-tile hands LDS stage (t+1)&1 to the consumers.  In the single-role kernel above every
-// wave serialises load-issue -> MFMA -> wait -> convert -> LDS write, and all units idle ~70 % of the time.
-// ------------------------------------------------------------------------------------------------------------
-constexpr int kWsThreads = 512;
-constexpr int kDepth = 3;
-
-template <int ALAY, int BLAY, bool SB>
-__global__ __launch_bounds__(kWsThreads, 4) void gemm_f16x3_ws(const SplitArgs args) {
-    const SfGemm& g = args.g;
-    constexpr int BM = 128, BN = 128, TM = 2, TN = 2, WN = 2;
-    __shared__ __attribute__((aligned(16))) _Float16 sA[2][2][BM * LDK];     // [stage][hi|lo][rows][LDK]
-    __shared__ __attribute__((aligned(16))) _Float16 sB[2][SB ? 2 : 1][BN * LDK];
-
-    const int tid = threadIdx.x;
-    const bool producer = tid >= kThreads;              // wave-uniform (waves 4..7)
-    const int ptid = tid & (kThreads - 1);
-    const int lane = tid & 63, wave = (tid >> 6) & 3;
-    const int wm = wave / WN, wn = wave % WN;
-    const int mt = (g.M + BM - 1) / BM, nt = (g.N + BN - 1) / BN;
-    const sf::TileCoord tc = sf::xcd_tile(blockIdx.x, gridDim.x, mt, nt);
-    const int ksp = g.k_splits > 1 ? g.k_splits : 1;
-    const int n0 = tc.n_tile * BN, m0 = tc.m_tile * BM, z = tc.z / ksp, split = tc.z % ksp;
-    const int nk_all = (g.K + BK - 1) / BK;
-    const int kt_beg = (int)((int64_t)nk_all * split / ksp), kt_end = (int)((int64_t)nk_all * (split + 1) / ksp);
-    const int nk = kt_end - kt_beg;
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    if (producer) {
-        Operand<BM, ALAY> opa;
-        Operand<BN, BLAY> opb;
-        typename Operand<BM, ALAY>::Regs ra[kDepth];
-        typename Operand<BN, BLAY>::Regs rb[kDepth];
-        if (ALAY == 2) opa.init(g.A_hi, g.A_lo, args.a_bytes, (int)g.lda_h, g.K, g.M, m0, 0, 0, ptid);
-        else opa.init(g.A + (int64_t)z * g.strideA, nullptr, args.a_bytes, (int)g.lda, g.K, g.M, m0, 0, 0, ptid);
-        opb.init(reinterpret_cast<const char*>(g.B) + (int64_t)z * g.strideB * (BLAY == SF_LAYOUT_F16_K_MINOR ? 2 : 4), nullptr,
-                 args.b_bytes, (int)g.ldb, g.K, g.N, n0, g.b_group, g.b_group_stride, ptid);
-        RowCursor ca, cb;                     // row offset of the NEXT tile to be loaded
-        ca.init(0, (int)g.lda, 0);
-        cb.init(g.b_group, (int)g.ldb, g.b_group_stride);
-        for (int t = 0; t < kt_beg; ++t) { ca.advance(); cb.advance(); }
-#pragma unroll
-        for (int u = 0; u < kDepth; ++u) {
-            if (u < nk) {
-                opa.load((kt_beg + u) * BK, ca.off, ra[u]);
-                opb.load((kt_beg + u) * BK, cb.off, rb[u]);
-                ca.advance();
-                cb.advance();
-            }
-        }
-        opa.store(kt_beg * BK, sA[0][0], sA[0][1], ra[0]);
-        opb.template store<SB>(kt_beg * BK, sB[0][0], sB[0][SB ? 1 : 0], rb[0]);
-        __syncthreads();
-        for (int base = 0; base < nk; base += kDepth) {
-#pragma unroll
-            for (int u = 0; u < kDepth; ++u) {
-                const int t = base + u;                 // tile the consumers work on in this step
-                if (t < nk) {
-                    // register set u held tile t (already in LDS): refill it with tile t + kDepth ...
-                    if (t + kDepth < nk && !(args.dbg & 1)) {
-                        opa.load((kt_beg + t + kDepth) * BK, ca.off, ra[u]);
-                        opb.load((kt_beg + t + kDepth) * BK, cb.off, rb[u]);
-                        ca.advance();
-                        cb.advance();
-                    }
-                    // ... and hand tile t + 1 (loaded kDepth - 1 steps ago) to LDS stage (t + 1) & 1
-                    if (t + 1 < nk && !(args.dbg & 4)) {
-                        constexpr int kNextSet[3] = {1, 2, 0};
-                        const int st = (t + 1) & 1;
-                        opa.store((kt_beg + t + 1) * BK, sA[st][0], sA[st][1], ra[kNextSet[u]]);
-                        opb.template store<SB>((kt_beg + t + 1) * BK, sB[st][0], sB[st][SB ? 1 : 0], rb[kNextSet[u]]);
-                    }
-                    __syncthreads();
-                }
-            }
-        }
-        return;                                          // producers take no part in the epilogue
-    }
-
-    // ---------------- consumers ----------------
-    __syncthreads();                                     // stage 0 filled
-    const int khalf = lane >> 5, l31 = lane & 31;
-    for (int t = 0; t < nk; ++t) {
-        const int st = t & 1;
-        if (args.dbg & 2) { __syncthreads(); continue; }
-        const _Float16* pah = sA[st][0] + (wm * TM * 32 + l31) * LDK + khalf * 8;
-        const _Float16* pal = sA[st][1] + (wm * TM * 32 + l31) * LDK + khalf * 8;
-        const _Float16* pbh = sB[st][0] + (wn * TN * 32 + l31) * LDK + khalf * 8;
-        const _Float16* pbl = sB[st][SB ? 1 : 0] + (wn * TN * 32 + l31) * LDK + khalf * 8;
-#pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {
-            f16x8 ah[TM], al[TM], bh[TN], bl[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                ah[i] = *reinterpret_cast<const f16x8*>(pah + i * 32 * LDK + ks * 16);
-                al[i] = *reinterpret_cast<const f16x8*>(pal + i * 32 * LDK + ks * 16);
-            }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                bh[j] = *reinterpret_cast<const f16x8*>(pbh + j * 32 * LDK + ks * 16);
-                if (SB) bl[j] = *reinterpret_cast<const f16x8*>(pbl + j * 32 * LDK + ks * 16);
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                    if (SB) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-                }
-        }
-        __syncthreads();
-    }
-    SfGemm gs = g;
-    if (ksp > 1) gs.C = g.C + (int64_t)split * g.split_stride;
-    if (sf::epilogue_vec_ok(gs, z)) {
-        // every consumer wave passed the last barrier of the loop, i.e. all LDS reads are done: stage 0 of A is free
-        sf::gemm_epilogue_vec<2, 2, TM, TN>(gs, acc, m0, n0, z, wm, wn, lane,
-                                            reinterpret_cast<float*>(&sA[0][0][0]) + wave * sf::kEpiScratchFloats);
-    } else {
-        gemm_epilogue<2, 2, TM, TN>(gs, acc, m0, n0, z, wm, wn, lane);
-    }
-}
-
-template <bool SB>
-int launch_ws(const SplitArgs& a, hipStream_t st) {
-    const SfGemm& g = a.g;
-    dim3 grid(sf::ceil_div(g.N, 128) * sf::ceil_div(g.M, 128) * g.batch * (g.k_splits > 1 ? g.k_splits : 1));
-    const int lay = g.a_layout * 4 + g.b_layout;
-    if (lay == 7) {                                     // K-minor fp32 A x stored fp16 B (attn @ v): B has no lo part
-        hipLaunchKernelGGL((gemm_f16x3_ws<1, 3, false>), grid, dim3(kWsThreads), 0, st, a);
-        return sf::check_launch("sf_gemm(f16x3, wave-specialised)");
-    }
-    switch (lay) {
-        case 0: hipLaunchKernelGGL((gemm_f16x3_ws<0, 0, SB>), grid, dim3(kWsThreads), 0, st, a); break;
-        case 5: hipLaunchKernelGGL((gemm_f16x3_ws<1, 1, SB>), grid, dim3(kWsThreads), 0, st, a); break;
-        case 8: hipLaunchKernelGGL((gemm_f16x3_ws<2, 0, SB>), grid, dim3(kWsThreads), 0, st, a); break;
-        default: return sf::fail(SF_ERR_UNSUPPORTED, "sf_gemm(f16x3): layout combination a=%d b=%d not built",
-                                 g.a_layout, g.b_layout);
-    }
-    return sf::check_launch("sf_gemm(f16x3, wave-specialised)");
-}
-
 template <int WM, int WN, int TM, int TN, bool SB>
 int launch_cfg(const SplitArgs& a, hipStream_t st) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -355,16 +198,12 @@ int pick_tile(const SplitArgs& a, hipStream_t st) {
         if (bm == 128) return launch_cfg<2, 2, 2, 2, SB>(a, st);
         if (bm == 256) return launch_cfg<2, 2, 4, 2, SB>(a, st);
         if (bm == 257) return launch_cfg<2, 2, 2, 4, SB>(a, st);
-        if (bm == 129) return launch_ws<SB>(a, st);
         if (bm == 64) return launch_cfg<1, 4, 2, 1, SB>(a, st);
         if (bm == 32) return launch_cfg<1, 4, 1, 1, SB>(a, st);
     }
-    // deep-K problems gain from the wave-specialised kernel's 3-tile prefetch; shallow ones are dominated by
-    // prologue/epilogue, where the single-role kernel (all waves store) is a little faster
-    static const int ws_min_k = getenv("SF_WS_MINK") ? atoi(getenv("SF_WS_MINK")) : 768;
-    if (padded(128) * 4 <= M * 5)
-        return (!g.conv3x3 && g.K / (g.k_splits > 1 ? g.k_splits : 1) >= ws_min_k) ? launch_ws<SB>(a, st)
-                                                                                      : launch_cfg<2, 2, 2, 2, SB>(a, st);
+    // (a wave-specialised producer/consumer variant of the 128x128 kernel was faster for K >= 768 early in the round;
+    // after the cheaper split and epilogue it measured 2-25 % slower at every batch size and was removed)
+    if (padded(128) * 4 <= M * 5) return launch_cfg<2, 2, 2, 2, SB>(a, st);
     if (padded(64) * 4 <= M * 5 || M > 32) return launch_cfg<1, 4, 2, 1, SB>(a, st);
     return launch_cfg<1, 4, 1, 1, SB>(a, st);
 }
@@ -476,7 +315,6 @@ int gemm_split_dispatch_inner(const SfGemm& g, hipStream_t st) {
     if (g.b_group % 32) return fail(SF_ERR_BAD_ARG, "sf_gemm(f16x3): b_group must be a multiple of 32");
     SplitArgs a;
     a.g = g;
-    a.dbg = getenv("SF_GEMM_DBG") ? atoi(getenv("SF_GEMM_DBG")) : 0;
     a.ts = getenv("SF_GEMM_TS_BUF") ? (long long*)strtoull(getenv("SF_GEMM_TS_BUF"), nullptr, 0) : nullptr;
     if (g.a_layout == SF_LAYOUT_SPLIT_F16) {
         if (!g.A_hi || !g.A_lo || g.lda_h <= 0 || (g.lda_h & 7))
