@@ -34,7 +34,10 @@ using namespace sf_split;
 struct SplitArgs {
     SfGemm g;
     int64_t a_bytes, b_bytes;      // bytes spanned by one batch image of A / B (buffer range check)
-    long long* ts;                 // SF_GEMM_TS_BUF: per-workgroup phase timestamps (experiments only)
+#ifdef SF_GEMM_TIMERS
+    long long* ts;                 // SF_GEMM_TS_BUF: per-workgroup phase timestamps (tools/gemm_one.py; built with
+                                   // tools/build_variant.sh timers gemm_split.hip -DSF_GEMM_TIMERS)
+#endif
 };
 
 template <int WM, int WN, int TM, int TN, int ALAY, int BLAY, bool SB>
@@ -56,8 +59,10 @@ __global__ __launch_bounds__(kThreads, (TM * TN >= 8) ? 2 : 3) void gemm_f16x3_m
     const int ksp = g.k_splits > 1 ? g.k_splits : 1;
     const int n0 = tc.n_tile * BN, m0 = tc.m_tile * BM, z = tc.z / ksp, split = tc.z % ksp;
 
+#ifdef SF_GEMM_TIMERS
     const long long ts0 = __builtin_readcyclecounter();
     const long long rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
     Operand<BM, ALAY> opa;
     Operand<BN, BLAY> opb;
     typename Operand<BM, ALAY>::Regs ra;
@@ -94,7 +99,9 @@ __global__ __launch_bounds__(kThreads, (TM * TN >= 8) ? 2 : 3) void gemm_f16x3_m
     opa.store(kt_beg * BK, sA[0], sA[1], ra);
     opb.template store<SB>(kt_beg * BK, sB[0], sB[SB ? 1 : 0], rb, conv ? conv_tap(kt_beg * BK) : -1);
     __syncthreads();
+#ifdef SF_GEMM_TIMERS
     const long long ts1 = __builtin_readcyclecounter();
+#endif
 
     const int khalf = lane >> 5, l31 = lane & 31;
     for (int kt = kt_beg; kt < kt_end; ++kt) {
@@ -142,7 +149,9 @@ __global__ __launch_bounds__(kThreads, (TM * TN >= 8) ? 2 : 3) void gemm_f16x3_m
             __syncthreads();
         }
     }
+#ifdef SF_GEMM_TIMERS
     const long long ts2 = __builtin_readcyclecounter();
+#endif
     SfGemm gs = g;
     if (ksp > 1) gs.C = g.C + (int64_t)split * g.split_stride;   // partial product of this K slice: its own slab
     if (sf::epilogue_vec_ok(gs, z)) {
@@ -152,6 +161,7 @@ __global__ __launch_bounds__(kThreads, (TM * TN >= 8) ? 2 : 3) void gemm_f16x3_m
     } else {
         gemm_epilogue<WM, WN, TM, TN>(gs, acc, m0, n0, z, wm, wn, lane);
     }
+#ifdef SF_GEMM_TIMERS
     if (args.ts && tid == 0) {
         long long* d = args.ts + (int64_t)blockIdx.x * 8;
         d[0] = ts0; d[1] = ts1; d[2] = ts2; d[3] = __builtin_readcyclecounter();
@@ -159,6 +169,7 @@ __global__ __launch_bounds__(kThreads, (TM * TN >= 8) ? 2 : 3) void gemm_f16x3_m
         d[6] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));      // XCC_ID[3:0]
         d[7] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));      // HW_ID
     }
+#endif
 }
 
 
@@ -315,7 +326,9 @@ int gemm_split_dispatch_inner(const SfGemm& g, hipStream_t st) {
     if (g.b_group % 32) return fail(SF_ERR_BAD_ARG, "sf_gemm(f16x3): b_group must be a multiple of 32");
     SplitArgs a;
     a.g = g;
+#ifdef SF_GEMM_TIMERS
     a.ts = getenv("SF_GEMM_TS_BUF") ? (long long*)strtoull(getenv("SF_GEMM_TS_BUF"), nullptr, 0) : nullptr;
+#endif
     if (g.a_layout == SF_LAYOUT_SPLIT_F16) {
         if (!g.A_hi || !g.A_lo || g.lda_h <= 0 || (g.lda_h & 7))
             return fail(SF_ERR_BAD_ARG, "sf_gemm(f16x3): SPLIT_F16 A needs A_hi/A_lo and lda_h %% 8 == 0");

@@ -1,5 +1,8 @@
 #!/usr/bin/env python3
-"""Run one sf_gemm shape N times (for rocprofv3 --pmc runs).  usage: gemm_one.py M K [epi] [precision]"""
+"""Run one sf_gemm shape N times (timing / rocprofv3 --pmc runs).  usage: gemm_one.py M K [epi] [precision]
+SF_N_IMG=24 sets the batch (images); SF_GEMM_TS=1 prints per-workgroup phase timers and the sustained clock, which
+needs a library built with the timers: tools/build_variant.sh timers gemm_split.hip -DSF_GEMM_TIMERS, then
+SF_HIP_LIB=streamflow_amd/csrc/build/variant_timers.so."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

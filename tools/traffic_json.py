@@ -6,7 +6,7 @@ bytes once).  usage: traffic_json.py <fetch_counter_collection.csv> <write_count
 import collections, csv, json, re, sys
 
 FAMILY = [(r"corr_build|split_pack", "corr_build"), (r"corr_lookup", "corr_lookup"),
-          (r"gemm_f16x3_\w+<1, 3", "gemm_attn"), (r"gemm_f16x3_ws<1, 1", "gemm_attn"), (r"gemm_f", "gemm"),
+          (r"gemm_f16x3_mfma<[^>]*, 1, [13], (true|false)>", "gemm_attn"), (r"gemm_f", "gemm"),
           (r"splitk_epilogue", "gemm"), (r"splitk_combine", "splitk_combine"), (r"dwconv_mfma", "dwconv15"),
           (r"dwconv_res_gelu_kernel<15>", "dwconv15"), (r"dwconv_res_gelu_kernel<7>", "dwconv7"),
           (r"softmax_rows", "softmax_rows"), (r"layernorm", "layernorm"), (r"temporal_attn", "temporal_attn"),
