@@ -40,8 +40,11 @@ struct SplitArgs {
 #endif
 };
 
+#ifndef SF_GEMM_WAVES
+#define SF_GEMM_WAVES 3          // workgroups per CU the register budget is sized for (128x128 tile)
+#endif
 template <int WM, int WN, int TM, int TN, int ALAY, int BLAY, bool SB>
-__global__ __launch_bounds__(kThreads, (TM * TN >= 8) ? 2 : 3) void gemm_f16x3_mfma(const SplitArgs args) {
+__global__ __launch_bounds__(kThreads, (TM * TN >= 8) ? 2 : SF_GEMM_WAVES) void gemm_f16x3_mfma(const SplitArgs args) {
     const SfGemm& g = args.g;
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     static_assert(WM * WN == 4, "4 waves per workgroup");
