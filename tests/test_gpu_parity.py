@@ -305,7 +305,7 @@ def test_spring_shape_smoke(dev):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("K", [200, 1544])          # single-role kernel / wave-specialised kernel (K >= 768)
+@pytest.mark.parametrize("K", [200, 1544])          # with and without a partial last k-tile
 def test_gemm_stored_fp16_operand(dev, K):
     """attn @ v with the attention matrix stored in fp16 (SF_LAYOUT_F16_K_MINOR): C = R + gamma * A B^T with
     A = v [M][K] fp32 (split hi+lo in the kernel), B [N][K] fp16 used as stored.  Reference in float64 on the SAME
