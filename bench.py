@@ -129,6 +129,9 @@ def main():
                     help="torch.distributed backend for the barrier / max-over-ranks (nccl = RCCL; gloo for dry runs)")
     ap.add_argument("--share-device", action="store_true",
                     help="dry-run aid: map every rank to cuda:LOCAL_RANK %% device_count (use with --dist-backend gloo)")
+    ap.add_argument("--serial-branches", action="store_true",
+                    help="enqueue the independent chains of an iteration on one stream (profiling aid: kernel-trace "
+                         "durations are then free of cross-branch contention and match the HIP-event table)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-breakdown", action="store_true")
     args = ap.parse_args()
@@ -162,6 +165,8 @@ def main():
     fmaps_c, cnets_c = syn.make_features(1000 + rank, B, T, h, w)
     fmaps, cnets = fmaps_c.to(dev), cnets_c.to(dev)
     eng = HotPathEngine(params, device=dev, T=T, use_graph=not args.no_graph, precision=args.precision)
+    if args.serial_branches:
+        eng.parallel_branches = False
 
     def step():
         eng.forward(fmaps, cnets, iters=iters, all_masks=args.all_masks)
