@@ -1,0 +1,124 @@
+"""Randomised shape sweep of the fused GEMM, the implicit 3x3 convolution and the correlation build / lookup through
+the C ABI against float64 torch references (-m gpu).  Seeds are fixed; shapes are drawn to hit the kernels' tails:
+M, N, K that are not multiples of the 128 / 128 / 32 tiles, single rows, ragged widths, batches."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    return torch.device("cuda:0")
+
+
+def _gelu(x):
+    return F.gelu(x)          # exact (erf) form
+
+
+def _ref_epilogue(epi, v, R, dw_w, dw_b, ops):
+    if epi == ops.EPI_GELU:
+        return _gelu(v)
+    if epi == ops.EPI_RELU:
+        return torch.relu(v)
+    if epi == ops.EPI_RES:
+        return R + v
+    if epi == ops.EPI_RES_GELU:
+        return _gelu(R + v)
+    if epi == ops.EPI_RES_GELU_DW1:
+        t = _gelu(R + v)
+        return _gelu(t + (dw_w[None, :, None] * t + dw_b[None, :, None]))
+    return v
+
+
+@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("prec", ["fp32", "f16x3"])
+def test_gemm_random_shapes(dev, seed, prec):
+    from streamflow_amd import ops
+    from streamflow_amd.ops import PackedLinear, Planes
+    rng = np.random.default_rng(1000 + seed)
+    M = int(rng.choice([1, 6, 31, 64, 126, 128, 129, 200, 324, 385]))
+    K = int(rng.choice([2, 7, 32, 33, 100, 128, 192, 324, 800]))
+    P = int(rng.choice([1, 17, 127, 128, 129, 300, 1000]))
+    n = int(rng.integers(1, 4))
+    epi = int(rng.choice([ops.EPI_NONE, ops.EPI_GELU, ops.EPI_RELU, ops.EPI_RES, ops.EPI_RES_GELU, ops.EPI_RES_GELU_DW1]))
+    alpha = float(rng.choice([1.0, 0.25]))
+    g = torch.Generator().manual_seed(seed)
+    Wt = torch.randn(M, K, generator=g) / max(K, 1) ** 0.5
+    bias = torch.randn(M, generator=g) * 0.1 if rng.random() < 0.8 else None
+    X = torch.randn(n, K, P, generator=g)
+    R = torch.randn(n, M, P, generator=g)
+    dw_w, dw_b = torch.randn(M, generator=g) * 0.5, torch.randn(M, generator=g) * 0.1
+    prev = ops.set_precision(prec)
+    try:
+        A = PackedLinear(Wt, bias, dev)
+        Y = torch.full((n, M, P), float("nan"), device=dev)
+        ops.gemm(A, Planes.of(X.to(dev)), Planes.of(Y), epi, R=Planes.of(R.to(dev)), dw_w=dw_w.to(dev),
+                 dw_b=dw_b.to(dev), alpha=alpha)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_precision(prev)
+    v = alpha * (torch.einsum("mk,zkp->zmp", Wt.double(), X.double()) + (bias.double()[None, :, None] if bias is not None else 0.0))
+    ref = _ref_epilogue(epi, v, R.double(), dw_w.double(), dw_b.double(), ops)
+    err = (Y.double().cpu() - ref).abs().max().item()
+    tol = 3e-5 if prec == "f16x3" else 2e-5
+    assert err < tol, (M, K, P, n, epi, prec, err)
+
+
+@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("prec", ["fp32", "f16x3"])
+def test_conv3x3_random_shapes(dev, seed, prec):
+    """Mask-head style implicit 3x3 convolution (update.py:756-759) on ragged images."""
+    from streamflow_amd import ops
+    from streamflow_amd.ops import PackedLinear, Planes
+    rng = np.random.default_rng(2000 + seed)
+    cin = int(rng.choice([32, 64, 128]))
+    cout = int(rng.choice([5, 64, 130, 256]))
+    h, w = int(rng.integers(3, 20)), int(rng.integers(3, 40))
+    n = int(rng.integers(1, 3))
+    g = torch.Generator().manual_seed(seed)
+    Wt = torch.randn(cout, cin, 3, 3, generator=g) / (9 * cin) ** 0.5
+    bias = torch.randn(cout, generator=g) * 0.1
+    X = torch.randn(n, cin, h, w, generator=g)
+    prev = ops.set_precision(prec)
+    try:
+        A = PackedLinear(Wt, bias, dev, conv3x3=True)
+        Y = torch.full((n, cout, h * w), float("nan"), device=dev)
+        ops.gemm(A, Planes.of(X.to(dev)), Planes.of(Y), ops.EPI_RELU, hw=(h, w))
+        torch.cuda.synchronize()
+    finally:
+        ops.set_precision(prev)
+    ref = torch.relu(F.conv2d(X.double(), Wt.double(), bias.double(), padding=1)).reshape(n, cout, h * w)
+    err = (Y.double().cpu() - ref).abs().max().item()
+    assert err < 3e-5, (cin, cout, h, w, n, prec, err)
+
+
+@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("prec", ["fp32", "f16x3"])
+def test_corr_random_shapes(dev, seed, prec):
+    """CorrBlock (core/corr.py) on ragged grids against the CPU oracle: pyramid levels and a lookup."""
+    from oracle import streamflow_oracle as orc
+    import streamflow_amd as sfa
+    from streamflow_amd import ops
+    rng = np.random.default_rng(3000 + seed)
+    B = int(rng.integers(1, 3))
+    D = int(rng.choice([16, 40, 256]))
+    h, w = int(rng.integers(16, 40)), int(rng.integers(16, 50))
+    g = torch.Generator().manual_seed(seed)
+    f1, f2 = torch.randn(B, D, h, w, generator=g), torch.randn(B, D, h, w, generator=g)
+    coords = orc.coords_grid(B, h, w) + torch.randn(B, 2, h, w, generator=g) * 4.0
+    prev = ops.set_precision(prec)
+    try:
+        blk = sfa.CorrBlock(f1.to(dev), f2.to(dev), num_levels=4, radius=4)
+        out = blk(coords.to(dev)).cpu()
+        lv = [t.cpu() for t in blk.corr_pyramid]
+    finally:
+        ops.set_precision(prev)
+    pyr = orc.corr_pyramid(f1, f2, 4)
+    for a, b_ in zip(lv, pyr):
+        assert a.shape == b_.shape and (a - b_).abs().max().item() < 3e-5
+    assert (out - orc.corr_lookup(pyr, coords, 4)).abs().max().item() < 5e-5
