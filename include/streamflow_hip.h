@@ -88,9 +88,11 @@ int sf_corr_lookup(const float* lvl0, const float* lvl1, const float* lvl2, cons
  * (update.py:466-479), mask head (update.py:756-759; 3x3 conv as implicit GEMM). */
 enum { SF_LAYOUT_K_MAJOR = 0,   /* A[k*lda + m]   /  B[k*ldb + n]   (rows of k)            */
        SF_LAYOUT_K_MINOR = 1,   /* A[m*lda + k]   /  B[n*ldb + k]   (k contiguous)          */
-       SF_LAYOUT_SPLIT_F16 = 2,/* A only, precision 1: weights pre-split on the host into two IEEE fp16
-                                    matrices A_hi/A_lo [M padded to 128][K padded to 32] (zero padded),
-                                    element (m,k) at m*lda_h + k, with w = hi + lo to ~22 bits         */
+       SF_LAYOUT_SPLIT_F16 = 2,/* A only, split precisions: weights pre-split on the host into two IEEE fp16
+                                    images A_hi/A_lo laid out in k-octet planes [K padded to 32 / 8][lda_h][8] with
+                                    lda_h = M padded to 128 (zero padded): element (m,k) at ((k/8)*lda_h + m)*8 + k%8,
+                                    w = hi + lo to ~22 bits.  16 bytes = one MFMA operand k-octet of one row, so a
+                                    tile is moved to LDS by buffer_load ... lds without passing through registers */
        SF_LAYOUT_F16_K_MINOR = 3 };/* B only, split precisions: B points to IEEE fp16 values B[n*ldb + k]
                                     (ldb, strideB in halfs; ldb % 2 == 0); used as they are, no lo part:
                                     a*b = ah*b + al*b.  The stored attention matrix (sf_softmax_rows).   */
@@ -127,7 +129,7 @@ typedef struct SfGemm {
     int32_t epilogue;
     int32_t precision;            /* SF_PRECISION_* */
     const void* A_hi; const void* A_lo;   /* SF_LAYOUT_SPLIT_F16 operand (shared by all batch indices) */
-    int64_t lda_h;                /* row stride of A_hi/A_lo in halfs (multiple of 8) */
+    int64_t lda_h;                /* rows per k-octet plane of A_hi/A_lo (M padded to 128) */
     int32_t a_padded;             /* K_MAJOR fp32 A is zero padded to [K up to 32][M up to 128]: no bounds checks */
     /* split-K (precision F16X3 only): the K range is cut into k_splits slices, slice s writes its partial
        product (epilogue must be SF_EPI_NONE, no bias) to C + s*split_stride; combine with sf_splitk_combine. */

@@ -86,7 +86,10 @@ __device__ __forceinline__ void pyramid_store(const BuildArgs& g, f32x16 (&acc)[
     // level 0 (3/4 of the bytes) is streamed past the caches: it would only displace the operand tiles in L2 and the
     // pooled levels, which are small enough (a quarter of level 0 together) to stay in the 256 MB Infinity Cache
     // for the lookups that follow
-    constexpr int kNt = 2;
+#ifndef SF_CORR_NT
+#define SF_CORR_NT 2
+#endif
+    constexpr int kNt = SF_CORR_NT;
 #pragma unroll
     for (int rq = 0; rq < 4; ++rq) {                        // register group: source pixels 8*rq + 4*khalf + (0..3)
         float v1[4][PR / 2], v2[4][PR / 4], v3[4];

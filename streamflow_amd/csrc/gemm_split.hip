@@ -11,7 +11,9 @@
 // Same interface, tiling and epilogues as gemm.hip.  Differences:
 //  * LDS holds the tiles ALREADY split, as f16 rows [x][k] (k contiguous, row stride BK+8 halfs = 80 B so
 //    the 16-byte fragment reads of 16 consecutive rows cover all 64 banks once);
-//  * weights are split and laid out [M][K] once on the host (SF_LAYOUT_SPLIT_F16); fp32 activations are split
+//  * weights are split once on the host into k-octet planes [K/8][M][8] (SF_LAYOUT_SPLIT_F16); the 128-row tile moves
+//    them HBM/L2 -> LDS with buffer_load ... lds (no registers, no ds_write: the VGPR -> LDS store path, ~79 B/clk per
+//    CU, is the scarcest resource of the loop), two LDS stages; fp32 activations are split
 //    on the fly while being staged (K-major source: 8 row loads per thread = one k-octet of one pixel;
 //    K-minor source: two 16-byte loads);
 //  * every global read is a buffer load: the per-thread byte offset (voffset) is computed once before the
@@ -48,12 +50,17 @@ __global__ __launch_bounds__(kThreads, (TM * TN >= 8) ? 2 : SF_GEMM_WAVES) void 
     const SfGemm& g = args.g;
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     static_assert(WM * WN == 4, "4 waves per workgroup");
-    // [hi|lo][rows][LDK]; ONE LDS stage (the next tile waits in registers), so 3 workgroups fit per CU
-    constexpr int kMainHalfs = 2 * BM * LDK + (SB ? 2 : 1) * BN * LDK;          // SB = false: B has no lo part
+    // B: [hi|lo][rows][LDK], ONE LDS stage (the next tile waits in registers).  A: the same for register-staged A; for
+    // pre-split weights on the 128-row tile (kDmaA) two DMA-filled stages [hi|lo][4 k-octets][128 rows][8].  52 KB at
+    // most, so 3 workgroups fit per CU.
+    constexpr bool kDmaA = (ALAY == 2) && (BM == 128);
+    constexpr int kAStage = 2 * (BK / 8) * BM * 8;                               // halfs of one DMA stage (hi + lo)
+    constexpr int kAHalfs = kDmaA ? 2 * kAStage : 2 * BM * LDK;
+    constexpr int kMainHalfs = kAHalfs + (SB ? 2 : 1) * BN * LDK;               // SB = false: B has no lo part
     constexpr int kEpiHalfs = 4 * sf::kEpiScratchFloats * 2;
-    __shared__ __attribute__((aligned(16))) _Float16 smem[kMainHalfs > kEpiHalfs ? kMainHalfs : kEpiHalfs];
+    __shared__ __attribute__((aligned(1024))) _Float16 smem[kMainHalfs > kEpiHalfs ? kMainHalfs : kEpiHalfs];
     _Float16 (*sA)[BM * LDK] = reinterpret_cast<_Float16 (*)[BM * LDK]>(smem);
-    _Float16 (*sB)[BN * LDK] = reinterpret_cast<_Float16 (*)[BN * LDK]>(smem + 2 * BM * LDK);
+    _Float16 (*sB)[BN * LDK] = reinterpret_cast<_Float16 (*)[BN * LDK]>(smem + kAHalfs);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -96,11 +103,31 @@ __global__ __launch_bounds__(kThreads, (TM * TN >= 8) ? 2 : SF_GEMM_WAVES) void 
     ca.init(0, (int)g.lda, 0);
     cb.init(g.b_group, (int)g.ldb, g.b_group_stride);
     for (int t = 0; t < kt_beg; ++t) { ca.advance(); cb.advance(); }       // split-K: start of this slice
-    opa.load(kt_beg * BK, ca.off, ra);
+    // ---- A by LDS-DMA (kDmaA): slot = k-octet * 128 + row = j * 256 + tid for the j-th of two 4 KB pieces per plane ----
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int a_plane = (int)(args.a_bytes);                                       // bytes of the hi (= lo) plane
+    const __amdgpu_buffer_rsrc_t rah = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.A_hi), 0, a_plane, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ral = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.A_lo), 0, a_plane, 0x00020000);
+    const int voa0 = ((tid >> 7) * (int)g.lda_h + m0 + (tid & 127)) * 16, voa1 = voa0 + 2 * (int)g.lda_h * 16;
+    auto issue_a = [&](int kt, int buf) {
+        char* dst = reinterpret_cast<char*>(smem) + buf * kAStage * 2 + wave_u * 1024;
+        const int so = kt * (BK / 8) * (int)g.lda_h * 16;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rah, (lds_ptr)(dst), 16, voa0, so, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rah, (lds_ptr)(dst + 4096), 16, voa1, so, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ral, (lds_ptr)(dst + kAStage), 16, voa0, so, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ral, (lds_ptr)(dst + kAStage + 4096), 16, voa1, so, 0, 0);
+    };
+
+    // the A piece is requested BEFORE the B loads of the same k-tile: vmcnt retires in order, so the wait that the B
+    // registers need also covers the DMA
+    if (kDmaA) issue_a(kt_beg, 0);
+    else opa.load(kt_beg * BK, ca.off, ra);
     if (conv) opb.load(kt_beg * BK, conv_off(kt_beg * BK), rb, conv_shift(kt_beg * BK));
     else opb.load(kt_beg * BK, cb.off, rb);
-    opa.store(kt_beg * BK, sA[0], sA[1], ra);
+    if (!kDmaA) opa.store(kt_beg * BK, sA[0], sA[1], ra);
     opb.template store<SB>(kt_beg * BK, sB[0], sB[SB ? 1 : 0], rb, conv ? conv_tap(kt_beg * BK) : -1);
+    if (kDmaA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 #ifdef SF_GEMM_TIMERS
     const long long ts1 = __builtin_readcyclecounter();
@@ -108,17 +135,23 @@ __global__ __launch_bounds__(kThreads, (TM * TN >= 8) ? 2 : SF_GEMM_WAVES) void 
 
     const int khalf = lane >> 5, l31 = lane & 31;
     for (int kt = kt_beg; kt < kt_end; ++kt) {
+        const int abuf = (kt - kt_beg) & 1;
         if (kt + 1 < kt_end) {
             ca.advance();
             cb.advance();
-            opa.load((kt + 1) * BK, ca.off, ra);
+            if (kDmaA) issue_a(kt + 1, abuf ^ 1);          // the other stage was last read one k-tile (two barriers) ago
+            else opa.load((kt + 1) * BK, ca.off, ra);
             if (conv) opb.load((kt + 1) * BK, conv_off((kt + 1) * BK), rb, conv_shift((kt + 1) * BK));
             else opb.load((kt + 1) * BK, cb.off, rb);
         }
         // keep the staged loads in flight across the MFMA block: nothing below may be hoisted above it
         __builtin_amdgcn_sched_barrier(0);
-        const _Float16* pah = sA[0] + (wm * TM * 32 + l31) * LDK + khalf * 8;
-        const _Float16* pal = sA[1] + (wm * TM * 32 + l31) * LDK + khalf * 8;
+        // A fragment of lane (row l31, k-half): register-staged image rows [x][LDK]; DMA image [k-octet][128 rows][8]
+        const _Float16* pah = kDmaA ? smem + abuf * kAStage + (khalf * BM + wm * TM * 32 + l31) * 8
+                                    : sA[0] + (wm * TM * 32 + l31) * LDK + khalf * 8;
+        const _Float16* pal = kDmaA ? pah + kAStage / 2 : sA[1] + (wm * TM * 32 + l31) * LDK + khalf * 8;
+        constexpr int kATile = kDmaA ? 32 * 8 : 32 * LDK;        // halfs between the 32-row tiles of a wave
+        constexpr int kAStep = kDmaA ? 2 * BM * 8 : 16;          // halfs per 16-deep k-step
         const _Float16* pbh = sB[0] + (wn * TN * 32 + l31) * LDK + khalf * 8;
         const _Float16* pbl = sB[SB ? 1 : 0] + (wn * TN * 32 + l31) * LDK + khalf * 8;
 #pragma unroll
@@ -126,8 +159,8 @@ __global__ __launch_bounds__(kThreads, (TM * TN >= 8) ? 2 : SF_GEMM_WAVES) void 
             f16x8 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                ah[i] = *reinterpret_cast<const f16x8*>(pah + i * 32 * LDK + ks * 16);
-                al[i] = *reinterpret_cast<const f16x8*>(pal + i * 32 * LDK + ks * 16);
+                ah[i] = *reinterpret_cast<const f16x8*>(pah + i * kATile + ks * kAStep);
+                al[i] = *reinterpret_cast<const f16x8*>(pal + i * kATile + ks * kAStep);
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
@@ -147,8 +180,9 @@ __global__ __launch_bounds__(kThreads, (TM * TN >= 8) ? 2 : SF_GEMM_WAVES) void 
         __builtin_amdgcn_sched_barrier(0);
         if (kt + 1 < kt_end) {
             __syncthreads();                       // every wave is done reading tile kt
-            opa.store((kt + 1) * BK, sA[0], sA[1], ra);
+            if (!kDmaA) opa.store((kt + 1) * BK, sA[0], sA[1], ra);
             opb.template store<SB>((kt + 1) * BK, sB[0], sB[SB ? 1 : 0], rb, conv ? conv_tap((kt + 1) * BK) : -1);
+            if (kDmaA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (already retired by the wait for rb)
             __syncthreads();
         }
     }
@@ -333,9 +367,10 @@ int gemm_split_dispatch_inner(const SfGemm& g, hipStream_t st) {
     a.ts = getenv("SF_GEMM_TS_BUF") ? (long long*)strtoull(getenv("SF_GEMM_TS_BUF"), nullptr, 0) : nullptr;
 #endif
     if (g.a_layout == SF_LAYOUT_SPLIT_F16) {
-        if (!g.A_hi || !g.A_lo || g.lda_h <= 0 || (g.lda_h & 7))
-            return fail(SF_ERR_BAD_ARG, "sf_gemm(f16x3): SPLIT_F16 A needs A_hi/A_lo and lda_h %% 8 == 0");
-        a.a_bytes = (int64_t)((g.M + 127) / 128 * 128) * g.lda_h * 2;
+        if (!g.A_hi || !g.A_lo || g.lda_h < (g.M + 127) / 128 * 128 || (g.lda_h & 127) ||
+            ((reinterpret_cast<uintptr_t>(g.A_hi) | reinterpret_cast<uintptr_t>(g.A_lo)) & 15))
+            return fail(SF_ERR_BAD_ARG, "sf_gemm(f16x3): SPLIT_F16 A needs 16-byte aligned A_hi/A_lo and lda_h = M padded to 128");
+        a.a_bytes = (int64_t)((g.K + 31) / 32 * 32) * g.lda_h * 2;          // [K up to 32 / 8][lda_h rows][8] halfs
     } else {
         a.a_bytes = span_bytes(g.a_layout, g.M, g.K, g.lda, 0, 0);
     }

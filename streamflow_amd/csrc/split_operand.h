@@ -68,7 +68,7 @@ struct Operand {
         for (int j = 0; j < NI; ++j) {
             const int idx = tid + j * kThreads;
             int xl, kq;
-            if (LAY == SF_LAYOUT_K_MAJOR) { xl = idx % BX; kq = idx / BX; }      // lanes walk x: coalesced rows
+            if (LAY == SF_LAYOUT_K_MAJOR || LAY == 2) { xl = idx % BX; kq = idx / BX; }   // lanes walk x: coalesced rows
             else { kq = idx % (BK / 8); xl = idx / (BK / 8); }                   // lanes walk k
             live[j] = (BX * (BK / 8)) % kThreads == 0 || idx < BX * (BK / 8);
             ko[j] = kUniformKo ? __builtin_amdgcn_readfirstlane(kq) : kq;
@@ -83,7 +83,7 @@ struct Operand {
             }
             else if (LAY == SF_LAYOUT_K_MINOR) voff[j] = (xc * ld + kq * 8) * 4;
             else if (LAY == SF_LAYOUT_F16_K_MINOR) voff[j] = (xc * ld + kq * 8) * 2;
-            else voff[j] = ((x0 + xl) * ld + kq * 8) * 2;       // host-padded to 128 rows: always in range
+            else voff[j] = (kq * ld + x0 + xl) * 16;            // k-octet planes [K/8][ld rows][8], host-padded: always in range
         }
     }
 
@@ -118,8 +118,8 @@ struct Operand {
                 // the tail k >= K inside a row reads the next row's finite values against zeroed A columns)
                 rg.ph[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[j] + k0 * 2, 0, 0);
             } else if (LAY == 2) {
-                rg.ph[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[j], k0 * 2, 0);
-                rg.pl[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_lo, voff[j], k0 * 2, 0);
+                rg.ph[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[j], (k0 / 8) * ld * 16, 0);
+                rg.pl[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_lo, voff[j], (k0 / 8) * ld * 16, 0);
             } else if (LAY == SF_LAYOUT_K_MAJOR) {
                 if (k0 + BK <= K) {
                     // interior k-tile (workgroup-uniform): one v_add per item, the row offsets are SGPR constants

@@ -165,16 +165,16 @@ class PackedLinear:
         self.wt = wt.contiguous()
         self.bias = None if bias is None else bias.detach().to(device=device, dtype=torch.float32).contiguous()
         self.conv3x3 = conv3x3
-        # split-precision image: w = hi + lo (fp16 each), rows [M padded to 128][K padded to 32], zero padded
+        # split-precision image: w = hi + lo (fp16 each) in k-octet planes [K padded to 32 / 8][M padded to 128][8], zero
+        # padded (SF_LAYOUT_SPLIT_F16): 16 bytes = one MFMA operand octet of one output row
         mp, kp = (self.M + 127) // 128 * 128, (self.K + 31) // 32 * 32
-        wm = w2.t().contiguous()                       # [M][K] fp32
+        wm = torch.zeros(mp, kp, dtype=torch.float32, device=device)
+        wm[: self.M, : self.K] = w2.t()
         hi = wm.to(torch.float16)
         lo = (wm - hi.float()).to(torch.float16)
-        self.hi = torch.zeros(mp, kp, dtype=torch.float16, device=device)
-        self.lo = torch.zeros(mp, kp, dtype=torch.float16, device=device)
-        self.hi[: self.M, : self.K] = hi
-        self.lo[: self.M, : self.K] = lo
-        self.lda_h = kp
+        self.hi = hi.view(mp, kp // 8, 8).permute(1, 0, 2).contiguous()
+        self.lo = lo.view(mp, kp // 8, 8).permute(1, 0, 2).contiguous()
+        self.lda_h = mp
 
 
 def gemm(A: PackedLinear, X: Planes, Y: Planes, epilogue: int = EPI_NONE, R: Optional[Planes] = None,

@@ -89,7 +89,10 @@ def test_packed_linear_layout():
     p = PackedLinear(w, None, "cpu")
     assert (p.K, p.M, p.lda) == (5, 6, 128) and tuple(p.wt.shape) == (32, 128)
     assert torch.equal(p.wt[:5, :6], w.view(6, 5).t()) and p.wt[:, 6:].abs().sum() == 0 and p.wt[5:].abs().sum() == 0
-    assert tuple(p.hi.shape) == (128, 32) and torch.equal((p.hi.float() + p.lo.float())[:6, :5], w.view(6, 5))
+    # split image: k-octet planes [K up to 32 / 8][M up to 128][8]; element (m, k) at [k // 8, m, k % 8]
+    assert tuple(p.hi.shape) == (4, 128, 8) and p.lda_h == 128
+    full = (p.hi.float() + p.lo.float()).permute(1, 0, 2).reshape(128, 32)
+    assert torch.equal(full[:6, :5], w.view(6, 5)) and full[6:].abs().sum() == 0 and full[:, 5:].abs().sum() == 0
     w3 = torch.randn(4, 3, 3, 3)
     p3 = PackedLinear(w3, None, "cpu", conv3x3=True)
     assert p3.K == 27 and p3.wt[(1 * 3 + 2) * 3 + 1, 2] == w3[2, 1, 1, 2]
