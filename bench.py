@@ -257,7 +257,7 @@ def main():
                 result["roofline"]["traffic"] = int((fam["fetch_kib_per_launch"] + fam["write_kib_per_launch"]) * 1024)
                 result["roofline"]["traffic_note"] = ("bytes per launch, mean over the family: 2 x FETCH_SIZE + WRITE_SIZE "
                                                       "from separate rocprofv3 --pmc passes of this workload "
-                                                      "(profiles/r01_f_pmc_hbm_traffic.md, profiles/r01_traffic.json)")
+                                                      "(profiles/r01_g_pmc_hbm_traffic.md, profiles/r01_traffic.json)")
         except (OSError, KeyError, ValueError):
             pass
         # north-star sub-metric: corr build + lookup against the HBM roofline (algorithmic bytes)
