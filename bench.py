@@ -30,6 +30,7 @@ WORKLOADS = {
     "sintel": (440, 1024, 4, 15),
     "demo256": (256, 256, 4, 4),
     "kitti": (376, 1248, 2, 15),
+    "spring": (1088, 1920, 4, 15),     # 1080p padded to /8: 136x240 grid, N = 32640 (use --clips 1; 17 GB of volumes)
 }
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: exact-fp32 MFMA = fp32 vector peak
 PEAK_F16_MFMA_TFLOPS = 2500.0      # dense f16/bf16 MFMA; the split path spends 3 MFMA flops per algorithmic flop

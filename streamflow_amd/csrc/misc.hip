@@ -87,9 +87,10 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 // One workgroup per row; the row lives in registers (up to kSmMax values per thread), so it is read once and
 // written once (the first version made three passes over memory: 1.4x the reads and 2x the writes).
-constexpr int kSmMax = 32;              // 256 threads x 32 = rows up to 8192 columns in registers
-__global__ __launch_bounds__(kBlock) void softmax_rows_kernel(float* x, int cols, _Float16* y16) {
-    __shared__ float red[kBlock / 64];
+constexpr int kSmMax = 32;              // values per thread: 256 threads cover rows up to 8192 columns, 1024 up to 32768
+template <int TPB>
+__global__ __launch_bounds__(TPB) void softmax_rows_kernel(float* x, int cols, _Float16* y16) {
+    __shared__ float red[TPB / 64];
     float* row = x + (int64_t)blockIdx.x * cols;
     _Float16* row16 = y16 ? y16 + (int64_t)blockIdx.x * cols : nullptr;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -97,14 +98,16 @@ __global__ __launch_bounds__(kBlock) void softmax_rows_kernel(float* x, int cols
     float m = -INFINITY;
 #pragma unroll
     for (int j = 0; j < kSmMax; ++j) {
-        const int c = tid + j * kBlock;
+        const int c = tid + j * TPB;
         v[j] = (c < cols) ? row[c] : -INFINITY;
         m = fmaxf(m, v[j]);
     }
     m = wave_max(m);
     if (lane == 0) red[wave] = m;
     __syncthreads();
-    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    m = red[0];
+#pragma unroll
+    for (int i = 1; i < TPB / 64; ++i) m = fmaxf(m, red[i]);
     __syncthreads();
     float s = 0.f;
 #pragma unroll
@@ -115,11 +118,18 @@ __global__ __launch_bounds__(kBlock) void softmax_rows_kernel(float* x, int cols
     s = wave_sum(s);
     if (lane == 0) red[wave] = s;
     __syncthreads();
-    s = (red[0] + red[1]) + (red[2] + red[3]);
-    const float inv = 1.0f / s;
+    // fixed summation tree over the waves (pairs, then pairs of pairs ...): the same value in every thread
+    float part[TPB / 64];
+#pragma unroll
+    for (int i = 0; i < TPB / 64; ++i) part[i] = red[i];
+#pragma unroll
+    for (int w = 1; w < TPB / 64; w *= 2)
+#pragma unroll
+        for (int i = 0; i + w < TPB / 64; i += 2 * w) part[i] += part[i + w];
+    const float inv = 1.0f / part[0];
 #pragma unroll
     for (int j = 0; j < kSmMax; ++j) {
-        const int c = tid + j * kBlock;
+        const int c = tid + j * TPB;
         if (c < cols) {
             if (row16) row16[c] = (_Float16)(v[j] * inv);
             else row[c] = v[j] * inv;
@@ -452,8 +462,10 @@ extern "C" int sf_flow_update(float* coords1, const float* delta, float* flow_a,
 extern "C" int sf_softmax_rows(float* x, int64_t rows, int cols, void* out_f16, void* stream) {
     SF_REQUIRE(x && rows > 0 && cols > 0, "sf_softmax_rows: bad args");
     SF_REQUIRE(rows <= 0x7fffffffLL, "sf_softmax_rows: too many rows");
-    if (cols <= kSmMax * kBlock)
-        hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(kBlock), 0, (hipStream_t)stream, x, cols, (_Float16*)out_f16);
+    if (cols <= kSmMax * 256)
+        hipLaunchKernelGGL(softmax_rows_kernel<256>, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, cols, (_Float16*)out_f16);
+    else if (cols <= kSmMax * 1024)      // high-resolution rows (1080p: 32640 columns) still make one pass
+        hipLaunchKernelGGL(softmax_rows_kernel<1024>, dim3((unsigned)rows), dim3(1024), 0, (hipStream_t)stream, x, cols, (_Float16*)out_f16);
     else
         hipLaunchKernelGGL(softmax_rows_long_kernel, dim3((unsigned)rows), dim3(kBlock), 0, (hipStream_t)stream, x, cols, (_Float16*)out_f16);
     return sf::check_launch("sf_softmax_rows");

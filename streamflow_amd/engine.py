@@ -143,8 +143,8 @@ class _Plan:
         # split-precision modes keep the materialised matrix in fp16 (half the bytes of the HBM-bound attn @ v that
         # every iteration repeats; measured effect on the final flow: 4e-6 px mean EPE); self.attn is then only the
         # logits scratch of the one-time softmax
-        self.attn16 = (torch.empty(n, P, P, dtype=torch.float16, device=device)
-                       if attn_f16 and self.attn_rows == P and P % 2 == 0 else None)
+        self.attn16 = (torch.empty(n, self.attn_rows, P, dtype=torch.float16, device=device)
+                       if attn_f16 and P % 2 == 0 else None)       # whole matrix, or one row chunk (high resolution)
         spec = [("qk", 2 * HDIM), ("corr", COR_PLANES), ("flow", 2), ("hid", 960), ("xa", 640), ("xb", 640),
                 ("cor256", 256), ("cat256", 256), ("f128", 128),
                 ("concat", 640),                       # [nets | inps | mf | mf_global | mf_temporal]
@@ -220,7 +220,7 @@ class HotPathEngine:
             ops.softmax_rows(pl.attn, n * rows, P, out16=pl.attn16)
         else:                                     # last, shorter chunk: rows of each image are not contiguous
             for img in range(n):
-                ops.softmax_rows(pl.attn[img], rows, P)
+                ops.softmax_rows(pl.attn[img], rows, P, out16=None if pl.attn16 is None else pl.attn16[img])
 
     # ---------------------------------------------------------------------------------------------
     def _setup(self, pl: _Plan, fmaps: torch.Tensor, cnets: torch.Tensor) -> None:
@@ -284,10 +284,10 @@ class HotPathEngine:
             for i0 in range(0, P, pl.attn_rows):
                 rows = min(pl.attn_rows, P - i0)
                 self._attention_rows(pl, i0, rows)
-                ops.gemm_raw(A=pl.v128.ptr, B=pl.attn.data_ptr(), C=pl.mfg.ptr + 4 * i0, R=pl.mf.ptr + 4 * i0,
+                ops.gemm_raw(A=pl.v128.ptr, B=attn_ptr, C=pl.mfg.ptr + 4 * i0, R=pl.mf.ptr + 4 * i0,
                              gamma=W.gamma.data_ptr(), M=HDIM, N=rows, K=P, batch=n, lda=P, ldb=P, ldc=P, ldr=P,
                              strideA=pl.v128.img_stride, strideB=pl.attn_rows * P, strideC=pl.mfg.img_stride,
-                             strideR=pl.mf.img_stride, a_layout=LAYOUT_K_MINOR, b_layout=LAYOUT_K_MINOR, alpha=1.0,
+                             strideR=pl.mf.img_stride, a_layout=LAYOUT_K_MINOR, b_layout=attn_lay, alpha=1.0,
                              epilogue=EPI_AXPY)
         elif ks > 1 and P % 4 == 0:
             # attn @ v streams the N x N matrix (HBM-bound) but has only N/128 * images workgroups: split K so that
