@@ -1,7 +1,10 @@
 // Depthwise KxK convolution fused with bias, residual and exact GELU:
 //     y = gelu(x + dwconv_KxK(x) + b)            (reference core/update.py:33-34, kernels 15 and 7)
 //
-// VALU-bound stencil (225 or 49 FMAs per output).  One workgroup owns one (image, channel) plane
+// Two kernels.  (1) fp32 stencil on the VALU, below (exact fp32 mode, and K = 7 in every mode).  (2) For K = 15 in the
+// split precisions, banded-Toeplitz GEMMs on the matrix cores: dwconv_mfma_kernel further down.
+//
+// (1) VALU-bound stencil (225 or 49 FMAs per output).  One workgroup owns one (image, channel) plane
 // strip: the strip plus its K/2 halo is staged once in LDS (zero padded, so the inner loop has no
 // bounds checks), each thread produces a 4x4 output tile from a sliding window held in registers
 // (one ds_read_b128 row segment feeds 4 output columns x K taps).  The K*K weights of the channel sit in LDS

@@ -3,17 +3,16 @@
 // Reference: core/corr.py:7-21,46-54 (build), :23-44 (lookup), core/utils/utils.py:65-79 (sampler).
 //
 // BUILD.  C[i][j] = <f1[:,i], f2[:,j]> / sqrt(D) is a dense contraction, so it runs on the matrix
-// cores (exact-fp32 v_mfma_f32_32x32x2_f32).  The GEMM "N" tile is not a run of 256 consecutive
+// cores (exact-fp32 v_mfma_f32_32x32x2_f32, or split fp16 operands fed by LDS-DMA: see corr_build_dma_kernel).  The GEMM "N" tile is not a run of 256 consecutive
 // targets but an 8-row x 32-column PATCH of the target image: every 2x2, 4x4 and 8x8 pooling block of
 // levels 1..3 then lies inside one wave's accumulators, so the three avg-pool levels are produced in
-// the epilogue (vertical pairs = different accumulators, horizontal pairs = lane^1, lane^2, lane^4
-// shuffles) and every pyramid cell is written exactly once and never re-read
+// the epilogue (vertical pairs = different accumulators, horizontal pairs = DPP lane shifts) and every pyramid cell is written exactly once and never re-read
 // (algorithmic bytes: 2*N*D*4 feature reads + N*cells*4 writes).
 // Stores are 128-byte runs (32 lanes x consecutive x) for level 0.
 //
-// LOOKUP.  HBM-bound gather.  A workgroup owns 64 consecutive source pixels of one pyramid level:
+// LOOKUP.  HBM-bound gather.  A workgroup owns 32 consecutive source pixels of one pyramid level:
 // it gathers their 10x10 bilinear footprints into LDS (lanes walk the 40-byte footprint rows), then
-// emits the 81 taps per pixel with lanes running over PIXELS, so every output store is a 256-byte
+// emits the 81 taps per pixel with lanes running over PIXELS, so every output store is a 128-byte
 // run inside one of the 324 channel planes (NCHW output, no transposing copy as in the reference).
 #include "sf_common.h"
 #include "split_operand.h"
