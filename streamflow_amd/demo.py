@@ -47,3 +47,27 @@ def predict_frames(model: Callable, frames: Sequence[torch.Tensor], T: int = 4, 
         out = model(imgs)
         flows += [padder.unpad(out[k][0]).cpu() for k in range(T - 1) if keep[k]]
     return flows
+
+
+def predict_clips_warm_start(model: Callable, clips: Sequence[Sequence[torch.Tensor]], iters: int = 15
+                             ) -> List[List[torch.Tensor]]:
+    """Warm-started evaluation of consecutive clips of ONE scene, the loop of the reference's
+    `create_sintel_submission_mf_warmup` (evaluate_mf.py:286-304): every clip starts from the previous clip's
+    low-resolution flows pushed forward along themselves (`forward_interpolate`, utils.py:34-62).
+
+    clips: sequence of clips, each a list of T image tensors [1,3,H,W] in 0..255 (already padded to /8), as
+    `SKFlow_MF8.forward` takes them.  Returns the list of per-clip flow lists.  Unlike the reference nothing leaves
+    the GPU between clips: the reference round-trips every low-resolution flow through numpy / scipy on the host."""
+    from .utils import forward_interpolate
+    flow_prev = None
+    out: List[List[torch.Tensor]] = []
+    for images in clips:
+        if flow_prev is None:
+            # first clip of a scene: a zero initial flow is what `flow_init=None` means (coords1 = coords0 + 0,
+            # streamflow.py:112-115) and makes the model return the low-resolution flows as well
+            b, _, H, W = images[0].shape
+            flow_prev = [torch.zeros(b, 2, H // 8, W // 8, device=images[0].device) for _ in range(len(images) - 1)]
+        flows, lowres = model(list(images), iters=iters, flow_init=flow_prev, test_mode=True)
+        flow_prev = [forward_interpolate(l[0])[None] for l in lowres]
+        out.append(flows)
+    return out

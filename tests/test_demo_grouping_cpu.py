@@ -48,3 +48,26 @@ def test_predict_frames_pads_groups_and_unpads():
     assert len(flows) == 8 and all(f.shape == (2, H, W) for f in flows)
     assert [int(f[0, 0, 0]) for f in flows] == list(range(8))
     assert seen == [[0, 1, 2, 3], [3, 4, 5, 6], [5, 6, 7, 8]]
+
+
+def test_warm_start_loop_plumbing(monkeypatch):
+    """predict_clips_warm_start hands every clip the forward-interpolated low-resolution flows of the previous one
+    (evaluate_mf.py:296-304); the first clip starts from zeros.  Model and interpolation are fakes here (CPU)."""
+    import torch
+    from streamflow_amd import demo, utils
+    seen = []
+
+    def fake_interp(f):
+        return f + 1.0
+    monkeypatch.setattr(utils, "forward_interpolate", fake_interp)
+
+    def model(images, iters, flow_init, test_mode):
+        assert test_mode and iters == 3 and len(flow_init) == len(images) - 1
+        seen.append([f.clone() for f in flow_init])
+        low = [f + 10.0 for f in flow_init]
+        return [torch.zeros(1, 2, 16, 24) for _ in low], low
+    clips = [[torch.zeros(1, 3, 16, 24) for _ in range(3)] for _ in range(3)]
+    out = demo.predict_clips_warm_start(model, clips, iters=3)
+    assert len(out) == 3 and len(out[0]) == 2
+    assert all(float(f.abs().max()) == 0.0 for f in seen[0]) and seen[0][0].shape == (1, 2, 2, 3)
+    assert all(torch.all(f == 11.0) for f in seen[1]) and all(torch.all(f == 22.0) for f in seen[2])

@@ -384,3 +384,35 @@ def test_forward_interpolate_full_size_vs_oracle(dev):
     assert all(tuple(v) in pairs_in for v in out[0].reshape(2, -1).t().tolist())
     z = sfa.forward_interpolate(torch.zeros(1, 2, 16, 24, device=dev))
     assert torch.count_nonzero(z).item() == 0
+
+
+@pytest.mark.gpu
+def test_warm_start_clip_loop_vs_oracle(dev):
+    """evaluate_mf.py:286-304: two consecutive clips of a scene, the second started from the forward-interpolated
+    low-resolution flows of the first.  The whole loop (model forward + GPU forward_interpolate) against the oracle's."""
+    from oracle import streamflow_oracle as orc
+    from streamflow_amd import demo, synthetic as syn
+    from streamflow_amd.model import SKFlow_MF8, default_args
+    B, T, h, w, iters = 1, 4, 16, 24, 4
+    P = syn.make_params(11, T)
+    feats = [syn.make_features(100 + c, B, T, h, w) for c in range(2)]
+    model = SKFlow_MF8(default_args(T=T, Encoder="InjectEncoder")).to(dev)
+    model.load_state_dict(dict(P), strict=True)
+    clips = [[torch.zeros(B, 3, 8 * h, 8 * w, device=dev) for _ in range(T)] for _ in range(2)]
+    calls = {"n": 0}
+    inner = model._features
+
+    def features(imgs):                               # the stand-in encoders inject the clip's seeded features
+        f, c = feats[calls["n"]]
+        calls["n"] += 1
+        model.fnet.features, model.cnet.features = f.to(dev), c.to(dev)
+        return inner(imgs)
+    model._features = features
+    got = demo.predict_clips_warm_start(model, clips, iters=iters)
+    # oracle loop
+    init = None
+    for c in range(2):
+        ups, low = orc.hotpath_forward(feats[c][0], feats[c][1], P, iters, flow_init=init)
+        for i in range(T - 1):
+            assert orc.epe(got[c][i].cpu(), ups[i]) <= 1e-3, (c, i)
+        init = [orc.forward_interpolate(l[0])[None] for l in low]
