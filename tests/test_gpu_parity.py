@@ -416,3 +416,28 @@ def test_warm_start_clip_loop_vs_oracle(dev):
         for i in range(T - 1):
             assert orc.epe(got[c][i].cpu(), ups[i]) <= 1e-3, (c, i)
         init = [orc.forward_interpolate(l[0])[None] for l in low]
+
+
+@pytest.mark.gpu
+def test_bench_contract_line(dev):
+    """bench.py prints ONE JSON line with the driver's contract fields plus `roofline` and `cpu_baseline`
+    (a reduced run: demo256 workload, 2 clips, 2 steps)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                        "--workload", "demo256", "--clips", "2"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["metric"] == "flow_fields_per_sec" and d["n_gpus"] == 1 and d["steps"] == 2 and d["value"] > 0
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+    assert set(d["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"} and d["cpu_baseline"]["kind"] == "port"
+    assert d["epe_vs_oracle"]["value"] <= 1e-3
