@@ -2,8 +2,8 @@
 """Headline benchmark: flow-fields/sec of the StreamFlow hot path at Sintel shape (436x1024 padded to
 440x1024 -> 55x128 feature grid), T=4 frames (3 flow fields per clip), iters=15, one clip per GPU per step.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+    python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1: the ranks are spawned by this process)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N > 1, external launcher)
 
 A "step" = one full pass of the hot path over one clip per rank: corr volumes + pyramids for the 3 pairs,
 context split, GMA attention matrix, 15 refinement iterations (lookup, motion encoder, aggregate, temporal
@@ -13,8 +13,12 @@ independent, so N GPUs run N replicas with no data-path collective (torch.distri
 barrier and the max-over-ranks timing the contract asks for).
 """
 import argparse
+import glob
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -85,29 +89,70 @@ def timed_steps(step_fn, steps: int, warmup: int, world: int, sync_fn, barrier_f
     return allreduce_max_fn(dt)
 
 
-def cpu_baseline(fmaps, cnets, params, iters_total: int, sample_iters: int, pairs: int):
-    """The CPU oracle (PyTorch-CPU restatement of the reference path, kind='port') on the host cores,
-    bounded: setup + `sample_iters` iterations are timed, the clip time is extrapolated linearly in the
-    iteration count (every iteration does identical work)."""
+def cpu_baseline(fmaps, cnets, params, iters: int, pairs: int, runs: int = 3):
+    """The CPU oracle (PyTorch-CPU restatement of the reference path, kind='port') on the host cores: the WHOLE clip
+    (setup + all `iters` iterations, mask head, upsampling) is timed `runs` times after one short warm-up pass; the
+    median is reported.  Returns (record, upsampled flows of the last run)."""
     from oracle import streamflow_oracle as orc
     cores = min(usable_cores(), 64)
     torch.set_num_threads(cores)
     log(f"cpu baseline: oracle on {cores} host threads (os.cpu_count()={os.cpu_count()})")
     orc.hotpath_forward(fmaps, cnets, params, 1)        # untimed: thread pool start-up and first-touch page faults
     log("cpu baseline: warm-up pass done")
-    t0 = time.perf_counter()
-    ups1, _ = orc.hotpath_forward(fmaps, cnets, params, 1)
-    t1 = time.perf_counter()
-    log(f"cpu baseline: setup+1 iteration took {t1 - t0:.1f}s")
-    ups2, _ = orc.hotpath_forward(fmaps, cnets, params, sample_iters)
-    t2 = time.perf_counter()
-    per_iter = max(((t2 - t1) - (t1 - t0)) / (sample_iters - 1), 1e-9)
-    setup = max((t1 - t0) - per_iter, 0.0)
-    clip = setup + iters_total * per_iter
+    times, ups = [], None
+    for r in range(runs):
+        t0 = time.perf_counter()
+        ups, _ = orc.hotpath_forward(fmaps, cnets, params, iters)
+        times.append(time.perf_counter() - t0)
+        log(f"cpu baseline: run {r + 1}/{runs}: {times[-1]:.1f}s for one clip, {iters} iterations")
+    clip = statistics.median(times)
     return {"value": pairs / clip, "unit": "flow-fields/s", "cores": cores, "kind": "port",
-            "sample": f"oracle timed for setup+1 and setup+{sample_iters} iterations of one clip "
-                      f"({t1 - t0:.1f}s + {t2 - t1:.1f}s), extrapolated to {iters_total} iterations: {clip:.1f} s/clip",
-            "s_per_clip": clip}, ups2
+            "sample": f"oracle on one whole clip of the step ({pairs} flow fields, all {iters} iterations), 1 warm-up pass + "
+                      f"{runs} timed runs ({', '.join('%.1f' % t for t in times)} s), median {clip:.1f} s/clip",
+            "s_per_clip": clip}, ups
+
+
+def newest_traffic_file():
+    """profiles/rNN*_traffic.json of the latest round (names sort by round); None if there is none."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]*traffic.json")))
+    return files[-1] if files else None
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n: int, argv, script: str = None) -> int:
+    """`python bench.py --gpus N` typed directly: start one child process per GPU (RANK/LOCAL_RANK/WORLD_SIZE/
+    MASTER_* in its environment, exactly what torch.distributed.run would set) BEFORE this process has touched the
+    GPU, wait for them, return the worst exit code.  Rank 0 inherits stdout and prints the one JSON line."""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + list(argv), env=env))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                code = p.poll()
+                if code is None:
+                    continue
+                pending.remove(p)
+                if code != 0:                      # one rank failed: the others would hang in the next barrier
+                    rc = rc or code
+                    for q in pending:
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
 
 
 def main():
@@ -134,6 +179,7 @@ def main():
                     help="enqueue the independent chains of an iteration on one stream (profiling aid: kernel-trace "
                          "durations are then free of cross-branch contention and match the HIP-event table)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-runs", type=int, default=3, help="timed whole-clip runs of the CPU oracle (median reported)")
     ap.add_argument("--no-kernel-breakdown", action="store_true")
     args = ap.parse_args()
 
@@ -142,9 +188,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # typed as `python bench.py --gpus N`: this process becomes the launcher.  Nothing above has initialised the
+        # GPU (importing torch does not), and nothing below runs here: the ranks are children, never an exec.
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
     if args.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 "
-                         "--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE=1")
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
     if args.share_device:
         local_rank %= torch.cuda.device_count()
@@ -234,33 +283,46 @@ def main():
             kern["gemm"] = {"launches_per_step": sum(kern[k]["launches_per_step"] for k in fam), "ms_per_step": round(ms, 4),
                             "avg_us": None, "tflops": round(fl / (ms * 1e-3) / 1e12, 2), "gbps_algorithmic": None}
         dom = max((k for k in kern if not k.startswith("gemm M")), key=lambda k: kern[k]["ms_per_step"])
-        if kern[dom]["tflops"] and dom.startswith("gemm"):
-            # algorithmic (fp32-equivalent) TFLOP/s; the f16x3 path issues 3 f16 MFMA flops per algorithmic flop,
-            # so its matrix-core roof for algorithmic flops is 2500/3
-            peak = {"fp32": PEAK_FP32_MFMA_TFLOPS, "f16x3": PEAK_F16_MFMA_TFLOPS / 3.0,
-                    "f16x2": PEAK_F16_MFMA_TFLOPS / 2.0}[args.precision]
-            result["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": kern[dom]["tflops"],
-                                  "peak": round(peak, 1), "unit": "TFLOP/s",
-                                  "frac": round(kern[dom]["tflops"] / peak, 4), "traffic": None,
-                                  "method": "sum of algorithmic FLOPs / sum of HIP-event durations over all launches "
-                                            "of the kernel family in one instrumented step"}
+        # HBM traffic of every family from the committed rocprofv3 PMC passes (bench.py cannot run the profiler on
+        # itself): newest profiles/rNN*traffic.json
+        traffic, tfile = {}, newest_traffic_file()
+        if tfile:
+            try:
+                with open(tfile) as f:
+                    traffic = json.load(f)
+            except (OSError, ValueError):
+                traffic = {}
+        d = kern[dom]
+        n_launch = max(d["launches_per_step"], 1)
+        ms = d["ms_per_step"]
+        fam = traffic.get(dom)
+        pmc_bytes = int((fam["fetch_kib_per_launch"] + fam["write_kib_per_launch"]) * 1024) if fam else None
+        alg_bytes = summ[dom]["bytes"] / reps if dom in summ else 0.0
+        alg_flops = summ[dom]["flops"] / reps if dom in summ else sum(summ[k]["flops"] for k in summ if k.startswith("gemm M")) / reps
+        if not alg_bytes and args.gemm_shapes:
+            alg_bytes = sum(summ[k]["bytes"] for k in summ if k.startswith("gemm M")) / reps
+        # which roof binds: time floor of the matrix cores (algorithmic flops x MFMA products per flop / dense peak)
+        # against the time floor of HBM (bytes the family really moves -- PMC when available, else algorithmic)
+        peak_tf = {"fp32": PEAK_FP32_MFMA_TFLOPS, "f16x3": PEAK_F16_MFMA_TFLOPS / 3.0,
+                   "f16x2": PEAK_F16_MFMA_TFLOPS / 2.0}[args.precision]
+        t_mfma = alg_flops / (peak_tf * 1e12) if alg_flops else 0.0
+        t_hbm = (pmc_bytes * n_launch if pmc_bytes else alg_bytes) / (PEAK_HBM_GBPS * 1e9)
+        if alg_flops and t_mfma >= t_hbm:
+            result["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": d["tflops"], "peak": round(peak_tf, 1),
+                                  "unit": "TFLOP/s", "frac": round(d["tflops"] / peak_tf, 4)}
         else:
-            result["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": kern[dom]["gbps_algorithmic"],
-                                  "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                                  "frac": round((kern[dom]["gbps_algorithmic"] or 0) / PEAK_HBM_GBPS, 4),
-                                  "traffic": None}
-        # HBM traffic of the dominant family from the committed rocprofv3 PMC pass (bench.py cannot run the profiler)
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
-                tr = json.load(f)
-            fam = tr.get(result["roofline"]["kernel"])
-            if fam:
-                result["roofline"]["traffic"] = int((fam["fetch_kib_per_launch"] + fam["write_kib_per_launch"]) * 1024)
-                result["roofline"]["traffic_note"] = ("bytes per launch, mean over the family: 2 x FETCH_SIZE + WRITE_SIZE "
-                                                      "from separate rocprofv3 --pmc passes of this workload "
-                                                      "(profiles/r01_g_pmc_hbm_traffic.md, profiles/r01_traffic.json)")
-        except (OSError, KeyError, ValueError):
-            pass
+            gbps = alg_bytes / (ms * 1e-3) / 1e9 if ms else 0.0
+            result["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": round(gbps, 1), "peak": PEAK_HBM_GBPS,
+                                  "unit": "GB/s", "frac": round(gbps / PEAK_HBM_GBPS, 4)}
+        result["roofline"].update({
+            "traffic": pmc_bytes, "launches_per_step": n_launch, "avg_launch_us": round(1e3 * ms / n_launch, 2),
+            "algorithmic_bytes_per_launch": int(alg_bytes / n_launch), "algorithmic_tflops": d["tflops"],
+            "floor_ms_per_step": {"mfma": round(1e3 * t_mfma, 2), "hbm": round(1e3 * t_hbm, 2)},
+            "method": "family totals of one instrumented step (HIP events around every launch on the launch stream): "
+                      "achieved = algorithmic bytes (operands read once + result written once) or flops / summed "
+                      "duration; bound = the larger of the two time floors, the HBM floor priced with the PMC bytes",
+            "traffic_note": (f"bytes per launch, mean over the family: 2 x FETCH_SIZE + WRITE_SIZE from separate rocprofv3 "
+                             f"--pmc passes of this workload ({os.path.relpath(tfile, ROOT)})") if pmc_bytes else None})
         # north-star sub-metric: corr build + lookup against the HBM roofline (algorithmic bytes)
         cb, cl = kern.get("corr_build"), kern.get("corr_lookup")
         if cb and cl:
@@ -274,16 +336,17 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import streamflow_oracle as orc
-        sample_iters = 2 if args.workload != "demo256" else 3
-        # bounded sample: the first clip of the step only
-        base, ups_cpu = cpu_baseline(fmaps_c[:1], cnets_c[:1], params, iters, sample_iters, pairs)
+        # bounded sample: ONE clip of the step -- the LAST one of the batch, so that the comparison below also
+        # exercises the highest image indices / buffer offsets of the batched launches
+        last = B - 1
+        base, ups_cpu = cpu_baseline(fmaps_c[last:last + 1], cnets_c[last:last + 1], params, iters, pairs, args.cpu_runs)
         result["cpu_baseline"] = base
-        chk = HotPathEngine(params, device=dev, T=T, use_graph=False, precision=args.precision)
-        chk._plans = eng._plans
-        ups_gpu, _ = chk.forward(fmaps[:1].contiguous(), cnets[:1].contiguous(), iters=sample_iters)
-        result["epe_vs_oracle"] = {"value": max(orc.epe(a.cpu(), b) for a, b in zip(ups_gpu, ups_cpu)),
-                                   "unit": "px", "iters": sample_iters,
-                                   "note": "max over the 3 pairs of mean EPE, HIP path vs CPU oracle, full shape"}
+        # the SAME engine, plan and (graph) launch sequence the timed region used, all `iters` iterations
+        ups_gpu, _ = eng.forward(fmaps, cnets, iters=iters, all_masks=args.all_masks)
+        result["epe_vs_oracle"] = {"value": max(orc.epe(a[last:last + 1].cpu(), b) for a, b in zip(ups_gpu, ups_cpu)),
+                                   "unit": "px", "iters": iters, "clip": last, "clips_in_launch": B,
+                                   "note": "max over the pairs of the mean EPE, HIP path (the timed batched launch "
+                                           "sequence, last clip of the batch) vs CPU oracle, full shape, all iterations"}
 
     if rank == 0 and world == 1 and args.clips != 1 and not args.no_kernel_breakdown:
         # single-clip latency: the same engine and kernels with one clip per launch (tails and launch gaps show)
@@ -303,8 +366,9 @@ def main():
             result["single_clip"] = {"error": str(e)[:200]}
 
     if rank == 0:
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
     if world > 1:
+        barrier()                           # rank 0 may still be in its instrumented pass: leave together
         dist.destroy_process_group()
 
 

@@ -43,8 +43,10 @@ def coords_grid(batch: int, ht: int, wd: int) -> Tensor:
 # ----------------------------------------------------------------------------------------------
 # a4: bilinear_sampler                              core/utils/utils.py:65-79
 # ----------------------------------------------------------------------------------------------
-def bilinear_sampler(img: Tensor, coords: Tensor) -> Tensor:
-    """img [M,C,Hi,Wi]; coords [M,Ho,Wo,2] pixel coordinates (x,y) -> [M,C,Ho,Wo].
+def bilinear_sampler(img: Tensor, coords: Tensor, mask: bool = False):
+    """img [M,C,Hi,Wi]; coords [M,Ho,Wo,2] pixel coordinates (x,y) -> [M,C,Ho,Wo]
+    (and, with mask=True, the [M,Ho,Wo,1] float indicator of utils.py:75-77: normalised coordinates strictly
+    inside (-1, 1)).
 
     The reference normalises pixel coords to [-1,1] (utils.py:69-70) and hands them to
     ``F.grid_sample(align_corners=True)`` (bilinear, zero padding), which maps them back with
@@ -76,8 +78,12 @@ def bilinear_sampler(img: Tensor, coords: Tensor) -> Tensor:
     w01 = (fx * (1 - fy)).unsqueeze(1)
     w10 = ((1 - fx) * fy).unsqueeze(1)
     w11 = (fx * fy).unsqueeze(1)
-    return (tap(y0, x0) * w00 + tap(y0, x0 + 1) * w01
-            + tap(y0 + 1, x0) * w10 + tap(y0 + 1, x0 + 1) * w11)
+    out = (tap(y0, x0) * w00 + tap(y0, x0 + 1) * w01
+           + tap(y0 + 1, x0) * w10 + tap(y0 + 1, x0 + 1) * w11)
+    if mask:
+        inside = (gx > -1) & (gy > -1) & (gx < 1) & (gy < 1)
+        return out, inside.unsqueeze(-1).float()
+    return out
 
 
 # ----------------------------------------------------------------------------------------------

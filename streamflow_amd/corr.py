@@ -17,6 +17,7 @@ class CorrBlock:
     ``blk(coords)`` returns ``[B, 4*81, h, w]`` float32 contiguous (corr.py:23-44).
     """
 
+    @ops.on_tensor_device
     def __init__(self, fmap1: torch.Tensor, fmap2: torch.Tensor, num_levels: int = 4, radius: int = 4):
         if num_levels != 4 or radius != 4:
             raise RuntimeError("CorrBlock: the HIP path is built for num_levels=4, radius=4 "
@@ -34,6 +35,7 @@ class CorrBlock:
         self._keep = (f1, f2)
         self.corr_pyramid = lv
 
+    @ops.on_tensor_device
     def __call__(self, coords: torch.Tensor) -> torch.Tensor:
         B, h, w = self.shape
         c = coords.contiguous().float()
@@ -44,6 +46,7 @@ class CorrBlock:
         return out
 
     @staticmethod
+    @ops.on_tensor_device
     def corr(fmap1: torch.Tensor, fmap2: torch.Tensor) -> torch.Tensor:
         """[B,h,w,1,h,w] = f1^T f2 / sqrt(D) (corr.py:46-54)."""
         f1 = fmap1.contiguous().float()

@@ -12,6 +12,7 @@ Image index convention everywhere: img = clip * (T-1) + pair   (the reference's 
 """
 from __future__ import annotations
 
+import contextlib
 import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -199,14 +200,21 @@ class HotPathEngine:
         self.W = HotPathWeights(state_dict, self.device, T)
         self.use_graph = use_graph
         self._plans: Dict[Tuple[int, int, int, int], _Plan] = {}
+        self.max_plans = int(os.environ.get("SF_MAX_PLANS", "4"))
 
     # ---------------------------------------------------------------------------------------------
     def plan(self, Bc: int, h: int, w: int, D: int) -> _Plan:
+        """Buffers (and captured graph) for one input shape; at most `max_plans` shapes are kept, least recently used
+        evicted first (a dataset with varying image sizes would otherwise pin several GB per distinct shape)."""
         key = (Bc, h, w, D)
-        if key not in self._plans:
-            self._plans[key] = _Plan(self.W, Bc, h, w, D, self.device, self.attn_chunk_rows,
-                                     attn_f16=self.precision != ops.PRECISION_FP32)
-        return self._plans[key]
+        pl = self._plans.pop(key, None)
+        if pl is None:
+            while len(self._plans) >= max(1, self.max_plans):
+                self._plans.pop(next(iter(self._plans)))            # dicts keep insertion order: first = oldest
+            pl = _Plan(self.W, Bc, h, w, D, self.device, self.attn_chunk_rows,
+                       attn_f16=self.precision != ops.PRECISION_FP32)
+        self._plans[key] = pl                                        # (re)insert as most recent
+        return pl
 
     # ---------------------------------------------------------------------------------------------
     def _attention_rows(self, pl: _Plan, i0: int, rows: int) -> None:
@@ -313,16 +321,23 @@ class HotPathEngine:
         # streamflow.py:138 + :133 for the next iteration
         ops.flow_update(pl.coords1, pl.delta, pl.flow, pl.mf.slice(HDIM - 2, HDIM), n, h, w)
 
-    def _run(self, pl: _Plan, fmaps: torch.Tensor, cnets: torch.Tensor, iters: int, all_masks: bool) -> None:
+    @contextlib.contextmanager
+    def _kernel_context(self, pl: _Plan):
+        """Package-wide kernel settings for the duration of one forward: arithmetic mode and the split-K scratch."""
         prev = ops.set_precision(self.precision)
+        prev_ws = ops.SPLIT_WS
         ops.SPLIT_WS = pl.splitws.tensor().view(-1) if self.auto_split_k else None
         try:
+            yield
+        finally:
+            ops.set_precision(prev)
+            ops.SPLIT_WS = prev_ws
+
+    def _run(self, pl: _Plan, fmaps: torch.Tensor, cnets: torch.Tensor, iters: int, all_masks: bool) -> None:
+        with self._kernel_context(pl):
             self._setup(pl, fmaps, cnets)
             for it in range(iters):
                 self._iteration(pl, with_mask=all_masks or it == iters - 1)
-        finally:
-            ops.set_precision(prev)
-            ops.SPLIT_WS = None
         flow_t = pl.flow.tensor().view(pl.n, 2, pl.h, pl.w)
         mask_t = pl.mask.tensor().view(pl.n, 576, pl.h, pl.w)
         _lib.check(_lib.load().sf_upsample_flow(flow_t.data_ptr(), mask_t.data_ptr(), pl.up.data_ptr(), pl.n, pl.h,
@@ -336,56 +351,57 @@ class HotPathEngine:
         """fmaps [B,T,D,h,w], cnets [B,T-1,256,h,w] fp32 on the GPU.
         Returns (flows_up, flows_lowres): T-1 tensors [B,2,8h,8w] and [B,2,h,w] (views into engine buffers,
         valid until the next forward of the same shape)."""
+        with torch.cuda.device(self.device):      # streams, launches and graph capture all belong to self.device
+            pl = self._begin(fmaps, cnets, flow_init)
+            Bc, T, h, w = pl.Bc, pl.Pn + 1, pl.h, pl.w
+            if self.use_graph:
+                self._forward_graph(pl, fmaps, cnets, iters, all_masks)
+            else:
+                self._run(pl, fmaps, cnets, iters, all_masks)
+            up = pl.up.view(Bc, T - 1, 2, 8 * h, 8 * w)
+            low = pl.flow.tensor().view(Bc, T - 1, 2, h, w)
+            return [up[:, i] for i in range(T - 1)], [low[:, i] for i in range(T - 1)]
+
+    def _begin(self, fmaps: torch.Tensor, cnets: torch.Tensor, flow_init) -> _Plan:
+        """Shared entry checks of both forward flavours + loop-state initialisation (streamflow.py:111-115)."""
         ops._dev_check(fmaps)
         ops._dev_check(cnets)
+        if fmaps.device != self.device or cnets.device != self.device:
+            raise RuntimeError(f"inputs live on {fmaps.device} / {cnets.device}, engine was built for {self.device}")
         Bc, T, D, h, w = fmaps.shape
         if T - 1 != self.W.pairs or tuple(cnets.shape) != (Bc, T - 1, 2 * HDIM, h, w):
             raise RuntimeError(f"shape mismatch: fmaps {tuple(fmaps.shape)}, cnets {tuple(cnets.shape)}, "
                                f"weights built for T={self.W.pairs + 1}")
         pl = self.plan(Bc, h, w, D)
-        n, P = pl.n, pl.P
+        n = pl.n
         coords1 = pl.coords1.tensor().view(n, 2, h, w)
         _lib.check(_lib.load().sf_coords_grid(coords1.data_ptr(), n, h, w, _lib.stream()), "sf_coords_grid")
         if flow_init is not None:                          # streamflow.py:114-115
+            if len(flow_init) != T - 1:
+                raise RuntimeError(f"flow_init needs {T - 1} tensors, got {len(flow_init)}")
             for i, f in enumerate(flow_init):
                 coords1.view(Bc, T - 1, 2, h, w)[:, i] += f.to(coords1)
         ops.flow_update(pl.coords1, None, pl.flow, pl.mf.slice(HDIM - 2, HDIM), n, h, w)
-        if self.use_graph:
-            self._forward_graph(pl, fmaps, cnets, iters, all_masks)
-        else:
-            self._run(pl, fmaps, cnets, iters, all_masks)
-        up = pl.up.view(Bc, T - 1, 2, 8 * h, 8 * w)
-        low = pl.flow.tensor().view(Bc, T - 1, 2, h, w)
-        return [up[:, i] for i in range(T - 1)], [low[:, i] for i in range(T - 1)]
+        return pl
 
     @torch.no_grad()
     def forward_all_iterations(self, fmaps: torch.Tensor, cnets: torch.Tensor, iters: int = 12,
                                flow_init: Optional[Sequence[torch.Tensor]] = None) -> List[List[torch.Tensor]]:
         """Training-mode return of the reference (streamflow.py:139-149): for every pair, the list of upsampled
         predictions after each iteration (mask head + convex upsampling run every iteration; no graph)."""
-        ops._dev_check(fmaps)
-        ops._dev_check(cnets)
-        Bc, T, D, h, w = fmaps.shape
-        pl = self.plan(Bc, h, w, D)
-        n = pl.n
-        coords1 = pl.coords1.tensor().view(n, 2, h, w)
-        _lib.check(_lib.load().sf_coords_grid(coords1.data_ptr(), n, h, w, _lib.stream()), "sf_coords_grid")
-        if flow_init is not None:
-            for i, f in enumerate(flow_init):
-                coords1.view(Bc, T - 1, 2, h, w)[:, i] += f.to(coords1)
-        ops.flow_update(pl.coords1, None, pl.flow, pl.mf.slice(HDIM - 2, HDIM), n, h, w)
-        prev = ops.set_precision(self.precision)
-        self._setup(pl, fmaps, cnets)
-        preds: List[List[torch.Tensor]] = [[] for _ in range(T - 1)]
-        for _ in range(iters):
-            self._iteration(pl, with_mask=True)
-            ops.set_precision(self.precision)
-            up = ops.upsample_flow(pl.flow.tensor().view(n, 2, h, w), pl.mask.tensor().view(n, 576, h, w))
-            up = up.view(Bc, T - 1, 2, 8 * h, 8 * w)
-            for i in range(T - 1):
-                preds[i].append(up[:, i])
-        ops.set_precision(prev)
-        return preds
+        with torch.cuda.device(self.device):
+            pl = self._begin(fmaps, cnets, flow_init)
+            Bc, T, h, w, n = pl.Bc, pl.Pn + 1, pl.h, pl.w, pl.n
+            preds: List[List[torch.Tensor]] = [[] for _ in range(T - 1)]
+            with self._kernel_context(pl):
+                self._setup(pl, fmaps, cnets)
+                for _ in range(iters):
+                    self._iteration(pl, with_mask=True)
+                    up = ops.upsample_flow(pl.flow.tensor().view(n, 2, h, w), pl.mask.tensor().view(n, 576, h, w))
+                    up = up.view(Bc, T - 1, 2, 8 * h, 8 * w)
+                    for i in range(T - 1):
+                        preds[i].append(up[:, i])
+            return preds
 
     def _forward_graph(self, pl: _Plan, fmaps, cnets, iters, all_masks) -> None:
         key = (iters, all_masks)

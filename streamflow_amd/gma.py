@@ -30,6 +30,7 @@ class Attention(nn.Module, _Packed):
         self.scale = dim_head ** -0.5
         self.to_qk = nn.Conv2d(dim, heads * dim_head * 2, 1, bias=False)
 
+    @ops.on_tensor_device
     def forward(self, fmap: torch.Tensor) -> torch.Tensor:
         x = fmap.contiguous().float()
         ops._dev_check(x)
@@ -66,6 +67,7 @@ class Aggregate(nn.Module, _Packed):
             raise RuntimeError("Aggregate: heads*dim_head must equal dim (no `project` conv on the HIP path)")
         self.project = None
 
+    @ops.on_tensor_device
     def forward(self, attn: torch.Tensor, fmap: torch.Tensor) -> torch.Tensor:
         x = fmap.contiguous().float()
         a = attn.contiguous().float()

@@ -83,6 +83,35 @@ def _launch(name: str, flops: float, nbytes: float, fn) -> None:
         PROFILER.launch(name, flops, nbytes, fn)
 
 
+def on_tensor_device(fn):
+    """Run `fn` with the device of its first tensor / Planes / torch.device argument current.  The C ABI enqueues on
+    the stream it is given and `_lib.stream()` is the CURRENT device's stream, so a launch on tensors of another GPU
+    would otherwise mix a device-0 stream with device-1 pointers."""
+    import functools
+
+    def _device(a):
+        if isinstance(a, torch.Tensor):
+            return a.device if a.is_cuda else None
+        if isinstance(a, Planes):
+            return a.base.device
+        if isinstance(a, torch.device):
+            return a if a.type == "cuda" else None
+        if isinstance(a, (list, tuple)) and a:
+            return _device(a[0])
+        return None
+
+    @functools.wraps(fn)
+    def wrapped(*args, **kw):
+        for a in list(args) + list(kw.values()):
+            d = _device(a)
+            if d is not None:
+                with torch.cuda.device(d):
+                    return fn(*args, **kw)
+        return fn(*args, **kw)
+
+    return wrapped
+
+
 def _dev_check(t: torch.Tensor) -> None:
     if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
         raise RuntimeError("streamflow_amd ops need contiguous float32 tensors on the GPU "
@@ -177,6 +206,7 @@ class PackedLinear:
         self.lda_h = mp
 
 
+@on_tensor_device
 def gemm(A: PackedLinear, X: Planes, Y: Planes, epilogue: int = EPI_NONE, R: Optional[Planes] = None,
          dw_w: Optional[torch.Tensor] = None, dw_b: Optional[torch.Tensor] = None, alpha: float = 1.0,
          hw: Optional[Sequence[int]] = None) -> None:
@@ -208,7 +238,9 @@ def gemm(A: PackedLinear, X: Planes, Y: Planes, epilogue: int = EPI_NONE, R: Opt
     if SPLIT_WS is not None and prec != PRECISION_FP32:
         g.split_ws, g.split_ws_floats = SPLIT_WS.data_ptr(), SPLIT_WS.numel()
     name = "gemm" if not PROFILE_SHAPES else f"gemm M{g.M} K{g.K} b{g.batch} e{g.epilogue}"
-    _launch(name, 2.0 * g.M * g.N * g.K * g.batch, 0,
+    # algorithmic bytes: activations in (each input row once) + result out (+ residual in) per image, weights once
+    nbytes = 4.0 * g.batch * g.N * (X.rows + g.M * (2 if R is not None else 1)) + 4.0 * g.M * g.K
+    _launch(name, 2.0 * g.M * g.N * g.K * g.batch, nbytes,
             lambda: _lib.check(_lib.load().sf_gemm(C.byref(g), _lib.stream()), "sf_gemm"))
 
 
@@ -220,10 +252,14 @@ def gemm_raw(**kw) -> None:
         setattr(g, k, v)
     g.precision = PRECISION
     name = "gemm_attn" if g.a_layout == LAYOUT_K_MINOR else "gemm"
-    _launch(name, 2.0 * g.M * g.N * g.K * g.batch, 0,
+    eb = 2.0 if g.b_layout == LAYOUT_F16_K_MINOR else 4.0
+    nbytes = g.batch * (4.0 * g.M * g.K + eb * g.K * g.N + 4.0 * g.M * g.N * (2 if g.R else 1) *
+                        (g.k_splits if g.k_splits > 1 else 1))
+    _launch(name, 2.0 * g.M * g.N * g.K * g.batch, nbytes,
             lambda: _lib.check(_lib.load().sf_gemm(C.byref(g), _lib.stream()), "sf_gemm"))
 
 
+@on_tensor_device
 def splitk_combine(partial: torch.Tensor, split_stride: int, k_splits: int, part_img_stride: int, R: Planes,
                    gamma: torch.Tensor, out: Planes) -> None:
     assert R.rows == out.rows and R.n_img == out.n_img
@@ -233,6 +269,7 @@ def splitk_combine(partial: torch.Tensor, split_stride: int, k_splits: int, part
                 out.ptr, out.img_stride, R.n_img, R.rows * R.P, _lib.stream()), "sf_splitk_combine"))
 
 
+@on_tensor_device
 def dwconv_res_gelu(X: Planes, wgt: torch.Tensor, bias: torch.Tensor, Y: Planes, h: int, w: int, k: int) -> None:
     assert X.rows == Y.rows == wgt.shape[0] and X.P == h * w
     _launch("dwconv%d" % k, 2.0 * k * k * X.n_img * X.rows * h * w, 8.0 * X.n_img * X.rows * h * w,
@@ -242,6 +279,7 @@ def dwconv_res_gelu(X: Planes, wgt: torch.Tensor, bias: torch.Tensor, Y: Planes,
                                "sf_dwconv_res_gelu"))
 
 
+@on_tensor_device
 def layernorm_cm(X: Planes, gamma: torch.Tensor, beta: torch.Tensor, Y: Planes, eps: float = 1e-5) -> None:
     _launch("layernorm", 0, 8.0 * X.n_img * X.rows * X.P,
             lambda: _lib.check(_lib.load().sf_layernorm_cm(X.ptr, X.img_stride, gamma.data_ptr(), beta.data_ptr(),
@@ -249,6 +287,7 @@ def layernorm_cm(X: Planes, gamma: torch.Tensor, beta: torch.Tensor, Y: Planes, 
                                                            _lib.stream()), "sf_layernorm_cm"))
 
 
+@on_tensor_device
 def temporal_attn(QKV: Planes, OUT: Planes, B: int, TT: int, C_: int) -> None:
     assert QKV.img_stride == 3 * C_ * QKV.P and OUT.img_stride == C_ * OUT.P and QKV.n_img == B * TT
     _launch("temporal_attn", 0, 16.0 * QKV.n_img * C_ * QKV.P,
@@ -256,6 +295,7 @@ def temporal_attn(QKV: Planes, OUT: Planes, B: int, TT: int, C_: int) -> None:
                                "sf_temporal_attn"))
 
 
+@on_tensor_device
 def softmax_rows(x: torch.Tensor, rows: int, cols: int, out16: Optional[torch.Tensor] = None) -> None:
     """In place, or (out16: fp16 [rows][cols]) written as half precision with x left as scratch."""
     assert out16 is None or (out16.dtype == torch.float16 and out16.numel() >= rows * cols)
@@ -265,6 +305,7 @@ def softmax_rows(x: torch.Tensor, rows: int, cols: int, out16: Optional[torch.Te
                                                            _lib.stream()), "sf_softmax_rows"))
 
 
+@on_tensor_device
 def coords_grid(batch: int, ht: int, wd: int, device) -> torch.Tensor:
     out = torch.empty(batch, 2, ht, wd, dtype=torch.float32, device=device)
     _lib.ptr(out)
@@ -272,6 +313,7 @@ def coords_grid(batch: int, ht: int, wd: int, device) -> torch.Tensor:
     return out
 
 
+@on_tensor_device
 def context_split(cnets: torch.Tensor, nets: Planes, inps: Planes, hdim: int) -> None:
     """cnets [n_img, 2*hdim, P]-like contiguous tensor."""
     _dev_check(cnets)
@@ -279,6 +321,7 @@ def context_split(cnets: torch.Tensor, nets: Planes, inps: Planes, hdim: int) ->
                                             nets.n_img, hdim, nets.P, _lib.stream()), "sf_context_split")
 
 
+@on_tensor_device
 def flow_update(coords1: Planes, delta: Optional[Planes], flow_a: Optional[Planes], flow_b: Optional[Planes],
                 n_img: int, h: int, w: int) -> None:
     assert coords1.img_stride == 2 * h * w and (delta is None or delta.img_stride == 2 * h * w)
@@ -289,6 +332,7 @@ def flow_update(coords1: Planes, delta: Optional[Planes], flow_a: Optional[Plane
         n_img, h, w, _lib.stream()), "sf_flow_update"))
 
 
+@on_tensor_device
 def upsample_flow(flow: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
     """flow [n,2,h,w], mask [n,576,h,w] -> [n,2,8h,8w] (reference streamflow.py:82-93)."""
     _dev_check(flow)
@@ -300,6 +344,7 @@ def upsample_flow(flow: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
     return out
 
 
+@on_tensor_device
 def forward_interpolate(flow: torch.Tensor) -> torch.Tensor:
     """flow [n,2,h,w] -> [n,2,h,w] (reference utils.py:34-62, on the device)."""
     _dev_check(flow)
@@ -320,6 +365,7 @@ def corr_build_ws_bytes(B: int, pairs: int, D: int, h: int, w: int) -> int:
     return int(_lib.load().sf_corr_build_ws_bytes(B, pairs, D, h, w))
 
 
+@on_tensor_device
 def corr_build(f1_ptr: int, f2_ptr: int, clip_stride: int, pair_stride: int, lvls: Sequence[torch.Tensor],
                lvl_pair_stride: Optional[Sequence[int]], B: int, pairs: int, D: int, h: int, w: int,
                ws: Optional[torch.Tensor] = None) -> None:
@@ -340,6 +386,7 @@ def corr_build(f1_ptr: int, f2_ptr: int, clip_stride: int, pair_stride: int, lvl
         "sf_corr_build_pyramid"))
 
 
+@on_tensor_device
 def corr_lookup(lvls: Sequence[torch.Tensor], lvl_pair_stride: Optional[Sequence[int]], coords: Planes,
                 out: Planes, B: int, pairs: int, h: int, w: int) -> None:
     assert out.rows == 324 and out.n_img == B * pairs and coords.img_stride == 2 * h * w
@@ -352,6 +399,7 @@ def corr_lookup(lvls: Sequence[torch.Tensor], lvl_pair_stride: Optional[Sequence
         _lib.stream()), "sf_corr_lookup"))
 
 
+@on_tensor_device
 def bilinear_sampler(img: torch.Tensor, coords: torch.Tensor, want_mask: bool = False):
     _dev_check(img)
     _dev_check(coords)

@@ -50,6 +50,7 @@ class PCBlock4_Deep_nopool_res(nn.Module, _Packed):
         xb = _planes_like(X.n_img, W.c_in, X.P, dev)
         run_skblock(W, X, Y, hid, xa, xb, h, w, final_gelu)
 
+    @ops.on_tensor_device
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         x = x.contiguous().float()
         ops._dev_check(x)
@@ -92,6 +93,7 @@ class SKMotionEncoder6_Deep_nopool_res(nn.Module, _Packed):
         self.conv.run(cat256, out.slice(0, self.out_dim - 2), h, w)
         out.slice(self.out_dim - 2, self.out_dim).tensor().copy_(flow.tensor())
 
+    @ops.on_tensor_device
     def forward(self, flow: torch.Tensor, corr: torch.Tensor, attention=None) -> torch.Tensor:
         flow = flow.contiguous().float()
         corr = corr.contiguous().float()
@@ -167,6 +169,7 @@ class TransformerBlock(nn.Module, _Packed):
         ops.gemm(W["fc1"], ln, hid, EPI_GELU)
         ops.gemm(W["fc2"], hid, Y, EPI_RES, R=tx)
 
+    @ops.on_tensor_device
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """x [S, T, C] tokens (reference layout) -> [S, T, C]."""
         S, TT, C = x.shape
@@ -184,6 +187,7 @@ class TemporalLayer2(nn.Module):
         super().__init__()
         self.transformer_block = zero_module(TransformerBlock(dim))
 
+    @ops.on_tensor_device
     def forward(self, x: torch.Tensor, HW):
         H, W = HW[0], HW[1]
         S, TT, C = x.shape
@@ -213,6 +217,7 @@ class SKUpdateBlock_TAM_v3(nn.Module, _Packed):
         self.transformer_block = TemporalLayer2(dim=embed_dim)
         self.flow_head = PCBlock4_Deep_nopool_res(embed_dim * (args.T - 1), 2 * (args.T - 1), args.k_conv)
 
+    @ops.on_tensor_device
     def forward(self, nets, inps, corrs, flows, attentions, T: Optional[int] = None):
         nets = nets.contiguous().float()
         ops._dev_check(nets)

@@ -149,7 +149,9 @@ def main():
 
         # ---- a4 bilinear_sampler (incl. out-of-range and exactly-integer coordinates) ----
         img, crd = cases.bilinear_inputs()
-        save("bilinear_sampler", out=ref_utils.bilinear_sampler(img, crd))
+        out_m, in_mask = ref_utils.bilinear_sampler(img, crd, mask=True)          # utils.py:75-77: strict in-bounds mask
+        assert torch.equal(out_m, ref_utils.bilinear_sampler(img, crd))
+        save("bilinear_sampler", out=out_m, mask=in_mask)
 
         # ---- a1-a3 corr build, pyramid, lookup (odd grid 17x19 -> levels 17x19, 8x9, 4x4, 2x2) ----
         for tag, (B, D, h, w, seed) in cases.CORR_CASES.items():

@@ -60,3 +60,45 @@ def test_usable_cores_positive():
     sys.path.insert(0, REPO)
     import bench
     assert 1 <= bench.usable_cores() <= (os.cpu_count() or 1)
+
+
+def test_spawn_ranks_sets_rendezvous_env_and_reports_failures(tmp_path):
+    """`python bench.py --gpus N` typed directly spawns its own ranks (bench.spawn_ranks): every child gets
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / one common MASTER_PORT; a failing rank's exit code is
+    returned and the remaining ranks are stopped instead of waiting in a barrier forever."""
+    sys.path.insert(0, REPO)
+    import bench
+    script = tmp_path / "child.py"
+    script.write_text(
+        "import os, sys, time\n"
+        "r = os.environ['RANK']\n"
+        "open(os.path.join(sys.argv[1], 'rank' + r), 'w').write(' '.join(os.environ[k] for k in "
+        "('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')))\n"
+        "if len(sys.argv) > 2 and r == '1':\n"
+        "    sys.exit(7)\n"
+        "if len(sys.argv) > 2:\n"
+        "    time.sleep(60)\n")
+    assert bench.spawn_ranks(3, [str(tmp_path)], script=str(script)) == 0
+    recs = [(tmp_path / f"rank{r}").read_text().split() for r in range(3)]
+    assert [r[0] for r in recs] == ["0", "1", "2"] and [r[1] for r in recs] == ["0", "1", "2"]
+    assert all(r[2] == "3" and r[3] == "127.0.0.1" for r in recs) and len({r[4] for r in recs}) == 1
+    t0 = time.time()
+    assert bench.spawn_ranks(2, [str(tmp_path), "fail"], script=str(script)) == 7
+    assert time.time() - t0 < 30                     # rank 0 (sleeping 60 s) was terminated
+
+
+def test_bench_gpus_gt1_does_not_touch_gpu_in_launcher(monkeypatch):
+    """The launcher branch must run before any GPU initialisation: with N > 1 and no WORLD_SIZE, main() hands over to
+    spawn_ranks and exits with its code without ever calling torch.cuda.is_available()."""
+    sys.path.insert(0, REPO)
+    import bench
+    seen = {}
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "2"])
+    monkeypatch.setattr(bench, "spawn_ranks", lambda n, argv, script=None: seen.update(n=n, argv=list(argv)) or 0)
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: (_ for _ in ()).throw(AssertionError("GPU touched")))
+    try:
+        bench.main()
+    except SystemExit as e:
+        assert e.code == 0
+    assert seen == {"n": 4, "argv": ["--gpus", "4", "--steps", "2"]}

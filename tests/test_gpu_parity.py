@@ -74,6 +74,7 @@ def test_bilinear_sampler(golden, dev):
     out, mask = ops.bilinear_sampler(img.to(dev), crd.to(dev).contiguous(), want_mask=True)
     close(out, golden("bilinear_sampler")["out"], 5e-6, what="bilinear_sampler")
     assert mask.shape == (5, 4, 9, 1)
+    assert np.array_equal(mask.cpu().numpy(), golden("bilinear_sampler")["mask"])      # utils.py:75-77, strict bounds
 
 
 @pytest.mark.parametrize("tag", list(cases.CORR_CASES))
@@ -238,6 +239,60 @@ def test_sintel_shape_vs_oracle(dev, precision):
         e = orc.epe(ups[i], ups_o[i])
         print(f"sintel-shape {precision} pair {i}: EPE vs oracle = {e:.3e}")
         assert e <= 1e-3
+
+
+def test_headline_config_batched_vs_oracle(dev):
+    """BASELINE.json's headline configuration exactly as bench.py times it: 440x1024 (55x128 grid), T=4, ALL 15
+    iterations, 8 clips batched through every launch (the per-GPU share of config 4's batch 64), HIP-graph replay,
+    default precision.  The first and the LAST clip of the batch (image indices 0-2 and 21-23: the highest buffer
+    offsets of the 6 GB volume / attention allocations) are compared with the CPU oracle run on those clips alone."""
+    from oracle import streamflow_oracle as orc
+    from streamflow_amd import synthetic as syn
+    from streamflow_amd.engine import HotPathEngine
+    B, T, h, w, iters = 8, 4, 55, 128, 15
+    P = syn.make_params(0, T)
+    fmaps, cnets = syn.make_features(1000, B, T, h, w)
+    eng = HotPathEngine(P, device=dev, T=T, use_graph=True)
+    fd, cd = fmaps.to(dev), cnets.to(dev)
+    eng.forward(fd, cd, iters=iters)                       # capture
+    ups, low = eng.forward(fd, cd, iters=iters)            # replay
+    ups = [u.cpu() for u in ups]
+    assert all(torch.isfinite(u).all() for u in ups)
+    for clip in (0, B - 1):
+        ups_o, _ = orc.hotpath_forward(fmaps[clip:clip + 1], cnets[clip:clip + 1], P, iters)
+        for i in range(T - 1):
+            e = orc.epe(ups[i][clip:clip + 1], ups_o[i])
+            mag = ups_o[i].norm(dim=1).mean().item()
+            print(f"headline config, clip {clip} of {B}, pair {i}: EPE vs oracle after {iters} iterations = {e:.3e} px "
+                  f"(mean |flow| {mag:.2f} px)")
+            assert e <= 1e-3, (clip, i, e)
+    # clips are independent: the same clip at another batch position must give the same flows
+    fd2 = fd.clone()
+    fd2[3], cd2 = fd[B - 1], cd.clone()
+    cd2[3] = cd[B - 1]
+    ups2, _ = eng.forward(fd2, cd2, iters=iters)
+    for i in range(T - 1):
+        assert orc.epe(ups2[i][3:4].cpu(), ups[i][B - 1:B]) <= 1e-4
+
+
+def test_engine_on_non_current_device():
+    """An engine built for cuda:1 while cuda:0 is the current device must launch on cuda:1's streams."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    from oracle import streamflow_oracle as orc
+    from streamflow_amd import synthetic as syn
+    from streamflow_amd.engine import HotPathEngine
+    torch.cuda.set_device(0)
+    d1 = torch.device("cuda:1")
+    B, T, h, w = 1, 4, 16, 24
+    P = syn.make_params(3, T)
+    fmaps, cnets = syn.make_features(3, B, T, h, w)
+    for graph in (False, True):
+        eng = HotPathEngine(P, device=d1, T=T, use_graph=graph)
+        ups, _ = eng.forward(fmaps.to(d1), cnets.to(d1), iters=3)
+        ups_o, _ = orc.hotpath_forward(fmaps, cnets, P, 3)
+        assert torch.cuda.current_device() == 0
+        assert max(orc.epe(u.cpu(), o) for u, o in zip(ups, ups_o)) <= 1e-3
 
 
 def test_kitti_shape_T2_vs_oracle(dev):
@@ -441,3 +496,28 @@ def test_bench_contract_line(dev):
     assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
     assert set(d["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"} and d["cpu_baseline"]["kind"] == "port"
     assert d["epe_vs_oracle"]["value"] <= 1e-3
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_self_launched(dev):
+    """`python bench.py --gpus 2` as typed (no external launcher): the process spawns its two ranks before touching
+    the GPU, each rank runs main()'s N > 1 branch (process group, per-rank device, barrier, max-over-ranks all-reduce);
+    both ranks share the one GPU of this box and rendezvous over gloo.  One JSON line, whole-job aggregate."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--share-device", "--dist-backend",
+                        "gloo", "--workload", "demo256", "--clips", "2", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak"
+    assert d["config"]["clips_per_step_all_gpus"] == 4 and d["config"]["parallelism"] == "replicas2"
+    # value = flow fields of ALL ranks / max-over-ranks time
+    assert abs(d["value"] - 2 * 2 * 3 * 2 / (d["ms_per_step"] * 2 / 1e3)) / d["value"] < 1e-6
+    assert "cpu_baseline" not in d                       # rank 0 at N = 1 only

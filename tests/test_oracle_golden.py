@@ -25,6 +25,10 @@ def test_coords_grid_bit_exact(golden):
 def test_bilinear_sampler(golden):
     img, crd = cases.bilinear_inputs()
     close(orc.bilinear_sampler(img, crd), golden("bilinear_sampler")["out"], 2e-6)
+    out, mask = orc.bilinear_sampler(img, crd, mask=True)
+    g = golden("bilinear_sampler")["mask"]
+    assert 0 < g.sum() < g.size                                  # the fixture has both inside and outside points
+    assert np.array_equal(mask.numpy(), g)
 
 
 @pytest.mark.parametrize("tag", list(cases.CORR_CASES))
