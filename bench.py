@@ -170,6 +170,10 @@ def main():
                          "the default skips the 14 mask heads whose results test_mode discards)")
     ap.add_argument("--precision", default="f16x3", choices=["f16x3", "fp32", "f16x2"],
                     help="f16x3: split-fp16 MFMA with fp32 accumulation (fp32-class accuracy); fp32: exact fp32 MFMA")
+    ap.add_argument("--corr-dtype", default="f16", choices=["f16", "f32"],
+                    help="storage of the correlation pyramids: f16 = fp16 cells built with single f16 MFMA products "
+                         "(BASELINE.json config 2: 'bf16 corr build+lookup'); f32 = fp32 cells as the reference keeps "
+                         "them, built in --precision arithmetic")
     ap.add_argument("--gemm-shapes", action="store_true", help="per-shape GEMM rows in the kernel table")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for the barrier / max-over-ranks (nccl = RCCL; gloo for dry runs)")
@@ -203,7 +207,17 @@ def main():
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
-            dist.init_process_group("gloo")
+            # gloo announces its connections on stdout; rank 0's stdout must carry exactly one JSON line
+            sys.stdout.flush()
+            keep = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                dist.init_process_group("gloo")
+                dist.barrier()
+            finally:
+                sys.stdout.flush()
+                os.dup2(keep, 1)
+                os.close(keep)
 
     from streamflow_amd import ops, synthetic as syn
     from streamflow_amd.engine import HotPathEngine
@@ -214,7 +228,8 @@ def main():
     params = syn.make_params(0, T)
     fmaps_c, cnets_c = syn.make_features(1000 + rank, B, T, h, w)
     fmaps, cnets = fmaps_c.to(dev), cnets_c.to(dev)
-    eng = HotPathEngine(params, device=dev, T=T, use_graph=not args.no_graph, precision=args.precision)
+    eng = HotPathEngine(params, device=dev, T=T, use_graph=not args.no_graph, precision=args.precision,
+                        corr_dtype=args.corr_dtype)
     if args.serial_branches:
         eng.parallel_branches = False
 
@@ -244,11 +259,14 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": {"fp32": "fp32", "f16x3": "f16x3-split (fp32 accumulate)",
-                  "f16x2": "f16x2 (weights hi+lo, activations fp16; fp32 accumulate)"}[args.precision], "data": "synthetic",
+                  "f16x2": "f16x2 (weights hi+lo, activations fp16; fp32 accumulate)"}[args.precision] +
+                 ("; fp16 correlation volumes" if args.corr_dtype == "f16" else ""), "data": "synthetic",
         "config": {"workload": f"{args.workload}_{H}x{W}_T{T}_iters{iters}", "clips_per_gpu_per_step": B,
                    "clips_per_step_all_gpus": world * B,
                    "flow_fields_per_clip": pairs, "feature_grid": [h, w], "parallelism": f"replicas{world}",
                    "hip_graph": not args.no_graph, "mask_head_every_iteration": bool(args.all_masks),
+                   "corr_volume": {"f16": "fp16 cells, single f16 MFMA product, fp32 accumulate",
+                                   "f32": "fp32 cells"}[args.corr_dtype],
                    "precision": {"fp32": "exact fp32 (v_mfma_f32_32x32x2_f32)",
                                  "f16x3": "split fp16x3 (x=hi+lo, 3x v_mfma_f32_32x32x16_f16, fp32 accumulate)",
                                  "f16x2": "weights hi+lo fp16, activations fp16 (2x v_mfma_f32_32x32x16_f16)"}[args.precision]},
@@ -256,7 +274,8 @@ def main():
 
     if rank == 0 and not args.no_kernel_breakdown:
         # instrumented eager pass: HIP events around every launch on the launch stream
-        eager = HotPathEngine(params, device=dev, T=T, use_graph=False, precision=args.precision)
+        eager = HotPathEngine(params, device=dev, T=T, use_graph=False, precision=args.precision,
+                              corr_dtype=args.corr_dtype)
         eager._plans = eng._plans                       # reuse buffers
         eager.parallel_branches = False                 # serial launches: clean per-kernel durations
         ops.PROFILE_SHAPES = args.gemm_shapes
@@ -295,7 +314,9 @@ def main():
         d = kern[dom]
         n_launch = max(d["launches_per_step"], 1)
         ms = d["ms_per_step"]
-        fam = traffic.get(dom)
+        same = (traffic.get("_workload", "sintel") == args.workload and int(traffic.get("_clips", 8)) == B and
+                traffic.get("_corr_dtype", "f32") == args.corr_dtype and traffic.get("_precision", "f16x3") == args.precision)
+        fam = traffic.get(dom) if same else None           # PMC bytes only describe the configuration they were taken on
         pmc_bytes = int((fam["fetch_kib_per_launch"] + fam["write_kib_per_launch"]) * 1024) if fam else None
         alg_bytes = summ[dom]["bytes"] / reps if dom in summ else 0.0
         alg_flops = summ[dom]["flops"] / reps if dom in summ else sum(summ[k]["flops"] for k in summ if k.startswith("gemm M")) / reps

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SF_VERSION 100
+#define SF_VERSION 101
 
 enum {
     SF_OK = 0,
@@ -59,7 +59,9 @@ int sf_bilinear_sampler(const float* img, const float* coords, float* out, float
  * registers, so every pyramid cell is written once and level 0 is never re-read.
  * lvl_pair_stride: HOST array of 4 strides in floats (ignored when pairs == 1; may be NULL then).
  * num_levels must be 4 (streamflow.py:38).  precision: SF_PRECISION_FP32 (exact fp32 MFMA, k-ordered fmaf
- * chain) or SF_PRECISION_F16X3 (split fp16, fp32 accumulate; see sf_gemm). */
+ * chain), SF_PRECISION_F16X3 (split fp16, fp32 accumulate; see sf_gemm) -- both write fp32 volumes -- or
+ * SF_PRECISION_F16: lvl0..lvl3 then point to IEEE fp16 cells (same indexing, lvl_pair_stride in cells; half the
+ * bytes), products are single f16 MFMAs with fp32 accumulation. */
 int sf_corr_build_pyramid(const float* f1, const float* f2, int64_t f_clip_stride, int64_t f_pair_stride,
                           float* lvl0, float* lvl1, float* lvl2, float* lvl3,
                           const int64_t* lvl_pair_stride, int B, int pairs, int D, int h, int w,
@@ -75,11 +77,12 @@ int64_t sf_corr_build_ws_bytes(int B, int pairs, int D, int h, int w);
  * (x/2^l + a - r, y/2^l + b' - r), bilinear, zeros outside (first window axis moves x, corr.py:31-37).
  * out image img starts at out + img*out_img_stride (floats), channel stride h*w, so the caller can
  * write straight into a wider concatenation buffer.  Volumes are addressed as in
- * sf_corr_build_pyramid.  radius must be 4, num_levels 4. */
+ * sf_corr_build_pyramid.  radius must be 4, num_levels 4.  vol_precision: the precision the volumes were built
+ * with -- SF_PRECISION_F16 means lvl0..lvl3 hold fp16 cells (taps are blended in fp32), anything else fp32 cells. */
 int sf_corr_lookup(const float* lvl0, const float* lvl1, const float* lvl2, const float* lvl3,
                    const int64_t* lvl_pair_stride, const float* coords, float* out,
                    int64_t out_img_stride, int B, int pairs, int h, int w, int num_levels, int radius,
-                   void* stream);
+                   int vol_precision, void* stream);
 
 /* ---- generic fused GEMM: every 1x1 conv / nn.Linear / einsum on the path ------------------------
  * C[z][m][n] = epilogue( alpha * ( sum_k A[z][m][k] * B[z][k][n] + bias[m] ) )
@@ -99,8 +102,12 @@ enum { SF_LAYOUT_K_MAJOR = 0,   /* A[k*lda + m]   /  B[k*ldb + n]   (rows of k) 
 enum { SF_PRECISION_FP32 = 0,   /* exact fp32: v_mfma_f32_32x32x2_f32, k-ordered fmaf chain          */
        SF_PRECISION_F16X3 = 1,  /* split precision: x = hi+lo (fp16 each); a*b = ah*bh + ah*bl + al*bh
                                     on v_mfma_f32_32x32x16_f16 with fp32 accumulation (~2^-22 relative)  */
-       SF_PRECISION_F16X2 = 2 };/* A (weights) split hi+lo, B (activations) rounded once to fp16:
+       SF_PRECISION_F16X2 = 2,  /* A (weights) split hi+lo, B (activations) rounded once to fp16:
                                     a*b = ah*b + al*b, 2 MFMAs; error = the fp16 rounding of B (2^-11 rel.) */
+       SF_PRECISION_F16 = 3 };  /* correlation volumes only (sf_corr_build_pyramid / sf_corr_lookup): features rounded
+                                    once to fp16, one f16 MFMA per product with fp32 accumulation, every pyramid cell
+                                    STORED as IEEE fp16 -- the "bf16/fp16 volume" configurations of BASELINE.json
+                                    (the reference's own deployment runs under fp16 autocast, demo.py:427-456) */
 enum { SF_EPI_NONE = 0,         /* C = v                              v = alpha*(acc+bias)   */
        SF_EPI_GELU = 1,         /* C = gelu(v)                        exact erf GELU         */
        SF_EPI_RELU = 2,         /* C = max(v,0)                                              */
@@ -150,6 +157,26 @@ int sf_gemm(const SfGemm* g, void* stream);
 int sf_splitk_combine(const float* partial, int64_t split_stride, int k_splits, int64_t part_img_stride,
                       const float* R, int64_t r_img_stride, const float* gamma, float* out,
                       int64_t out_img_stride, int n_img, int64_t floats_per_img, void* stream);
+
+/* ---- a6' + a7 fused: GMA aggregation without the N x N matrix (demo.py:235-258; == gma.py:53-65 + 91-104) ----------
+ * out[img][d][p] = mf[img][d][p] + gamma[0] * sum_j softmax_j(scale * <q_p, k_j>) * v[img][d][j]     (heads = 1, dim 128)
+ * The reference's demo recomputes softmax(q k^T) v in every refinement iteration (flash_attn_func or a naive einsum)
+ * instead of keeping the attention matrix; this is that path: online softmax, logits never leave the CU.
+ *   sf_gma_flash_pack_qk: once per clip.  qk [n_img][256][P] fp32 (rows 0..127 = q, 128..255 = k: the to_qk output,
+ *       gma.py:57) -> fp16 (hi, lo) operand images in `ws` (q pre-scaled by scale * log2 e).
+ *   sf_gma_flash_aggregate: every iteration.  v [n_img][128][P] (to_v output), mf and out [n_img][128][P] planes with
+ *       image strides in floats; packs v into `ws`, then one fused kernel.  qk_products = MFMA products per logit:
+ *       3 = split precision (q_hi k_hi + q_lo k_hi + q_hi k_lo, fp32-class logits), 2 = k rounded to fp16,
+ *       1 = q and k rounded to fp16 (the arithmetic of the reference's fp16 flash-attn path).  Softmax weights and v
+ *       enter the second contraction as fp16 (like the materialised matrix of sf_softmax_rows), accumulation is fp32.
+ * ws: caller-owned scratch of sf_gma_flash_ws_bytes(n_img, P) bytes, 16-byte aligned; must persist from pack_qk to the
+ * last aggregate of the clip. */
+int64_t sf_gma_flash_ws_bytes(int n_img, int P);
+int sf_gma_flash_pack_qk(const float* qk, int64_t qk_img_stride, void* ws, int64_t ws_bytes, int n_img, int P,
+                         float scale, void* stream);
+int sf_gma_flash_aggregate(void* ws, int64_t ws_bytes, const float* v, int64_t v_img_stride, const float* mf,
+                           int64_t mf_img_stride, const float* gamma, float* out, int64_t out_img_stride,
+                           int n_img, int P, int qk_products, void* stream);
 
 /* ---- row softmax (gma.py:63): x [rows][cols] ----------------------------------------------------
  * out_f16 == NULL: in place.  Otherwise the weights are written as IEEE fp16 to out_f16 [rows][cols] (x is then

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SF_HIP_LIB") or os.path.join(_HERE, "libstreamflow_hip.so")
 
 LAYOUT_K_MAJOR, LAYOUT_K_MINOR, LAYOUT_SPLIT_F16, LAYOUT_F16_K_MINOR = 0, 1, 2, 3
-PRECISION_FP32, PRECISION_F16X3, PRECISION_F16X2 = 0, 1, 2
+PRECISION_FP32, PRECISION_F16X3, PRECISION_F16X2, PRECISION_F16 = 0, 1, 2, 3
 EPI_NONE, EPI_GELU, EPI_RELU, EPI_RES, EPI_RES_GELU, EPI_RES_GELU_DW1, EPI_AXPY = range(7)
 
 _vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
@@ -49,9 +49,12 @@ SIGNATURES = {
     "sf_corr_build_pyramid": (_i, [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, C.POINTER(_i64), _i, _i, _i, _i, _i, _i, _i,
                                    _vp, _i64, _vp]),
     "sf_corr_build_ws_bytes": (_i64, [_i, _i, _i, _i, _i]),
-    "sf_corr_lookup": (_i, [_vp, _vp, _vp, _vp, C.POINTER(_i64), _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _vp]),
+    "sf_corr_lookup": (_i, [_vp, _vp, _vp, _vp, C.POINTER(_i64), _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "sf_gemm": (_i, [C.POINTER(SfGemm), _vp]),
     "sf_gemm_split_ws_floats": (_i64, [_i, _i, _i, _i]),
+    "sf_gma_flash_ws_bytes": (_i64, [_i, _i]),
+    "sf_gma_flash_pack_qk": (_i, [_vp, _i64, _vp, _i64, _i, _i, _f, _vp]),
+    "sf_gma_flash_aggregate": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i, _i, _i, _vp]),
     "sf_softmax_rows": (_i, [_vp, _i64, _i, _vp, _vp]),
     "sf_splitk_combine": (_i, [_vp, _i64, _i, _i64, _vp, _i64, _vp, _vp, _i64, _i, _i64, _vp]),
     "sf_dwconv_res_gelu": (_i, [_vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _vp]),
@@ -86,7 +89,7 @@ def load() -> C.CDLL:
             raise RuntimeError(f"{LIB_PATH} does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
-    if lib.sf_version() < 100:
+    if lib.sf_version() < 101:
         raise RuntimeError("libstreamflow_hip.so is too old; rebuild")
     _lib = lib
     return lib

@@ -15,10 +15,13 @@ class CorrBlock:
     ``CorrBlock(fmap1, fmap2, num_levels=4, radius=4)`` builds ``corr_pyramid`` (list of
     ``[B*h*w, 1, h>>l, w>>l]`` tensors, reference corr.py:13-21) in a single fused kernel;
     ``blk(coords)`` returns ``[B, 4*81, h, w]`` float32 contiguous (corr.py:23-44).
+    ``dtype=torch.float16`` (an extension; the reference always keeps fp32 volumes) stores the pyramid as fp16
+    cells built with single f16 MFMA products -- the bf16/fp16 volume configurations of BASELINE.json.
     """
 
     @ops.on_tensor_device
-    def __init__(self, fmap1: torch.Tensor, fmap2: torch.Tensor, num_levels: int = 4, radius: int = 4):
+    def __init__(self, fmap1: torch.Tensor, fmap2: torch.Tensor, num_levels: int = 4, radius: int = 4,
+                 dtype: torch.dtype = torch.float32):
         if num_levels != 4 or radius != 4:
             raise RuntimeError("CorrBlock: the HIP path is built for num_levels=4, radius=4 "
                                "(the only values the StreamFlow model uses, streamflow.py:38-39)")
@@ -30,7 +33,9 @@ class CorrBlock:
         self.num_levels, self.radius = num_levels, radius
         self.shape = (B, h, w)
         N = h * w
-        lv = [torch.empty(B * N, 1, h >> l, w >> l, dtype=torch.float32, device=f1.device) for l in range(4)]
+        if dtype not in (torch.float32, torch.float16):
+            raise RuntimeError(f"CorrBlock: volume dtype must be float32 or float16, got {dtype}")
+        lv = [torch.empty(B * N, 1, h >> l, w >> l, dtype=dtype, device=f1.device) for l in range(4)]
         ops.corr_build(f1.data_ptr(), f2.data_ptr(), D * N, 0, lv, None, B, 1, D, h, w)
         self._keep = (f1, f2)
         self.corr_pyramid = lv

@@ -1,0 +1,278 @@
+// Fused GMA aggregation: out = mf + gamma * softmax(scale * q k^T) v  without an N x N tensor.
+//
+// Reference: demo.py:235-258 (the demo's Aggregate recomputes softmax(q k^T) v in every refinement iteration through
+// flash_attn_func, or a naive einsum) == core/gma.py:53-65 + 91-104 (attention matrix computed once, attn @ v per
+// iteration).  Same mathematics; this is the path for resolutions whose N x N matrix cannot be kept (1080p: 4.2 GB per
+// image), selectable for any shape.
+//
+// Operands are packed ONCE into the exact byte images the matrix cores want, so the main loop has no conversion,
+// no transposition and no VGPR staging -- tiles go HBM/L2 -> LDS by buffer_load ... lds:
+//   q, k  (constant over the refinement loop: functions of the context features) -> IEEE fp16 (hi [, lo]) k-octet
+//         planes [(d/8)][Ppad][8]; q is pre-multiplied by scale * log2(e) so that softmax is exp2(s - max);
+//   v     (changes every iteration)  -> fp16 key-octet planes [(key/8)][128 d][8] with the 16 keys of an MFMA k-step
+//         permuted into the order in which the logits' accumulator registers hold them (below).
+// One workgroup = 128 queries (4 waves x 32), streaming 64-key tiles:
+//   S^T[key][query] = K Q^T  (v_mfma_f32_32x32x16_f16, A = K fragment from LDS, B = Q fragment held in registers):
+//        the C/D layout puts ONE query in a lane (col = lane & 31) and 16 keys in its registers, so the running max /
+//        sum of the online softmax are in-lane reductions plus one exchange with lane ^ 32;
+//   P^T -> fp16 in registers is directly the B operand of  O^T[d][query] += V^T P^T : lane (query, khalf) holds keys
+//        (r & 3) + 8 (r >> 2) + 4 khalf of a 32-key block in registers r = 0..15, i.e. for the k-step m (registers
+//        8m..8m+7) the keys 16 m + (i & 3) + 8 (i >> 2) + 4 khalf -- the v pack stores exactly that order, so the V
+//        fragment is one lane-linear ds_read_b128;
+//   epilogue: O^T / rowsum, gamma, residual; lanes run over queries = consecutive pixels: 128-byte stores.
+// QKP = MFMA products per logit block: 1 (q_hi k_hi), 2 (+ q_lo k_hi), 3 (+ q_hi k_lo: the f16x3 split, fp32-class
+// logits).  P and V are single fp16 (the materialised path already stores the attention matrix in fp16).
+#include "sf_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) void* lds_ptr;
+
+constexpr int HD = 128;              // head dim (GMA: heads = 1, dim_head = 128)
+constexpr int BQ = 128, BJ = 64;     // queries per workgroup, keys per tile
+constexpr int KPLANE = (HD / 8) * BJ * 16;      // bytes of a K tile (hi or lo): 16 d-octets x 64 keys x 16 B = 16 KB
+constexpr int VTILE = (BJ / 8) * HD * 16;       // bytes of a V tile: 8 key-octets x 128 d x 16 B = 16 KB
+
+struct FlashArgs {
+    const char* ws;                 // per image: [Qh | Ql | Kh | Kl | Vp], each 256 * Ppad bytes
+    const float* mf; const float* gamma; float* out;
+    int64_t mf_img_stride, out_img_stride;
+    int P, Ppad;
+};
+
+__host__ __device__ inline int64_t plane_bytes(int Ppad) { return (int64_t)256 * Ppad; }
+
+// ---- pack q, k: qk planes [img][2*HD][P] fp32 (rows 0..127 = q, 128..255 = k) -------------------------------------------
+__global__ __launch_bounds__(256) void flash_pack_qk_kernel(const float* qk, int64_t qk_img_stride, char* ws, int P, int Ppad,
+                                                            float qscale) {
+    const int p = blockIdx.x * 256 + threadIdx.x, dq = blockIdx.y & 15, side = blockIdx.y >> 4, img = blockIdx.z;
+    if (p >= Ppad) return;
+    const float* src = qk + (int64_t)img * qk_img_stride + (int64_t)(side * HD + dq * 8) * P + p;
+    const float mul = side == 0 ? qscale : 1.0f;
+    f16x8 hi, lo;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float x = (p < P) ? src[(int64_t)i * P] * mul : 0.f;
+        const _Float16 h = (_Float16)x;                    // round to nearest: x = hi + lo to ~22 bits
+        hi[i] = h;
+        lo[i] = (_Float16)(x - (float)h);
+    }
+    char* img_ws = ws + (int64_t)img * 5 * plane_bytes(Ppad);
+    char* dst = img_ws + (int64_t)(side * 2) * plane_bytes(Ppad) + ((int64_t)dq * Ppad + p) * 16;
+    *reinterpret_cast<f16x8*>(dst) = hi;
+    *reinterpret_cast<f16x8*>(dst + plane_bytes(Ppad)) = lo;
+}
+
+// ---- pack v: planes [img][HD][P] fp32 -> fp16 [(key/8)][HD][8], keys of each 16-group in accumulator-register order ----
+__global__ __launch_bounds__(256) void flash_pack_v_kernel(const float* v, int64_t v_img_stride, char* ws, int P, int Ppad) {
+    const int o = blockIdx.x * 32 + (threadIdx.x & 31);            // key octet
+    const int d = blockIdx.y * 8 + (threadIdx.x >> 5), img = blockIdx.z;
+    if (o * 8 >= Ppad) return;
+    const int khalf = o & 1, base = (o >> 1) * 16 + 4 * khalf;     // keys base + {0,1,2,3, 8,9,10,11}
+    const float* row = v + (int64_t)img * v_img_stride + (int64_t)d * P;
+    f16x8 h;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int key = base + (i & 3) + 8 * (i >> 2);
+        h[i] = (_Float16)((key < P) ? row[key] : 0.f);
+    }
+    char* dst = ws + (int64_t)img * 5 * plane_bytes(Ppad) + 4 * plane_bytes(Ppad) + ((int64_t)o * HD + d) * 16;
+    *reinterpret_cast<f16x8*>(dst) = h;
+}
+
+__device__ __forceinline__ float xor32(float v) {          // value of lane ^ 32
+    return __shfl_xor(v, 32, 64);
+}
+
+template <int QKP>
+__global__ __launch_bounds__(256, (QKP == 3) ? 1 : 2) void gma_flash_kernel(const FlashArgs g) {
+    constexpr bool kKlo = (QKP == 3);
+    constexpr int KSTAGE = KPLANE * (kKlo ? 2 : 1);
+    __shared__ __attribute__((aligned(1024))) char smem[2 * KSTAGE + 2 * VTILE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int khalf = lane >> 5, l31 = lane & 31;
+    const int img = blockIdx.y, q0 = blockIdx.x * BQ;
+    const int P = g.P, Ppad = g.Ppad;
+    const int plane = (int)plane_bytes(Ppad);                       // < 2 GiB (host-checked)
+    const char* ws = g.ws + (int64_t)img * 5 * plane;
+    const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(ws), 0, 2 * plane, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(ws) + 2 * (int64_t)plane, 0, 2 * plane, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(ws) + 4 * (int64_t)plane, 0, plane, 0x00020000);
+
+    // ---- Q fragments of this lane's query (B operand: 8 consecutive d per k-half), held for the whole kernel ----
+    const int q = q0 + wave * 32 + l31;                              // < Ppad always (Ppad is a multiple of 128)
+    f16x8 qh[HD / 16], ql[(QKP >= 2) ? HD / 16 : 1];
+#pragma unroll
+    for (int ks = 0; ks < HD / 16; ++ks) {
+        const int off = ((ks * 2 + khalf) * Ppad + q) * 16;
+        qh[ks] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rq, off, 0, 0));
+        if (QKP >= 2) ql[ks] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rq, off, plane, 0));
+    }
+
+    // ---- tile DMA: K tile = 16 d-octet rows of 64 keys x 16 B (1 KB pieces), V tile = 16 KB contiguous ----
+    auto issue = [&](int t, int buf) {
+        const int j0 = t * BJ;
+        char* kb = smem + buf * KSTAGE;
+        char* vb = smem + 2 * KSTAGE + buf * VTILE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int dq = wave * 4 + i;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (lds_ptr)(kb + dq * 1024), 16, (j0 + lane) * 16, dq * Ppad * 16, 0, 0);
+            if (kKlo)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (lds_ptr)(kb + KPLANE + dq * 1024), 16, (j0 + lane) * 16,
+                                                         plane + dq * Ppad * 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int piece = wave * 4 + i;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lds_ptr)(vb + piece * 1024), 16, lane * 16, j0 * (HD * 2) + piece * 1024, 0, 0);
+        }
+    };
+
+    f32x16 o[HD / 32];
+#pragma unroll
+    for (int t = 0; t < HD / 32; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+    float m_run = -1.0e30f, l_run = 0.f;
+
+    const int nt = Ppad / BJ;
+    issue(0, 0);
+    for (int t = 0; t < nt; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's pieces of tile t have landed ...
+        __builtin_amdgcn_s_barrier();                             // ... everyone's; the other stage is no longer read
+        if (t + 1 < nt) issue(t + 1, (t + 1) & 1);
+        const char* kb = smem + (t & 1) * KSTAGE;
+        const char* vb = smem + 2 * KSTAGE + (t & 1) * VTILE;
+
+        // ---- logits (transposed): s[sub][r] = <k_key, q_query>, key = j0 + sub*32 + (r&3) + 8(r>>2) + 4 khalf ----
+        f32x16 s[2];
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[sub][r] = 0.f;
+        }
+#pragma unroll
+        for (int ks = 0; ks < HD / 16; ++ks) {
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+                const int off = ((ks * 2 + khalf) * BJ + sub * 32 + l31) * 16;
+                const f16x8 kh = *reinterpret_cast<const f16x8*>(kb + off);
+                if (QKP >= 2) s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[ks], s[sub], 0, 0, 0);
+                if (kKlo) {
+                    const f16x8 kl = *reinterpret_cast<const f16x8*>(kb + KPLANE + off);
+                    s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[ks], s[sub], 0, 0, 0);
+                }
+                s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[ks], s[sub], 0, 0, 0);
+            }
+        }
+        // ---- online softmax for this lane's query ----
+        if ((t + 1) * BJ > P) {                                   // last tile with padded keys (workgroup-uniform)
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = t * BJ + sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                    s[sub][r] = (key < P) ? s[sub][r] : -1.0e30f;
+                }
+        }
+        float mx = s[0][0];
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[sub][r]);
+        mx = fmaxf(mx, xor32(mx));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+        float psum = 0.f;
+        f16x8 pf[4];                                              // P^T as B operands: k-step kk = sub*2 + m
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __builtin_amdgcn_exp2f(s[sub][r] - m_new);
+                const _Float16 ph = (_Float16)p;
+                psum += (float)ph;                                // normalise by what is actually multiplied
+                pf[sub * 2 + (r >> 3)][r & 7] = ph;
+            }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int td = 0; td < HD / 32; ++td)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[td][r] *= alpha;
+        // ---- O^T += V^T P^T ----
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+            for (int td = 0; td < HD / 32; ++td) {
+                const f16x8 vf = *reinterpret_cast<const f16x8*>(vb + ((2 * kk + khalf) * HD + td * 32 + l31) * 16);
+                o[td] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[kk], o[td], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue: out[d][q] = mf[d][q] + gamma * O^T[d][q] / rowsum ----
+    const float l_tot = l_run + xor32(l_run);
+    const float w = g.gamma[0] / l_tot;
+    if (q < P) {
+        const float* mf = g.mf + (int64_t)img * g.mf_img_stride + q;
+        float* out = g.out + (int64_t)img * g.out_img_stride + q;
+#pragma unroll
+        for (int td = 0; td < HD / 32; ++td)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int d = td * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                out[(int64_t)d * P] = mf[(int64_t)d * P] + w * o[td][r];
+            }
+    }
+}
+
+}  // namespace
+
+extern "C" int64_t sf_gma_flash_ws_bytes(int n_img, int P) {
+    if (n_img <= 0 || P <= 0) return 0;
+    const int Ppad = sf::ceil_div(P, BQ) * BQ;
+    return (int64_t)n_img * 5 * plane_bytes(Ppad);
+}
+
+extern "C" int sf_gma_flash_pack_qk(const float* qk, int64_t qk_img_stride, void* ws, int64_t ws_bytes, int n_img, int P,
+                                    float scale, void* stream) {
+    SF_REQUIRE(qk && ws, "sf_gma_flash_pack_qk: null pointer");
+    SF_REQUIRE(n_img > 0 && P > 0 && n_img <= 65535, "sf_gma_flash_pack_qk: bad dims");
+    SF_REQUIRE(ws_bytes >= sf_gma_flash_ws_bytes(n_img, P) && (reinterpret_cast<uintptr_t>(ws) & 15) == 0,
+               "sf_gma_flash_pack_qk: workspace too small or misaligned");
+    const int Ppad = sf::ceil_div(P, BQ) * BQ;
+    SF_REQUIRE(2 * plane_bytes(Ppad) < ((int64_t)1 << 31), "sf_gma_flash_pack_qk: image too large");
+    hipLaunchKernelGGL(flash_pack_qk_kernel, dim3(sf::ceil_div(Ppad, 256), 32, n_img), dim3(256), 0, (hipStream_t)stream, qk,
+                       qk_img_stride, (char*)ws, P, Ppad, scale * 1.44269504088896340736f);
+    return sf::check_launch("sf_gma_flash_pack_qk");
+}
+
+extern "C" int sf_gma_flash_aggregate(void* ws, int64_t ws_bytes, const float* v, int64_t v_img_stride, const float* mf,
+                                      int64_t mf_img_stride, const float* gamma, float* out, int64_t out_img_stride,
+                                      int n_img, int P, int qk_products, void* stream) {
+    SF_REQUIRE(ws && v && mf && gamma && out, "sf_gma_flash_aggregate: null pointer");
+    SF_REQUIRE(n_img > 0 && P > 0 && n_img <= 65535, "sf_gma_flash_aggregate: bad dims");
+    SF_REQUIRE(qk_products >= 1 && qk_products <= 3, "sf_gma_flash_aggregate: qk_products must be 1, 2 or 3");
+    SF_REQUIRE(ws_bytes >= sf_gma_flash_ws_bytes(n_img, P) && (reinterpret_cast<uintptr_t>(ws) & 15) == 0,
+               "sf_gma_flash_aggregate: workspace too small or misaligned");
+    const int Ppad = sf::ceil_div(P, BQ) * BQ;
+    SF_REQUIRE(2 * plane_bytes(Ppad) < ((int64_t)1 << 31), "sf_gma_flash_aggregate: image too large");
+    hipLaunchKernelGGL(flash_pack_v_kernel, dim3(sf::ceil_div(Ppad / 8, 32), HD / 8, n_img), dim3(256), 0, (hipStream_t)stream,
+                       v, v_img_stride, (char*)ws, P, Ppad);
+    FlashArgs g;
+    g.ws = (const char*)ws; g.mf = mf; g.gamma = gamma; g.out = out;
+    g.mf_img_stride = mf_img_stride; g.out_img_stride = out_img_stride; g.P = P; g.Ppad = Ppad;
+    dim3 grid(Ppad / BQ, n_img);
+    switch (qk_products) {
+        case 1: hipLaunchKernelGGL(gma_flash_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, g); break;
+        case 2: hipLaunchKernelGGL(gma_flash_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, g); break;
+        default: hipLaunchKernelGGL(gma_flash_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, g); break;
+    }
+    return sf::check_launch("sf_gma_flash_aggregate");
+}

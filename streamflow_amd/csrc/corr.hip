@@ -41,7 +41,31 @@ struct BuildArgs {
     int pcols;
     float scale;
     int vec_a, vec_b;
+    // DMA kernels: 1-D grid, XCD-aware order [image][patch block][m-tile][patch in block]: the `pblk` target patches of
+    // a block stay in the XCD's L2 while all m-tiles stream past them (np = patches per image, mt = m-tiles)
+    int np, mt, pblk;
+    int vec_store;               // w % 4 == 0 and 16-byte aligned level bases: transposed 16-byte epilogue stores
 };
+
+struct TileId { int img, m_tile, patch; };
+__device__ __forceinline__ TileId build_tile(const BuildArgs& g, int id) {
+    const int per_img = g.np * g.mt;
+    TileId t;
+    t.img = id / per_img;
+    int r = id % per_img;
+    const int full = g.np / g.pblk;                        // full patch blocks
+    if (r < full * g.pblk * g.mt) {
+        const int blk = r / (g.pblk * g.mt), r2 = r % (g.pblk * g.mt);
+        t.m_tile = r2 / g.pblk;
+        t.patch = blk * g.pblk + r2 % g.pblk;
+    } else {
+        r -= full * g.pblk * g.mt;
+        const int rem = g.np - full * g.pblk;
+        t.m_tile = r / rem;
+        t.patch = full * g.pblk + r % rem;
+    }
+    return t;
+}
 
 // Store side of the epilogue.  One v_mul + one buffer_store per level-0 cell: the wave's 32 source rows are addressed
 // from a per-wave buffer resource (32-bit offsets; the row / patch-row part rides in the scalar offset), horizontal
@@ -60,28 +84,44 @@ __device__ __forceinline__ float dpp_shl4(float v) {     // lane + 4 inside a ro
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x104, 0xF, 0xF, true));
 }
 
-template <bool kGuard>
+// one volume cell through a buffer store: fp32 (dword) or IEEE fp16 (round to nearest, short store)
+template <typename OutT, int kAux>
+__device__ __forceinline__ void store_cell(float v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    if constexpr (sizeof(OutT) == 4) {
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, kAux);
+    } else {
+        const _Float16 hv = (_Float16)v;
+        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, hv), r, voff, soff, kAux);
+    }
+}
+
+template <bool kGuard, typename OutT>
 __device__ __forceinline__ void pyramid_store(const BuildArgs& g, f32x16 (&acc)[PR], int b, int pair, int m0, int wave,
                                               int py0, int px0, int lane) {
+    constexpr int ES = sizeof(OutT);
+    OutT* const lv0 = reinterpret_cast<OutT*>(g.lvl[0]);
+    OutT* const lv1 = reinterpret_cast<OutT*>(g.lvl[1]);
+    OutT* const lv2 = reinterpret_cast<OutT*>(g.lvl[2]);
+    OutT* const lv3 = reinterpret_cast<OutT*>(g.lvl[3]);
     const int khalf = lane >> 5, l31 = lane & 31;
     const int P0 = g.hl[0] * g.wl[0], P1 = g.hl[1] * g.wl[1], P2 = g.hl[2] * g.wl[2], P3 = g.hl[3] * g.wl[3];
     const int i0 = m0 + wave * 32;                          // first source pixel of the wave
     const int64_t row0 = (int64_t)b * g.N + i0;
     constexpr int kSpan = 0x7ffffff0, kDrop = (int)0x80000000u;
     const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(
-        g.lvl[0] + pair * g.lvl_pair_stride[0] + row0 * P0 + py0 * g.wl[0] + px0, 0, kSpan, 0x00020000);
+        lv0 + pair * g.lvl_pair_stride[0] + row0 * P0 + py0 * g.wl[0] + px0, 0, kSpan, 0x00020000);
     const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(
-        g.lvl[1] + pair * g.lvl_pair_stride[1] + row0 * P1 + (py0 >> 1) * g.wl[1] + (px0 >> 1), 0, kSpan, 0x00020000);
+        lv1 + pair * g.lvl_pair_stride[1] + row0 * P1 + (py0 >> 1) * g.wl[1] + (px0 >> 1), 0, kSpan, 0x00020000);
     const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(
-        g.lvl[2] + pair * g.lvl_pair_stride[2] + row0 * P2 + (py0 >> 2) * g.wl[2] + (px0 >> 2), 0, kSpan, 0x00020000);
+        lv2 + pair * g.lvl_pair_stride[2] + row0 * P2 + (py0 >> 2) * g.wl[2] + (px0 >> 2), 0, kSpan, 0x00020000);
     const __amdgpu_buffer_rsrc_t r3 = __builtin_amdgcn_make_buffer_rsrc(
-        g.lvl[3] + pair * g.lvl_pair_stride[3] + row0 * P3 + (py0 >> 3) * g.wl[3] + (px0 >> 3), 0, kSpan, 0x00020000);
+        lv3 + pair * g.lvl_pair_stride[3] + row0 * P3 + (py0 >> 3) * g.wl[3] + (px0 >> 3), 0, kSpan, 0x00020000);
     const int x = px0 + l31;
     // per-lane offsets; a lane whose column lies outside the level is dropped for good
-    const int vo0 = (!kGuard || x < g.wl[0]) ? (4 * khalf * P0 + l31) * 4 : kDrop;
-    const int vo1 = (!kGuard || (x >> 1) < g.wl[1]) ? (4 * khalf * P1 + (l31 >> 1)) * 4 : kDrop;
-    const int vo2 = (!kGuard || (x >> 2) < g.wl[2]) ? (4 * khalf * P2 + (l31 >> 2)) * 4 : kDrop;
-    const int vo3 = (!kGuard || (x >> 3) < g.wl[3]) ? (4 * khalf * P3 + (l31 >> 3)) * 4 : kDrop;
+    const int vo0 = (!kGuard || x < g.wl[0]) ? (4 * khalf * P0 + l31) * ES : kDrop;
+    const int vo1 = (!kGuard || (x >> 1) < g.wl[1]) ? (4 * khalf * P1 + (l31 >> 1)) * ES : kDrop;
+    const int vo2 = (!kGuard || (x >> 2) < g.wl[2]) ? (4 * khalf * P2 + (l31 >> 2)) * ES : kDrop;
+    const int vo3 = (!kGuard || (x >> 3) < g.wl[3]) ? (4 * khalf * P3 + (l31 >> 3)) * ES : kDrop;
     // level 0 (3/4 of the bytes) is streamed past the caches: it would only displace the operand tiles in L2 and the
     // pooled levels, which are small enough (a quarter of level 0 together) to stay in the 256 MB Infinity Cache
     // for the lookups that follow
@@ -102,8 +142,7 @@ __device__ __forceinline__ void pyramid_store(const BuildArgs& g, f32x16 (&acc)[
             for (int t = 0; t < PR; ++t) {
                 v0[t] = acc[t][r] * g.scale;
                 const bool ok = !kGuard || (iok[ri] && py0 + t < g.hl[0]);
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v0[t]), r0, ok ? vo0 : kDrop,
-                                                      (rr * P0 + t * g.wl[0]) * 4, kNt);
+                store_cell<OutT, kNt>(v0[t], r0, ok ? vo0 : kDrop, (rr * P0 + t * g.wl[0]) * ES);
             }
 #pragma unroll
             for (int t = 0; t < PR / 2; ++t) {
@@ -124,8 +163,7 @@ __device__ __forceinline__ void pyramid_store(const BuildArgs& g, f32x16 (&acc)[
 #pragma unroll
                 for (int t = 0; t < PR / 2; ++t) {
                     const bool ok = !kGuard || (iok[ri] && (py0 >> 1) + t < g.hl[1]);
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v1[ri][t]), r1, ok ? vo1 : kDrop,
-                                                          ((ri + 8 * rq) * P1 + t * g.wl[1]) * 4, 0);
+                    store_cell<OutT, 0>(v1[ri][t], r1, ok ? vo1 : kDrop, ((ri + 8 * rq) * P1 + t * g.wl[1]) * ES);
                 }
         }
         if ((l31 & 3) == 0) {
@@ -134,31 +172,156 @@ __device__ __forceinline__ void pyramid_store(const BuildArgs& g, f32x16 (&acc)[
 #pragma unroll
                 for (int t = 0; t < PR / 4; ++t) {
                     const bool ok = !kGuard || (iok[ri] && (py0 >> 2) + t < g.hl[2]);
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v2[ri][t]), r2, ok ? vo2 : kDrop,
-                                                          ((ri + 8 * rq) * P2 + t * g.wl[2]) * 4, 0);
+                    store_cell<OutT, 0>(v2[ri][t], r2, ok ? vo2 : kDrop, ((ri + 8 * rq) * P2 + t * g.wl[2]) * ES);
                 }
         }
         if ((l31 & 7) == 0) {
 #pragma unroll
             for (int ri = 0; ri < 4; ++ri) {
                 const bool ok = !kGuard || (iok[ri] && (py0 >> 3) < g.hl[3]);
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v3[ri]), r3, ok ? vo3 : kDrop,
-                                                      ((ri + 8 * rq) * P3) * 4, 0);
+                store_cell<OutT, 0>(v3[ri], r3, ok ? vo3 : kDrop, ((ri + 8 * rq) * P3) * ES);
             }
         }
     }
 }
 
-// Epilogue shared by both arithmetic modes: scale, write level 0, pool levels 1..3 in registers.
-// acc[t][r]: target patch row t (0..7), MFMA C/D register r -> source pixel (r&3)+8*(r>>2)+4*(lane>>5) of the
-// wave's 32-pixel block, lane&31 = target patch column.
+// ---- vector store side (w % 4 == 0): 16-byte stores after a transpose through LDS -------------------------------------
+// The dword path above issues 170 store instructions per wave (256 bytes each) and the build is bound by exactly that:
+// store ISSUE, not bandwidth (2.8 TB/s of writes at best).  Here every pair of patch rows (two 32x32 accumulator
+// tiles) goes through a per-wave LDS scratch (row stride 36 floats: conflict-free dword writes, 16-byte aligned rows)
+// and comes back with a lane owning FOUR consecutive target columns of one source row (row = lane/8 + 8q, columns
+// 4*(lane%8)..+3): level 0 leaves as 16-byte (fp32) / 8-byte (fp16) stores, 1 KB per instruction, and the horizontal
+// pooling partners of levels 1 and 2 sit in the same lane (no DPP); only level 3 needs one lane exchange.
+// 60 store instructions per wave instead of 170.  Needs w % 4 == 0 (every configuration of BASELINE.json); odd widths
+// take the dword path.
+constexpr int kTrStride = 36;
+constexpr int kTrTile = 32 * kTrStride;                   // floats per transposed tile
+typedef unsigned int st_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int st_u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned pack_h2(float a, float b) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    h2 v;
+    v[0] = (_Float16)a;
+    v[1] = (_Float16)b;
+    return __builtin_bit_cast(unsigned, v);
+}
+
+template <bool kGuard, typename OutT>
+__device__ __forceinline__ void pyramid_store_vec(const BuildArgs& g, f32x16 (&acc)[PR], int b, int pair, int m0, int wave,
+                                                  int py0, int px0, int lane, float* scratch) {
+    constexpr int ES = sizeof(OutT);
+    OutT* const lv0 = reinterpret_cast<OutT*>(g.lvl[0]);
+    OutT* const lv1 = reinterpret_cast<OutT*>(g.lvl[1]);
+    OutT* const lv2 = reinterpret_cast<OutT*>(g.lvl[2]);
+    OutT* const lv3 = reinterpret_cast<OutT*>(g.lvl[3]);
+    const int khalf = lane >> 5, l31 = lane & 31;
+    const int rrow = lane >> 3, xq = (lane & 7) * 4;        // read-back coordinates: source row rrow + 8q, columns xq..xq+3
+    const int P0 = g.hl[0] * g.wl[0], P1 = g.hl[1] * g.wl[1], P2 = g.hl[2] * g.wl[2], P3 = g.hl[3] * g.wl[3];
+    const int i0 = m0 + wave * 32;
+    const int64_t row0 = (int64_t)b * g.N + i0;
+    constexpr int kSpan = 0x7ffffff0, kDrop = (int)0x80000000u;
+    const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(
+        lv0 + pair * g.lvl_pair_stride[0] + row0 * P0 + py0 * g.wl[0] + px0, 0, kSpan, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(
+        lv1 + pair * g.lvl_pair_stride[1] + row0 * P1 + (py0 >> 1) * g.wl[1] + (px0 >> 1), 0, kSpan, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(
+        lv2 + pair * g.lvl_pair_stride[2] + row0 * P2 + (py0 >> 2) * g.wl[2] + (px0 >> 2), 0, kSpan, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r3 = __builtin_amdgcn_make_buffer_rsrc(
+        lv3 + pair * g.lvl_pair_stride[3] + row0 * P3 + (py0 >> 3) * g.wl[3] + (px0 >> 3), 0, kSpan, 0x00020000);
+    const int x = px0 + xq;                                 // first of this lane's four columns (w % 4 == 0: all in or all out)
+    const int co0 = (!kGuard || x < g.wl[0]) ? xq * ES : kDrop;
+    const int co1 = (!kGuard || (x >> 1) < g.wl[1]) ? (xq >> 1) * ES : kDrop;
+    const int co2 = (!kGuard || (x >> 2) < g.wl[2]) ? (xq >> 2) * ES : kDrop;
+    const int co3 = (!kGuard || (x >> 3) < g.wl[3]) ? (xq >> 3) * ES : kDrop;
+#ifndef SF_CORR_NT
+#define SF_CORR_NT 2
+#endif
+    constexpr int kNt = SF_CORR_NT;
+    float l2s[PR / 4][4];                                       // level-2 values (one per lane and source row)
+#pragma unroll
+    for (int t2 = 0; t2 < PR / 4; ++t2) {
+        float l1s[4];                                           // sum of the two level-1 values of the first row pair
+#pragma unroll
+        for (int u2 = 0; u2 < 2; ++u2) {
+            const int tp = 2 * t2 + u2;
+            // ---- transpose patch rows 2tp, 2tp+1 (a wave's DS operations execute in order: no barrier) ----
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    scratch[u * kTrTile + ((r & 3) + 8 * (r >> 2) + 4 * khalf) * kTrStride + l31] = acc[2 * tp + u][r] * g.scale;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int rr = rrow + 8 * q;
+                const bool iok = !kGuard || (i0 + rr < g.N);
+                const float4 a = *reinterpret_cast<const float4*>(scratch + rr * kTrStride + xq);
+                const float4 c = *reinterpret_cast<const float4*>(scratch + kTrTile + rr * kTrStride + xq);
+                const bool ok0 = !kGuard || (iok && py0 + 2 * tp < g.hl[0]);
+                const bool ok1 = !kGuard || (iok && py0 + 2 * tp + 1 < g.hl[0]);
+                const int so = (rr * P0 + 2 * tp * g.wl[0]) * ES;
+                if constexpr (ES == 4) {
+                    st_u32x4 va, vc;
+                    va[0] = __builtin_bit_cast(unsigned, a.x); va[1] = __builtin_bit_cast(unsigned, a.y);
+                    va[2] = __builtin_bit_cast(unsigned, a.z); va[3] = __builtin_bit_cast(unsigned, a.w);
+                    vc[0] = __builtin_bit_cast(unsigned, c.x); vc[1] = __builtin_bit_cast(unsigned, c.y);
+                    vc[2] = __builtin_bit_cast(unsigned, c.z); vc[3] = __builtin_bit_cast(unsigned, c.w);
+                    __builtin_amdgcn_raw_buffer_store_b128(va, r0, ok0 ? co0 : kDrop, so, kNt);
+                    __builtin_amdgcn_raw_buffer_store_b128(vc, r0, ok1 ? co0 : kDrop, so + g.wl[0] * ES, kNt);
+                } else {
+                    st_u32x2 va, vc;
+                    va[0] = pack_h2(a.x, a.y); va[1] = pack_h2(a.z, a.w);
+                    vc[0] = pack_h2(c.x, c.y); vc[1] = pack_h2(c.z, c.w);
+                    __builtin_amdgcn_raw_buffer_store_b64(va, r0, ok0 ? co0 : kDrop, so, kNt);
+                    __builtin_amdgcn_raw_buffer_store_b64(vc, r0, ok1 ? co0 : kDrop, so + g.wl[0] * ES, kNt);
+                }
+                // level 1: 2x2 means of (patch rows 2tp, 2tp+1) x (columns 0-1, 2-3)
+                const float p0 = 0.25f * ((a.x + c.x) + (a.y + c.y)), p1 = 0.25f * ((a.z + c.z) + (a.w + c.w));
+                const bool ok = !kGuard || (iok && (py0 >> 1) + tp < g.hl[1]);
+                const int s1 = (rr * P1 + tp * g.wl[1]) * ES;
+                if constexpr (ES == 4) {
+                    st_u32x2 v;
+                    v[0] = __builtin_bit_cast(unsigned, p0);
+                    v[1] = __builtin_bit_cast(unsigned, p1);
+                    __builtin_amdgcn_raw_buffer_store_b64(v, r1, ok ? co1 : kDrop, s1, 0);
+                } else {
+                    __builtin_amdgcn_raw_buffer_store_b32(pack_h2(p0, p1), r1, ok ? co1 : kDrop, s1, 0);
+                }
+                // level 2: mean of the four level-1 cells of patch rows 4 t2 .. 4 t2 + 3
+                if (u2 == 0) l1s[q] = p0 + p1;
+                else {
+                    l2s[t2][q] = 0.25f * (l1s[q] + (p0 + p1));
+                    const bool ok2 = !kGuard || (iok && (py0 >> 2) + t2 < g.hl[2]);
+                    store_cell<OutT, 0>(l2s[t2][q], r2, ok2 ? co2 : kDrop, (rr * P2 + t2 * g.wl[2]) * ES);
+                }
+            }
+        }
+    }
+    // ---- level 3: the two level-2 rows of this lane and of the neighbouring column quad ----
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int rr = rrow + 8 * q;
+        const float s3 = l2s[0][q] + l2s[1][q];
+        const float l3 = 0.25f * (s3 + dpp_xor1(s3));
+        const bool ok = (lane & 1) == 0 && (!kGuard || (i0 + rr < g.N && (py0 >> 3) < g.hl[3]));
+        store_cell<OutT, 0>(l3, r3, ok ? co3 : kDrop, (rr * P3) * ES);
+    }
+}
+
+// scratch: per-wave LDS region of 2 * kTrTile floats (the main-loop buffers, after a workgroup barrier), or nullptr.
+template <typename OutT = float, bool kVec = false>
 __device__ __forceinline__ void pyramid_epilogue(const BuildArgs& g, f32x16 (&acc)[PR], int b, int pair, int m0, int wave,
-                                                 int py0, int px0, int lane) {
+                                                 int py0, int px0, int lane, float* scratch = nullptr) {
     const bool interior = m0 + BM <= g.N && py0 + PR <= g.hl[0] && px0 + PC <= g.wl[0] &&
                           (py0 >> 1) + PR / 2 <= g.hl[1] && (py0 >> 2) + PR / 4 <= g.hl[2] && (py0 >> 3) < g.hl[3] &&
                           ((px0 + PC) >> 1) <= g.wl[1] && ((px0 + PC) >> 2) <= g.wl[2] && ((px0 + PC) >> 3) <= g.wl[3];
-    if (interior) pyramid_store<false>(g, acc, b, pair, m0, wave, py0, px0, lane);
-    else pyramid_store<true>(g, acc, b, pair, m0, wave, py0, px0, lane);
+    if constexpr (kVec) {                    // one flavour per kernel instantiation: both inlined cost registers (spills)
+        if (interior) pyramid_store_vec<false, OutT>(g, acc, b, pair, m0, wave, py0, px0, lane, scratch);
+        else pyramid_store_vec<true, OutT>(g, acc, b, pair, m0, wave, py0, px0, lane, scratch);
+    } else {
+        if (interior) pyramid_store<false, OutT>(g, acc, b, pair, m0, wave, py0, px0, lane);
+        else pyramid_store<true, OutT>(g, acc, b, pair, m0, wave, py0, px0, lane);
+    }
 }
 
 __global__ __launch_bounds__(kThreads, 2) void corr_build_kernel(const BuildArgs g) {
@@ -295,18 +458,20 @@ __global__ __launch_bounds__(256) void split_pack_kernel(const float* f1, const 
 
 typedef __attribute__((address_space(3))) void* lds_ptr;
 
+template <bool kVec>
 __global__ __launch_bounds__(kThreads, NSTAGE == 2 ? 3 : 2) void corr_build_dma_kernel(const BuildArgs g, const char* ws, int Dp) {
     using namespace sf_split;
     __shared__ __attribute__((aligned(1024))) char smem[NSTAGE * STAGE];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int khalf = lane >> 5, l31 = lane & 31;
-    const int b = blockIdx.z / g.pairs, pair = blockIdx.z % g.pairs;
-    const int m0 = blockIdx.y * BM;
-    const int py0 = (blockIdx.x / g.pcols) * PR, px0 = (blockIdx.x % g.pcols) * PC;
+    const TileId tile = build_tile(g, sf::xcd_linear_id(blockIdx.x, gridDim.x));
+    const int b = tile.img / g.pairs, pair = tile.img % g.pairs;
+    const int m0 = tile.m_tile * BM;
+    const int py0 = (tile.patch / g.pcols) * PR, px0 = (tile.patch % g.pcols) * PC;
     const int half = (Dp / 8) * g.N * 16;                       // bytes of one hi (or lo) plane (< 2 GiB, host-checked)
-    const char* imgA = ws + (int64_t)(blockIdx.z * 2 + 0) * 2 * half;
-    const char* imgB = ws + (int64_t)(blockIdx.z * 2 + 1) * 2 * half;
+    const char* imgA = ws + (int64_t)(tile.img * 2 + 0) * 2 * half;
+    const char* imgB = ws + (int64_t)(tile.img * 2 + 1) * 2 * half;
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(imgA), 0, 2 * half, 0x00020000);
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(imgB), 0, 2 * half, 0x00020000);
     // per-thread source offsets (pixels / patch cells past the image are clamped: their products are never stored)
@@ -357,7 +522,96 @@ __global__ __launch_bounds__(kThreads, NSTAGE == 2 ? 3 : 2) void corr_build_dma_
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t], 0, 0, 0);
         }
     }
-    pyramid_epilogue(g, acc, b, pair, m0, wave, py0, px0, lane);
+    if (kVec) __syncthreads();                                   // the stage buffers become the transpose scratch
+    pyramid_epilogue<float, kVec>(g, acc, b, pair, m0, wave, py0, px0, lane,
+                                  reinterpret_cast<float*>(smem) + wave * 2 * kTrTile);
+}
+
+// ---- fp16 build (SF_PRECISION_F16): single f16 product, fp32 accumulation, volume stored as IEEE fp16 ------------
+// The "bf16/fp16 volume" configurations of BASELINE.json (configs 2 and 5): features are rounded ONCE to fp16 (round to
+// nearest) by pack_f16_kernel into k-octet planes [(k/8)*N + pixel][k%8], the contraction is one
+// v_mfma_f32_32x32x16_f16 per 32x32x16 block (a third of the split build's matrix work) and every pyramid cell is
+// written as fp16 (half the bytes of the fp32 volume, which is what bounds this kernel).  Stage = 32-deep:
+// A 4 k-octets x 128 px x 16 B = 8 KB, B 4 x 256 x 16 B = 16 KB; the same 24 KB / two-stage ring as the split build.
+constexpr int FK = 32;                               // k per stage
+constexpr int FST_A = (FK / 8) * BM * 16;            // 8192
+constexpr int FST_B = (FK / 8) * BN * 16;            // 16384
+constexpr int FSTAGE = FST_A + FST_B;
+
+__global__ __launch_bounds__(256) void pack_f16_kernel(const float* f1, const float* f2, int64_t f_clip_stride,
+                                                       int64_t f_pair_stride, char* ws, int pairs, int D, int Dp, int N) {
+    using namespace sf_split;
+    const int px = blockIdx.x * 256 + threadIdx.x, kq = blockIdx.y;
+    const int side = blockIdx.z & 1, img = blockIdx.z >> 1;             // img = b * pairs + pair
+    if (px >= N) return;
+    const float* f = (side ? f2 : f1) + (int64_t)(img / pairs) * f_clip_stride + (int64_t)(img % pairs) * f_pair_stride;
+    f16x8 h;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) h[i] = (_Float16)((kq * 8 + i < D) ? f[(int64_t)(kq * 8 + i) * N + px] : 0.f);
+    const int64_t plane = (int64_t)(Dp / 8) * N * 16;
+    *reinterpret_cast<f16x8*>(ws + (int64_t)blockIdx.z * plane + ((int64_t)kq * N + px) * 16) = h;
+}
+
+template <bool kVec>
+__global__ __launch_bounds__(kThreads, 3) void corr_build_f16_kernel(const BuildArgs g, const char* ws, int Dp) {
+    using namespace sf_split;
+    __shared__ __attribute__((aligned(1024))) char smem[2 * FSTAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int khalf = lane >> 5, l31 = lane & 31;
+    const TileId tile = build_tile(g, sf::xcd_linear_id(blockIdx.x, gridDim.x));
+    const int b = tile.img / g.pairs, pair = tile.img % g.pairs;
+    const int m0 = tile.m_tile * BM;
+    const int py0 = (tile.patch / g.pcols) * PR, px0 = (tile.patch % g.pcols) * PC;
+    const int plane = (Dp / 8) * g.N * 16;                      // bytes of one packed image (< 2 GiB, host-checked)
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(ws) + (int64_t)(tile.img * 2 + 0) * plane, 0, plane, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(ws) + (int64_t)(tile.img * 2 + 1) * plane, 0, plane, 0x00020000);
+    // A slot = kq*128 + px: a piece of 256 threads covers two k-octets; B slot = kq*256 + cell: one k-octet per piece.
+    // Pixels / patch cells past the image are clamped: their products are never stored.
+    const int voa = ((tid >> 7) * g.N + min(m0 + (tid & 127), g.N - 1)) * 16;
+    const int vob = (min(py0 + tid / PC, g.h - 1) * g.w + min(px0 + tid % PC, g.w - 1)) * 16;
+    const int kq_step = g.N * 16;
+
+    auto issue = [&](int kt, int buf) {
+        char* sb = smem + buf * FSTAGE + wave * 1024;
+        const int so = kt * (FK / 8) * kq_step;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)(sb), 16, voa, so, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)(sb + 4096), 16, voa, so + 2 * kq_step, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr)(sb + FST_A + j * 4096), 16, vob, so + j * kq_step, 0, 0);
+    };
+
+    f32x16 acc[PR];
+#pragma unroll
+    for (int t = 0; t < PR; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    const int nk = Dp / FK;
+    const int offa = (khalf * BM + wave * 32 + l31) * 16;
+    const int offb = FST_A + (khalf * BN + l31) * 16;
+    issue(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's pieces of stage kt have landed ...
+        __builtin_amdgcn_s_barrier();                            // ... everyone's; the other slot is no longer read
+        if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+        const char* sb = smem + (kt & 1) * FSTAGE;
+#pragma unroll
+        for (int ks = 0; ks < FK / 16; ++ks) {
+            const f16x8 a = *reinterpret_cast<const f16x8*>(sb + offa + ks * 2 * BM * 16);
+#pragma unroll
+            for (int t = 0; t < PR; ++t) {
+                const f16x8 bv = *reinterpret_cast<const f16x8*>(sb + offb + ks * 2 * BN * 16 + t * PC * 16);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bv, acc[t], 0, 0, 0);
+            }
+        }
+    }
+    if (kVec) __syncthreads();                                   // the stage buffers become the transpose scratch
+    pyramid_epilogue<_Float16, kVec>(g, acc, b, pair, m0, wave, py0, px0, lane,
+                                     reinterpret_cast<float*>(smem) + wave * 2 * kTrTile);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -427,6 +681,100 @@ __global__ __launch_bounds__(kThreads) void corr_lookup_kernel(const LookupArgs 
     }
 }
 
+// ---- lookup in fp16 volumes (SF_PRECISION_F16 builds) -----------------------------------------------------------
+// One workgroup owns 32 consecutive source pixels for ALL four levels (coordinates read once).
+//  gather: the 4 x 32 footprints (10 x 10 fp16 cells) go to LDS through a flat item index whose fastest part is the
+//          cell, so the 64 lanes of a load instruction walk consecutive cells of ONE footprint (6-7 cache lines per
+//          instruction; lanes over pixels would touch 64 lines); loads are clamped + selected, not branched;
+//  taps:   item = (channel group of three `a`, tap row, level, pixel QUAD): a lane blends the same three taps for four
+//          consecutive pixels and stores 16 bytes per channel -- 1 KB per store instruction instead of 256 B (the
+//          dword version of this kernel is bound by store issue, like the build epilogue was).  Needs N % 4 == 0 and
+//          16-byte aligned output planes (every BASELINE configuration); otherwise dword stores.
+// Taps are blended in fp32 from the stored fp16 cells.
+constexpr int FSTR = 102;          // halves per footprint in LDS (even: rows of 10 halves stay 4-byte aligned)
+constexpr int LQ = LP / 4;         // pixel quads per workgroup
+
+template <bool kVec>
+__global__ __launch_bounds__(kThreads) void corr_lookup_f16_kernel(const LookupArgs g) {
+    __shared__ __attribute__((aligned(16))) _Float16 win[4 * LP * FSTR];
+    __shared__ float sfx[4 * LP], sfy[4 * LP];
+    __shared__ int sx0[4 * LP], sy0[4 * LP];
+    const int tid = threadIdx.x;
+    const int img = blockIdx.y;
+    const int b = img / g.pairs, pair = img % g.pairs;
+    const int p0 = blockIdx.x * LP;
+    if (tid < 4 * LP) {
+        const int pix = tid % LP, l = tid / LP;
+        const int p = min(p0 + pix, g.N - 1);
+        const float inv = 1.0f / (float)(1 << l);
+        float cx = g.coords[((int64_t)img * 2 + 0) * g.N + p] * inv;
+        float cy = g.coords[((int64_t)img * 2 + 1) * g.N + p] * inv;
+        // anything this far out samples only zero padding; also swallows NaN/inf
+        if (!(cx > -1.0e6f && cx < 1.0e6f)) cx = -1.0e6f;
+        if (!(cy > -1.0e6f && cy < 1.0e6f)) cy = -1.0e6f;
+        const float fx0 = floorf(cx), fy0 = floorf(cy);
+        sx0[tid] = (int)fx0;
+        sy0[tid] = (int)fy0;
+        sfx[tid] = cx - fx0;
+        sfy[tid] = cy - fy0;
+    }
+    __syncthreads();
+    // ---- gather: flat item = ((level * 32 + pixel) * 100 + cell) ----
+#pragma unroll 1
+    for (int l = 0; l < 4; ++l) {
+        const int hl = g.hl[l], wl = g.wl[l];
+        const _Float16* vol = reinterpret_cast<const _Float16*>(g.lvl[l]) + pair * g.lvl_pair_stride[l] +
+                              ((int64_t)b * g.N + p0) * hl * wl;                        // workgroup-uniform
+        constexpr int kIt = (LP * FP * FP + kThreads - 1) / kThreads;                     // 13 (the last one partial)
+        _Float16 v[kIt];
+        bool ok[kIt];
+#pragma unroll
+        for (int j = 0; j < kIt; ++j) {
+            const int it = min(tid + j * kThreads, LP * FP * FP - 1);
+            const int pix = it / (FP * FP), cell = it % (FP * FP);
+            const int yy = sy0[l * LP + pix] - RAD + cell / FP, xx = sx0[l * LP + pix] - RAD + cell % FP;
+            ok[j] = (p0 + pix < g.N) && yy >= 0 && yy < hl && xx >= 0 && xx < wl;
+            const int pc = min(pix, g.N - 1 - p0);
+            v[j] = vol[pc * hl * wl + min(max(yy, 0), hl - 1) * wl + min(max(xx, 0), wl - 1)];
+        }
+#pragma unroll
+        for (int j = 0; j < kIt; ++j) {
+            const int it = tid + j * kThreads;
+            if (it < LP * FP * FP) win[(l * LP + it / (FP * FP)) * FSTR + it % (FP * FP)] = ok[j] ? v[j] : (_Float16)0.f;
+        }
+    }
+    __syncthreads();
+    // ---- taps: channel = l*81 + a*9 + bb (a moves x, corr.py:31-37) ----
+    float* out = g.out + (int64_t)img * g.out_img_stride + p0;
+    for (int it = tid; it < 4 * WIN * 3 * LQ; it += kThreads) {
+        const int pq = it % LQ, r1 = it / LQ, ag = r1 % 3, r2 = r1 / 3, bb = r2 % WIN, l = r2 / WIN;
+        float res[3][4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int pix = pq * 4 + e;
+            const float fx = sfx[l * LP + pix], fy = sfy[l * LP + pix];
+            const float w00 = (1.f - fx) * (1.f - fy), w01 = fx * (1.f - fy), w10 = (1.f - fx) * fy, w11 = fx * fy;
+            const _Float16* c = win + (l * LP + pix) * FSTR + bb * FP + ag * 3;
+            float c0[4], c1[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { c0[k] = (float)c[k]; c1[k] = (float)c[FP + k]; }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) res[k][e] = c0[k] * w00 + c0[k + 1] * w01 + c1[k] * w10 + c1[k + 1] * w11;
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float* o = out + (int64_t)(l * WIN * WIN + (ag * 3 + k) * WIN + bb) * g.N + pq * 4;
+            if (kVec) {
+                if (p0 + pq * 4 < g.N) *reinterpret_cast<float4*>(o) = make_float4(res[k][0], res[k][1], res[k][2], res[k][3]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (p0 + pq * 4 + e < g.N) o[e] = res[k][e];
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // generic bilinear sampler (API parity for utils.bilinear_sampler; not on the fused path)
 // ------------------------------------------------------------------------------------------------
@@ -462,7 +810,7 @@ __global__ void bilinear_sampler_kernel(const float* img, const float* coords, f
 
 extern "C" int64_t sf_corr_build_ws_bytes(int B, int pairs, int D, int h, int w) {
     if (B <= 0 || pairs <= 0 || D <= 0 || h <= 0 || w <= 0) return 0;
-    return (int64_t)2 * B * pairs * (sf::ceil_div(D, DK) * DK) * h * w * 4;      // (f1, f2) x images x (hi + lo) planes
+    return (int64_t)2 * B * pairs * (sf::ceil_div(D, FK) * FK) * h * w * 4;      // (f1, f2) x images x (hi + lo) planes
 }
 
 extern "C" int sf_corr_build_pyramid(const float* f1, const float* f2, int64_t f_clip_stride, int64_t f_pair_stride,
@@ -474,9 +822,9 @@ extern "C" int sf_corr_build_pyramid(const float* f1, const float* f2, int64_t f
     SF_REQUIRE(B > 0 && pairs > 0 && D > 0 && h > 0 && w > 0, "sf_corr_build_pyramid: bad dims");
     SF_REQUIRE(pairs == 1 || lvl_pair_stride, "sf_corr_build_pyramid: pairs > 1 needs lvl_pair_stride");
     SF_REQUIRE(num_levels == 4, "sf_corr_build_pyramid: num_levels must be 4 (got %d)", num_levels);
-    SF_REQUIRE(precision == SF_PRECISION_FP32 || precision == SF_PRECISION_F16X3,
+    SF_REQUIRE(precision == SF_PRECISION_FP32 || precision == SF_PRECISION_F16X3 || precision == SF_PRECISION_F16,
                "sf_corr_build_pyramid: precision %d not supported", precision);
-    const int Dp = sf::ceil_div(D, DK) * DK;
+    const int Dp = sf::ceil_div(D, FK) * FK;                 // multiple of both stage depths (16 and 32)
     SF_REQUIRE(precision == SF_PRECISION_FP32 || (int64_t)Dp * h * w * 4 < ((int64_t)1 << 31),
                "sf_corr_build_pyramid: feature image larger than 2 GiB");
     SF_REQUIRE(precision == SF_PRECISION_FP32 ||
@@ -503,11 +851,39 @@ extern "C" int sf_corr_build_pyramid(const float* f1, const float* f2, int64_t f
     g.vec_b = ((w & 3) == 0) && ((f_clip_stride & 3) == 0) && ((f_pair_stride & 3) == 0) &&
               ((reinterpret_cast<uintptr_t>(f2) & 15) == 0);
     dim3 grid(g.pcols * sf::ceil_div(h, PR), sf::ceil_div(g.N, BM), B * pairs);
+    g.np = (int)grid.x; g.mt = (int)grid.y;
+    {
+        bool al = (w % 4 == 0);
+        for (int l = 0; l < 4; ++l) {
+            al = al && (reinterpret_cast<uintptr_t>(g.lvl[l]) & 15) == 0;
+            if (pairs > 1) al = al && ((g.lvl_pair_stride[l] * (precision == SF_PRECISION_F16 ? 2 : 4)) & 15) == 0;
+        }
+        g.vec_store = al ? 1 : 0;
+    }
+    // patches per L2-resident block: ~1.75 MB of packed target features (of the 4 MiB L2 of an XCD)
+    const int patch_bytes = BN * Dp * (precision == SF_PRECISION_F16 ? 2 : 4);
+    g.pblk = (7 << 18) / patch_bytes;
+    g.pblk = g.pblk < 1 ? 1 : (g.pblk > g.np ? g.np : g.pblk);
+    const int64_t n_wg = (int64_t)g.np * g.mt * B * pairs;
+    SF_REQUIRE(precision == SF_PRECISION_FP32 || n_wg < ((int64_t)1 << 31), "sf_corr_build_pyramid: grid too large");
     if (precision == SF_PRECISION_F16X3) {
         hipLaunchKernelGGL(split_pack_kernel, dim3(sf::ceil_div(g.N, 256), Dp / 8, 2 * B * pairs), dim3(256), 0,
                            (hipStream_t)stream, f1, f2, f_clip_stride, f_pair_stride, (char*)split_ws, pairs, D, Dp, g.N);
-        hipLaunchKernelGGL(corr_build_dma_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, g,
-                           (const char*)split_ws, Dp);
+        if (g.vec_store)
+            hipLaunchKernelGGL(corr_build_dma_kernel<true>, dim3((unsigned)n_wg), dim3(kThreads), 0, (hipStream_t)stream, g,
+                               (const char*)split_ws, Dp);
+        else
+            hipLaunchKernelGGL(corr_build_dma_kernel<false>, dim3((unsigned)n_wg), dim3(kThreads), 0, (hipStream_t)stream, g,
+                               (const char*)split_ws, Dp);
+    } else if (precision == SF_PRECISION_F16) {
+        hipLaunchKernelGGL(pack_f16_kernel, dim3(sf::ceil_div(g.N, 256), Dp / 8, 2 * B * pairs), dim3(256), 0,
+                           (hipStream_t)stream, f1, f2, f_clip_stride, f_pair_stride, (char*)split_ws, pairs, D, Dp, g.N);
+        if (g.vec_store)
+            hipLaunchKernelGGL(corr_build_f16_kernel<true>, dim3((unsigned)n_wg), dim3(kThreads), 0, (hipStream_t)stream, g,
+                               (const char*)split_ws, Dp);
+        else
+            hipLaunchKernelGGL(corr_build_f16_kernel<false>, dim3((unsigned)n_wg), dim3(kThreads), 0, (hipStream_t)stream, g,
+                               (const char*)split_ws, Dp);
     } else
         hipLaunchKernelGGL(corr_build_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, g);
     return sf::check_launch("sf_corr_build_pyramid");
@@ -516,7 +892,7 @@ extern "C" int sf_corr_build_pyramid(const float* f1, const float* f2, int64_t f
 extern "C" int sf_corr_lookup(const float* lvl0, const float* lvl1, const float* lvl2, const float* lvl3,
                               const int64_t* lvl_pair_stride, const float* coords, float* out,
                               int64_t out_img_stride, int B, int pairs, int h, int w, int num_levels, int radius,
-                              void* stream) {
+                              int vol_precision, void* stream) {
     SF_REQUIRE(lvl0 && lvl1 && lvl2 && lvl3 && coords && out, "sf_corr_lookup: null pointer");
     SF_REQUIRE(B > 0 && pairs > 0 && h > 0 && w > 0, "sf_corr_lookup: bad dims");
     SF_REQUIRE(pairs == 1 || lvl_pair_stride, "sf_corr_lookup: pairs > 1 needs lvl_pair_stride");
@@ -530,6 +906,17 @@ extern "C" int sf_corr_lookup(const float* lvl0, const float* lvl1, const float*
     for (int l = 0; l < 4; ++l) {
         g.hl[l] = h >> l; g.wl[l] = w >> l;
         g.lvl_pair_stride[l] = (pairs > 1) ? lvl_pair_stride[l] : 0;
+    }
+    if (vol_precision == SF_PRECISION_F16) {
+        SF_REQUIRE((int64_t)LP * h * w * 2 < ((int64_t)1 << 31), "sf_corr_lookup: feature grid too large");
+        const bool vec = (g.N % 4 == 0) && (out_img_stride % 4 == 0) && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+        if (vec)
+            hipLaunchKernelGGL(corr_lookup_f16_kernel<true>, dim3(sf::ceil_div(g.N, LP), B * pairs), dim3(kThreads), 0,
+                               (hipStream_t)stream, g);
+        else
+            hipLaunchKernelGGL(corr_lookup_f16_kernel<false>, dim3(sf::ceil_div(g.N, LP), B * pairs), dim3(kThreads), 0,
+                               (hipStream_t)stream, g);
+        return sf::check_launch("sf_corr_lookup(f16)");
     }
     dim3 grid(sf::ceil_div(g.N, LP), 4, B * pairs);
     hipLaunchKernelGGL(corr_lookup_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, g);

@@ -42,6 +42,9 @@ struct SplitArgs {
 #endif
 };
 
+#ifndef SF_GEMM_FRAG_PREFETCH
+#define SF_GEMM_FRAG_PREFETCH 0
+#endif
 #ifndef SF_GEMM_WAVES
 #define SF_GEMM_WAVES 3          // workgroups per CU the register budget is sized for (128x128 tile)
 #endif
@@ -154,6 +157,44 @@ __global__ __launch_bounds__(kThreads, (TM * TN >= 8) ? 2 : SF_GEMM_WAVES) void 
         constexpr int kAStep = kDmaA ? 2 * BM * 8 : 16;          // halfs per 16-deep k-step
         const _Float16* pbh = sB[0] + (wn * TN * 32 + l31) * LDK + khalf * 8;
         const _Float16* pbl = sB[SB ? 1 : 0] + (wn * TN * 32 + l31) * LDK + khalf * 8;
+#if SF_GEMM_FRAG_PREFETCH
+        // all fragment reads of the k-tile are issued before its first MFMA (2 k-steps x 8 x ds_read_b128 = 64 VGPRs):
+        // the LDS latency is exposed once per k-tile instead of once per register reuse (hipcc otherwise recycles 24
+        // fragment registers and waits lgkmcnt(0) three times per k-step)
+        f16x8 ah[BK / 16][TM], al[BK / 16][TM], bh[BK / 16][TN], bl[BK / 16][TN];
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                ah[ks][i] = *reinterpret_cast<const f16x8*>(pah + i * kATile + ks * kAStep);
+                al[ks][i] = *reinterpret_cast<const f16x8*>(pal + i * kATile + ks * kAStep);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                bh[ks][j] = *reinterpret_cast<const f16x8*>(pbh + j * 32 * LDK + ks * 16);
+                if (SB) bl[ks][j] = *reinterpret_cast<const f16x8*>(pbl + j * 32 * LDK + ks * 16);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            // product-major order: the three MFMAs that hit one accumulator are TM*TN instructions apart
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks][i], bh[ks][j], acc[i][j], 0, 0, 0);
+            if (SB) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks][i], bl[ks][j], acc[i][j], 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks][i], bh[ks][j], acc[i][j], 0, 0, 0);
+        }
+#else
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
             f16x8 ah[TM], al[TM], bh[TN], bl[TN];
@@ -177,6 +218,7 @@ __global__ __launch_bounds__(kThreads, (TM * TN >= 8) ? 2 : SF_GEMM_WAVES) void 
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                 }
         }
+#endif
         __builtin_amdgcn_sched_barrier(0);
         if (kt + 1 < kt_end) {
             __syncthreads();                       // every wave is done reading tile kt

@@ -116,7 +116,7 @@ class _Plan:
     """Buffers for one (clips, pairs, h, w) shape."""
 
     def __init__(self, W: HotPathWeights, Bc: int, h: int, w: int, D: int, device, attn_chunk_rows: int = 0,
-                 attn_f16: bool = False):
+                 attn_f16: bool = False, corr_f16: bool = False, flash: Optional[bool] = None):
         Pn = W.pairs
         n, P = Bc * Pn, h * w
         self.Bc, self.Pn, self.h, self.w, self.n, self.P, self.D = Bc, Pn, h, w, n, P, D
@@ -128,7 +128,10 @@ class _Plan:
                                "is undefined there (needs images >= 128 px per side)")
         dims = [(h >> l, w >> l) for l in range(4)]
         self.lvl_pair_stride = [Bc * P * hl * wl for hl, wl in dims]
-        self.lvls = [torch.empty(Pn * s, dtype=torch.float32, device=device) for s in self.lvl_pair_stride]
+        # correlation pyramids of all pairs: fp32 cells, or fp16 cells (corr_dtype='f16': half the bytes of the
+        # HBM-bound build and lookups; BASELINE.json configs 2 and 5)
+        self.lvls = [torch.empty(Pn * s, dtype=torch.float16 if corr_f16 else torch.float32, device=device)
+                     for s in self.lvl_pair_stride]
         # scratch of the split-precision volume build: (hi, lo) fp16 planes of every f1 / f2 image
         self.corr_ws = torch.empty(max(ops.corr_build_ws_bytes(Bc, Pn, D, h, w), 16), dtype=torch.uint8, device=device)
         # GMA attention: materialise the N x N matrix once (reference core/gma.py) when an image's matrix fits the
@@ -140,6 +143,13 @@ class _Plan:
         else:
             lim = max(1, (ATTN_ROW_LIMIT - 1) // P)
             self.attn_rows = min(P, lim if attn_chunk_rows <= 0 else min(attn_chunk_rows, lim))
+        # fused path (sf_gma_flash_*): softmax(q k^T) v recomputed inside one kernel per iteration, logits never leave
+        # the CU.  flash=None: used whenever the matrix would have to be chunked (split precisions only).
+        self.flash = bool(flash) if flash is not None else (attn_f16 and self.attn_rows < P and attn_chunk_rows <= 0)
+        self.flash_ws = None
+        if self.flash:
+            self.flash_ws = torch.empty(ops.gma_flash_ws_bytes(n, P), dtype=torch.uint8, device=device)
+            self.attn_rows = 1                     # no attention matrix at all: placeholders only
         self.attn = torch.empty(n, self.attn_rows, P, dtype=torch.float32, device=device)
         # split-precision modes keep the materialised matrix in fp16 (half the bytes of the HBM-bound attn @ v that
         # every iteration repeats; measured effect on the final flow: 4e-6 px mean EPE); self.attn is then only the
@@ -180,12 +190,17 @@ class HotPathEngine:
     """`forward(fmaps, cnets, iters)` == reference loop in test_mode (streamflow.py:110-147)."""
 
     def __init__(self, state_dict: Dict[str, torch.Tensor], device="cuda:0", T: Optional[int] = None,
-                 use_graph: bool = False, precision: Optional[str] = None):
+                 use_graph: bool = False, precision: Optional[str] = None, corr_dtype: str = "f32"):
         """precision: 'f16x3' (split fp16, fp32-class accuracy, default), 'fp32' (exact fp32 MFMA) or 'f16x2'
         (weights split, activations rounded to fp16: ~1e-4 px EPE, faster);
-        None = the package-wide setting (streamflow_amd.ops.PRECISION)."""
+        None = the package-wide setting (streamflow_amd.ops.PRECISION).
+        corr_dtype: 'f32' keeps the correlation pyramids in fp32 as the reference does (corr.py:13, arithmetic =
+        `precision`); 'f16' stores them as fp16 and builds them with single f16 MFMA products (SF_PRECISION_F16)."""
         _lib.load()
         self.precision = ops.PRECISION if precision is None else ops._PRECISION_NAMES[precision]
+        if corr_dtype not in ("f32", "f16"):
+            raise RuntimeError(f"corr_dtype must be 'f32' or 'f16', got {corr_dtype!r}")
+        self.corr_f16 = corr_dtype == "f16"
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("HotPathEngine needs an MI355X device (cuda:N); there is no CPU fallback")
@@ -196,6 +211,14 @@ class HotPathEngine:
         self.auto_split_k = os.environ.get("SF_AUTO_SPLITK", "1") != "0"
         self.attn_chunk_rows = int(os.environ.get("SF_ATTN_CHUNK_ROWS", "0"))  # > 0 forces the recompute path
         self.attn_k_splits = min(4, int(os.environ.get("SF_ATTN_KSPLITS", "3")))     # 1 = no split-K (<= 4)
+        # GMA aggregation: 'matrix' = attention matrix materialised once (gma.py), chunked recompute when it cannot be
+        # kept; 'flash' = fused recompute kernel every iteration (demo.py:235-258); 'auto' = flash exactly when the
+        # matrix would have to be chunked (high resolution)
+        self.gma_mode = os.environ.get("SF_GMA_MODE", "auto")
+        if self.gma_mode not in ("auto", "matrix", "flash"):
+            raise RuntimeError(f"SF_GMA_MODE must be auto, matrix or flash, got {self.gma_mode!r}")
+        # MFMA products per logit of the fused kernel: 3 = split precision (fp32-class), 2 / 1 = k / q and k in fp16
+        self.flash_qk_products = int(os.environ.get("SF_FLASH_QKP", "0")) or (2 if self.precision == ops.PRECISION_F16X2 else 3)
         self._side = torch.cuda.Stream(device=self.device)
         self.W = HotPathWeights(state_dict, self.device, T)
         self.use_graph = use_graph
@@ -211,8 +234,13 @@ class HotPathEngine:
         if pl is None:
             while len(self._plans) >= max(1, self.max_plans):
                 self._plans.pop(next(iter(self._plans)))            # dicts keep insertion order: first = oldest
-            pl = _Plan(self.W, Bc, h, w, D, self.device, self.attn_chunk_rows,
-                       attn_f16=self.precision != ops.PRECISION_FP32)
+            split = self.precision != ops.PRECISION_FP32
+            if self.gma_mode == "flash" and not split:
+                raise RuntimeError("gma_mode='flash' needs a split precision (f16x3 / f16x2); the exact fp32 mode keeps "
+                                   "the materialised / chunked attention path")
+            flash = {"auto": None, "matrix": False, "flash": True}[self.gma_mode]
+            pl = _Plan(self.W, Bc, h, w, D, self.device, self.attn_chunk_rows, attn_f16=split, corr_f16=self.corr_f16,
+                       flash=flash)
         self._plans[key] = pl                                        # (re)insert as most recent
         return pl
 
@@ -243,7 +271,9 @@ class HotPathEngine:
         ops.context_split(cnets, pl.nets, pl.inps, HDIM)
         # a6: attn = softmax(scale * q k^T) over the context features (gma.py:53-65), computed once
         ops.gemm(W.to_qk, pl.inps, pl.qk, EPI_NONE)
-        if pl.attn_rows == P:
+        if pl.flash:
+            ops.gma_flash_pack_qk(pl.qk, pl.flash_ws, float(HDIM) ** -0.5)       # q, k are constant over the loop
+        elif pl.attn_rows == P:
             self._attention_rows(pl, 0, P)
 
     def _iteration(self, pl: _Plan, with_mask: bool) -> None:
@@ -287,7 +317,10 @@ class HotPathEngine:
         ks = self.attn_k_splits if self.precision != ops.PRECISION_FP32 else 1
         attn_ptr, attn_lay = ((pl.attn16.data_ptr(), LAYOUT_F16_K_MINOR) if pl.attn16 is not None
                               else (pl.attn.data_ptr(), LAYOUT_K_MINOR))
-        if pl.attn_rows < P:
+        if pl.flash:
+            # fused recompute (K6' of SURVEY.md): one kernel, online softmax, logits never written
+            ops.gma_flash_aggregate(pl.flash_ws, pl.v128, pl.mf, W.gamma, pl.mfg, self.flash_qk_products)
+        elif pl.attn_rows < P:
             # high-resolution path: recompute the attention rows chunk by chunk (K6' of SURVEY.md)
             for i0 in range(0, P, pl.attn_rows):
                 rows = min(pl.attn_rows, P - i0)

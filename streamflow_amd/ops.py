@@ -15,7 +15,8 @@ import torch
 
 from . import _lib
 from ._lib import (EPI_AXPY, EPI_GELU, EPI_NONE, EPI_RELU, EPI_RES, EPI_RES_GELU, EPI_RES_GELU_DW1,  # noqa: F401
-                   LAYOUT_K_MAJOR, LAYOUT_K_MINOR, LAYOUT_SPLIT_F16, LAYOUT_F16_K_MINOR, PRECISION_F16X2, PRECISION_F16X3, PRECISION_FP32,
+                   LAYOUT_K_MAJOR, LAYOUT_K_MINOR, LAYOUT_SPLIT_F16, LAYOUT_F16_K_MINOR, PRECISION_F16, PRECISION_F16X2, PRECISION_F16X3,
+                   PRECISION_FP32,
                    SfGemm)
 
 # Arithmetic mode of every GEMM-shaped op (sf_gemm, corr build):
@@ -305,6 +306,31 @@ def softmax_rows(x: torch.Tensor, rows: int, cols: int, out16: Optional[torch.Te
                                                            _lib.stream()), "sf_softmax_rows"))
 
 
+def gma_flash_ws_bytes(n_img: int, P: int) -> int:
+    return int(_lib.load().sf_gma_flash_ws_bytes(n_img, P))
+
+
+@on_tensor_device
+def gma_flash_pack_qk(QK: Planes, ws: torch.Tensor, scale: float) -> None:
+    """QK [n_img][256][P] (to_qk output) -> packed fp16 operand images in ws (once per clip)."""
+    assert QK.rows == 256 and ws.dtype == torch.uint8
+    _launch("flash_pack_qk", 0, 4.0 * QK.n_img * 256 * QK.P * 2,
+            lambda: _lib.check(_lib.load().sf_gma_flash_pack_qk(QK.ptr, QK.img_stride, ws.data_ptr(), ws.numel(), QK.n_img,
+                                                                QK.P, float(scale), _lib.stream()), "sf_gma_flash_pack_qk"))
+
+
+@on_tensor_device
+def gma_flash_aggregate(ws: torch.Tensor, V: Planes, MF: Planes, gamma: torch.Tensor, OUT: Planes, qk_products: int = 3) -> None:
+    """OUT = MF + gamma * softmax(scale q k^T) V, fused (no N x N tensor); q, k come packed in ws."""
+    assert V.rows == MF.rows == OUT.rows == 128 and V.n_img == MF.n_img == OUT.n_img
+    n, P = V.n_img, V.P
+    # algorithmic: the two contractions; bytes: v, mf in, out (q/k/v tiles are re-read from L2 by every query tile)
+    _launch("gma_flash", 4.0 * n * P * P * 128, 4.0 * n * 128 * P * 3 + 2.0 * n * 128 * P * 2,
+            lambda: _lib.check(_lib.load().sf_gma_flash_aggregate(
+                ws.data_ptr(), ws.numel(), V.ptr, V.img_stride, MF.ptr, MF.img_stride, gamma.data_ptr(), OUT.ptr,
+                OUT.img_stride, n, P, int(qk_products), _lib.stream()), "sf_gma_flash_aggregate"))
+
+
 @on_tensor_device
 def coords_grid(batch: int, ht: int, wd: int, device) -> torch.Tensor:
     out = torch.empty(batch, 2, ht, wd, dtype=torch.float32, device=device)
@@ -369,15 +395,19 @@ def corr_build_ws_bytes(B: int, pairs: int, D: int, h: int, w: int) -> int:
 def corr_build(f1_ptr: int, f2_ptr: int, clip_stride: int, pair_stride: int, lvls: Sequence[torch.Tensor],
                lvl_pair_stride: Optional[Sequence[int]], B: int, pairs: int, D: int, h: int, w: int,
                ws: Optional[torch.Tensor] = None) -> None:
-    """ws: scratch of corr_build_ws_bytes() bytes for the split-precision build (allocated here when omitted)."""
+    """ws: scratch of corr_build_ws_bytes() bytes for the split-precision / fp16 builds (allocated here when omitted).
+    The dtype of `lvls` selects the volume format: float32 (arithmetic = the package precision, fp32 or f16x3) or
+    float16 (SF_PRECISION_F16: single f16 products, fp16 cells)."""
     N = h * w
-    prec = min(PRECISION, PRECISION_F16X3)
+    vol16 = lvls[0].dtype == torch.float16
+    assert all(t.dtype == lvls[0].dtype for t in lvls) and lvls[0].dtype in (torch.float16, torch.float32)
+    prec = PRECISION_F16 if vol16 else min(PRECISION, PRECISION_F16X3)
     need = corr_build_ws_bytes(B, pairs, D, h, w) if prec != PRECISION_FP32 else 0
     if need and (ws is None or ws.numel() * ws.element_size() < need):
         ws = torch.empty(need, dtype=torch.uint8, device=lvls[0].device)
     cells = sum((h >> l) * (w >> l) for l in range(4))
     # algorithmic bytes per (clip, pair): both feature maps read once + every pyramid cell written once
-    nbytes = B * pairs * (2.0 * N * D * 4 + 4.0 * N * cells)
+    nbytes = B * pairs * (2.0 * N * D * 4 + (2.0 if vol16 else 4.0) * N * cells)
     _launch("corr_build", 2.0 * N * N * D * B * pairs, nbytes, lambda: _lib.check(
         _lib.load().sf_corr_build_pyramid(
             f1_ptr, f2_ptr, clip_stride, pair_stride, lvls[0].data_ptr(), lvls[1].data_ptr(), lvls[2].data_ptr(),
@@ -391,12 +421,13 @@ def corr_lookup(lvls: Sequence[torch.Tensor], lvl_pair_stride: Optional[Sequence
                 out: Planes, B: int, pairs: int, h: int, w: int) -> None:
     assert out.rows == 324 and out.n_img == B * pairs and coords.img_stride == 2 * h * w
     N = h * w
+    vol16 = lvls[0].dtype == torch.float16
     # algorithmic bytes per image: 10x10 footprint x 4 levels read + coords + 324 output channels
-    nbytes = B * pairs * (N * 4 * 100 * 4.0 + N * 2 * 4.0 + N * 324 * 4.0)
+    nbytes = B * pairs * (N * 4 * 100 * (2.0 if vol16 else 4.0) + N * 2 * 4.0 + N * 324 * 4.0)
     _launch("corr_lookup", 0, nbytes, lambda: _lib.check(_lib.load().sf_corr_lookup(
         lvls[0].data_ptr(), lvls[1].data_ptr(), lvls[2].data_ptr(), lvls[3].data_ptr(),
         pair_strides(lvl_pair_stride), coords.ptr, out.ptr, out.img_stride, B, pairs, h, w, 4, 4,
-        _lib.stream()), "sf_corr_lookup"))
+        PRECISION_F16 if vol16 else PRECISION_FP32, _lib.stream()), "sf_corr_lookup"))
 
 
 @on_tensor_device

@@ -26,7 +26,8 @@ def test_every_declared_symbol_is_exported(lib):
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
     assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
-    assert lib.sf_version() == 100
+    version = int(re.search(r"#define SF_VERSION (\d+)", hdr).group(1))
+    assert lib.sf_version() == version >= 101
 
 
 def test_struct_layout_matches_header():

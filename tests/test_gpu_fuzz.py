@@ -122,3 +122,38 @@ def test_corr_random_shapes(dev, seed, prec):
     for a, b_ in zip(lv, pyr):
         assert a.shape == b_.shape and (a - b_).abs().max().item() < 3e-5
     assert (out - orc.corr_lookup(pyr, coords, 4)).abs().max().item() < 5e-5
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_corr_fp16_volume_random_shapes(dev, seed):
+    """fp16 correlation volumes (SF_PRECISION_F16: single f16 products, fp16 cells; BASELINE configs 2/5) on ragged
+    grids.  Build: against the oracle pyramid of the fp16-ROUNDED features (what the kernel multiplies), tolerance =
+    one fp16 rounding of the stored cell (2^-11 relative) + fp32 accumulation noise.  Lookup: against the oracle
+    lookup run on the GPU's own stored cells, so only the fp32 tap blending differs."""
+    from oracle import streamflow_oracle as orc
+    import streamflow_amd as sfa
+    rng = np.random.default_rng(4000 + seed)
+    B = int(rng.integers(1, 3))
+    D = int(rng.choice([16, 40, 256]))
+    h, w = int(rng.integers(16, 40)), int(rng.integers(16, 50))
+    g = torch.Generator().manual_seed(100 + seed)
+    f1, f2 = torch.randn(B, D, h, w, generator=g), torch.randn(B, D, h, w, generator=g)
+    coords = orc.coords_grid(B, h, w) + torch.randn(B, 2, h, w, generator=g) * 4.0
+    coords[:, :, 0, 0] = torch.tensor([-6.0, 2.0])
+    coords[:, :, 1, 1] = torch.tensor([float(w + 9), float(h + 9)])
+    coords[:, :, 2, 2] = torch.tensor([3.0, 4.0])
+    blk = sfa.CorrBlock(f1.to(dev), f2.to(dev), num_levels=4, radius=4, dtype=torch.float16)
+    out = blk(coords.to(dev)).cpu()
+    lv = [t.cpu() for t in blk.corr_pyramid]
+    assert all(t.dtype == torch.float16 for t in lv)
+    pyr = orc.corr_pyramid(f1.half().float(), f2.half().float(), 4)
+    for l, (a, b_) in enumerate(zip(lv, pyr)):
+        assert a.shape == b_.shape
+        err = (a.float() - b_).abs()
+        tol = 2.0 ** -11 * b_.abs() + 3e-5
+        assert (err <= tol).all(), (l, (err - tol).max().item())
+    ref = orc.corr_lookup([t.float() for t in lv], coords, 4)
+    assert out.dtype == torch.float32 and (out - ref).abs().max().item() < 5e-5
+    # and the fp16 path stays within fp16-storage distance of the exact fp32 volume
+    exact = orc.corr_pyramid(f1, f2, 4)[0]
+    assert (lv[0].float() - exact).abs().max().item() < 2e-3 * max(1.0, exact.abs().max().item())

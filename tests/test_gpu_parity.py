@@ -275,6 +275,25 @@ def test_headline_config_batched_vs_oracle(dev):
         assert orc.epe(ups2[i][3:4].cpu(), ups[i][B - 1:B]) <= 1e-4
 
 
+def test_fp16_volume_mode_within_parity_budget(dev):
+    """corr_dtype='f16' (fp16 correlation pyramids built with single f16 products; BASELINE configs 2 and 5): the
+    final flows must stay inside the 1e-3 px budget against the fp32 oracle -- 15 iterations at a small shape, and the
+    full Sintel shape (55x128 grid, 15 iterations, one clip)."""
+    from oracle import streamflow_oracle as orc
+    from streamflow_amd import synthetic as syn
+    from streamflow_amd.engine import HotPathEngine
+    for (B, T, h, w, seed) in ((1, 4, 16, 24, 5), (1, 4, 55, 128, 7)):
+        P = syn.make_params(seed, T)
+        fmaps, cnets = syn.make_features(seed, B, T, h, w)
+        ups_o, _ = orc.hotpath_forward(fmaps, cnets, P, 15)
+        eng = HotPathEngine(P, device=dev, T=T, corr_dtype="f16")
+        ups, _ = eng.forward(fmaps.to(dev), cnets.to(dev), iters=15)
+        assert eng.plan(B, h, w, 256).lvls[0].dtype == torch.float16
+        e = max(orc.epe(u.cpu(), o) for u, o in zip(ups, ups_o))
+        print(f"fp16 volumes, {h}x{w} grid: 15-iteration EPE vs fp32 oracle = {e:.3e}")
+        assert e <= 1e-3, (h, w, e)
+
+
 def test_engine_on_non_current_device():
     """An engine built for cuda:1 while cuda:0 is the current device must launch on cuda:1's streams."""
     if torch.cuda.device_count() < 2:
@@ -333,6 +352,68 @@ def test_chunked_attention_path_vs_golden(golden, dev):
     for i in range(T - 1):
         e = orc.epe(ups[i].cpu(), torch.from_numpy(g[f"up{i}"]))
         assert e <= 1e-3, e
+
+
+@pytest.mark.parametrize("P", [64, 323, 1000, 7040])
+@pytest.mark.parametrize("qkp", [1, 2, 3])
+def test_gma_flash_kernel_vs_float64(dev, P, qkp):
+    """sf_gma_flash_*: out = mf + gamma * softmax(scale q k^T) v (demo.py:235-258 == gma.py:53-65,91-104) against a
+    float64 evaluation on the same q, k, v.  P = 323 / 1000 exercise the padded key tail and the partial query tile.
+    qk_products = 3 is the split-precision (fp32-class) logit path; 1 and 2 round k (and q) to fp16 once."""
+    from streamflow_amd import ops
+    from streamflow_amd.ops import Planes
+    gen = torch.Generator().manual_seed(P * 10 + qkp)
+    n = 2
+    qk = torch.randn(n, 256, P, generator=gen)
+    qk[:, :128] *= 1.5                                        # logits with a spread of a few units after scaling
+    v = torch.randn(n, 128, P, generator=gen)
+    mf = torch.randn(n, 128, P, generator=gen)
+    gamma = torch.tensor([0.61])
+    ws = torch.empty(ops.gma_flash_ws_bytes(n, P), dtype=torch.uint8, device=dev)
+    out = torch.full((n, 128, P), float("nan"), device=dev)
+    scale = 128 ** -0.5
+    ops.gma_flash_pack_qk(Planes.of(qk.to(dev)), ws, scale)
+    ops.gma_flash_aggregate(ws, Planes.of(v.to(dev)), Planes.of(mf.to(dev)), gamma.to(dev), Planes.of(out), qkp)
+    torch.cuda.synchronize()
+    q64, k64 = qk[:, :128].double(), qk[:, 128:].double()
+    attn = torch.softmax(scale * torch.einsum("ndi,ndj->nij", q64, k64), dim=-1)
+    ref = mf.double() + 0.61 * torch.einsum("nij,ndj->ndi", attn, v.double())
+    err = (out.double().cpu() - ref).abs().max().item()
+    tol = {3: 4e-4, 2: 1.5e-3, 1: 3e-3}[qkp]                  # fp16 softmax weights / v: ~2^-11 relative on O(1) values
+    print(f"flash P={P} qk_products={qkp}: max abs err vs float64 = {err:.2e}")
+    assert err < tol, (P, qkp, err)
+
+
+@pytest.mark.parametrize("qkp", [1, 2, 3])
+def test_engine_flash_mode_vs_golden(golden, dev, qkp, monkeypatch):
+    """The whole loop with the fused GMA aggregation (gma_mode='flash': no attention matrix at all) against the
+    reference forward, for every logit precision; the 15-iteration small-shape run bounds the accumulated effect."""
+    from oracle import streamflow_oracle as orc
+    from streamflow_amd import synthetic as syn
+    from streamflow_amd.engine import HotPathEngine
+    monkeypatch.setenv("SF_GMA_MODE", "flash")
+    monkeypatch.setenv("SF_FLASH_QKP", str(qkp))
+    tag = "forward_T4"
+    g = golden(tag)
+    B, T, H, W, iters, seed, use_init = cases.FORWARD_CASES[tag]
+    P, fmaps, cnets, finit, iters = cases.forward_inputs(tag)
+    for graph in (False, True):
+        eng = HotPathEngine(P, device=dev, T=T, use_graph=graph)
+        ups, _ = eng.forward(fmaps.to(dev), cnets.to(dev), iters=iters)
+        pl = eng.plan(B, H // 8, W // 8, 256)
+        assert pl.flash and pl.attn.numel() <= pl.n * pl.P
+        for i in range(T - 1):
+            e = orc.epe(ups[i].cpu(), torch.from_numpy(g[f"up{i}"]))
+            assert e <= 1e-3, (qkp, graph, i, e)
+    B, T, h, w = 1, 4, 16, 24
+    P = syn.make_params(5, T)
+    fmaps, cnets = syn.make_features(5, B, T, h, w)
+    ups_o, _ = orc.hotpath_forward(fmaps, cnets, P, 15)
+    eng = HotPathEngine(P, device=dev, T=T)
+    ups, _ = eng.forward(fmaps.to(dev), cnets.to(dev), iters=15)
+    e = max(orc.epe(u.cpu(), o) for u, o in zip(ups, ups_o))
+    print(f"flash GMA, qk_products={qkp}: 15-iteration EPE vs oracle = {e:.3e}")
+    assert e <= 1e-3, (qkp, e)
 
 
 def test_spring_shape_smoke(dev):
