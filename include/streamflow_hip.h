@@ -212,6 +212,21 @@ int sf_context_split(const float* cnets, float* nets, int64_t nets_img_stride, f
 int sf_flow_update(float* coords1, const float* delta, float* flow_a, int64_t flow_a_img_stride,
                    float* flow_b, int64_t flow_b_img_stride, int n_img, int h, int w, void* stream);
 
+/* ---- f1: Twins_CSC encoder (core/encoders/twins_csc.py:59-85 over timm's twins_svt_large stages 1-2) -----------------
+ * Token planes [n_img][C][N]: N = H*W tokens of the (T*h) x w grid of a clip, channel = head*32 + d (head dim 32).
+ * Linear layers / strided convs of the encoder use sf_gemm, LayerNorms sf_layernorm_cm; these three are the rest.
+ * sf_window_attn: timm LocallyGroupedAttn core.  qkv [n_img][3C][H*W] (rows q | k | v, the qkv Linear output) ->
+ *     out [n_img][C][H*W] = softmax(q k^T / sqrt(32)) v inside non-overlapping ws x ws windows.  Windows reaching past
+ *     the grid are completed with zero tokens, whose k and v are qkv_bias (timm pads after the norm, before the Linear).
+ * sf_subsample_attn: timm GlobalSubSampleAttn core.  q [n_img][C][N], kv [n_img][2C][M] (rows k | v) -> out [n_img][C][N].
+ * sf_dwconv3x3_res: timm PosConv: y = x + depthwise3x3(x) + b on [n_img][C][H][W]; w [C][9]. */
+int sf_window_attn(const float* qkv, int64_t qkv_img_stride, const float* qkv_bias, float* out, int64_t out_img_stride,
+                   int n_img, int C, int heads, int H, int W, int ws, void* stream);
+int sf_subsample_attn(const float* q, int64_t q_img_stride, const float* kv, int64_t kv_img_stride, float* out,
+                      int64_t out_img_stride, int n_img, int C, int heads, int N, int M, void* stream);
+int sf_dwconv3x3_res(const float* x, int64_t x_img_stride, const float* w, const float* b, float* y,
+                     int64_t y_img_stride, int n_img, int C, int H, int W, void* stream);
+
 /* ---- K12 convex upsampling (streamflow.py:82-93) -------------------------------------------------
  * flow [n][2][h][w], mask [n][9*64][h][w] -> out [n][2][8h][8w]. */
 int sf_upsample_flow(const float* flow, const float* mask, float* out, int n, int h, int w, void* stream);

@@ -62,6 +62,9 @@ SIGNATURES = {
     "sf_temporal_attn": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "sf_context_split": (_i, [_vp, _vp, _i64, _vp, _i64, _i, _i, _i, _vp]),
     "sf_flow_update": (_i, [_vp, _vp, _vp, _i64, _vp, _i64, _i, _i, _i, _vp]),
+    "sf_window_attn": (_i, [_vp, _i64, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _vp]),
+    "sf_subsample_attn": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _vp]),
+    "sf_dwconv3x3_res": (_i, [_vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp]),
     "sf_upsample_flow": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "sf_forward_interpolate": (_i, [_vp, _vp, _i, _i, _i, _vp]),
 }

@@ -477,6 +477,9 @@ extern "C" int sf_layernorm_cm(const float* x, int64_t x_img_stride, const float
     if (C == 128)
         hipLaunchKernelGGL(layernorm_cm_split_kernel<32>, dim3(sf::ceil_div(P, kLnPix), n_img), dim3(kBlock), 0,
                            (hipStream_t)stream, x, x_img_stride, gamma, beta, y, y_img_stride, P, eps);
+    else if (C == 256)                                       // second stage of the Twins_CSC encoder
+        hipLaunchKernelGGL(layernorm_cm_split_kernel<64>, dim3(sf::ceil_div(P, kLnPix), n_img), dim3(kBlock), 0,
+                           (hipStream_t)stream, x, x_img_stride, gamma, beta, y, y_img_stride, P, eps);
     else
         hipLaunchKernelGGL(layernorm_cm_kernel, dim3(sf::ceil_div(P, kBlock), n_img), dim3(kBlock), 0,
                            (hipStream_t)stream, x, x_img_stride, gamma, beta, y, y_img_stride, C, P, eps);

@@ -2,14 +2,21 @@
 
 * Middlebury ``.flo``: float32 magic 202021.25 (the bytes ``PIEH``), int32 width, int32 height, then height*width
   interleaved (u, v) float32 pairs, row-major (reference core/utils/frame_utils.py:13-29, 85-114).
-* KITTI flow PNG arithmetic: uint16 channels (u, v, valid), value = 64*flow + 2^15
-  (frame_utils.py:117-122, 137-141); only the codec arithmetic is here -- reading/writing 16-bit PNGs needs cv2,
-  which this image does not have.
+* KITTI flow PNG: 16-bit RGB PNG with channels (R, G, B) = (u, v, valid), value = 64*flow + 2^15
+  (frame_utils.py:117-122, 137-141: cv2 reads/writes BGR and the reference flips the channel axis, so the FILE holds
+  u in R).  cv2 is not in this image: a small PNG codec (zlib + the five PNG row filters, 8/16-bit gray / RGB / RGBA,
+  non-interlaced) is included, which is all the KITTI devkit files need.
+* PFM (FlyingThings ground truth, frame_utils.py:48-83): 'PF' / 'Pf' header, rows stored bottom-up, sign of the scale
+  = endianness.
+* ``.flo5`` (Spring: an HDF5 container with one gzip dataset, frame_utils.py:31-47,130-135) is NOT built: HDF5 needs
+  h5py, which the image lacks.
 * Metrics: end-point error map, Sintel-style EPE / 1px / 3px / 5px (evaluate_mf.py:484-497) and the KITTI
   F1-all outlier rate: epe > 3 px and epe/|gt| > 5 % over valid pixels (evaluate_mf.py:124-133).
 """
 from __future__ import annotations
 
+import struct
+import zlib
 from typing import Dict, Tuple
 
 import numpy as np
@@ -78,3 +85,134 @@ def kitti_f1(flow: np.ndarray, gt: np.ndarray, valid: np.ndarray) -> Dict[str, f
     val = np.asarray(valid).reshape(-1) >= 0.5
     out = (epe > 3.0) & ((epe / np.maximum(mag, 1e-30)) > 0.05)
     return {"epe": float(epe[val].mean()), "f1": float(100.0 * out[val].mean())}
+
+
+# ---- PNG (16-bit capable), for the KITTI flow format ---------------------------------------------------------------------------
+_PNG_SIG = b"\x89PNG\r\n\x1a\n"
+_PNG_CHANNELS = {0: 1, 2: 3, 4: 2, 6: 4}
+
+
+def write_png(path: str, img: np.ndarray) -> None:
+    """uint8 / uint16 array [H, W] or [H, W, C] (C = 1, 2, 3, 4) -> non-interlaced PNG (filter 0 rows, zlib level 6)."""
+    a = np.asarray(img)
+    if a.ndim == 2:
+        a = a[:, :, None]
+    if a.dtype not in (np.uint8, np.uint16) or a.ndim != 3 or a.shape[2] not in (1, 2, 3, 4):
+        raise ValueError(f"write_png: need uint8/uint16 [H, W(, C<=4)], got {a.dtype} {a.shape}")
+    h, w, c = a.shape
+    ctype = {1: 0, 2: 4, 3: 2, 4: 6}[c]
+    depth = 8 * a.dtype.itemsize
+    rows = a.astype(">u2" if depth == 16 else np.uint8).reshape(h, -1).view(np.uint8).reshape(h, -1)
+    raw = np.concatenate([np.zeros((h, 1), np.uint8), rows], axis=1).tobytes()
+
+    def chunk(tag: bytes, data: bytes) -> bytes:
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+
+    with open(path, "wb") as f:
+        f.write(_PNG_SIG + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, 0)) +
+                chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
+
+
+def read_png(path: str) -> np.ndarray:
+    """Non-interlaced 8/16-bit gray / gray+alpha / RGB / RGBA PNG -> uint8 / uint16 [H, W, C] (C squeezed when 1)."""
+    with open(path, "rb") as f:
+        data = f.read()
+    if data[:8] != _PNG_SIG:
+        raise IOError(f"{path}: not a PNG file")
+    pos, idat, hdr = 8, [], None
+    while pos + 8 <= len(data):
+        n, tag = struct.unpack(">I", data[pos:pos + 4])[0], data[pos + 4:pos + 8]
+        body = data[pos + 8:pos + 8 + n]
+        if tag == b"IHDR":
+            hdr = struct.unpack(">IIBBBBB", body)
+        elif tag == b"IDAT":
+            idat.append(body)
+        elif tag == b"IEND":
+            break
+        pos += 12 + n
+    if hdr is None:
+        raise IOError(f"{path}: no IHDR chunk")
+    w, h, depth, ctype, _, _, interlace = hdr
+    if depth not in (8, 16) or ctype not in _PNG_CHANNELS or interlace:
+        raise IOError(f"{path}: unsupported PNG (bit depth {depth}, colour type {ctype}, interlace {interlace})")
+    c = _PNG_CHANNELS[ctype]
+    bpp = c * depth // 8                                   # bytes per pixel = filter distance
+    stride = w * bpp
+    raw = np.frombuffer(zlib.decompress(b"".join(idat)), np.uint8)
+    if raw.size != h * (stride + 1):
+        raise IOError(f"{path}: truncated image data")
+    raw = raw.reshape(h, stride + 1)
+    out = np.zeros((h, stride), np.uint8)
+    prev = np.zeros(stride, np.int32)
+    for y in range(h):
+        ft, line = int(raw[y, 0]), raw[y, 1:].astype(np.int32)
+        if ft == 0:
+            cur = line
+        elif ft == 2:                                      # Up
+            cur = (line + prev) & 255
+        else:                                              # Sub / Average / Paeth depend on the pixel to the left
+            cur = np.zeros(stride, np.int32)
+            for x in range(stride):
+                a = cur[x - bpp] if x >= bpp else 0
+                b = prev[x]
+                cc = prev[x - bpp] if x >= bpp else 0
+                if ft == 1:
+                    pred = a
+                elif ft == 3:
+                    pred = (a + b) >> 1
+                elif ft == 4:
+                    p = a + b - cc
+                    pa, pb, pc = abs(p - a), abs(p - b), abs(p - cc)
+                    pred = a if (pa <= pb and pa <= pc) else (b if pb <= pc else cc)
+                else:
+                    raise IOError(f"{path}: bad filter type {ft}")
+                cur[x] = (line[x] + pred) & 255
+        out[y] = cur
+        prev = cur
+    img = out.view(">u2").astype(np.uint16) if depth == 16 else out
+    img = img.reshape(h, w, c)
+    return img[:, :, 0] if c == 1 else img
+
+
+def write_flow_kitti(path: str, flow: np.ndarray) -> None:
+    """reference writeFlowKITTI (frame_utils.py:137-141): [H, W, 2] -> 16-bit PNG, (R, G, B) = (u, v, 1) codes."""
+    write_png(path, kitti_encode(flow))
+
+
+def read_flow_kitti(path: str) -> Tuple[np.ndarray, np.ndarray]:
+    """reference readFlowKITTI (frame_utils.py:117-122): 16-bit RGB PNG -> (flow [H, W, 2] float32, valid [H, W])."""
+    img = read_png(path)
+    if img.ndim != 3 or img.shape[2] < 3 or img.dtype != np.uint16:
+        raise IOError(f"{path}: KITTI flow needs a 16-bit RGB PNG, got {img.dtype} {img.shape}")
+    return kitti_decode(img[:, :, :3])
+
+
+# ---- PFM -----------------------------------------------------------------------------------------------------------------
+def read_pfm(path: str) -> np.ndarray:
+    """reference readPFM (frame_utils.py:48-83): float32 [H, W] ('Pf') or [H, W, 3] ('PF'), rows flipped to top-down."""
+    with open(path, "rb") as f:
+        header = f.readline().rstrip()
+        if header not in (b"PF", b"Pf"):
+            raise IOError(f"{path}: not a PFM file")
+        dims = f.readline().split()
+        if len(dims) != 2:
+            raise IOError(f"{path}: malformed PFM header")
+        w, h = int(dims[0]), int(dims[1])
+        scale = float(f.readline().rstrip())
+        data = np.fromfile(f, "<f4" if scale < 0 else ">f4")
+    c = 3 if header == b"PF" else 1
+    if data.size != w * h * c:
+        raise IOError(f"{path}: truncated PFM file")
+    img = data.reshape((h, w, 3) if c == 3 else (h, w)).astype(np.float32)
+    return np.flipud(img).copy()
+
+
+def write_pfm(path: str, img: np.ndarray) -> None:
+    """float32 [H, W] or [H, W, 3] -> little-endian PFM (scale -1), rows bottom-up."""
+    a = np.asarray(img, np.float32)
+    if a.ndim not in (2, 3) or (a.ndim == 3 and a.shape[2] != 3):
+        raise ValueError(f"write_pfm: need [H, W] or [H, W, 3], got {a.shape}")
+    with open(path, "wb") as f:
+        f.write(b"PF\n" if a.ndim == 3 else b"Pf\n")
+        f.write(f"{a.shape[1]} {a.shape[0]}\n-1.0\n".encode())
+        np.flipud(a).astype("<f4").tofile(f)

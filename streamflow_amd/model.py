@@ -7,7 +7,7 @@
 
 State-dict keys of the hot path (``att.*``, ``update_block.*``) are the reference's, so published
 checkpoints load.  The refinement loop runs in :class:`streamflow_amd.engine.HotPathEngine` (HIP kernels);
-the encoders are stand-ins (see encoders.py).
+the encoder is the reference's ``Twins_CSC`` on the same kernels (encoders.py; stand-ins exist for tests).
 """
 from __future__ import annotations
 
@@ -25,7 +25,7 @@ from .update import SKUpdateBlock_TAM_v3
 UPDATE_BLOCKS = {"SKUpdateBlock_TAM_v3": SKUpdateBlock_TAM_v3}
 
 
-def default_args(T: int = 4, Encoder: str = "PatchEncoder", **kw) -> Namespace:
+def default_args(T: int = 4, Encoder: str = "Twins_CSC", **kw) -> Namespace:
     """The canonical StreamFlow flag set (reference scripts/infer.sh:12-26, train_mf.py:375,396,462)."""
     a = Namespace(model_name="SKFlow_MF8", Encoder=Encoder, UpdateBlock="SKUpdateBlock_TAM_v3",
                   MotionEncoder="SKMotionEncoder6_Deep_nopool_res", use_gma=True, k_conv=[1, 15],
@@ -48,7 +48,7 @@ class SKFlow_MF8(nn.Module):
         args.corr_radius = 4
         if args.Encoder not in ENCODERS:
             raise RuntimeError(f"Encoder '{args.Encoder}' is not available in this build (have {list(ENCODERS)}); "
-                               "Twins_CSC is scoped as the next component (SURVEY.md 8f)")
+                               "the other encoders of the reference are ablations no script selects (SURVEY.md 2a)")
         if args.UpdateBlock not in UPDATE_BLOCKS:
             raise RuntimeError(f"UpdateBlock '{args.UpdateBlock}' is not built (have {list(UPDATE_BLOCKS)})")
         self.fnet = ENCODERS[args.Encoder](args, norm_fn="instance")
@@ -107,21 +107,25 @@ class SKFlow_MF8(nn.Module):
 
 class StreamFlowT4(SKFlow_MF8):
     """Self-contained T=4 model of the reference's demo (demo.py:376-470): images [B,T,3,H,W] already in [-1,1],
-    iters=15, test_mode=True by default.  `ckpt` may be a path ({'model': state_dict} or a bare dict, keys optionally
-    prefixed 'module.'); hot-path keys are loaded strictly, encoder keys are skipped (stand-in encoder)."""
+    iters=15, test_mode=True by default.  `ckpt` may be a path or an already loaded object ({'model': state_dict} or a
+    bare dict, keys optionally prefixed 'module.').  With the default Twins_CSC encoder the whole checkpoint is loaded
+    strictly (demo.py:388-389); with a stand-in encoder only the hot-path keys are (and must match exactly)."""
 
-    def __init__(self, ckpt: Optional[str] = None, Encoder: str = "PatchEncoder", use_graph: bool = True):
+    def __init__(self, ckpt=None, Encoder: str = "Twins_CSC", use_graph: bool = True):
         super().__init__(default_args(T=4, Encoder=Encoder, use_graph=use_graph))
         if ckpt is not None:
-            obj = torch.load(ckpt, map_location="cpu")
+            obj = torch.load(ckpt, map_location="cpu") if isinstance(ckpt, (str, bytes)) or hasattr(ckpt, "read") else ckpt
             sd = obj["model"] if isinstance(obj, dict) and "model" in obj else obj
             sd = {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}
-            hot = {k: v for k, v in sd.items() if k.startswith(("att.", "update_block."))}
-            mine = {k for k in self.state_dict() if k.startswith(("att.", "update_block."))}
-            if set(hot) != mine:
-                raise RuntimeError(f"checkpoint hot-path keys mismatch: missing {sorted(mine - set(hot))[:5]}, "
-                                   f"unexpected {sorted(set(hot) - mine)[:5]}")
-            self.load_state_dict(hot, strict=False)
+            if Encoder == "Twins_CSC":
+                self.load_state_dict(sd, strict=True)
+            else:
+                hot = {k: v for k, v in sd.items() if k.startswith(("att.", "update_block."))}
+                mine = {k for k in self.state_dict() if k.startswith(("att.", "update_block."))}
+                if set(hot) != mine:
+                    raise RuntimeError(f"checkpoint hot-path keys mismatch: missing {sorted(mine - set(hot))[:5]}, "
+                                       f"unexpected {sorted(set(hot) - mine)[:5]}")
+                self.load_state_dict(hot, strict=False)
         for p in self.parameters():
             p.requires_grad = False
 

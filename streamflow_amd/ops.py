@@ -306,6 +306,35 @@ def softmax_rows(x: torch.Tensor, rows: int, cols: int, out16: Optional[torch.Te
                                                            _lib.stream()), "sf_softmax_rows"))
 
 
+@on_tensor_device
+def window_attn(QKV: Planes, qkv_bias: torch.Tensor, OUT: Planes, heads: int, H: int, W: int, ws: int = 7) -> None:
+    """timm LocallyGroupedAttn core on token planes (encoder; see include/streamflow_hip.h)."""
+    C = OUT.rows
+    assert QKV.rows == 3 * C and QKV.P == H * W == OUT.P and qkv_bias.numel() == 3 * C
+    _launch("window_attn", 4.0 * QKV.n_img * H * W * ws * ws * C, 4.0 * QKV.n_img * 4 * C * H * W,
+            lambda: _lib.check(_lib.load().sf_window_attn(QKV.ptr, QKV.img_stride, qkv_bias.data_ptr(), OUT.ptr, OUT.img_stride,
+                                                          QKV.n_img, C, heads, H, W, ws, _lib.stream()), "sf_window_attn"))
+
+
+@on_tensor_device
+def subsample_attn(Q: Planes, KV: Planes, OUT: Planes, heads: int) -> None:
+    """timm GlobalSubSampleAttn core: OUT = softmax(q k^T / sqrt(32)) v, keys/values = the M sub-sampled tokens."""
+    C = Q.rows
+    assert KV.rows == 2 * C and OUT.rows == C and Q.P == OUT.P and Q.n_img == KV.n_img == OUT.n_img
+    _launch("subsample_attn", 4.0 * Q.n_img * Q.P * KV.P * C, 4.0 * Q.n_img * C * (2 * Q.P + 2 * KV.P),
+            lambda: _lib.check(_lib.load().sf_subsample_attn(Q.ptr, Q.img_stride, KV.ptr, KV.img_stride, OUT.ptr, OUT.img_stride,
+                                                             Q.n_img, C, heads, Q.P, KV.P, _lib.stream()), "sf_subsample_attn"))
+
+
+@on_tensor_device
+def dwconv3x3_res(X: Planes, wgt: torch.Tensor, bias: torch.Tensor, Y: Planes, H: int, W: int) -> None:
+    """timm PosConv: Y = X + depthwise3x3(X) + b on [n_img][C][H][W]."""
+    assert X.rows == Y.rows == wgt.shape[0] and X.P == H * W
+    _launch("dwconv3", 18.0 * X.n_img * X.rows * H * W, 8.0 * X.n_img * X.rows * H * W,
+            lambda: _lib.check(_lib.load().sf_dwconv3x3_res(X.ptr, X.img_stride, wgt.data_ptr(), bias.data_ptr(), Y.ptr,
+                                                            Y.img_stride, X.n_img, X.rows, H, W, _lib.stream()), "sf_dwconv3x3_res"))
+
+
 def gma_flash_ws_bytes(n_img: int, P: int) -> int:
     return int(_lib.load().sf_gma_flash_ws_bytes(n_img, P))
 

@@ -114,3 +114,53 @@ def make_features(seed: int, B: int, T: int, h: int, w: int, D: int = 256) -> Tu
     fmaps = torch.stack(frames, dim=1).contiguous()
     cnets = randn(seed, "cnet", (B, T - 1, 2 * HDIM, h, w))
     return fmaps, cnets
+
+
+# ---- Twins_CSC encoder (reference core/encoders/twins_csc.py:37-57: first two stages of timm's twins_svt_large) ----------
+TWINS_DIMS = (128, 256)
+TWINS_HEADS = (4, 8)
+TWINS_SR = (8, 4)
+TWINS_PATCH = (4, 2)
+
+
+def twins_param_shapes() -> List[Tuple[str, Tuple[int, ...]]]:
+    """(key, shape) of the encoder's state dict below `fnet.` / `cnet.` (what remains after twins_csc.py:52-57 deletes
+    stages 3-4 and the head; the 1024-wide final `svt.norm` of the timm model survives and is part of the checkpoint)."""
+    s: List[Tuple[str, Tuple[int, ...]]] = []
+    cin = 3
+    for i, (E, k, sr) in enumerate(zip(TWINS_DIMS, TWINS_PATCH, TWINS_SR)):
+        pe = f"svt.patch_embeds.{i}"
+        s += [(pe + ".proj.weight", (E, cin, k, k)), (pe + ".proj.bias", (E,)), (pe + ".norm.weight", (E,)), (pe + ".norm.bias", (E,))]
+        for j in range(2):
+            b = f"svt.blocks.{i}.{j}"
+            s += [(b + ".norm1.weight", (E,)), (b + ".norm1.bias", (E,))]
+            if j == 0:                      # LocallyGroupedAttn
+                s += [(b + ".attn.qkv.weight", (3 * E, E)), (b + ".attn.qkv.bias", (3 * E,))]
+            else:                           # GlobalSubSampleAttn
+                s += [(b + ".attn.q.weight", (E, E)), (b + ".attn.q.bias", (E,)),
+                      (b + ".attn.kv.weight", (2 * E, E)), (b + ".attn.kv.bias", (2 * E,)),
+                      (b + ".attn.sr.weight", (E, E, sr, sr)), (b + ".attn.sr.bias", (E,)),
+                      (b + ".attn.norm.weight", (E,)), (b + ".attn.norm.bias", (E,))]
+            s += [(b + ".attn.proj.weight", (E, E)), (b + ".attn.proj.bias", (E,)),
+                  (b + ".norm2.weight", (E,)), (b + ".norm2.bias", (E,)),
+                  (b + ".mlp.fc1.weight", (4 * E, E)), (b + ".mlp.fc1.bias", (4 * E,)),
+                  (b + ".mlp.fc2.weight", (E, 4 * E)), (b + ".mlp.fc2.bias", (E,))]
+        s += [(f"svt.pos_block.{i}.proj.0.weight", (E, 1, 3, 3)), (f"svt.pos_block.{i}.proj.0.bias", (E,))]
+        cin = E
+    s += [("svt.norm.weight", (1024,)), ("svt.norm.bias", (1024,))]
+    return s
+
+
+def make_twins_params(seed: int = 0, gain: float = 1.0) -> Dict[str, torch.Tensor]:
+    """fp32 CPU tensors for every Twins_CSC key: weights ~ N(0, gain^2 / fan_in), biases ~ N(0, 0.1^2) (non-zero qkv bias
+    matters: zero-padded window tokens act through it), LayerNorm weights 1 + 0.1 N."""
+    out: Dict[str, torch.Tensor] = {}
+    for key, shape in twins_param_shapes():
+        if ".norm" in key and key.endswith("weight"):
+            t = 1.0 + randn(seed, key, shape, 0.1)
+        elif key.endswith("bias"):
+            t = randn(seed, key, shape, 0.1)
+        else:
+            t = randn(seed, key, shape, gain / np.sqrt(int(np.prod(shape[1:]))))
+        out[key] = t
+    return out

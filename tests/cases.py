@@ -91,3 +91,13 @@ def interp_inputs(tag):
     points outside the image (dropped by the reference's `valid` mask)."""
     seed, h, w, scale = INTERP_CASES[tag]
     return syn.randn(seed, "interp.flow", (2, h, w), scale)
+
+
+TWINS_CASES = {"twins_a": (1, 4, 64, 96, 91), "twins_b": (2, 3, 40, 72, 92)}      # B, T, H, W, seed (token grids not multiples of 7)
+
+
+def twins_inputs(tag):
+    """Normalised frames [B,T,3,H,W] in [-1,1] and the encoder's synthetic parameters."""
+    B, T, H, W, seed = TWINS_CASES[tag]
+    x = torch.tanh(syn.randn(seed, "twins.x", (B, T, 3, H, W)))
+    return syn.make_twins_params(seed), x

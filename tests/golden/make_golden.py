@@ -83,6 +83,107 @@ class _DropPath(nn.Identity):
         super().__init__()
 
 
+# ---- timm.models.twins stand-in (published semantics of timm/models/twins.py; own code) ------------------------------------
+class _LocallyGroupedAttn(nn.Module):
+    def __init__(self, dim, num_heads=8, attn_drop=0.0, proj_drop=0.0, ws=1):
+        super().__init__()
+        assert ws != 1 and dim % num_heads == 0
+        self.dim, self.num_heads, self.ws = dim, num_heads, ws
+        self.scale = (dim // num_heads) ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3, bias=True)
+        self.proj = nn.Linear(dim, dim)
+
+    def forward(self, x, size):
+        import torch.nn.functional as F
+        B, N, C = x.shape
+        H, W = size
+        x = x.view(B, H, W, C)
+        pad_r = (self.ws - W % self.ws) % self.ws
+        pad_b = (self.ws - H % self.ws) % self.ws
+        x = F.pad(x, (0, 0, 0, pad_r, 0, pad_b))
+        _, Hp, Wp, _ = x.shape
+        _h, _w = Hp // self.ws, Wp // self.ws
+        x = x.reshape(B, _h, self.ws, _w, self.ws, C).transpose(2, 3)
+        qkv = self.qkv(x).reshape(B, _h * _w, self.ws * self.ws, 3, self.num_heads, C // self.num_heads).permute(3, 0, 1, 4, 2, 5)
+        q, k, v = qkv.unbind(0)
+        attn = ((q * self.scale) @ k.transpose(-2, -1)).softmax(dim=-1)
+        x = (attn @ v).transpose(2, 3).reshape(B, _h, _w, self.ws, self.ws, C)
+        x = x.transpose(2, 3).reshape(B, _h * self.ws, _w * self.ws, C)
+        if pad_r > 0 or pad_b > 0:
+            x = x[:, :H, :W, :].contiguous()
+        return self.proj(x.reshape(B, N, C))
+
+
+class _GlobalSubSampleAttn(nn.Module):
+    def __init__(self, dim, num_heads=8, attn_drop=0.0, proj_drop=0.0, sr_ratio=1):
+        super().__init__()
+        self.dim, self.num_heads, self.sr_ratio = dim, num_heads, sr_ratio
+        self.scale = (dim // num_heads) ** -0.5
+        self.q = nn.Linear(dim, dim, bias=True)
+        self.kv = nn.Linear(dim, dim * 2, bias=True)
+        self.proj = nn.Linear(dim, dim)
+        if sr_ratio > 1:
+            self.sr = nn.Conv2d(dim, dim, kernel_size=sr_ratio, stride=sr_ratio)
+            self.norm = nn.LayerNorm(dim)
+        else:
+            self.sr = self.norm = None
+
+    def forward(self, x, size):
+        B, N, C = x.shape
+        q = self.q(x).reshape(B, N, self.num_heads, C // self.num_heads).permute(0, 2, 1, 3)
+        if self.sr is not None:
+            x = x.permute(0, 2, 1).reshape(B, C, *size)
+            x = self.sr(x).reshape(B, C, -1).permute(0, 2, 1)
+            x = self.norm(x)
+        kv = self.kv(x).reshape(B, -1, 2, self.num_heads, C // self.num_heads).permute(2, 0, 3, 1, 4)
+        k, v = kv.unbind(0)
+        attn = ((q * self.scale) @ k.transpose(-2, -1)).softmax(dim=-1)
+        return self.proj((attn @ v).transpose(1, 2).reshape(B, N, C))
+
+
+class _TwinsBlock(nn.Module):
+    def __init__(self, dim, num_heads, mlp_ratio, sr_ratio, ws):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim, eps=1e-6)
+        self.attn = (_GlobalSubSampleAttn(dim, num_heads, 0.0, 0.0, sr_ratio) if ws == 1
+                     else _LocallyGroupedAttn(dim, num_heads, 0.0, 0.0, ws))
+        self.norm2 = nn.LayerNorm(dim, eps=1e-6)
+        self.mlp = _TimmMlp(dim, int(dim * mlp_ratio))
+
+    def forward(self, x, size):
+        x = x + self.attn(self.norm1(x), size)
+        return x + self.mlp(self.norm2(x))
+
+
+class _PosConv(nn.Module):
+    def __init__(self, in_chans, embed_dim):
+        super().__init__()
+        self.proj = nn.Sequential(nn.Conv2d(in_chans, embed_dim, 3, 1, 1, bias=True, groups=embed_dim))
+
+    def forward(self, x, size):
+        B, N, C = x.shape
+        feat = x.transpose(1, 2).view(B, C, *size)
+        return (self.proj(feat) + feat).flatten(2).transpose(1, 2)
+
+
+class _TwinsSvtLarge(nn.Module):
+    """What `timm.create_model('twins_svt_large')` returns, as far as twins_csc.py touches it: four stages of
+    patch_embeds / pos_drops / blocks / pos_block, a final norm and a head (stages 3-4 and the head are deleted by the
+    reference, twins_csc.py:52-57, so they are placeholders here)."""
+
+    def __init__(self):
+        super().__init__()
+        dims, heads, depths, srs = [128, 256, 512, 1024], [4, 8, 16, 32], [2, 2, 18, 2], [8, 4, 2, 1]
+        self.patch_embeds = nn.ModuleList([nn.Identity() for _ in dims])          # replaced by the reference (:42-47)
+        self.pos_drops = nn.ModuleList([nn.Dropout(p=0.0) for _ in dims])
+        self.blocks = nn.ModuleList([
+            nn.ModuleList([_TwinsBlock(dims[k], heads[k], 4, srs[k], 1 if i % 2 == 1 else 7) for i in range(depths[k])])
+            if k < 2 else nn.ModuleList() for k in range(4)])
+        self.pos_block = nn.ModuleList([_PosConv(d, d) if k < 2 else nn.Identity() for k, d in enumerate(dims)])
+        self.norm = nn.LayerNorm(1024, eps=1e-6)
+        self.head = nn.Linear(1024, 1000)
+
+
 class InjectEncoder(nn.Module):
     """Stand-in encoder: ignores pixel values, returns the tensor stored in ``.features``
     (sliced to the number of frames it is called with)."""
@@ -96,8 +197,15 @@ class InjectEncoder(nn.Module):
 
 
 def install_stubs():
-    _module("timm")
+    timm_mod = _module("timm")
+
+    def create_model(name, pretrained=False, **kw):
+        assert name == "twins_svt_large" and not pretrained
+        return _TwinsSvtLarge()
+    timm_mod.create_model = create_model
     _module("timm.models")
+    tw = _module("timm.models.twins")
+    tw.GlobalSubSampleAttn, tw.LocallyGroupedAttn = _GlobalSubSampleAttn, _LocallyGroupedAttn
     vt = _module("timm.models.vision_transformer")
     vt.Attention = _TimmAttention
     for name in ("timm.layers", "timm.models.layers"):
@@ -201,6 +309,18 @@ def main():
         # ---- f4 forward_interpolate (scipy griddata nearest; warm start of the next clip) -------------
         for tag in cases.INTERP_CASES:
             save(tag, out=ref_utils.forward_interpolate(cases.interp_inputs(tag)))
+
+        # ---- f1 Twins_CSC encoder: the reference's PatchEmbed-over-(T H) and stage loop over the timm stand-in ----
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("ref_twins_csc", os.path.join(REF, "core", "encoders", "twins_csc.py"))
+        ref_twins = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(ref_twins)
+        for tag in cases.TWINS_CASES:
+            P, x = cases.twins_inputs(tag)
+            enc = ref_twins.Twins_CSC(pretrained=False)
+            enc.load_state_dict(dict(P), strict=True)            # key names / shapes of the checkpoint contract
+            enc.eval()
+            save(tag, out=enc(x))
 
         # ---- a12 full forward through SKFlow_MF8.forward (config-1 style plumbing) -----------
         for tag, (B, T, H, W, iters, seed, use_init) in cases.FORWARD_CASES.items():

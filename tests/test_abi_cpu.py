@@ -106,3 +106,30 @@ def test_input_padder_matches_reference_formula():
     (y,) = p.pad(x)
     assert y.shape[-2:] == (440, 1024) and p._pad == [0, 0, 2, 2]
     assert p.unpad(y).shape == x.shape
+
+
+def test_full_checkpoint_contract_with_twins_encoder(tmp_path):
+    """f1: with the Twins_CSC encoder the model exposes the reference's COMPLETE state dict -- fnet.svt.* and cnet.svt.*
+    (74 keys each: first two twins_svt_large stages + the surviving final norm, twins_csc.py:40-57) next to att.* and
+    update_block.* -- and StreamFlowT4(ckpt) loads a DataParallel-style checkpoint file strictly (demo.py:388-389)."""
+    import streamflow_amd as sfa
+    from streamflow_amd import synthetic as syn
+    hot = syn.make_params(0, 4)
+    enc = syn.make_twins_params(1)
+    assert len(enc) == 74 and enc["svt.blocks.0.1.attn.sr.weight"].shape == (128, 128, 8, 8)
+    assert enc["svt.blocks.1.0.attn.qkv.bias"].shape == (768,) and enc["svt.norm.weight"].shape == (1024,)
+    sd = dict(hot)
+    sd.update({"fnet." + k: v for k, v in enc.items()})
+    sd.update({"cnet." + k: v + 0.0 for k, v in enc.items()})
+    m = sfa.SKFlow_MF8(sfa.default_args(T=4))                      # default encoder = Twins_CSC
+    assert set(m.state_dict()) == set(sd)
+    m.load_state_dict(sd, strict=True)
+    path = tmp_path / "streamflow.pth"
+    torch.save({"model": {"module." + k: v for k, v in sd.items()}}, path)
+    t4 = sfa.StreamFlowT4(str(path))
+    assert torch.equal(t4.state_dict()["cnet.svt.pos_block.1.proj.0.weight"], sd["cnet.svt.pos_block.1.proj.0.weight"])
+    bad = dict(sd)
+    bad.pop("fnet.svt.blocks.0.0.attn.qkv.bias")
+    torch.save(bad, path)
+    with pytest.raises(RuntimeError, match="fnet.svt.blocks.0.0.attn.qkv.bias"):
+        sfa.StreamFlowT4(str(path))

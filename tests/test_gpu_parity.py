@@ -602,3 +602,48 @@ def test_bench_two_ranks_self_launched(dev):
     # value = flow fields of ALL ranks / max-over-ranks time
     assert abs(d["value"] - 2 * 2 * 3 * 2 / (d["ms_per_step"] * 2 / 1e3)) / d["value"] < 1e-6
     assert "cpu_baseline" not in d                       # rank 0 at N = 1 only
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", list(cases.TWINS_CASES))
+def test_twins_csc_encoder_vs_reference(golden, dev, tag, precision):
+    """f1: the Twins_CSC encoder on the HIP kernels (sf_gemm for every Linear / strided conv, sf_layernorm_cm,
+    sf_window_attn, sf_subsample_attn, sf_dwconv3x3_res) against the reference's Twins_CSC.forward output (golden:
+    the reference's PatchEmbed-over-(T H) and stage loop executed over the timm stand-in) and against the CPU oracle."""
+    from oracle import twins_oracle as two
+    from streamflow_amd.encoders import Twins_CSC
+    P, x = cases.twins_inputs(tag)
+    enc = Twins_CSC().to(dev)
+    enc.load_state_dict(dict(P), strict=True)
+    out = enc(x.to(dev))
+    B, T, H, W, _ = cases.TWINS_CASES[tag]
+    assert out.shape == (B, T, 256, H // 8, W // 8) and out.is_cuda
+    close(out, golden(tag)["out"], 5e-4, 2e-4, what=tag + " vs reference")
+    close(out, two.twins_csc_forward(x, P), 5e-4, 2e-4, what=tag + " vs oracle")
+
+
+@pytest.mark.gpu
+def test_real_frames_end_to_end_with_twins_encoder(dev):
+    """No stand-in anywhere: frames in 0..255 -> Twins_CSC fnet / cnet -> refinement loop -> flows, through the
+    reference's SKFlow_MF8 signature; against the CPU oracles chained the same way (encoder oracle -> hot-path oracle)."""
+    from oracle import streamflow_oracle as orc, twins_oracle as two
+    from streamflow_amd import synthetic as syn
+    from streamflow_amd.model import SKFlow_MF8, default_args
+    B, T, H, W, iters = 1, 4, 128, 192, 4
+    hot, ef, ec = syn.make_params(21, T), syn.make_twins_params(22), syn.make_twins_params(23)
+    sd = dict(hot)
+    sd.update({"fnet." + k: v for k, v in ef.items()})
+    sd.update({"cnet." + k: v for k, v in ec.items()})
+    model = SKFlow_MF8(default_args(T=T)).to(dev)
+    model.load_state_dict(sd, strict=True)
+    frames = [(syn.randn(24, f"frame{t}", (B, 3, H, W)).sigmoid() * 255.0) for t in range(T)]
+    ups = model([f.to(dev) for f in frames], iters=iters, test_mode=True)
+    imgs = 2 * (torch.stack(frames, dim=1) / 255.0) - 1.0
+    fmaps = two.twins_csc_forward(imgs, ef)
+    cnets = two.twins_csc_forward(imgs[:, :-1], ec)
+    ups_o, _ = orc.hotpath_forward(fmaps, cnets, hot, iters)
+    assert len(ups) == T - 1 and ups[0].shape == (B, 2, H, W)
+    for i in range(T - 1):
+        e = orc.epe(ups[i].cpu(), ups_o[i])
+        print(f"real frames -> Twins_CSC -> loop, pair {i}: EPE vs chained oracles = {e:.3e}")
+        assert e <= 1e-3, (i, e)

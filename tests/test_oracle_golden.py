@@ -120,3 +120,17 @@ def test_forward_interpolate(golden, tag):
     """f4: bit-exact against the reference's scipy griddata result (values are copies of input flow entries)."""
     out = orc.forward_interpolate(cases.interp_inputs(tag))
     assert torch.equal(out, torch.from_numpy(golden(tag)["out"]))
+
+
+@pytest.mark.parametrize("tag", list(cases.TWINS_CASES))
+def test_twins_csc_encoder(golden, tag):
+    """f1: the restated Twins_CSC encoder against the reference's Twins_CSC.forward executed over the timm stand-in
+    (token grids 64x24, 30x18 / 15x9: none a multiple of the 7x7 window, so the zero-padded window tokens matter)."""
+    from oracle import twins_oracle as two
+    P, x = cases.twins_inputs(tag)
+    out = two.twins_csc_forward(x, P)
+    g = golden(tag)["out"]
+    B, T, H, W, _ = cases.TWINS_CASES[tag]
+    assert tuple(out.shape) == g.shape == (B, T, 256, H // 8, W // 8)
+    assert np.abs(g).mean() > 0.1
+    close(out, g, 2e-4, 1e-4)
