@@ -168,9 +168,17 @@ def main():
     ap.add_argument("--all-masks", action="store_true",
                     help="run the mask head every iteration as the reference literally does (outputs identical; "
                          "the default skips the 14 mask heads whose results test_mode discards)")
-    ap.add_argument("--precision", default="f16x3", choices=["f16x3", "fp32", "f16x2"],
-                    help="f16x3: split-fp16 MFMA with fp32 accumulation (fp32-class accuracy); fp32: exact fp32 MFMA")
-    ap.add_argument("--corr-dtype", default="f16", choices=["f16", "f32"],
+    ap.add_argument("--preset", default=None, choices=["config2_fp16", "fp32_class"],
+                    help="named arithmetic configuration (streamflow_amd/presets.py); default config2_fp16 = BASELINE.json "
+                         "configuration 2 ('bf16'): activations fp16 into split-precision weights, fp16 correlation "
+                         "volumes, fused fp16 GMA aggregation, fp32 accumulation everywhere.  fp32_class = the library "
+                         "default (split precision everywhere, fp32 volumes).  --precision / --corr-dtype / --gma override")
+    ap.add_argument("--precision", default=None, choices=["f16x3", "fp32", "f16x2"],
+                    help="f16x3: split-fp16 MFMA with fp32 accumulation (fp32-class accuracy); fp32: exact fp32 MFMA; "
+                         "f16x2: weights split, activations rounded once to fp16")
+    ap.add_argument("--gma", default=None, choices=["auto", "matrix", "flash"], help="GMA aggregation path (engine gma_mode)")
+    ap.add_argument("--flash-qkp", type=int, default=None, choices=[1, 2, 3], help="MFMA products per logit of the fused GMA kernel")
+    ap.add_argument("--corr-dtype", default=None, choices=["f16", "f32"],
                     help="storage of the correlation pyramids: f16 = fp16 cells built with single f16 MFMA products "
                          "(BASELINE.json config 2: 'bf16 corr build+lookup'); f32 = fp32 cells as the reference keeps "
                          "them, built in --precision arithmetic")
@@ -219,8 +227,20 @@ def main():
                 os.dup2(keep, 1)
                 os.close(keep)
 
-    from streamflow_amd import ops, synthetic as syn
+    from streamflow_amd import ops, presets, synthetic as syn
     from streamflow_amd.engine import HotPathEngine
+    cfg = presets.engine_kwargs(args.preset or presets.BENCH_PRESET)
+    if args.precision:
+        cfg["precision"] = args.precision
+    if args.corr_dtype:
+        cfg["corr_dtype"] = args.corr_dtype
+    if args.gma:
+        cfg["gma_mode"] = args.gma
+    if args.flash_qkp:
+        cfg["flash_qk_products"] = args.flash_qkp
+    if cfg["precision"] == "fp32" and cfg["gma_mode"] == "flash":
+        cfg["gma_mode"] = "auto"                       # the exact fp32 mode keeps the materialised attention path
+    args.precision, args.corr_dtype = cfg["precision"], cfg["corr_dtype"]
 
     H, W, T, iters = WORKLOADS[args.workload]
     h, w, B = H // 8, W // 8, args.clips
@@ -228,8 +248,7 @@ def main():
     params = syn.make_params(0, T)
     fmaps_c, cnets_c = syn.make_features(1000 + rank, B, T, h, w)
     fmaps, cnets = fmaps_c.to(dev), cnets_c.to(dev)
-    eng = HotPathEngine(params, device=dev, T=T, use_graph=not args.no_graph, precision=args.precision,
-                        corr_dtype=args.corr_dtype)
+    eng = HotPathEngine(params, device=dev, T=T, use_graph=not args.no_graph, **cfg)
     if args.serial_branches:
         eng.parallel_branches = False
 
@@ -265,8 +284,11 @@ def main():
                    "clips_per_step_all_gpus": world * B,
                    "flow_fields_per_clip": pairs, "feature_grid": [h, w], "parallelism": f"replicas{world}",
                    "hip_graph": not args.no_graph, "mask_head_every_iteration": bool(args.all_masks),
+                   "preset": args.preset or presets.BENCH_PRESET,
                    "corr_volume": {"f16": "fp16 cells, single f16 MFMA product, fp32 accumulate",
                                    "f32": "fp32 cells"}[args.corr_dtype],
+                   "gma": f"{eng.gma_mode}" + (f" (fused recompute, {eng.flash_qk_products} MFMA product(s) per logit)"
+                                                if eng.gma_mode == "flash" else ""),
                    "precision": {"fp32": "exact fp32 (v_mfma_f32_32x32x2_f32)",
                                  "f16x3": "split fp16x3 (x=hi+lo, 3x v_mfma_f32_32x32x16_f16, fp32 accumulate)",
                                  "f16x2": "weights hi+lo fp16, activations fp16 (2x v_mfma_f32_32x32x16_f16)"}[args.precision]},
@@ -274,8 +296,7 @@ def main():
 
     if rank == 0 and not args.no_kernel_breakdown:
         # instrumented eager pass: HIP events around every launch on the launch stream
-        eager = HotPathEngine(params, device=dev, T=T, use_graph=False, precision=args.precision,
-                              corr_dtype=args.corr_dtype)
+        eager = HotPathEngine(params, device=dev, T=T, use_graph=False, **cfg)
         eager._plans = eng._plans                       # reuse buffers
         eager.parallel_branches = False                 # serial launches: clean per-kernel durations
         ops.PROFILE_SHAPES = args.gemm_shapes
@@ -368,6 +389,28 @@ def main():
                                    "unit": "px", "iters": iters, "clip": last, "clips_in_launch": B,
                                    "note": "max over the pairs of the mean EPE, HIP path (the timed batched launch "
                                            "sequence, last clip of the batch) vs CPU oracle, full shape, all iterations"}
+
+    if rank == 0 and world == 1 and not args.no_kernel_breakdown and cfg == presets.engine_kwargs(presets.BENCH_PRESET):
+        # the same workload in the library's fp32-class arithmetic (split precision everywhere, fp32 volumes), so that
+        # both named configurations are on record from one run on one box
+        try:
+            ref_eng = HotPathEngine(params, device=dev, T=T, use_graph=not args.no_graph, **presets.engine_kwargs("fp32_class"))
+            for _ in range(2):
+                ref_eng.forward(fmaps, cnets, iters=iters, all_masks=args.all_masks)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                ref_eng.forward(fmaps, cnets, iters=iters, all_masks=args.all_masks)
+            torch.cuda.synchronize()
+            dtr = (time.perf_counter() - t0) / 5
+            result["fp32_class_mode"] = {"value": B * pairs / dtr, "unit": "flow-fields/s", "ms_per_step": 1e3 * dtr,
+                                         "config": presets.engine_kwargs("fp32_class"),
+                                         "note": "same workload, split precision f16x3 in every contraction, fp32 volumes, "
+                                                 "materialised fp16 attention matrix (EPE vs oracle ~2e-5 px)"}
+            del ref_eng
+            torch.cuda.empty_cache()
+        except RuntimeError as e:
+            result["fp32_class_mode"] = {"error": str(e)[:200]}
 
     if rank == 0 and world == 1 and args.clips != 1 and not args.no_kernel_breakdown:
         # single-clip latency: the same engine and kernels with one clip per launch (tails and launch gaps show)

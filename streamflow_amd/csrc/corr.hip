@@ -46,6 +46,9 @@ struct BuildArgs {
     // a block stay in the XCD's L2 while all m-tiles stream past them (np = patches per image, mt = m-tiles)
     int np, mt, pblk;
     int vec_store;               // w % 4 == 0 and 16-byte aligned level bases: transposed 16-byte epilogue stores
+#ifdef SF_CORR_TIMERS
+    long long* ts;               // SF_CORR_TS_BUF: per-workgroup phase timestamps (tools/corr_one.py)
+#endif
 };
 
 struct TileId { int img, m_tile, patch; };
@@ -557,6 +560,10 @@ template <bool kVec>
 __global__ __launch_bounds__(kThreads, 3) void corr_build_f16_kernel(const BuildArgs g, const char* ws, int Dp) {
     using namespace sf_split;
     __shared__ __attribute__((aligned(1024))) char smem[2 * FSTAGE];
+#ifdef SF_CORR_TIMERS
+    const long long ts0 = __builtin_readcyclecounter();
+    const long long rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int khalf = lane >> 5, l31 = lane & 31;
@@ -610,9 +617,19 @@ __global__ __launch_bounds__(kThreads, 3) void corr_build_f16_kernel(const Build
             }
         }
     }
+#ifdef SF_CORR_TIMERS
+    const long long ts1 = __builtin_readcyclecounter();
+#endif
     if (kVec) __syncthreads();                                   // the stage buffers become the transpose scratch
     pyramid_epilogue<_Float16, kVec>(g, acc, b, pair, m0, wave, py0, px0, lane,
                                      reinterpret_cast<float*>(smem) + wave * 2 * kTrTile);
+#ifdef SF_CORR_TIMERS
+    if (g.ts && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        long long* d = g.ts + (int64_t)blockIdx.x * 8;
+        d[0] = ts0; d[1] = ts1; d[2] = __builtin_readcyclecounter(); d[3] = rt0; d[4] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -853,6 +870,9 @@ extern "C" int sf_corr_build_pyramid(const float* f1, const float* f2, int64_t f
               ((reinterpret_cast<uintptr_t>(f2) & 15) == 0);
     dim3 grid(g.pcols * sf::ceil_div(h, PR), sf::ceil_div(g.N, BM), B * pairs);
     g.np = (int)grid.x; g.mt = (int)grid.y;
+#ifdef SF_CORR_TIMERS
+    g.ts = getenv("SF_CORR_TS_BUF") ? (long long*)strtoull(getenv("SF_CORR_TS_BUF"), nullptr, 0) : nullptr;
+#endif
     {
         bool al = (w % 4 == 0);
         for (int l = 0; l < 4; ++l) {

@@ -381,7 +381,7 @@ int gemm_split_dispatch_inner(const SfGemm& g, hipStream_t st);
 
 int gemm_split_dispatch(const SfGemm& g, hipStream_t st) {
     // automatic split-K through caller-provided scratch
-    if (g.k_splits == 0 && g.split_ws) {
+    if (g.k_splits == 0 && g.split_ws && !g.conv3x3) {            // (the implicit 3x3 conv has no split-K form)
         const int ks = auto_splits(g.M, g.N, g.K, g.batch);
         const int64_t slab = (int64_t)g.batch * g.M * g.N;
         if (ks > 1 && g.split_ws_floats >= ks * slab) {

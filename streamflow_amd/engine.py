@@ -190,12 +190,17 @@ class HotPathEngine:
     """`forward(fmaps, cnets, iters)` == reference loop in test_mode (streamflow.py:110-147)."""
 
     def __init__(self, state_dict: Dict[str, torch.Tensor], device="cuda:0", T: Optional[int] = None,
-                 use_graph: bool = False, precision: Optional[str] = None, corr_dtype: str = "f32"):
+                 use_graph: bool = False, precision: Optional[str] = None, corr_dtype: str = "f32",
+                 gma_mode: Optional[str] = None, flash_qk_products: Optional[int] = None):
         """precision: 'f16x3' (split fp16, fp32-class accuracy, default), 'fp32' (exact fp32 MFMA) or 'f16x2'
         (weights split, activations rounded to fp16: ~1e-4 px EPE, faster);
         None = the package-wide setting (streamflow_amd.ops.PRECISION).
         corr_dtype: 'f32' keeps the correlation pyramids in fp32 as the reference does (corr.py:13, arithmetic =
-        `precision`); 'f16' stores them as fp16 and builds them with single f16 MFMA products (SF_PRECISION_F16)."""
+        `precision`); 'f16' stores them as fp16 and builds them with single f16 MFMA products (SF_PRECISION_F16).
+        gma_mode: 'matrix' = attention matrix materialised once per clip (gma.py), 'flash' = fused recompute kernel every
+        iteration (demo.py:235-258), 'auto' (default) = flash exactly when the matrix cannot be kept (high resolution).
+        flash_qk_products: MFMA products per logit of the fused kernel (3 = split precision, 1 = fp16 q and k).
+        See streamflow_amd.presets for the two named configurations."""
         _lib.load()
         self.precision = ops.PRECISION if precision is None else ops._PRECISION_NAMES[precision]
         if corr_dtype not in ("f32", "f16"):
@@ -214,11 +219,14 @@ class HotPathEngine:
         # GMA aggregation: 'matrix' = attention matrix materialised once (gma.py), chunked recompute when it cannot be
         # kept; 'flash' = fused recompute kernel every iteration (demo.py:235-258); 'auto' = flash exactly when the
         # matrix would have to be chunked (high resolution)
-        self.gma_mode = os.environ.get("SF_GMA_MODE", "auto")
+        self.gma_mode = gma_mode or os.environ.get("SF_GMA_MODE", "auto")
         if self.gma_mode not in ("auto", "matrix", "flash"):
-            raise RuntimeError(f"SF_GMA_MODE must be auto, matrix or flash, got {self.gma_mode!r}")
+            raise RuntimeError(f"gma_mode must be auto, matrix or flash, got {self.gma_mode!r}")
         # MFMA products per logit of the fused kernel: 3 = split precision (fp32-class), 2 / 1 = k / q and k in fp16
-        self.flash_qk_products = int(os.environ.get("SF_FLASH_QKP", "0")) or (2 if self.precision == ops.PRECISION_F16X2 else 3)
+        self.flash_qk_products = (int(flash_qk_products or 0) or int(os.environ.get("SF_FLASH_QKP", "0"))
+                                  or (2 if self.precision == ops.PRECISION_F16X2 else 3))
+        if self.flash_qk_products not in (1, 2, 3):
+            raise RuntimeError(f"flash_qk_products must be 1, 2 or 3, got {self.flash_qk_products}")
         self._side = torch.cuda.Stream(device=self.device)
         self.W = HotPathWeights(state_dict, self.device, T)
         self.use_graph = use_graph
@@ -287,13 +295,26 @@ class HotPathEngine:
             if side is not main:
                 side.wait_stream(main)
 
+        @contextlib.contextmanager
+        def on_side():
+            # the automatic split-K scratch (ops.SPLIT_WS) is ONE buffer: only the main stream may use it while
+            # the two streams run concurrently
+            keep = ops.SPLIT_WS
+            if side is not main:
+                ops.SPLIT_WS = None
+            try:
+                with torch.cuda.stream(side):
+                    yield
+            finally:
+                ops.SPLIT_WS = keep
+
         def join():
             if side is not main:
                 main.wait_stream(side)
 
         # a9: motion encoder (update.py:329-339).  flow branch (convf1 -> convf2) on the side stream ...
         fork()
-        with torch.cuda.stream(side):
+        with on_side():
             ops.gemm(W.convf1, pl.flow, pl.f128, EPI_NONE)
             run_skblock(W.convf2, pl.f128, pl.cat256.slice(192, 256), pl.hid2, pl.xa2, pl.xb2, h, w)
         # ... while the main stream does a3 (correlation lookup for all pairs, streamflow.py:132) and the corr branch
@@ -304,7 +325,7 @@ class HotPathEngine:
         sk(W.conv, pl.cat256, pl.mf.slice(0, HDIM - 2))            # mf = cat(out, flow); flow rows kept by flow_update
         # a10: temporal transformer block over the T-1 tokens of each pixel (update.py:481-484,770), side stream
         fork()
-        with torch.cuda.stream(side):
+        with on_side():
             ops.layernorm_cm(pl.mf, W.ln1_w, W.ln1_b, pl.ln128)
             ops.gemm(W.qkv, pl.ln128, pl.qkv, EPI_NONE)
             ops.temporal_attn(pl.qkv, pl.att128, Bc, Pn, HDIM)

@@ -83,7 +83,9 @@ class SKFlow_MF8(nn.Module):
     @torch.no_grad()
     def forward(self, images: Sequence[torch.Tensor], iters: int = 12, flow_init=None, upsample: bool = True,
                 test_mode: bool = False):
-        """images: list of T tensors [B,3,H,W] with values in 0..255 (reference streamflow.py:95-100)."""
+        """images: list of T tensors [B,3,H,W] with values in 0..255 (reference streamflow.py:95-100).
+        `upsample` is part of the reference signature but is never read in its body (streamflow.py:95-149 always
+        upsamples); it is accepted and ignored here for the same reason."""
         imgs = torch.stack(list(images), dim=1)
         imgs = 2 * (imgs / 255.0) - 1.0
         return self._forward_normalised(imgs, iters, flow_init, test_mode)

@@ -8,6 +8,7 @@ reference) are just kernels writing into row slices of a wider buffer.
 from __future__ import annotations
 
 import ctypes as C
+import math
 from dataclasses import dataclass, replace
 from typing import Optional, Sequence
 
@@ -196,18 +197,28 @@ class PackedLinear:
         self.bias = None if bias is None else bias.detach().to(device=device, dtype=torch.float32).contiguous()
         self.conv3x3 = conv3x3
         # split-precision image: w = hi + lo (fp16 each) in k-octet planes [K padded to 32 / 8][M padded to 128][8], zero
-        # padded (SF_LAYOUT_SPLIT_F16): 16 bytes = one MFMA operand octet of one output row
+        # padded (SF_LAYOUT_SPLIT_F16): 16 bytes = one MFMA operand octet of one output row.
+        # The tensor is first scaled by a power of two so that max|w| lands in [1, 2): fp16 keeps 11 bits only for
+        # |x| >= 6.1e-5, so the lo part of an unscaled small weight (|w| < 0.12) would fall into fp16 subnormals
+        # (absolute spacing 6e-8) and a layer whose weights are all ~1e-3 would keep ~15 bits instead of ~21.  The
+        # scale is exact (power of two) and is undone in the epilogue: alpha' = alpha / s, bias' = bias * s.
         mp, kp = (self.M + 127) // 128 * 128, (self.K + 31) // 32 * 32
+        wmax = float(w2.abs().max()) if w2.numel() else 0.0
+        if not torch.isfinite(torch.tensor(wmax)):
+            raise RuntimeError("PackedLinear: non-finite weight")
+        self.split_scale = 2.0 ** min(14, max(-14, -math.floor(math.log2(wmax)))) if wmax > 0 else 1.0
         wm = torch.zeros(mp, kp, dtype=torch.float32, device=device)
-        wm[: self.M, : self.K] = w2.t()
+        wm[: self.M, : self.K] = w2.t() * self.split_scale
         hi = wm.to(torch.float16)
         lo = (wm - hi.float()).to(torch.float16)
         self.hi = hi.view(mp, kp // 8, 8).permute(1, 0, 2).contiguous()
         self.lo = lo.view(mp, kp // 8, 8).permute(1, 0, 2).contiguous()
         self.lda_h = mp
+        self.bias_split = None if self.bias is None else (self.bias * self.split_scale).contiguous()
+        # achieved split accuracy relative to the largest weight (reported, used by tests)
+        self.split_error = float(((hi.float() + lo.float()) - wm).abs().max() / max(wmax * self.split_scale, 1e-30))
 
 
-@on_tensor_device
 def gemm(A: PackedLinear, X: Planes, Y: Planes, epilogue: int = EPI_NONE, R: Optional[Planes] = None,
          dw_w: Optional[torch.Tensor] = None, dw_b: Optional[torch.Tensor] = None, alpha: float = 1.0,
          hw: Optional[Sequence[int]] = None) -> None:
@@ -226,6 +237,9 @@ def gemm(A: PackedLinear, X: Planes, Y: Planes, epilogue: int = EPI_NONE, R: Opt
     if prec != PRECISION_FP32:
         g.a_layout = LAYOUT_SPLIT_F16
         g.A_hi, g.A_lo, g.lda_h = A.hi.data_ptr(), A.lo.data_ptr(), A.lda_h
+        # the split image holds split_scale * W: C = alpha/s * (s W X + s b)
+        alpha = alpha / A.split_scale
+        g.bias = None if A.bias_split is None else A.bias_split.data_ptr()
     g.b_group, g.b_group_stride = X.group, X.group_stride
     if R is not None:
         assert R.rows == A.M and R.n_img == Y.n_img

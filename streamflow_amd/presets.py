@@ -1,0 +1,29 @@
+"""Named arithmetic configurations of the hot path (one place, used by bench.py, the tests and the docs).
+
+``fp32_class`` -- the library default.  Every contraction in split precision (x = hi + lo in fp16, three MFMA products,
+    fp32 accumulation: ~2^-20 relative), correlation pyramids kept in fp32 as the reference keeps them (corr.py:13),
+    GMA attention matrix materialised (fused recompute only where the matrix cannot be kept).  Flows agree with the
+    fp32 reference to ~1e-5 px.
+``config2_fp16`` -- BASELINE.json configuration 2 ("Sintel-shape 436x1024 T=4 iters=15 bf16"): the arithmetic class of
+    the reference's own deployment, which runs the whole network under fp16 autocast (evaluate_mf.py:1106,
+    demo.py:427-456), but with fp32 accumulation everywhere and split-precision WEIGHTS: activations are rounded once
+    to fp16 when they enter a contraction (f16x2), correlation volumes are fp16 cells built with single f16 products,
+    the GMA aggregation is the fused recompute kernel with fp16 q / k / v (what flash_attn_func computes in the
+    reference's demo).  ~1.3e-4 px EPE against the fp32 oracle at the headline shape after 15 iterations: 8x inside
+    the 1e-3 budget.
+"""
+from __future__ import annotations
+
+from typing import Dict
+
+PRESETS: Dict[str, Dict[str, object]] = {
+    "fp32_class": dict(precision="f16x3", corr_dtype="f32", gma_mode="auto", flash_qk_products=3),
+    "config2_fp16": dict(precision="f16x2", corr_dtype="f16", gma_mode="flash", flash_qk_products=1),
+}
+BENCH_PRESET = "config2_fp16"
+
+
+def engine_kwargs(name: str) -> Dict[str, object]:
+    if name not in PRESETS:
+        raise RuntimeError(f"unknown preset {name!r} (have {list(PRESETS)})")
+    return dict(PRESETS[name])

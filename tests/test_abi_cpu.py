@@ -92,8 +92,15 @@ def test_packed_linear_layout():
     assert torch.equal(p.wt[:5, :6], w.view(6, 5).t()) and p.wt[:, 6:].abs().sum() == 0 and p.wt[5:].abs().sum() == 0
     # split image: k-octet planes [K up to 32 / 8][M up to 128][8]; element (m, k) at [k // 8, m, k % 8]
     assert tuple(p.hi.shape) == (4, 128, 8) and p.lda_h == 128
-    full = (p.hi.float() + p.lo.float()).permute(1, 0, 2).reshape(128, 32)
+    # the image holds split_scale * W (power of two, max|w| scaled into [1, 2)); undone by alpha / bias in ops.gemm
+    assert p.split_scale == 2.0 ** -4 and p.split_error == 0.0
+    full = (p.hi.float() + p.lo.float()).permute(1, 0, 2).reshape(128, 32) / p.split_scale
     assert torch.equal(full[:6, :5], w.view(6, 5)) and full[6:].abs().sum() == 0 and full[:, 5:].abs().sum() == 0
+    # a layer of tiny weights keeps ~21 bits after scaling (unscaled, its lo parts would be fp16 subnormals: ~15 bits)
+    tiny = PackedLinear(torch.randn(64, 96, 1, 1, generator=torch.Generator().manual_seed(0)) * 1e-3,
+                        torch.ones(64), "cpu")
+    assert tiny.split_scale >= 128 and tiny.split_error < 2.0 ** -20
+    assert torch.equal(tiny.bias_split, tiny.bias * tiny.split_scale)
     w3 = torch.randn(4, 3, 3, 3)
     p3 = PackedLinear(w3, None, "cpu", conv3x3=True)
     assert p3.K == 27 and p3.wt[(1 * 3 + 2) * 3 + 1, 2] == w3[2, 1, 1, 2]

@@ -157,3 +157,29 @@ def test_corr_fp16_volume_random_shapes(dev, seed):
     # and the fp16 path stays within fp16-storage distance of the exact fp32 volume
     exact = orc.corr_pyramid(f1, f2, 4)[0]
     assert (lv[0].float() - exact).abs().max().item() < 2e-3 * max(1.0, exact.abs().max().item())
+
+
+@pytest.mark.parametrize("wscale", [1e-3, 1.0, 1e3])
+def test_split_gemm_weight_magnitudes(dev, wscale):
+    """the fp16 (hi, lo) split loses bits when the lo part falls into fp16 subnormals (small weights) and
+    saturates above 65504.  Weights are therefore scaled by a per-tensor power of two before splitting (undone exactly in
+    the epilogue): the split GEMM must keep its ~2^-20 relative accuracy for layers of tiny and of huge weights."""
+    from streamflow_amd import ops
+    from streamflow_amd.ops import Planes, PackedLinear
+    g = torch.Generator().manual_seed(11)
+    M, K, P, n = 200, 160, 300, 2
+    Wt = torch.randn(M, K, generator=g) * wscale / K ** 0.5
+    bias = torch.randn(M, generator=g) * wscale * 0.1
+    X = torch.randn(n, K, P, generator=g)
+    A = PackedLinear(Wt.view(M, K, 1, 1), bias, dev)
+    Y = torch.full((n, M, P), float("nan"), device=dev)
+    prev = ops.set_precision("f16x3")
+    try:
+        ops.gemm(A, Planes.of(X.to(dev)), Planes.of(Y), ops.EPI_NONE, alpha=0.5)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_precision(prev)
+    ref = 0.5 * (torch.einsum("mk,nkp->nmp", Wt.double(), X.double()) + bias.double()[None, :, None])
+    err = (Y.double().cpu() - ref).abs().max().item() / ref.abs().max().item()
+    print(f"weights x {wscale:g}: split scale {A.split_scale:g}, split error {A.split_error:.1e}, max rel err {err:.2e}")
+    assert err < 3e-6, (wscale, err)

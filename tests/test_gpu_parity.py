@@ -241,29 +241,36 @@ def test_sintel_shape_vs_oracle(dev, precision):
         assert e <= 1e-3
 
 
-def test_headline_config_batched_vs_oracle(dev):
+_HEADLINE_ORACLE = {}
+
+
+@pytest.mark.parametrize("preset", ["config2_fp16", "fp32_class"])
+def test_headline_config_batched_vs_oracle(dev, preset):
     """BASELINE.json's headline configuration exactly as bench.py times it: 440x1024 (55x128 grid), T=4, ALL 15
-    iterations, 8 clips batched through every launch (the per-GPU share of config 4's batch 64), HIP-graph replay,
-    default precision.  The first and the LAST clip of the batch (image indices 0-2 and 21-23: the highest buffer
-    offsets of the 6 GB volume / attention allocations) are compared with the CPU oracle run on those clips alone."""
+    iterations, 8 clips batched through every launch (the per-GPU share of config 4's batch 64), HIP-graph replay, in
+    both named arithmetic configurations (streamflow_amd/presets.py: the bench default `config2_fp16` and the library
+    default `fp32_class`).  The first and the LAST clip of the batch (image indices 0-2 and 21-23: the highest buffer
+    offsets of the multi-GB volume / attention allocations) are compared with the CPU oracle run on those clips alone."""
     from oracle import streamflow_oracle as orc
-    from streamflow_amd import synthetic as syn
+    from streamflow_amd import presets, synthetic as syn
     from streamflow_amd.engine import HotPathEngine
     B, T, h, w, iters = 8, 4, 55, 128, 15
     P = syn.make_params(0, T)
     fmaps, cnets = syn.make_features(1000, B, T, h, w)
-    eng = HotPathEngine(P, device=dev, T=T, use_graph=True)
+    eng = HotPathEngine(P, device=dev, T=T, use_graph=True, **presets.engine_kwargs(preset))
     fd, cd = fmaps.to(dev), cnets.to(dev)
     eng.forward(fd, cd, iters=iters)                       # capture
     ups, low = eng.forward(fd, cd, iters=iters)            # replay
     ups = [u.cpu() for u in ups]
     assert all(torch.isfinite(u).all() for u in ups)
     for clip in (0, B - 1):
-        ups_o, _ = orc.hotpath_forward(fmaps[clip:clip + 1], cnets[clip:clip + 1], P, iters)
+        if clip not in _HEADLINE_ORACLE:                          # ~20 s of CPU per clip: shared by the two presets
+            _HEADLINE_ORACLE[clip] = orc.hotpath_forward(fmaps[clip:clip + 1], cnets[clip:clip + 1], P, iters)[0]
+        ups_o = _HEADLINE_ORACLE[clip]
         for i in range(T - 1):
             e = orc.epe(ups[i][clip:clip + 1], ups_o[i])
             mag = ups_o[i].norm(dim=1).mean().item()
-            print(f"headline config, clip {clip} of {B}, pair {i}: EPE vs oracle after {iters} iterations = {e:.3e} px "
+            print(f"headline config [{preset}], clip {clip} of {B}, pair {i}: EPE vs oracle after {iters} iterations = {e:.3e} px "
                   f"(mean |flow| {mag:.2f} px)")
             assert e <= 1e-3, (clip, i, e)
     # clips are independent: the same clip at another batch position must give the same flows
