@@ -188,8 +188,9 @@ int sf_softmax_rows(float* x, int64_t rows, int cols, void* out_f16, void* strea
  * y = gelu(x + dwconv(x) + b);  plane (img, c) of x is the [h][w] map at x + img*x_img_stride + c*h*w
  * (same for y with y_img_stride); wgt [C][K][K], bias [C].  x and y must not overlap.
  * precision SF_PRECISION_FP32: fp32 FMA stencil on the VALU.  Split precisions: every kernel row is a banded
- * Toeplitz GEMM on the matrix cores with (hi, lo) fp16 operands and fp32 accumulation (same arithmetic as sf_gemm's
- * SF_PRECISION_F16X3; F16X2 is treated as F16X3 here). */
+ * Toeplitz GEMM on the matrix cores with fp32 accumulation, weights always split (hi, lo); the activation is split too
+ * (SF_PRECISION_F16X3, three products) or rounded once to fp16 (SF_PRECISION_F16X2, two products; the residual x stays
+ * exact fp32) -- the same rules as sf_gemm. */
 int sf_dwconv_res_gelu(const float* x, int64_t x_img_stride, const float* wgt, const float* bias, float* y,
                        int64_t y_img_stride, int n_img, int C, int h, int w, int ksize, int precision, void* stream);
 
