@@ -96,9 +96,13 @@ enum { SF_LAYOUT_K_MAJOR = 0,   /* A[k*lda + m]   /  B[k*ldb + n]   (rows of k) 
                                     lda_h = M padded to 128 (zero padded): element (m,k) at ((k/8)*lda_h + m)*8 + k%8,
                                     w = hi + lo to ~22 bits.  16 bytes = one MFMA operand k-octet of one row, so a
                                     tile is moved to LDS by buffer_load ... lds without passing through registers */
-       SF_LAYOUT_F16_K_MINOR = 3 };/* B only, split precisions: B points to IEEE fp16 values B[n*ldb + k]
+       SF_LAYOUT_F16_K_MINOR = 3,  /* B only, split precisions: B points to IEEE fp16 values B[n*ldb + k]
                                     (ldb, strideB in halfs; ldb % 2 == 0); used as they are, no lo part:
                                     a*b = ah*b + al*b.  The stored attention matrix (sf_softmax_rows).   */
+       SF_LAYOUT_F16_K_MAJOR = 4 };/* B only, SF_PRECISION_F16X2 with a SPLIT_F16 A: IEEE fp16 rows B[k*ldb + n]
+                                    (ldb, strideB in halfs; N, ldb, strideB even) -- what a producing sf_gemm stores
+                                    with c_f16 = 1.  Bit-identical to handing the fp32 values over (F16X2 rounds a
+                                    B operand to fp16 on load), at half the bytes.                          */
 enum { SF_PRECISION_FP32 = 0,   /* exact fp32: v_mfma_f32_32x32x2_f32, k-ordered fmaf chain          */
        SF_PRECISION_F16X3 = 1,  /* split precision: x = hi+lo (fp16 each); a*b = ah*bh + ah*bl + al*bh
                                     on v_mfma_f32_32x32x16_f16 with fp32 accumulation (~2^-22 relative)  */
@@ -145,6 +149,9 @@ typedef struct SfGemm {
        and k_splits == 0, the library may split K on its own for small grids with deep K (F16X3 only): partial
        products go to the scratch and a second kernel applies bias / epilogue.  Results are deterministic. */
     float* split_ws; int64_t split_ws_floats;
+    /* c_f16 = 1 (split precisions, 16-byte-aligned C, N % 4 == 0, ldc % 4 == 0): C points to IEEE fp16 storage, results are
+       rounded to nearest and stored as halves (ldc, strideC in halves): the K-major fp16 operand of the next sf_gemm. */
+    int32_t c_f16;
 } SfGemm;
 
 /* floats of scratch that let sf_gemm auto-split a problem of this size (0 if it never would) */
@@ -188,9 +195,9 @@ int sf_softmax_rows(float* x, int64_t rows, int cols, void* out_f16, void* strea
  * y = gelu(x + dwconv(x) + b);  plane (img, c) of x is the [h][w] map at x + img*x_img_stride + c*h*w
  * (same for y with y_img_stride); wgt [C][K][K], bias [C].  x and y must not overlap.
  * precision SF_PRECISION_FP32: fp32 FMA stencil on the VALU.  Split precisions: every kernel row is a banded
- * Toeplitz GEMM on the matrix cores with fp32 accumulation, weights always split (hi, lo); the activation is split too
- * (SF_PRECISION_F16X3, three products) or rounded once to fp16 (SF_PRECISION_F16X2, two products; the residual x stays
- * exact fp32) -- the same rules as sf_gemm. */
+ * Toeplitz GEMM on the matrix cores with (hi, lo) fp16 operands and fp32 accumulation (same arithmetic as sf_gemm's
+ * SF_PRECISION_F16X3; F16X2 is treated as F16X3 here: a two-product form with one staged plane measured 12 % SLOWER,
+ * its exact residual has to be re-read from global memory). */
 int sf_dwconv_res_gelu(const float* x, int64_t x_img_stride, const float* wgt, const float* bias, float* y,
                        int64_t y_img_stride, int n_img, int C, int h, int w, int ksize, int precision, void* stream);
 

@@ -187,7 +187,10 @@ __global__ __launch_bounds__(256, (QKP == 3) ? 1 : 2) void gma_flash_kernel(cons
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[sub][r]);
         mx = fmaxf(mx, xor32(mx));
         const float m_new = fmaxf(m_run, mx);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        // the running maximum of a query stops growing after a few tiles: rescale the 64 accumulator registers only when
+        // some lane of the wave needs it (wave-uniform branch)
+        const bool grew = __any(m_new > m_run);
+        const float alpha = grew ? __builtin_amdgcn_exp2f(m_run - m_new) : 1.0f;
         m_run = m_new;
         float psum = 0.f;
         f16x8 pf[4];                                              // P^T as B operands: k-step kk = sub*2 + m
@@ -201,10 +204,12 @@ __global__ __launch_bounds__(256, (QKP == 3) ? 1 : 2) void gma_flash_kernel(cons
                 pf[sub * 2 + (r >> 3)][r & 7] = ph;
             }
         l_run = l_run * alpha + psum;
+        if (grew) {
 #pragma unroll
-        for (int td = 0; td < HD / 32; ++td)
+            for (int td = 0; td < HD / 32; ++td)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[td][r] *= alpha;
+                for (int r = 0; r < 16; ++r) o[td][r] *= alpha;
+        }
         // ---- O^T += V^T P^T ----
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {

@@ -143,10 +143,7 @@ struct DwmArgs {
     int vec_ok;       // rows are 16-byte aligned: float4 staging loads
 };
 
-// kXLo = true: x = hi + lo, three MFMA products (SF_PRECISION_F16X3).  kXLo = false (SF_PRECISION_F16X2): the activation is
-// rounded once to fp16 like every activation entering a contraction in that mode -- one staged plane, two products
-// (x_hi * w_lo + x_hi * w_hi), the exact fp32 residual is re-read from global memory (just staged: L2 hits).
-template <int KS, bool kXLo>
+template <int KS>
 __global__ __launch_bounds__(256, 2) void dwconv_mfma_kernel(const DwmArgs g) {
     using namespace sf_split;
     constexpr int R = KS / 2;
@@ -160,8 +157,8 @@ __global__ __launch_bounds__(256, 2) void dwconv_mfma_kernel(const DwmArgs g) {
     const int noct = (g.w16 + 16) / 8;                          // octets per staged row: columns -8 .. w16 + 7
     const int plane_bytes = rows_in * g.stride16 * 16;
     char* hi = lds;
-    char* lo = lds + plane_bytes;                               // (unused when !kXLo)
-    float* wz = reinterpret_cast<float*>(lds + (kXLo ? 2 : 1) * plane_bytes);
+    char* lo = lds + plane_bytes;
+    float* wz = reinterpret_cast<float*>(lds + 2 * plane_bytes);
 
     // ---- the channel's Toeplitz fragments -> registers --------------------------------------------------
     for (int i = tid; i < KS * WZ; i += 256) {
@@ -220,16 +217,9 @@ __global__ __launch_bounds__(256, 2) void dwconv_mfma_kernel(const DwmArgs g) {
 #pragma unroll
             for (int u = 0; u < FU; ++u) {
                 if (off[u] < 0) continue;
-                if (kXLo) {
-                    const Split8 s8 = split8(v[u]);
-                    *reinterpret_cast<f16x8*>(hi + off[u]) = s8.hi;
-                    *reinterpret_cast<f16x8*>(lo + off[u]) = s8.lo;
-                } else {
-                    f16x8 h8;
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) h8[i] = (_Float16)v[u][i];
-                    *reinterpret_cast<f16x8*>(hi + off[u]) = h8;
-                }
+                const Split8 s8 = split8(v[u]);
+                *reinterpret_cast<f16x8*>(hi + off[u]) = s8.hi;
+                *reinterpret_cast<f16x8*>(lo + off[u]) = s8.lo;
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -256,7 +246,7 @@ __global__ __launch_bounds__(256, 2) void dwconv_mfma_kernel(const DwmArgs g) {
 #pragma unroll
             for (int j = 0; j < TG; ++j) {
                 ah[0][j] = *reinterpret_cast<const f16x8*>(hi + offj[j]);
-                if (kXLo) al[0][j] = *reinterpret_cast<const f16x8*>(lo + offj[j]);
+                al[0][j] = *reinterpret_cast<const f16x8*>(lo + offj[j]);
             }
 #pragma unroll
             for (int ky = 0; ky < KS; ++ky) {
@@ -265,13 +255,11 @@ __global__ __launch_bounds__(256, 2) void dwconv_mfma_kernel(const DwmArgs g) {
 #pragma unroll
                     for (int j = 0; j < TG; ++j) {
                         ah[nxt][j] = *reinterpret_cast<const f16x8*>(hi + offj[j] + (ky + 1) * row_step);
-                        if (kXLo) al[nxt][j] = *reinterpret_cast<const f16x8*>(lo + offj[j] + (ky + 1) * row_step);
+                        al[nxt][j] = *reinterpret_cast<const f16x8*>(lo + offj[j] + (ky + 1) * row_step);
                     }
                 }
-                if (kXLo) {
 #pragma unroll
-                    for (int j = 0; j < TG; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[cur][j], bh[ky], acc[j], 0, 0, 0);
-                }
+                for (int j = 0; j < TG; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[cur][j], bh[ky], acc[j], 0, 0, 0);
 #pragma unroll
                 for (int j = 0; j < TG; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[cur][j], bl[ky], acc[j], 0, 0, 0);
 #pragma unroll
@@ -287,9 +275,8 @@ __global__ __launch_bounds__(256, 2) void dwconv_mfma_kernel(const DwmArgs g) {
                 for (int r = 0; r < 4; ++r) {
                     const bool ok = (gx0 + j * 16 < g.w) && (gy0 + r < g.h);
                     const int xo = xoff0 + r * row_step + min(j, ntx - 1 - tx0) * 32;
-                    float xv;
-                    if (kXLo) xv = (float)*reinterpret_cast<const _Float16*>(hi + xo) + (float)*reinterpret_cast<const _Float16*>(lo + xo);
-                    else xv = ok ? xp[(gy0 + r) * g.w + gx0 + j * 16] : 0.f;
+                    const float xv = (float)*reinterpret_cast<const _Float16*>(hi + xo) +
+                                     (float)*reinterpret_cast<const _Float16*>(lo + xo);
                     const float o = sf::gelu_erf(xv + (acc[j][r] + bv));
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), ry,
                                                           ok ? off0 + (r * g.w + j * 16) * 4 : (int)0x80000000u, 0, 0);
@@ -320,10 +307,9 @@ extern "C" int sf_dwconv_res_gelu(const float* x, int64_t x_img_stride, const fl
         // rows per strip: as many 16-row tiles as fit ~60 KB of LDS (two fp16 planes)
         const int h16 = sf::ceil_div(h, 16) * 16;
         int strip = h16;
-        const size_t planes = (precision == SF_PRECISION_F16X2) ? 1 : 2;
-        while (strip > 16 && planes * (strip + ksize - 1) * m.stride16 * 16 > 60 * 1024) strip -= 16;
+        while (strip > 16 && (size_t)2 * (strip + ksize - 1) * m.stride16 * 16 > 60 * 1024) strip -= 16;
         m.strip_h = strip;
-        const size_t lds = planes * (strip + ksize - 1) * m.stride16 * 16 + (size_t)ksize * 64 * sizeof(float);
+        const size_t lds = (size_t)2 * (strip + ksize - 1) * m.stride16 * 16 + (size_t)ksize * 64 * sizeof(float);
         SF_REQUIRE(lds <= 64 * 1024, "sf_dwconv_res_gelu: width %d too large for the matrix-core kernel", w);
         m.vec_ok = ((w & 3) == 0) && ((x_img_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
         // several images of a channel per workgroup (the Toeplitz fragments are built once), but keep >= ~2048 workgroups
@@ -334,10 +320,7 @@ extern "C" int sf_dwconv_res_gelu(const float* x, int64_t x_img_stride, const fl
         m.imgs_per_wg = sf::ceil_div(n_img, groups);
         dim3 grid(C, strips, sf::ceil_div(n_img, m.imgs_per_wg));
         SF_REQUIRE(strips <= 65535 && grid.z <= 65535, "sf_dwconv_res_gelu: grid too large");
-        if (precision == SF_PRECISION_F16X2)
-            hipLaunchKernelGGL((dwconv_mfma_kernel<15, false>), grid, dim3(256), lds, (hipStream_t)stream, m);
-        else
-            hipLaunchKernelGGL((dwconv_mfma_kernel<15, true>), grid, dim3(256), lds, (hipStream_t)stream, m);
+        hipLaunchKernelGGL(dwconv_mfma_kernel<15>, grid, dim3(256), lds, (hipStream_t)stream, m);
         return sf::check_launch("sf_dwconv_res_gelu(mfma)");
     }
     DwArgs g;

@@ -163,8 +163,11 @@ __device__ __forceinline__ void gemm_epilogue_vec_impl(const SfGemm& g, f32x16 (
                               EPI == SF_EPI_AXPY);
     const int khalf = lane >> 5, l31 = lane & 31;
     const int rrow = lane >> 3, rcol = (lane & 7) * 4;       // read-back coordinates inside a 32x32 tile
-    const int c_bytes = (int)(((int64_t)(g.M - 1) * g.ldc + g.N) * 4);
-    __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(g.C + (int64_t)z * g.strideC, 0, c_bytes, 0x00020000);
+    // c_f16: C is IEEE fp16 storage (ldc / strideC in halves): four rounded values leave as one 8-byte store
+    const int ces = g.c_f16 ? 2 : 4;
+    const int c_bytes = (int)(((int64_t)(g.M - 1) * g.ldc + g.N) * ces);
+    __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<char*>(g.C) + (int64_t)z * g.strideC * ces, 0, c_bytes, 0x00020000);
     __amdgpu_buffer_rsrc_t rr = rc;
     if (kNeedsR) {
         const int mr = g.M - 1;
@@ -186,7 +189,7 @@ __device__ __forceinline__ void gemm_epilogue_vec_impl(const SfGemm& g, f32x16 (
         for (int q = 0; q < 4; ++q) {
             const int m = mt0 + rrow + 8 * q;
             const int mc = m < g.M ? m : g.M - 1;
-            crow[q] = m < g.M ? m * (int)g.ldc * 4 : kOobTerm;
+            crow[q] = m < g.M ? m * (int)g.ldc * ces : kOobTerm;
             bias[q] = has_bias ? g.bias[mc] : 0.f;
             if (EPI == SF_EPI_RES_GELU_DW1) { dww[q] = g.dw_w[mc]; dwb[q] = g.dw_b[mc]; }
             else { dww[q] = dwb[q] = 0.f; }
@@ -209,7 +212,7 @@ __device__ __forceinline__ void gemm_epilogue_vec_impl(const SfGemm& g, f32x16 (
             for (int r = 0; r < 16; ++r)
                 scratch[((r & 3) + 8 * (r >> 2) + 4 * khalf) * kEpiStride + l31] = acc[i][j][r];
             const int n = n0 + (wn * TN + j) * 32 + rcol;
-            const int ccol = n < g.N ? n * 4 : kOobTerm;
+            const int ccol = n < g.N ? n * ces : kOobTerm;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float4 a = *reinterpret_cast<const float4*>(scratch + (rrow + 8 * q) * kEpiStride + rcol);
@@ -224,7 +227,22 @@ __device__ __forceinline__ void gemm_epilogue_vec_impl(const SfGemm& g, f32x16 (
                     const float r = __builtin_bit_cast(float, ru);
                     o[e] = __builtin_bit_cast(unsigned, epi_apply<EPI>(v, r, dww[q], dwb[q], gam));
                 }
-                __builtin_amdgcn_raw_buffer_store_b128(o, rc, crow[q] + ccol, 0, SF_EPI_STORE_AUX);
+                if (g.c_f16) {                                   // wave-uniform
+                    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                    u32x2 oh;
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const unsigned u0 = o[2 * e], u1 = o[2 * e + 1];
+                        h2 hv;
+                        hv[0] = (_Float16)__builtin_bit_cast(float, u0);
+                        hv[1] = (_Float16)__builtin_bit_cast(float, u1);
+                        oh[e] = __builtin_bit_cast(unsigned, hv);
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b64(oh, rc, crow[q] + ccol, 0, SF_EPI_STORE_AUX);
+                } else {
+                    __builtin_amdgcn_raw_buffer_store_b128(o, rc, crow[q] + ccol, 0, SF_EPI_STORE_AUX);
+                }
             }
         }
     }
@@ -256,7 +274,7 @@ __device__ __forceinline__ bool epilogue_vec_ok(const SfGemm& g, int z) {
 
 // host-side guard for the 32-bit buffer offsets used above
 inline bool epilogue_spans_ok(const SfGemm& g) {
-    const int64_t c = ((int64_t)(g.M - 1) * g.ldc + g.N) * 4;
+    const int64_t c = ((int64_t)(g.M - 1) * g.ldc + g.N) * (g.c_f16 ? 2 : 4);
     int64_t r = 0;
     if (g.R) {
         const int mr = g.M - 1;

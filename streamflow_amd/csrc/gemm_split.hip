@@ -76,13 +76,14 @@ __global__ __launch_bounds__(kThreads, (TM * TN >= 8) ? 2 : SF_GEMM_WAVES) void 
     const long long ts0 = __builtin_readcyclecounter();
     const long long rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
+    typedef typename OperandSel<BN, BLAY>::type OperandB;
     Operand<BM, ALAY> opa;
-    Operand<BN, BLAY> opb;
+    OperandB opb;
     typename Operand<BM, ALAY>::Regs ra;
-    typename Operand<BN, BLAY>::Regs rb;
+    typename OperandB::Regs rb;
     if (ALAY == 2) opa.init(g.A_hi, g.A_lo, args.a_bytes, (int)g.lda_h, g.K, g.M, m0, 0, 0, tid);
     else opa.init(g.A + (int64_t)z * g.strideA, nullptr, args.a_bytes, (int)g.lda, g.K, g.M, m0, 0, 0, tid);
-    opb.init(reinterpret_cast<const char*>(g.B) + (int64_t)z * g.strideB * (BLAY == SF_LAYOUT_F16_K_MINOR ? 2 : 4), nullptr,
+    opb.init(reinterpret_cast<const char*>(g.B) + (int64_t)z * g.strideB * ((BLAY == SF_LAYOUT_F16_K_MINOR || BLAY == SF_LAYOUT_F16_K_MAJOR) ? 2 : 4), nullptr,
              args.b_bytes, (int)g.ldb, g.K, g.N, n0, g.b_group, g.b_group_stride, tid);
     const bool conv = (BLAY == SF_LAYOUT_K_MAJOR) && g.conv3x3;
     const int cin = conv ? g.K / 9 : 1;
@@ -265,6 +266,13 @@ int launch_cfg(const SplitArgs& a, hipStream_t st) {
         }
         return sf::fail(SF_ERR_UNSUPPORTED, "sf_gemm(f16x3): SF_LAYOUT_F16_K_MINOR B not built for this tile");
     }
+    if (lay == 12) {                                     // split weights x stored-fp16 K-major activations (F16X2 only)
+        if constexpr (!SB) {
+            hipLaunchKernelGGL((gemm_f16x3_mfma<WM, WN, TM, TN, 2, 4, false>), grid, dim3(kThreads), 0, st, a);
+            return sf::check_launch("sf_gemm(f16x2, fp16 B)");
+        }
+        return sf::fail(SF_ERR_UNSUPPORTED, "sf_gemm: SF_LAYOUT_F16_K_MAJOR B needs SF_PRECISION_F16X2");
+    }
     switch (lay) {
         case 0: hipLaunchKernelGGL((gemm_f16x3_mfma<WM, WN, TM, TN, 0, 0, SB>), grid, dim3(kThreads), 0, st, a); break;
         case 5: hipLaunchKernelGGL((gemm_f16x3_mfma<WM, WN, TM, TN, 1, 1, SB>), grid, dim3(kThreads), 0, st, a); break;
@@ -300,6 +308,7 @@ int pick_tile(const SplitArgs& a, hipStream_t st) {
 
 int64_t span_bytes(int layout, int X, int K, int64_t ld, int group, int64_t group_stride) {
     if (layout == SF_LAYOUT_F16_K_MINOR) return ((int64_t)(X - 1) * ld + K) * 2;
+    if (layout == SF_LAYOUT_F16_K_MAJOR) return ((int64_t)(K - 1) * ld + X) * 2;
     if (layout == SF_LAYOUT_K_MINOR) return ((int64_t)(X - 1) * ld + K) * 4;
     if (group > 0) return ((int64_t)((K - 1) / group) * group_stride + (int64_t)((K - 1) % group) * ld + X) * 4;
     return ((int64_t)(K - 1) * ld + X) * 4;
@@ -381,7 +390,7 @@ int gemm_split_dispatch_inner(const SfGemm& g, hipStream_t st);
 
 int gemm_split_dispatch(const SfGemm& g, hipStream_t st) {
     // automatic split-K through caller-provided scratch
-    if (g.k_splits == 0 && g.split_ws && !g.conv3x3) {            // (the implicit 3x3 conv has no split-K form)
+    if (g.k_splits == 0 && g.split_ws && !g.conv3x3 && !g.c_f16) {  // (no split-K form for the 3x3 conv / fp16 output)
         const int ks = auto_splits(g.M, g.N, g.K, g.batch);
         const int64_t slab = (int64_t)g.batch * g.M * g.N;
         if (ks > 1 && g.split_ws_floats >= ks * slab) {
@@ -421,6 +430,15 @@ int gemm_split_dispatch_inner(const SfGemm& g, hipStream_t st) {
         return fail(SF_ERR_UNSUPPORTED, "sf_gemm(f16x3): operand image larger than 2 GiB (32-bit buffer offsets)");
     // tile choice: the 128-row tile moves the fewest bytes per MAC; drop to 64/32 rows when padding M would
     // waste more than a quarter of the MFMAs
+    if (g.b_layout == SF_LAYOUT_F16_K_MAJOR) {
+        if (g.a_layout != SF_LAYOUT_SPLIT_F16 || g.precision != SF_PRECISION_F16X2 || (g.N & 1) || (g.ldb & 1) || (g.strideB & 1) ||
+            g.b_group || g.conv3x3 || (reinterpret_cast<uintptr_t>(g.B) & 3))
+            return fail(SF_ERR_UNSUPPORTED, "sf_gemm: SF_LAYOUT_F16_K_MAJOR B needs SF_PRECISION_F16X2, a SPLIT_F16 A, even N / ldb / "
+                                            "strideB, no grouping, 4-byte aligned B");
+        return pick_tile<false>(a, st);
+    }
+    if (g.c_f16 && ((g.N & 3) || (g.ldc & 3) || (g.strideC & 3) || (reinterpret_cast<uintptr_t>(g.C) & 15) || g.k_splits > 1))
+        return fail(SF_ERR_UNSUPPORTED, "sf_gemm: c_f16 needs N %% 4 == 0, ldc %% 4 == 0, strideC %% 4 == 0, 16-byte aligned C, no split-K");
     if (g.b_layout == SF_LAYOUT_F16_K_MINOR) {
         if (g.a_layout != SF_LAYOUT_K_MINOR || (g.ldb & 1) || g.b_group || g.conv3x3 || (reinterpret_cast<uintptr_t>(g.B) & 3))
             return fail(SF_ERR_UNSUPPORTED, "sf_gemm(f16x3): SF_LAYOUT_F16_K_MINOR B needs a K-minor A, even ldb, 4-byte aligned B");

@@ -188,6 +188,86 @@ struct Operand {
     }
 };
 
+// B operand stored as IEEE fp16 rows, K-major: B[k * ld + n] halves (SF_LAYOUT_F16_K_MAJOR) -- what a producing GEMM
+// writes with SfGemm.c_f16 when its only consumer is another contraction of the f16x2 mode (the FFN hidden
+// activations): the consumer would round the fp32 value to fp16 anyway, so storing the rounded value is bit-identical,
+// halves both HBM passes and removes the conversion from the loop.  One item = (pixel PAIR, k-octet): 8 dword loads
+// (two adjacent pixels of one row each), 8 v_perm to un-interleave them into two k-octets, two ds_write_b128.
+template <int BX>
+struct OperandF16KMajor {
+    static_assert(BX % 128 == 0, "pairs per k-octet must fill whole waves");
+    static constexpr int NI = (BX / 2 * (BK / 8) + kThreads - 1) / kThreads;
+    __amdgpu_buffer_rsrc_t rsrc;
+    int voff[NI], ko[NI], lds_off[NI];
+    int rowc[NI][8];
+    int K, ld;
+    struct Regs { unsigned w[NI][8]; };
+
+    __device__ __forceinline__ void init(const void* base, const void*, int64_t bytes, int ld_, int K_, int X, int x0, int,
+                                         int64_t, int tid) {
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+        K = K_; ld = ld_;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int idx = tid + j * kThreads;
+            const int pi = idx % (BX / 2);
+            ko[j] = __builtin_amdgcn_readfirstlane(idx / (BX / 2));        // 64 pairs = one wave per k-octet
+            lds_off[j] = (2 * pi) * LDK + ko[j] * 8;
+            // pairs past the operand are clamped (X is even, host-checked): loaded, never stored by the epilogue
+            const int xc = (x0 + 2 * pi < X) ? x0 + 2 * pi : X - 2;
+            voff[j] = xc * 2;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) rowc[j][i] = (ko[j] * 8 + i) * ld * 2;
+        }
+    }
+    __device__ __forceinline__ void set_conv3x3(int, int, int, int) {}
+
+    __device__ __forceinline__ void load(int k0, int tile_off, Regs& rg, int = 0) const {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            if (k0 + BK <= K) {
+                const int vo = voff[j] + tile_off * 2;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) rg.w[j][i] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, vo, rowc[j][i], 0);
+            } else {                                        // last, partial k-tile: rows past K are clamped (zeroed in store)
+                const int kb = ko[j] * 8;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int over = k0 + kb + i - (K - 1);
+                    const int r = (tile_off + (kb + i - (over > 0 ? over : 0)) * ld) * 2;
+                    rg.w[j][i] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff[j], r, 0);
+                }
+            }
+        }
+    }
+
+    template <bool kLo = false>
+    __device__ __forceinline__ void store(int k0, _Float16* lds_hi, _Float16*, Regs& rg, int = -1) const {
+        static_assert(!kLo, "a stored-fp16 operand has no lo part");
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            if (k0 + BK > K) {
+                const int k = k0 + ko[j] * 8;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) rg.w[j][i] = (k + i < K) ? rg.w[j][i] : 0u;
+            }
+            u32x4 p0, p1;                                   // pixel 2 pi (low halves) and 2 pi + 1 (high halves)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                p0[i] = __builtin_amdgcn_perm(rg.w[j][2 * i + 1], rg.w[j][2 * i], 0x05040100u);
+                p1[i] = __builtin_amdgcn_perm(rg.w[j][2 * i + 1], rg.w[j][2 * i], 0x07060302u);
+            }
+            *reinterpret_cast<u32x4*>(lds_hi + lds_off[j]) = p0;
+            *reinterpret_cast<u32x4*>(lds_hi + lds_off[j] + LDK) = p1;
+        }
+    }
+};
+
+template <int BX, int LAY>
+struct OperandSel { typedef Operand<BX, LAY> type; };
+template <int BX>
+struct OperandSel<BX, SF_LAYOUT_F16_K_MAJOR> { typedef OperandF16KMajor<BX> type; };
+
 // element offset of K-major row k0 (start of a k-tile) for a possibly grouped operand; tiles never straddle
 // groups (group % 32 == 0 is checked on the host)
 struct RowCursor {

@@ -49,10 +49,16 @@ class SKBlockWeights:
         self.dwk_b = f32(g("conv_list.1.bias"))
 
 
-def _scratch(buf: Planes, n_img: int, rows: int) -> Planes:
-    """Reinterpret a scratch allocation as contiguous [n_img][rows][P] planes."""
+def _scratch(buf: Planes, n_img: int, rows: int, f16: bool = False) -> Planes:
+    """Reinterpret a scratch allocation as contiguous [n_img][rows][P] planes (fp32, or fp16 values in the same memory)."""
     assert n_img * rows <= buf.n_img * buf.rows, "scratch too small"
-    return Planes(buf.base, buf.off, rows * buf.P, n_img, rows, buf.P)
+    return Planes(buf.base, buf.off, rows * buf.P, n_img, rows, buf.P, f16=f16)
+
+
+def hidden_f16_ok(P: int) -> bool:
+    """FFN hidden activations are handed from GEMM to GEMM as fp16 in the f16x2 mode (bit-identical: that mode rounds a
+    B operand to fp16 on load anyway) when the plane geometry allows 8-byte stores / dword loads."""
+    return ops.PRECISION == ops.PRECISION_F16X2 and P % 4 == 0 and os.environ.get("SF_HIDDEN_F16", "1") != "0"
 
 
 def run_skblock(W: SKBlockWeights, X: Planes, Y: Planes, hid: Planes, xa: Planes, xb: Planes, h: int, w: int,
@@ -62,7 +68,7 @@ def run_skblock(W: SKBlockWeights, X: Planes, Y: Planes, hid: Planes, xa: Planes
     y = ffn2(x4).  hid/xa/xb are scratch allocations (capacity >= n_img*c_mid / n_img*c_in rows)."""
     C = W.c_in
     assert X.rows == C and Y.rows == W.c_out and X.n_img == Y.n_img
-    hidden = _scratch(hid, X.n_img, W.c_mid)
+    hidden = _scratch(hid, X.n_img, W.c_mid, f16=hidden_f16_ok(X.P))
     a, b = _scratch(xa, X.n_img, C), _scratch(xb, X.n_img, C)
     ops.gemm(W.ffn1_0, X, hidden, EPI_GELU)
     # x1 = gelu(x + ffn1(x)); x2 = gelu(x1 + dw1x1(x1))  (both fused in the epilogue)

@@ -132,6 +132,8 @@ class Planes:
     P: int
     group: int = 0          # rows per group for '(B T) C -> B (T C)' views (0 = plain)
     group_stride: int = 0
+    f16: bool = False       # the planes hold IEEE fp16 values (img_stride then counts halves; `off` stays in floats of
+                            # the underlying fp32 allocation): GEMM-to-GEMM hand-over in the f16x2 mode (SfGemm.c_f16)
 
     @staticmethod
     def of(t: torch.Tensor) -> "Planes":
@@ -146,12 +148,16 @@ class Planes:
         return self.base.data_ptr() + 4 * self.off
 
     def slice(self, r0: int, r1: int) -> "Planes":
-        assert 0 <= r0 < r1 <= self.rows and self.group == 0
+        assert 0 <= r0 < r1 <= self.rows and self.group == 0 and not self.f16
         return replace(self, off=self.off + r0 * self.P, rows=r1 - r0)
 
     def tensor(self) -> torch.Tensor:
         """Materialise as a [n_img, rows, P] torch view (only for contiguous-row, ungrouped views)."""
         assert self.group == 0
+        if self.f16:
+            h = self.base.view(torch.float16)
+            return torch.as_strided(h, (self.n_img, self.rows, self.P), (self.img_stride, self.P, 1),
+                                    2 * (self.base.storage_offset() + self.off))
         return torch.as_strided(self.base, (self.n_img, self.rows, self.P), (self.img_stride, self.P, 1),
                                 self.base.storage_offset() + self.off)
 
@@ -234,6 +240,13 @@ def gemm(A: PackedLinear, X: Planes, Y: Planes, epilogue: int = EPI_NONE, R: Opt
     g.a_layout, g.b_layout = LAYOUT_K_MAJOR, LAYOUT_K_MAJOR
     g.a_padded = 1
     prec = PRECISION
+    if X.f16 or Y.f16:
+        if prec != PRECISION_F16X2:
+            raise RuntimeError("fp16 activation planes are a hand-over format of the f16x2 mode only")
+        if X.f16:
+            g.b_layout = _lib.LAYOUT_F16_K_MAJOR
+        if Y.f16:
+            g.c_f16 = 1
     if prec != PRECISION_FP32:
         g.a_layout = LAYOUT_SPLIT_F16
         g.A_hi, g.A_lo, g.lda_h = A.hi.data_ptr(), A.lo.data_ptr(), A.lda_h
@@ -254,7 +267,8 @@ def gemm(A: PackedLinear, X: Planes, Y: Planes, epilogue: int = EPI_NONE, R: Opt
         g.split_ws, g.split_ws_floats = SPLIT_WS.data_ptr(), SPLIT_WS.numel()
     name = "gemm" if not PROFILE_SHAPES else f"gemm M{g.M} K{g.K} b{g.batch} e{g.epilogue}"
     # algorithmic bytes: activations in (each input row once) + result out (+ residual in) per image, weights once
-    nbytes = 4.0 * g.batch * g.N * (X.rows + g.M * (2 if R is not None else 1)) + 4.0 * g.M * g.K
+    nbytes = (g.batch * g.N * ((2.0 if X.f16 else 4.0) * X.rows + (2.0 if Y.f16 else 4.0) * g.M +
+                               (4.0 * g.M if R is not None else 0.0)) + 4.0 * g.M * g.K)
     _launch(name, 2.0 * g.M * g.N * g.K * g.batch, nbytes,
             lambda: _lib.check(_lib.load().sf_gemm(C.byref(g), _lib.stream()), "sf_gemm"))
 
@@ -290,7 +304,7 @@ def dwconv_res_gelu(X: Planes, wgt: torch.Tensor, bias: torch.Tensor, Y: Planes,
     _launch("dwconv%d" % k, 2.0 * k * k * X.n_img * X.rows * h * w, 8.0 * X.n_img * X.rows * h * w,
             lambda: _lib.check(_lib.load().sf_dwconv_res_gelu(X.ptr, X.img_stride, wgt.data_ptr(), bias.data_ptr(),
                                                               Y.ptr, Y.img_stride, X.n_img, X.rows, h, w, k,
-                                                              PRECISION, _lib.stream()),
+                                                              min(PRECISION, PRECISION_F16X3), _lib.stream()),
                                "sf_dwconv_res_gelu"))
 
 

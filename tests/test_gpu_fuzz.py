@@ -183,3 +183,38 @@ def test_split_gemm_weight_magnitudes(dev, wscale):
     err = (Y.double().cpu() - ref).abs().max().item() / ref.abs().max().item()
     print(f"weights x {wscale:g}: split scale {A.split_scale:g}, split error {A.split_error:.1e}, max rel err {err:.2e}")
     assert err < 3e-6, (wscale, err)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_fp16_hidden_handover_is_bit_identical(dev, seed):
+    """In the f16x2 mode a B operand is rounded to fp16 when it is staged, so a producer that already stores the rounded
+    value (SfGemm.c_f16 -> SF_LAYOUT_F16_K_MAJOR in the consumer) must give BIT-IDENTICAL results to the fp32 hand-over,
+    for ragged M / K (partial k-tiles, partial row tiles) and every tile configuration."""
+    from streamflow_amd import ops
+    from streamflow_amd.ops import Planes, PackedLinear
+    rng = np.random.default_rng(7000 + seed)
+    C = int(rng.choice([128, 324, 640]))
+    H = int(rng.choice([192, 486, 960]))
+    Cout = int(rng.choice([6, 64, 126, 256, 640]))
+    P = int(rng.choice([96, 1000, 7040]))                      # multiples of 4
+    n = 2
+    g = torch.Generator().manual_seed(seed)
+    W1 = PackedLinear(torch.randn(H, C, 1, 1, generator=g) / C ** 0.5, torch.randn(H, generator=g) * 0.1, dev)
+    W2 = PackedLinear(torch.randn(Cout, H, 1, 1, generator=g) / H ** 0.5, torch.randn(Cout, generator=g) * 0.1, dev)
+    X = Planes.of(torch.randn(n, C, P, generator=g).to(dev))
+    prev = ops.set_precision("f16x2")
+    try:
+        hid32 = Planes.of(torch.empty(n, H, P, device=dev))
+        y32 = torch.full((n, Cout, P), float("nan"), device=dev)
+        ops.gemm(W1, X, hid32, ops.EPI_GELU)
+        ops.gemm(W2, hid32, Planes.of(y32), ops.EPI_NONE)
+        store = torch.empty(n, H, P, device=dev)               # fp32 allocation reused as fp16 planes
+        hid16 = Planes(store.view(-1), 0, H * P, n, H, P, f16=True)
+        y16 = torch.full((n, Cout, P), float("nan"), device=dev)
+        ops.gemm(W1, X, hid16, ops.EPI_GELU)
+        ops.gemm(W2, hid16, Planes.of(y16), ops.EPI_NONE)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_precision(prev)
+    assert torch.equal(hid16.tensor().float(), hid32.tensor().half().float())
+    assert torch.equal(y16, y32), (C, H, Cout, P, (y16 - y32).abs().max().item())
