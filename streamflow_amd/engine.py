@@ -74,8 +74,10 @@ def run_skblock(W: SKBlockWeights, X: Planes, Y: Planes, hid: Planes, xa: Planes
     # x1 = gelu(x + ffn1(x)); x2 = gelu(x1 + dw1x1(x1))  (both fused in the epilogue)
     ops.gemm(W.ffn1_2, hidden, a, EPI_RES_GELU_DW1, R=X, dw_w=W.dw1_w, dw_b=W.dw1_b)
     ops.dwconv_res_gelu(a, W.dwk_w, W.dwk_b, b, h, w, W.k)                     # x3 = gelu(x2 + dwKxK(x2))
-    ops.gemm(W.pw, b, a, EPI_RES_GELU, R=b)                                     # x4 = gelu(x3 + pw(x3))
-    ops.gemm(W.ffn2_0, a, hidden, EPI_GELU)
+    # x4 is read by ffn2.0 only: the same GEMM-to-GEMM hand-over as the hidden activations (x2 in `xa` is dead by now)
+    a4 = _scratch(xa, X.n_img, C, f16=hidden_f16_ok(X.P))
+    ops.gemm(W.pw, b, a4, EPI_RES_GELU, R=b)                                    # x4 = gelu(x3 + pw(x3))
+    ops.gemm(W.ffn2_0, a4, hidden, EPI_GELU)
     ops.gemm(W.ffn2_2, hidden, Y, EPI_GELU if final_gelu else EPI_NONE)
 
 
@@ -337,8 +339,9 @@ class HotPathEngine:
             ops.temporal_attn(pl.qkv, pl.att128, Bc, Pn, HDIM)
             ops.gemm(W.proj, pl.att128, pl.tx128, EPI_RES, R=pl.mf)
             ops.layernorm_cm(pl.tx128, W.ln2_w, W.ln2_b, pl.ln128)
-            ops.gemm(W.fc1, pl.ln128, pl.h256, EPI_GELU)
-            ops.gemm(W.fc2, pl.h256, pl.mft, EPI_RES, R=pl.tx128)
+            h256 = _scratch(pl.h256, pl.n, 256, f16=hidden_f16_ok(P))             # fc1 -> fc2 only
+            ops.gemm(W.fc1, pl.ln128, h256, EPI_GELU)
+            ops.gemm(W.fc2, h256, pl.mft, EPI_RES, R=pl.tx128)
         # a7: global aggregation  mfg = mf + gamma * attn @ to_v(mf)   (gma.py:91-104), main stream
         ops.gemm(W.to_v, pl.mf, pl.v128, EPI_NONE)
         ks = self.attn_k_splits if self.precision != ops.PRECISION_FP32 else 1
