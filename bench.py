@@ -173,7 +173,7 @@ def main():
                          "configuration 2 ('bf16'): activations fp16 into split-precision weights, fp16 correlation "
                          "volumes, fused fp16 GMA aggregation, fp32 accumulation everywhere.  fp32_class = the library "
                          "default (split precision everywhere, fp32 volumes).  --precision / --corr-dtype / --gma override")
-    ap.add_argument("--precision", default=None, choices=["f16x3", "fp32", "f16x2"],
+    ap.add_argument("--precision", default=None, choices=["f16x3", "fp32", "f16x2", "f16"],
                     help="f16x3: split-fp16 MFMA with fp32 accumulation (fp32-class accuracy); fp32: exact fp32 MFMA; "
                          "f16x2: weights split, activations rounded once to fp16")
     ap.add_argument("--gma", default=None, choices=["auto", "matrix", "flash"], help="GMA aggregation path (engine gma_mode)")
@@ -190,6 +190,9 @@ def main():
     ap.add_argument("--serial-branches", action="store_true",
                     help="enqueue the independent chains of an iteration on one stream (profiling aid: kernel-trace "
                          "durations are then free of cross-branch contention and match the HIP-event table)")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="experiment: split the clips of a step over S engines replayed concurrently on S streams "
+                         "(fills the partial last round of one engine's launches with the other's workgroups)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-runs", type=int, default=3, help="timed whole-clip runs of the CPU oracle (median reported)")
     ap.add_argument("--no-kernel-breakdown", action="store_true")
@@ -252,8 +255,25 @@ def main():
     if args.serial_branches:
         eng.parallel_branches = False
 
-    def step():
-        eng.forward(fmaps, cnets, iters=iters, all_masks=args.all_masks)
+    if args.streams > 1:
+        assert B % args.streams == 0, "--clips must be a multiple of --streams"
+        args.no_kernel_breakdown = args.no_cpu_baseline = True
+        bs = B // args.streams
+        engs = [HotPathEngine(params, device=dev, T=T, use_graph=not args.no_graph, **cfg) for _ in range(args.streams)]
+        strs = [torch.cuda.Stream(device=dev) for _ in range(args.streams)]
+        parts = [(fmaps[i * bs:(i + 1) * bs].contiguous(), cnets[i * bs:(i + 1) * bs].contiguous()) for i in range(args.streams)]
+
+        def step():
+            cur = torch.cuda.current_stream()
+            for e, st, (f, c) in zip(engs, strs, parts):
+                st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    e.forward(f, c, iters=iters, all_masks=args.all_masks)
+            for st in strs:
+                cur.wait_stream(st)
+    else:
+        def step():
+            eng.forward(fmaps, cnets, iters=iters, all_masks=args.all_masks)
 
     def barrier():
         if world > 1:
@@ -278,7 +298,8 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": {"fp32": "fp32", "f16x3": "f16x3-split (fp32 accumulate)",
-                  "f16x2": "f16x2 (weights hi+lo, activations fp16; fp32 accumulate)"}[args.precision] +
+                  "f16x2": "f16x2 (weights hi+lo, activations fp16; fp32 accumulate)",
+                  "f16": "f16 (weights and activations fp16; fp32 accumulate)"}[args.precision] +
                  ("; fp16 correlation volumes" if args.corr_dtype == "f16" else ""), "data": "synthetic",
         "config": {"workload": f"{args.workload}_{H}x{W}_T{T}_iters{iters}", "clips_per_gpu_per_step": B,
                    "clips_per_step_all_gpus": world * B,
@@ -291,7 +312,8 @@ def main():
                                                 if eng.gma_mode == "flash" else ""),
                    "precision": {"fp32": "exact fp32 (v_mfma_f32_32x32x2_f32)",
                                  "f16x3": "split fp16x3 (x=hi+lo, 3x v_mfma_f32_32x32x16_f16, fp32 accumulate)",
-                                 "f16x2": "weights hi+lo fp16, activations fp16 (2x v_mfma_f32_32x32x16_f16)"}[args.precision]},
+                                 "f16x2": "weights hi+lo fp16, activations fp16 (2x v_mfma_f32_32x32x16_f16)",
+                                 "f16": "weights fp16, activations fp16 (1x v_mfma_f32_32x32x16_f16)"}[args.precision]},
     }
 
     if rank == 0 and not args.no_kernel_breakdown:
@@ -346,7 +368,7 @@ def main():
         # which roof binds: time floor of the matrix cores (algorithmic flops x MFMA products per flop / dense peak)
         # against the time floor of HBM (bytes the family really moves -- PMC when available, else algorithmic)
         peak_tf = {"fp32": PEAK_FP32_MFMA_TFLOPS, "f16x3": PEAK_F16_MFMA_TFLOPS / 3.0,
-                   "f16x2": PEAK_F16_MFMA_TFLOPS / 2.0}[args.precision]
+                   "f16x2": PEAK_F16_MFMA_TFLOPS / 2.0, "f16": PEAK_F16_MFMA_TFLOPS}[args.precision]
         t_mfma = alg_flops / (peak_tf * 1e12) if alg_flops else 0.0
         t_hbm = (pmc_bytes * n_launch if pmc_bytes else alg_bytes) / (PEAK_HBM_GBPS * 1e9)
         if alg_flops and t_mfma >= t_hbm:

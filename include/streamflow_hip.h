@@ -108,10 +108,12 @@ enum { SF_PRECISION_FP32 = 0,   /* exact fp32: v_mfma_f32_32x32x2_f32, k-ordered
                                     on v_mfma_f32_32x32x16_f16 with fp32 accumulation (~2^-22 relative)  */
        SF_PRECISION_F16X2 = 2,  /* A (weights) split hi+lo, B (activations) rounded once to fp16:
                                     a*b = ah*b + al*b, 2 MFMAs; error = the fp16 rounding of B (2^-11 rel.) */
-       SF_PRECISION_F16 = 3 };  /* correlation volumes only (sf_corr_build_pyramid / sf_corr_lookup): features rounded
-                                    once to fp16, one f16 MFMA per product with fp32 accumulation, every pyramid cell
-                                    STORED as IEEE fp16 -- the "bf16/fp16 volume" configurations of BASELINE.json
-                                    (the reference's own deployment runs under fp16 autocast, demo.py:427-456) */
+       SF_PRECISION_F16 = 3 };  /* both operands rounded once to fp16, ONE f16 MFMA per product, fp32 accumulation: the
+                                    arithmetic class of the reference's own deployment (fp16 autocast, demo.py:427-456).
+                                    sf_corr_build_pyramid / sf_corr_lookup: every pyramid cell is also STORED as fp16
+                                    (the "bf16/fp16 volume" configurations of BASELINE.json).  sf_gemm: needs SPLIT_F16
+                                    weights (their hi image is the round-to-nearest fp16 of the scaled weight); an fp32
+                                    A operand is treated as in F16X2 */
 enum { SF_EPI_NONE = 0,         /* C = v                              v = alpha*(acc+bias)   */
        SF_EPI_GELU = 1,         /* C = gelu(v)                        exact erf GELU         */
        SF_EPI_RELU = 2,         /* C = max(v,0)                                              */

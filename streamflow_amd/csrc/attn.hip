@@ -194,14 +194,22 @@ __global__ __launch_bounds__(256, (QKP == 3) ? 1 : 2) void gma_flash_kernel(cons
         m_run = m_new;
         float psum = 0.f;
         f16x8 pf[4];                                              // P^T as B operands: k-step kk = sub*2 + m
+        // two weights at a time: one v_cvt_pk_f16_f32 (round to nearest) and one v_dot2 that adds the two ROUNDED values
+        // to the row sum -- the row is normalised by what is actually multiplied
+        typedef _Float16 hp2 __attribute__((ext_vector_type(2)));
+        const hp2 ones = {(_Float16)1.0f, (_Float16)1.0f};
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = __builtin_amdgcn_exp2f(s[sub][r] - m_new);
-                const _Float16 ph = (_Float16)p;
-                psum += (float)ph;                                // normalise by what is actually multiplied
-                pf[sub * 2 + (r >> 3)][r & 7] = ph;
+            for (int r = 0; r < 16; r += 2) {
+                const float p0 = __builtin_amdgcn_exp2f(s[sub][r] - m_new), p1 = __builtin_amdgcn_exp2f(s[sub][r + 1] - m_new);
+                hp2 ph;
+                ph[0] = (_Float16)p0;
+                ph[1] = (_Float16)p1;
+                psum = __builtin_amdgcn_fdot2(ph, ones, psum, false);
+                const unsigned bits = __builtin_bit_cast(unsigned, ph);
+                pf[sub * 2 + (r >> 3)][r & 7] = __builtin_bit_cast(_Float16, (unsigned short)(bits & 0xffffu));
+                pf[sub * 2 + (r >> 3)][(r & 7) + 1] = __builtin_bit_cast(_Float16, (unsigned short)(bits >> 16));
             }
         l_run = l_run * alpha + psum;
         if (grew) {

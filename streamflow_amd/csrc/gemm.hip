@@ -299,15 +299,15 @@ extern "C" int sf_gemm(const SfGemm* gp, void* stream) {
     SF_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0 && g.batch > 0, "sf_gemm: bad dims M=%d N=%d K=%d batch=%d", g.M, g.N,
                g.K, g.batch);
     SF_REQUIRE(g.a_layout >= 0 && g.a_layout <= 2 && g.b_layout >= 0 && g.b_layout <= 4 && g.b_layout != 2, "sf_gemm: bad layout");
-    SF_REQUIRE(g.b_layout != SF_LAYOUT_F16_K_MAJOR || g.precision == SF_PRECISION_F16X2,
-               "sf_gemm: SF_LAYOUT_F16_K_MAJOR B needs SF_PRECISION_F16X2");
+    SF_REQUIRE(g.b_layout != SF_LAYOUT_F16_K_MAJOR || g.precision == SF_PRECISION_F16X2 || g.precision == SF_PRECISION_F16,
+               "sf_gemm: SF_LAYOUT_F16_K_MAJOR B needs SF_PRECISION_F16X2 or SF_PRECISION_F16");
     SF_REQUIRE(!g.c_f16 || g.precision != SF_PRECISION_FP32, "sf_gemm: c_f16 needs a split precision");
     SF_REQUIRE(g.b_layout != SF_LAYOUT_F16_K_MINOR || g.precision != SF_PRECISION_FP32,
                "sf_gemm: a stored-fp16 B operand needs a split precision");
     SF_REQUIRE(g.a_layout != SF_LAYOUT_SPLIT_F16 || g.precision != SF_PRECISION_FP32,
                "sf_gemm: SPLIT_F16 weights need precision F16X3");
     SF_REQUIRE(g.epilogue >= SF_EPI_NONE && g.epilogue <= SF_EPI_AXPY, "sf_gemm: bad epilogue %d", g.epilogue);
-    SF_REQUIRE(g.precision >= SF_PRECISION_FP32 && g.precision <= SF_PRECISION_F16X2,
+    SF_REQUIRE(g.precision >= SF_PRECISION_FP32 && g.precision <= SF_PRECISION_F16,
                "sf_gemm: precision %d not supported", g.precision);
     if (g.epilogue == SF_EPI_RES || g.epilogue == SF_EPI_RES_GELU || g.epilogue == SF_EPI_RES_GELU_DW1 ||
         g.epilogue == SF_EPI_AXPY)

@@ -48,8 +48,11 @@ struct SplitArgs {
 #ifndef SF_GEMM_WAVES
 #define SF_GEMM_WAVES 3          // workgroups per CU the register budget is sized for (128x128 tile)
 #endif
-template <int WM, int WN, int TM, int TN, int ALAY, int BLAY, bool SB>
+// PM = MFMA products per element product: 3 = f16x3 (A and B hi + lo), 2 = f16x2 (A hi + lo, B one fp16), 1 = f16 (both one
+// fp16: the arithmetic of an fp16-autocast deployment, with fp32 accumulation)
+template <int WM, int WN, int TM, int TN, int ALAY, int BLAY, int PM>
 __global__ __launch_bounds__(kThreads, (TM * TN >= 8) ? 2 : SF_GEMM_WAVES) void gemm_f16x3_mfma(const SplitArgs args) {
+    constexpr bool SB = (PM == 3), SA = (PM >= 2);
     const SfGemm& g = args.g;
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     static_assert(WM * WN == 4, "4 waves per workgroup");
@@ -57,8 +60,8 @@ __global__ __launch_bounds__(kThreads, (TM * TN >= 8) ? 2 : SF_GEMM_WAVES) void 
     // pre-split weights on the 128-row tile (kDmaA) two DMA-filled stages [hi|lo][4 k-octets][128 rows][8].  52 KB at
     // most, so 3 workgroups fit per CU.
     constexpr bool kDmaA = (ALAY == 2) && (BM == 128);
-    constexpr int kAStage = 2 * (BK / 8) * BM * 8;                               // halfs of one DMA stage (hi + lo)
-    constexpr int kAHalfs = kDmaA ? 2 * kAStage : 2 * BM * LDK;
+    constexpr int kAStage = (SA ? 2 : 1) * (BK / 8) * BM * 8;                    // halfs of one DMA stage (hi [+ lo])
+    constexpr int kAHalfs = kDmaA ? 2 * kAStage : (SA ? 2 : 1) * BM * LDK;
     constexpr int kMainHalfs = kAHalfs + (SB ? 2 : 1) * BN * LDK;               // SB = false: B has no lo part
     constexpr int kEpiHalfs = 4 * sf::kEpiScratchFloats * 2;
     __shared__ __attribute__((aligned(1024))) _Float16 smem[kMainHalfs > kEpiHalfs ? kMainHalfs : kEpiHalfs];
@@ -119,8 +122,10 @@ __global__ __launch_bounds__(kThreads, (TM * TN >= 8) ? 2 : SF_GEMM_WAVES) void 
         const int so = kt * (BK / 8) * (int)g.lda_h * 16;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rah, (lds_ptr)(dst), 16, voa0, so, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rah, (lds_ptr)(dst + 4096), 16, voa1, so, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(ral, (lds_ptr)(dst + kAStage), 16, voa0, so, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(ral, (lds_ptr)(dst + kAStage + 4096), 16, voa1, so, 0, 0);
+        if (SA) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ral, (lds_ptr)(dst + kAStage), 16, voa0, so, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ral, (lds_ptr)(dst + kAStage + 4096), 16, voa1, so, 0, 0);
+        }
     };
 
     // the A piece is requested BEFORE the B loads of the same k-tile: vmcnt retires in order, so the wait that the B
@@ -129,7 +134,7 @@ __global__ __launch_bounds__(kThreads, (TM * TN >= 8) ? 2 : SF_GEMM_WAVES) void 
     else opa.load(kt_beg * BK, ca.off, ra);
     if (conv) opb.load(kt_beg * BK, conv_off(kt_beg * BK), rb, conv_shift(kt_beg * BK));
     else opb.load(kt_beg * BK, cb.off, rb);
-    if (!kDmaA) opa.store(kt_beg * BK, sA[0], sA[1], ra);
+    if (!kDmaA) opa.template store<SA>(kt_beg * BK, sA[0], sA[SA ? 1 : 0], ra);
     opb.template store<SB>(kt_beg * BK, sB[0], sB[SB ? 1 : 0], rb, conv ? conv_tap(kt_beg * BK) : -1);
     if (kDmaA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -153,7 +158,7 @@ __global__ __launch_bounds__(kThreads, (TM * TN >= 8) ? 2 : SF_GEMM_WAVES) void 
         // A fragment of lane (row l31, k-half): register-staged image rows [x][LDK]; DMA image [k-octet][128 rows][8]
         const _Float16* pah = kDmaA ? smem + abuf * kAStage + (khalf * BM + wm * TM * 32 + l31) * 8
                                     : sA[0] + (wm * TM * 32 + l31) * LDK + khalf * 8;
-        const _Float16* pal = kDmaA ? pah + kAStage / 2 : sA[1] + (wm * TM * 32 + l31) * LDK + khalf * 8;
+        const _Float16* pal = kDmaA ? pah + kAStage / 2 : sA[SA ? 1 : 0] + (wm * TM * 32 + l31) * LDK + khalf * 8;   // (SA only)
         constexpr int kATile = kDmaA ? 32 * 8 : 32 * LDK;        // halfs between the 32-row tiles of a wave
         constexpr int kAStep = kDmaA ? 2 * BM * 8 : 16;          // halfs per 16-deep k-step
         const _Float16* pbh = sB[0] + (wn * TN * 32 + l31) * LDK + khalf * 8;
@@ -168,7 +173,7 @@ __global__ __launch_bounds__(kThreads, (TM * TN >= 8) ? 2 : SF_GEMM_WAVES) void 
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 ah[ks][i] = *reinterpret_cast<const f16x8*>(pah + i * kATile + ks * kAStep);
-                al[ks][i] = *reinterpret_cast<const f16x8*>(pal + i * kATile + ks * kAStep);
+                if (SA) al[ks][i] = *reinterpret_cast<const f16x8*>(pal + i * kATile + ks * kAStep);
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
@@ -180,10 +185,12 @@ __global__ __launch_bounds__(kThreads, (TM * TN >= 8) ? 2 : SF_GEMM_WAVES) void 
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
             // product-major order: the three MFMAs that hit one accumulator are TM*TN instructions apart
+            if (SA) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks][i], bh[ks][j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks][i], bh[ks][j], acc[i][j], 0, 0, 0);
+            }
             if (SB) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
@@ -202,7 +209,7 @@ __global__ __launch_bounds__(kThreads, (TM * TN >= 8) ? 2 : SF_GEMM_WAVES) void 
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 ah[i] = *reinterpret_cast<const f16x8*>(pah + i * kATile + ks * kAStep);
-                al[i] = *reinterpret_cast<const f16x8*>(pal + i * kATile + ks * kAStep);
+                if (SA) al[i] = *reinterpret_cast<const f16x8*>(pal + i * kATile + ks * kAStep);
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
@@ -214,7 +221,7 @@ __global__ __launch_bounds__(kThreads, (TM * TN >= 8) ? 2 : SF_GEMM_WAVES) void 
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     // small terms first, so the dominant hi*hi product is added to an already-formed correction
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    if (SA) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
                     if (SB) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                 }
@@ -223,7 +230,7 @@ __global__ __launch_bounds__(kThreads, (TM * TN >= 8) ? 2 : SF_GEMM_WAVES) void 
         __builtin_amdgcn_sched_barrier(0);
         if (kt + 1 < kt_end) {
             __syncthreads();                       // every wave is done reading tile kt
-            if (!kDmaA) opa.store((kt + 1) * BK, sA[0], sA[1], ra);
+            if (!kDmaA) opa.template store<SA>((kt + 1) * BK, sA[0], sA[SA ? 1 : 0], ra);
             opb.template store<SB>((kt + 1) * BK, sB[0], sB[SB ? 1 : 0], rb, conv ? conv_tap((kt + 1) * BK) : -1);
             if (kDmaA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (already retired by the wait for rb)
             __syncthreads();
@@ -253,30 +260,31 @@ __global__ __launch_bounds__(kThreads, (TM * TN >= 8) ? 2 : SF_GEMM_WAVES) void 
 }
 
 
-template <int WM, int WN, int TM, int TN, bool SB>
+template <int WM, int WN, int TM, int TN, int PM>
 int launch_cfg(const SplitArgs& a, hipStream_t st) {
+    constexpr bool SB = (PM == 3);
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     const SfGemm& g = a.g;
     dim3 grid(sf::ceil_div(g.N, BN) * sf::ceil_div(g.M, BM) * g.batch * (g.k_splits > 1 ? g.k_splits : 1));   // 1-D: see sf::xcd_tile
     const int lay = g.a_layout * 4 + g.b_layout;
     if (lay == 7) {
         if constexpr (!SB && TM * TN == 4) {             // only the 128x128 tile is built for the stored-fp16 B
-            hipLaunchKernelGGL((gemm_f16x3_mfma<WM, WN, TM, TN, 1, 3, false>), grid, dim3(kThreads), 0, st, a);
+            hipLaunchKernelGGL((gemm_f16x3_mfma<WM, WN, TM, TN, 1, 3, 2>), grid, dim3(kThreads), 0, st, a);
             return sf::check_launch("sf_gemm(f16x3)");
         }
         return sf::fail(SF_ERR_UNSUPPORTED, "sf_gemm(f16x3): SF_LAYOUT_F16_K_MINOR B not built for this tile");
     }
     if (lay == 12) {                                     // split weights x stored-fp16 K-major activations (F16X2 only)
         if constexpr (!SB) {
-            hipLaunchKernelGGL((gemm_f16x3_mfma<WM, WN, TM, TN, 2, 4, false>), grid, dim3(kThreads), 0, st, a);
+            hipLaunchKernelGGL((gemm_f16x3_mfma<WM, WN, TM, TN, 2, 4, PM>), grid, dim3(kThreads), 0, st, a);
             return sf::check_launch("sf_gemm(f16x2, fp16 B)");
         }
         return sf::fail(SF_ERR_UNSUPPORTED, "sf_gemm: SF_LAYOUT_F16_K_MAJOR B needs SF_PRECISION_F16X2");
     }
     switch (lay) {
-        case 0: hipLaunchKernelGGL((gemm_f16x3_mfma<WM, WN, TM, TN, 0, 0, SB>), grid, dim3(kThreads), 0, st, a); break;
-        case 5: hipLaunchKernelGGL((gemm_f16x3_mfma<WM, WN, TM, TN, 1, 1, SB>), grid, dim3(kThreads), 0, st, a); break;
-        case 8: hipLaunchKernelGGL((gemm_f16x3_mfma<WM, WN, TM, TN, 2, 0, SB>), grid, dim3(kThreads), 0, st, a); break;
+        case 0: hipLaunchKernelGGL((gemm_f16x3_mfma<WM, WN, TM, TN, 0, 0, PM>), grid, dim3(kThreads), 0, st, a); break;
+        case 5: hipLaunchKernelGGL((gemm_f16x3_mfma<WM, WN, TM, TN, 1, 1, PM>), grid, dim3(kThreads), 0, st, a); break;
+        case 8: hipLaunchKernelGGL((gemm_f16x3_mfma<WM, WN, TM, TN, 2, 0, PM>), grid, dim3(kThreads), 0, st, a); break;
         default: return sf::fail(SF_ERR_UNSUPPORTED, "sf_gemm(f16x3): layout combination a=%d b=%d not built",
                                  g.a_layout, g.b_layout);
     }
@@ -284,7 +292,7 @@ int launch_cfg(const SplitArgs& a, hipStream_t st) {
 }
 
 
-template <bool SB>
+template <int PM>
 int pick_tile(const SplitArgs& a, hipStream_t st) {
     const SfGemm& g = a.g;
     // tile choice: the 128-row tile moves the fewest bytes per MAC; drop to 64/32 rows when padding M would
@@ -293,17 +301,17 @@ int pick_tile(const SplitArgs& a, hipStream_t st) {
     auto padded = [&](int bm) { return (M + bm - 1) / bm * bm; };
     if (const char* e = getenv("SF_GEMM_BM")) {          // experiment knob
         const int bm = atoi(e);
-        if (bm == 128) return launch_cfg<2, 2, 2, 2, SB>(a, st);
-        if (bm == 256) return launch_cfg<2, 2, 4, 2, SB>(a, st);
-        if (bm == 257) return launch_cfg<2, 2, 2, 4, SB>(a, st);
-        if (bm == 64) return launch_cfg<1, 4, 2, 1, SB>(a, st);
-        if (bm == 32) return launch_cfg<1, 4, 1, 1, SB>(a, st);
+        if (bm == 128) return launch_cfg<2, 2, 2, 2, PM>(a, st);
+        if (bm == 256) return launch_cfg<2, 2, 4, 2, PM>(a, st);
+        if (bm == 257) return launch_cfg<2, 2, 2, 4, PM>(a, st);
+        if (bm == 64) return launch_cfg<1, 4, 2, 1, PM>(a, st);
+        if (bm == 32) return launch_cfg<1, 4, 1, 1, PM>(a, st);
     }
     // (a wave-specialised producer/consumer variant of the 128x128 kernel was faster for K >= 768 early in the round;
     // after the cheaper split and epilogue it measured 2-25 % slower at every batch size and was removed)
-    if (padded(128) * 4 <= M * 5) return launch_cfg<2, 2, 2, 2, SB>(a, st);
-    if (padded(64) * 4 <= M * 5 || M > 32) return launch_cfg<1, 4, 2, 1, SB>(a, st);
-    return launch_cfg<1, 4, 1, 1, SB>(a, st);
+    if (padded(128) * 4 <= M * 5) return launch_cfg<2, 2, 2, 2, PM>(a, st);
+    if (padded(64) * 4 <= M * 5 || M > 32) return launch_cfg<1, 4, 2, 1, PM>(a, st);
+    return launch_cfg<1, 4, 1, 1, PM>(a, st);
 }
 
 int64_t span_bytes(int layout, int X, int K, int64_t ld, int group, int64_t group_stride) {
@@ -431,20 +439,23 @@ int gemm_split_dispatch_inner(const SfGemm& g, hipStream_t st) {
     // tile choice: the 128-row tile moves the fewest bytes per MAC; drop to 64/32 rows when padding M would
     // waste more than a quarter of the MFMAs
     if (g.b_layout == SF_LAYOUT_F16_K_MAJOR) {
-        if (g.a_layout != SF_LAYOUT_SPLIT_F16 || g.precision != SF_PRECISION_F16X2 || (g.N & 1) || (g.ldb & 1) || (g.strideB & 1) ||
+        if (g.a_layout != SF_LAYOUT_SPLIT_F16 || (g.precision != SF_PRECISION_F16X2 && g.precision != SF_PRECISION_F16) || (g.N & 1) || (g.ldb & 1) || (g.strideB & 1) ||
             g.b_group || g.conv3x3 || (reinterpret_cast<uintptr_t>(g.B) & 3))
             return fail(SF_ERR_UNSUPPORTED, "sf_gemm: SF_LAYOUT_F16_K_MAJOR B needs SF_PRECISION_F16X2, a SPLIT_F16 A, even N / ldb / "
                                             "strideB, no grouping, 4-byte aligned B");
-        return pick_tile<false>(a, st);
+        return (g.precision == SF_PRECISION_F16) ? pick_tile<1>(a, st) : pick_tile<2>(a, st);
     }
     if (g.c_f16 && ((g.N & 3) || (g.ldc & 3) || (g.strideC & 3) || (reinterpret_cast<uintptr_t>(g.C) & 15) || g.k_splits > 1))
         return fail(SF_ERR_UNSUPPORTED, "sf_gemm: c_f16 needs N %% 4 == 0, ldc %% 4 == 0, strideC %% 4 == 0, 16-byte aligned C, no split-K");
     if (g.b_layout == SF_LAYOUT_F16_K_MINOR) {
         if (g.a_layout != SF_LAYOUT_K_MINOR || (g.ldb & 1) || g.b_group || g.conv3x3 || (reinterpret_cast<uintptr_t>(g.B) & 3))
             return fail(SF_ERR_UNSUPPORTED, "sf_gemm(f16x3): SF_LAYOUT_F16_K_MINOR B needs a K-minor A, even ldb, 4-byte aligned B");
-        return pick_tile<false>(a, st);
+        return pick_tile<2>(a, st);
     }
-    return (g.precision == SF_PRECISION_F16X2) ? pick_tile<false>(a, st) : pick_tile<true>(a, st);
+    // SF_PRECISION_F16 (one product) is built for pre-packed weights; an fp32 A operand (the attention / correlation
+    // contractions called through sf_gemm) is split on the fly as in F16X2
+    if (g.precision == SF_PRECISION_F16 && g.a_layout == SF_LAYOUT_SPLIT_F16) return pick_tile<1>(a, st);
+    return (g.precision != SF_PRECISION_F16X3) ? pick_tile<2>(a, st) : pick_tile<3>(a, st);
 }
 
 }  // namespace sf

@@ -58,7 +58,8 @@ def _scratch(buf: Planes, n_img: int, rows: int, f16: bool = False) -> Planes:
 def hidden_f16_ok(P: int) -> bool:
     """FFN hidden activations are handed from GEMM to GEMM as fp16 in the f16x2 mode (bit-identical: that mode rounds a
     B operand to fp16 on load anyway) when the plane geometry allows 8-byte stores / dword loads."""
-    return ops.PRECISION == ops.PRECISION_F16X2 and P % 4 == 0 and os.environ.get("SF_HIDDEN_F16", "1") != "0"
+    return (ops.PRECISION in (ops.PRECISION_F16X2, ops.PRECISION_F16) and P % 4 == 0 and
+            os.environ.get("SF_HIDDEN_F16", "1") != "0")
 
 
 def run_skblock(W: SKBlockWeights, X: Planes, Y: Planes, hid: Planes, xa: Planes, xb: Planes, h: int, w: int,
@@ -200,8 +201,8 @@ class HotPathEngine:
     def __init__(self, state_dict: Dict[str, torch.Tensor], device="cuda:0", T: Optional[int] = None,
                  use_graph: bool = False, precision: Optional[str] = None, corr_dtype: str = "f32",
                  gma_mode: Optional[str] = None, flash_qk_products: Optional[int] = None):
-        """precision: 'f16x3' (split fp16, fp32-class accuracy, default), 'fp32' (exact fp32 MFMA) or 'f16x2'
-        (weights split, activations rounded to fp16: ~1e-4 px EPE, faster);
+        """precision: 'f16x3' (split fp16, fp32-class accuracy, default), 'fp32' (exact fp32 MFMA), 'f16x2'
+        (weights split, activations rounded to fp16: ~1e-4 px EPE, faster) or 'f16' (weights and activations fp16);
         None = the package-wide setting (streamflow_amd.ops.PRECISION).
         corr_dtype: 'f32' keeps the correlation pyramids in fp32 as the reference does (corr.py:13, arithmetic =
         `precision`); 'f16' stores them as fp16 and builds them with single f16 MFMA products (SF_PRECISION_F16).
@@ -232,7 +233,7 @@ class HotPathEngine:
             raise RuntimeError(f"gma_mode must be auto, matrix or flash, got {self.gma_mode!r}")
         # MFMA products per logit of the fused kernel: 3 = split precision (fp32-class), 2 / 1 = k / q and k in fp16
         self.flash_qk_products = (int(flash_qk_products or 0) or int(os.environ.get("SF_FLASH_QKP", "0"))
-                                  or (2 if self.precision == ops.PRECISION_F16X2 else 3))
+                                  or {ops.PRECISION_F16X2: 2, ops.PRECISION_F16: 1}.get(self.precision, 3))
         if self.flash_qk_products not in (1, 2, 3):
             raise RuntimeError(f"flash_qk_products must be 1, 2 or 3, got {self.flash_qk_products}")
         self._side = torch.cuda.Stream(device=self.device)

@@ -24,9 +24,11 @@ from ._lib import (EPI_AXPY, EPI_GELU, EPI_NONE, EPI_RELU, EPI_RES, EPI_RES_GELU
 #   PRECISION_FP32  exact fp32 on v_mfma_f32_32x32x2_f32
 #   PRECISION_F16X3 split precision (x = hi + lo in fp16, 3 MFMAs per product, fp32 accumulate; ~2^-22 relative)
 #   PRECISION_F16X2 weights split hi + lo, activations rounded once to fp16 (2 MFMAs per product; 2^-11 relative on
-#                   the activations: ~1e-4 px EPE on the flows, opt-in)
+#                   the activations: ~1e-4 px EPE on the flows)
+#   PRECISION_F16   weights AND activations rounded once to fp16 (1 MFMA per product, fp32 accumulation): the reference's
+#                   deployed arithmetic class (fp16 autocast), opt-in
 PRECISION = PRECISION_F16X3
-_PRECISION_NAMES = {"fp32": PRECISION_FP32, "f16x3": PRECISION_F16X3, "f16x2": PRECISION_F16X2}
+_PRECISION_NAMES = {"fp32": PRECISION_FP32, "f16x3": PRECISION_F16X3, "f16x2": PRECISION_F16X2, "f16": PRECISION_F16}
 
 
 def set_precision(mode) -> int:
@@ -34,7 +36,7 @@ def set_precision(mode) -> int:
     global PRECISION
     prev = PRECISION
     PRECISION = _PRECISION_NAMES[mode] if isinstance(mode, str) else int(mode)
-    if PRECISION not in (PRECISION_FP32, PRECISION_F16X3, PRECISION_F16X2):
+    if PRECISION not in (PRECISION_FP32, PRECISION_F16X3, PRECISION_F16X2, PRECISION_F16):
         PRECISION = prev
         raise RuntimeError(f"unknown precision {mode}")
     return prev
@@ -241,8 +243,8 @@ def gemm(A: PackedLinear, X: Planes, Y: Planes, epilogue: int = EPI_NONE, R: Opt
     g.a_padded = 1
     prec = PRECISION
     if X.f16 or Y.f16:
-        if prec != PRECISION_F16X2:
-            raise RuntimeError("fp16 activation planes are a hand-over format of the f16x2 mode only")
+        if prec not in (PRECISION_F16X2, PRECISION_F16):
+            raise RuntimeError("fp16 activation planes are a hand-over format of the f16x2 / f16 modes only")
         if X.f16:
             g.b_layout = _lib.LAYOUT_F16_K_MAJOR
         if Y.f16:

@@ -11,6 +11,10 @@
     the GMA aggregation is the fused recompute kernel with fp16 q / k / v (what flash_attn_func computes in the
     reference's demo).  ~1.3e-4 px EPE against the fp32 oracle at the headline shape after 15 iterations: 8x inside
     the 1e-3 budget.
+
+Not a preset: ``precision='f16'`` (weights rounded to fp16 as well, one MFMA per product -- plain fp16-autocast
+arithmetic with fp32 accumulation) runs at 245 flow-fields/s but lands at 2.5e-3 px: outside the budget.  The systematic
+rounding of the WEIGHTS is what costs the accuracy, not the rounding of activations; hence split weights everywhere.
 """
 from __future__ import annotations
 

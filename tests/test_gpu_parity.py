@@ -192,8 +192,11 @@ def test_model_api_forward_vs_golden(golden, dev, precision):
 
 
 def test_f16x2_mode_within_parity_budget(dev):
-    """Opt-in f16x2 mode (activations rounded once to fp16): looser than f16x3 but must stay inside the 1e-3 px
-    EPE budget of the north star; 15 iterations at a small shape, against the CPU oracle."""
+    """f16x2 (activations rounded once to fp16, weights split) is looser than f16x3 but must stay inside the 1e-3 px EPE
+    budget of the north star; 15 iterations at a small shape, against the CPU oracle.  The single-product `f16` mode
+    (weights rounded to fp16 too: the arithmetic of an fp16-autocast deployment) is NOT parity-grade -- 3e-3 px here,
+    2.5e-3 px at the headline shape -- and is only checked to stay in that class: it exists to document why the weights
+    keep their lo part (245 vs 215 flow-fields/s would be the price of the budget)."""
     from oracle import streamflow_oracle as orc
     from streamflow_amd import synthetic as syn
     from streamflow_amd.engine import HotPathEngine
@@ -201,7 +204,7 @@ def test_f16x2_mode_within_parity_budget(dev):
     P = syn.make_params(5, T)
     fmaps, cnets = syn.make_features(5, B, T, h, w)
     ups_o, _ = orc.hotpath_forward(fmaps, cnets, P, 15)
-    for prec, bound in (("f16x2", 1e-3), ("f16x3", 5e-5)):
+    for prec, bound in (("f16", 1e-2), ("f16x2", 1e-3), ("f16x3", 5e-5)):
         eng = HotPathEngine(P, device=dev, T=T, precision=prec)
         ups, _ = eng.forward(fmaps.to(dev), cnets.to(dev), iters=15)
         e = max(orc.epe(u.cpu(), o) for u, o in zip(ups, ups_o))
