@@ -98,8 +98,16 @@ __global__ __launch_bounds__(kMaxThreads) void dwconv_res_gelu_kernel(const DwAr
         if (gy >= g.h) continue;
         const float* ctr = tile + (ty * TY + oy + R) * wp + tx * TX + R;
         float o[TX];
+        static_assert(TX % 2 == 0, "outputs are activated in pairs (packed fp32 GELU)");
 #pragma unroll
-        for (int ox = 0; ox < TX; ++ox) o[ox] = sf::gelu_erf(ctr[ox] + (acc[oy][ox] + bv));
+        for (int ox = 0; ox < TX; ox += 2) {
+            sf::f32x2 t;
+            t[0] = ctr[ox] + (acc[oy][ox] + bv);
+            t[1] = ctr[ox + 1] + (acc[oy][ox + 1] + bv);
+            const sf::f32x2 a = sf::gelu_erf2(t);
+            o[ox] = a[0];
+            o[ox + 1] = a[1];
+        }
         const int gx = tx * TX;
         if (g.vec_store && gx + 3 < g.w) {
             *reinterpret_cast<float4*>(yp + gy * g.w + gx) = make_float4(o[0], o[1], o[2], o[3]);
@@ -272,14 +280,23 @@ __global__ __launch_bounds__(256, 2) void dwconv_mfma_kernel(const DwmArgs g) {
 #pragma unroll
             for (int j = 0; j < TG; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const bool ok = (gx0 + j * 16 < g.w) && (gy0 + r < g.h);
-                    const int xo = xoff0 + r * row_step + min(j, ntx - 1 - tx0) * 32;
-                    const float xv = (float)*reinterpret_cast<const _Float16*>(hi + xo) +
-                                     (float)*reinterpret_cast<const _Float16*>(lo + xo);
-                    const float o = sf::gelu_erf(xv + (acc[j][r] + bv));
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), ry,
-                                                          ok ? off0 + (r * g.w + j * 16) * 4 : (int)0x80000000u, 0, 0);
+                for (int r = 0; r < 4; r += 2) {                  // two outputs at a time: packed fp32 GELU
+                    sf::f32x2 t;
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int xo = xoff0 + (r + u) * row_step + min(j, ntx - 1 - tx0) * 32;
+                        const float xv = (float)*reinterpret_cast<const _Float16*>(hi + xo) +
+                                         (float)*reinterpret_cast<const _Float16*>(lo + xo);
+                        t[u] = xv + (acc[j][r + u] + bv);
+                    }
+                    const sf::f32x2 a = sf::gelu_erf2(t);
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const bool ok = (gx0 + j * 16 < g.w) && (gy0 + r + u < g.h);
+                        const float o = a[u];
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), ry,
+                                                              ok ? off0 + ((r + u) * g.w + j * 16) * 4 : (int)0x80000000u, 0, 0);
+                    }
                 }
         }
     }

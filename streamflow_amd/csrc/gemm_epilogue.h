@@ -58,6 +58,21 @@ __device__ __forceinline__ float epi_apply(float v, float r, float dww, float dw
     return v;
 }
 
+// the same for two values at once (packed fp32 GELU)
+template <int EPI>
+__device__ __forceinline__ f32x2 epi_apply2(f32x2 v, f32x2 r, float dww, float dwb, float gam) {
+    if (EPI == SF_EPI_GELU) return gelu_erf2(v);
+    if (EPI == SF_EPI_RES_GELU) return gelu_erf2(r + v);
+    if (EPI == SF_EPI_RES_GELU_DW1) {
+        const f32x2 t = gelu_erf2(r + v);
+        return gelu_erf2(t + (splat2(dww) * t + splat2(dwb)));
+    }
+    f32x2 o;
+    o[0] = epi_apply<EPI>(v[0], r[0], dww, dwb, gam);
+    o[1] = epi_apply<EPI>(v[1], r[1], dww, dwb, gam);
+    return o;
+}
+
 template <int EPI, int WM, int WN, int TM, int TN>
 __device__ __forceinline__ void gemm_epilogue_impl(const SfGemm& g, f32x16 (&acc)[TM][TN], int m0, int n0, int z,
                                                    int wm, int wn, int lane) {
@@ -219,13 +234,19 @@ __device__ __forceinline__ void gemm_epilogue_vec_impl(const SfGemm& g, f32x16 (
                 const float av[4] = {a.x, a.y, a.z, a.w};
                 epi_u32x4 o;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float v = g.alpha * (av[e] + bias[q]);
+                for (int e = 0; e < 4; e += 2) {
+                    f32x2 v, r;
+                    v[0] = g.alpha * (av[e] + bias[q]);
+                    v[1] = g.alpha * (av[e + 1] + bias[q]);
                     // copy the element to a scalar first: __builtin_bit_cast applied directly to an ext-vector element
                     // lvalue reads the vector's FIRST element (clang quirk seen with ROCm 7.2)
-                    const unsigned ru = kNeedsR ? rv[j][q][e] : 0u;
-                    const float r = __builtin_bit_cast(float, ru);
-                    o[e] = __builtin_bit_cast(unsigned, epi_apply<EPI>(v, r, dww[q], dwb[q], gam));
+                    const unsigned ru0 = kNeedsR ? rv[j][q][e] : 0u, ru1 = kNeedsR ? rv[j][q][e + 1] : 0u;
+                    r[0] = __builtin_bit_cast(float, ru0);
+                    r[1] = __builtin_bit_cast(float, ru1);
+                    const f32x2 res = epi_apply2<EPI>(v, r, dww[q], dwb[q], gam);
+                    const float r0 = res[0], r1 = res[1];
+                    o[e] = __builtin_bit_cast(unsigned, r0);
+                    o[e + 1] = __builtin_bit_cast(unsigned, r1);
                 }
                 if (g.c_f16) {                                   // wave-uniform
                     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
