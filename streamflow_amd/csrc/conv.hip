@@ -13,6 +13,7 @@
 // lgkmcnt(0) drain -- and a register sliding window that cuts the LDS row reads 4x changed nothing: the
 // kernel is bound by VALU issue, 47 TFLOP/s of fp32 FMA.)
 #include "sf_common.h"
+#include <cstdlib>
 #include "split_operand.h"
 
 namespace {
@@ -149,14 +150,25 @@ struct DwmArgs {
     int w16;          // w rounded up to 16
     int stride16;     // LDS row stride in 16-byte units (= 8 halfs)
     int vec_ok;       // rows are 16-byte aligned: float4 staging loads
+#ifdef SF_DW_TIMERS
+    long long* ts;    // SF_DW_TS_BUF: per-workgroup phase cycles (tools/dwconv_one.py)
+#endif
 };
 
+#ifndef SF_DW_TG
+#define SF_DW_TG 4      // phase timers (tools/dwconv_one.py, -DSF_DW_TIMERS): with 2 tiles per wave the tile loop ran at 5.9k
+                        // cycles per pair against 1.4k of MFMA issue -- every kernel row waited for its ds_read_b128 round
+                        // trip behind 6 MFMAs; 4 tiles put 12 MFMAs behind each round trip
+#endif
+#ifndef SF_DW_FU
+#define SF_DW_FU 6      // octets a thread stages at a time: 6 x 256 >= the 1404 octets of a 55x128 strip, ONE global round trip
+#endif
 template <int KS>
 __global__ __launch_bounds__(256, 2) void dwconv_mfma_kernel(const DwmArgs g) {
     using namespace sf_split;
     constexpr int R = KS / 2;
     constexpr int WZ = 64;                                      // zero-padded weight row: w[ky][j - 24]
-    constexpr int TG = 2;                                       // adjacent column tiles a wave works on together
+    constexpr int TG = SF_DW_TG;                                // adjacent column tiles a wave works on together
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, kg = lane >> 4;
@@ -185,6 +197,10 @@ __global__ __launch_bounds__(256, 2) void dwconv_mfma_kernel(const DwmArgs g) {
         bl[ky] = s8.lo;
     }
     const float bv = g.bias[c];
+#ifdef SF_DW_TIMERS
+    long long t_stage = 0, t_comp = 0;
+    const long long t_begin = __builtin_readcyclecounter();
+#endif
     const int ntx = g.w16 / 16, nty = g.strip_h / 16;
     const int ngroups = nty * ((ntx + TG - 1) / TG);            // groups of up to TG adjacent column tiles
 
@@ -197,9 +213,12 @@ __global__ __launch_bounds__(256, 2) void dwconv_mfma_kernel(const DwmArgs g) {
         // LDS-only barriers: the previous image's output stores stay in flight (a __syncthreads would drain them)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                           // previous image's tiles are done with the LDS planes
+#ifdef SF_DW_TIMERS
+        const long long t0 = __builtin_readcyclecounter();
+#endif
         // ---- stage + split the strip (rows ys-R .., columns -8 ..), zero padded: one octet = 8 consecutive columns
         // of one row = one A-fragment slot; FU octets per thread at a time, all their loads issued before any is used
-        constexpr int FU = 4;
+        constexpr int FU = SF_DW_FU;
         for (int base = tid; base < rows_in * noct; base += 256 * FU) {
             float v[FU][8];
             int off[FU];
@@ -232,6 +251,10 @@ __global__ __launch_bounds__(256, 2) void dwconv_mfma_kernel(const DwmArgs g) {
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+#ifdef SF_DW_TIMERS
+        const long long t1 = __builtin_readcyclecounter();
+        t_stage += t1 - t0;
+#endif
 
         for (int grp = wave; grp < ngroups; grp += 4) {
             const int ty = grp % nty, tx0 = (grp / nty) * TG;
@@ -299,7 +322,16 @@ __global__ __launch_bounds__(256, 2) void dwconv_mfma_kernel(const DwmArgs g) {
                     }
                 }
         }
+#ifdef SF_DW_TIMERS
+        t_comp += __builtin_readcyclecounter() - t1;
+#endif
     }
+#ifdef SF_DW_TIMERS
+    if (g.ts && tid == 0) {
+        long long* d = g.ts + ((int64_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4;
+        d[0] = __builtin_readcyclecounter() - t_begin; d[1] = t_stage; d[2] = t_comp; d[3] = img_end - img0;
+    }
+#endif
 }
 
 }  // namespace
@@ -335,6 +367,9 @@ extern "C" int sf_dwconv_res_gelu(const float* x, int64_t x_img_stride, const fl
         if (groups > n_img) groups = n_img;
         if (groups < 1) groups = 1;
         m.imgs_per_wg = sf::ceil_div(n_img, groups);
+#ifdef SF_DW_TIMERS
+        m.ts = getenv("SF_DW_TS_BUF") ? (long long*)strtoull(getenv("SF_DW_TS_BUF"), nullptr, 0) : nullptr;
+#endif
         dim3 grid(C, strips, sf::ceil_div(n_img, m.imgs_per_wg));
         SF_REQUIRE(strips <= 65535 && grid.z <= 65535, "sf_dwconv_res_gelu: grid too large");
         hipLaunchKernelGGL(dwconv_mfma_kernel<15>, grid, dim3(256), lds, (hipStream_t)stream, m);

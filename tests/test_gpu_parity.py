@@ -450,6 +450,29 @@ def test_spring_shape_smoke(dev):
     assert (l0.reshape(-1) - ref).abs().max().item() < 1e-3
 
 
+def test_spring_shape_one_pair_vs_oracle(dev):
+    """BASELINE config 5 at full resolution against the oracle: 1088x1920 (136x240 grid, N = 32,640), ONE frame pair
+    (T=2), 2 iterations, in both presets -- the fused GMA kernel (the N x N matrix is never stored), the 4.3 GB (fp32) /
+    2.1 GB (fp16) correlation volume, lookups and the update block at that size.  The oracle needs ~15 GB of host RAM."""
+    from oracle import streamflow_oracle as orc
+    from streamflow_amd import presets, synthetic as syn
+    from streamflow_amd.engine import HotPathEngine
+    B, T, h, w, iters = 1, 2, 136, 240, 2
+    P = syn.make_params(19, T)
+    fmaps, cnets = syn.make_features(19, B, T, h, w)
+    ups_o, _ = orc.hotpath_forward(fmaps, cnets, P, iters)
+    for name in ("fp32_class", "config2_fp16"):
+        eng = HotPathEngine(P, device=dev, T=T, **presets.engine_kwargs(name))
+        ups, _ = eng.forward(fmaps.to(dev), cnets.to(dev), iters=iters)
+        pl = eng.plan(B, h, w, 256)
+        assert pl.flash and pl.attn.numel() <= pl.n * pl.P          # no attention matrix was materialised
+        e = orc.epe(ups[0].cpu(), ups_o[0])
+        print(f"spring shape, one pair, {iters} iterations [{name}]: EPE vs oracle = {e:.3e}")
+        assert ups[0].shape == (1, 2, 1088, 1920) and e <= 1e-3, (name, e)
+        del eng, pl
+        torch.cuda.empty_cache()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("K", [200, 1544])          # with and without a partial last k-tile
 def test_gemm_stored_fp16_operand(dev, K):

@@ -13,6 +13,16 @@ X = Planes.of(torch.randn(n, C, h * w, device=dev)); Y = Planes.of(torch.empty(n
 wgt = (torch.randn(C, k, k, device=dev) / k).contiguous(); b = torch.randn(C, device=dev) * 0.1
 for _ in range(3):
     ops.dwconv_res_gelu(X, wgt, b, Y, h, w, k)
+if os.environ.get("SF_DW_TS"):          # needs tools/build_variant.sh dwt conv.hip -DSF_DW_TIMERS + SF_HIP_LIB=.../variant_dwt.so
+    torch.cuda.synchronize()
+    ts = torch.zeros(65536 * 4, dtype=torch.int64, device=dev)
+    os.environ["SF_DW_TS_BUF"] = str(ts.data_ptr())
+    ops.dwconv_res_gelu(X, wgt, b, Y, h, w, k); torch.cuda.synchronize()
+    os.environ.pop("SF_DW_TS_BUF")
+    t = ts.view(-1, 4).cpu().double(); t = t[t[:, 3] > 0]
+    print(f"workgroups {t.shape[0]}, images per workgroup {t[:, 3].mean().item():.1f}")
+    print(f"total {t[:, 0].mean().item():.0f} cycles per workgroup; per image: stage {(t[:, 1] / t[:, 3]).mean().item():.0f}, "
+          f"compute+store {(t[:, 2] / t[:, 3]).mean().item():.0f}; setup {(t[:, 0] - t[:, 1] - t[:, 2]).mean().item():.0f}")
 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 s.record()
 reps = 20
