@@ -87,11 +87,18 @@ __device__ __forceinline__ float xor32(float v) {          // value of lane ^ 32
     return __shfl_xor(v, 32, 64);
 }
 
+#ifndef SF_FLASH_V1
+#define SF_FLASH_V1 1     // one-product kernel: ONE V stage (48 KB of LDS, 3 workgroups per CU) instead of two (64 KB, 2 per CU)
+#endif
 template <int QKP>
-__global__ __launch_bounds__(256, (QKP == 3) ? 1 : 2) void gma_flash_kernel(const FlashArgs g) {
+__global__ __launch_bounds__(256, (QKP == 3) ? 1 : ((QKP == 1 && SF_FLASH_V1) ? 3 : 2)) void gma_flash_kernel(const FlashArgs g) {
     constexpr bool kKlo = (QKP == 3);
     constexpr int KSTAGE = KPLANE * (kKlo ? 2 : 1);
-    __shared__ __attribute__((aligned(1024))) char smem[2 * KSTAGE + 2 * VTILE];
+    // kV1: K tiles double-buffered, V single-buffered.  V(t) is requested at the top of tile t (every wave has finished
+    // P V of tile t-1 by then) and has the logits + softmax of tile t to land; a second barrier precedes P V.
+    constexpr bool kV1 = (QKP == 1) && SF_FLASH_V1;
+    constexpr int NV = kV1 ? 1 : 2;
+    __shared__ __attribute__((aligned(1024))) char smem[2 * KSTAGE + NV * VTILE];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int khalf = lane >> 5, l31 = lane & 31;
@@ -114,10 +121,18 @@ __global__ __launch_bounds__(256, (QKP == 3) ? 1 : 2) void gma_flash_kernel(cons
     }
 
     // ---- tile DMA: K tile = 16 d-octet rows of 64 keys x 16 B (1 KB pieces), V tile = 16 KB contiguous ----
-    auto issue = [&](int t, int buf) {
+    auto issue_v = [&](int t, int buf) {
+        const int j0 = t * BJ;
+        char* vb = smem + 2 * KSTAGE + buf * VTILE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int piece = wave * 4 + i;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lds_ptr)(vb + piece * 1024), 16, lane * 16, j0 * (HD * 2) + piece * 1024, 0, 0);
+        }
+    };
+    auto issue_k = [&](int t, int buf) {
         const int j0 = t * BJ;
         char* kb = smem + buf * KSTAGE;
-        char* vb = smem + 2 * KSTAGE + buf * VTILE;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int dq = wave * 4 + i;
@@ -125,11 +140,6 @@ __global__ __launch_bounds__(256, (QKP == 3) ? 1 : 2) void gma_flash_kernel(cons
             if (kKlo)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (lds_ptr)(kb + KPLANE + dq * 1024), 16, (j0 + lane) * 16,
                                                          plane + dq * Ppad * 16, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int piece = wave * 4 + i;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lds_ptr)(vb + piece * 1024), 16, lane * 16, j0 * (HD * 2) + piece * 1024, 0, 0);
         }
     };
 
@@ -141,13 +151,18 @@ __global__ __launch_bounds__(256, (QKP == 3) ? 1 : 2) void gma_flash_kernel(cons
     float m_run = -1.0e30f, l_run = 0.f;
 
     const int nt = Ppad / BJ;
-    issue(0, 0);
+    issue_k(0, 0);
+    if (!kV1) issue_v(0, 0);
     for (int t = 0; t < nt; ++t) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's pieces of tile t have landed ...
         __builtin_amdgcn_s_barrier();                             // ... everyone's; the other stage is no longer read
-        if (t + 1 < nt) issue(t + 1, (t + 1) & 1);
+        if (kV1) issue_v(t, 0);                                   // (V first: its wait below leaves the K pieces in flight)
+        if (t + 1 < nt) {
+            issue_k(t + 1, (t + 1) & 1);
+            if (!kV1) issue_v(t + 1, (t + 1) & 1);
+        }
         const char* kb = smem + (t & 1) * KSTAGE;
-        const char* vb = smem + 2 * KSTAGE + (t & 1) * VTILE;
+        const char* vb = smem + 2 * KSTAGE + (kV1 ? 0 : (t & 1)) * VTILE;
 
         // ---- logits (transposed): s[sub][r] = <k_key, q_query>, key = j0 + sub*32 + (r&3) + 8(r>>2) + 4 khalf ----
         f32x16 s[2];
@@ -217,6 +232,11 @@ __global__ __launch_bounds__(256, (QKP == 3) ? 1 : 2) void gma_flash_kernel(cons
             for (int td = 0; td < HD / 32; ++td)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[td][r] *= alpha;
+        }
+        if (kV1) {                                                // V(t): 4 pieces per wave, requested before the K(t+1) pieces
+            if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
         }
         // ---- O^T += V^T P^T ----
 #pragma unroll
