@@ -62,7 +62,14 @@ __global__ __launch_bounds__(kThreads, (TM * TN >= 8) ? 2 : SF_GEMM_WAVES) void 
     constexpr bool kDmaA = (ALAY == 2) && (BM == 128);
     constexpr int kAStage = (SA ? 2 : 1) * (BK / 8) * BM * 8;                    // halfs of one DMA stage (hi [+ lo])
     constexpr int kAHalfs = kDmaA ? 2 * kAStage : (SA ? 2 : 1) * BM * LDK;
-    constexpr int kMainHalfs = kAHalfs + (SB ? 2 : 1) * BN * LDK;               // SB = false: B has no lo part
+#ifndef SF_GEMM_B2
+#define SF_GEMM_B2 1     // two B stages where they fit (no lo plane + DMA-fed A): ONE barrier per k-tile instead of two
+#endif
+    // kB2: B double-buffered in LDS.  The staged registers of tile kt+1 are written to the OTHER stage right after the
+    // MFMAs of tile kt (nobody reads that stage: it was last read in tile kt-1, a barrier ago), so the barrier that
+    // separated "everyone is done reading" from the store disappears.
+    constexpr bool kB2 = SF_GEMM_B2 && !SB && kDmaA;
+    constexpr int kMainHalfs = kAHalfs + (SB ? 2 : (kB2 ? 2 : 1)) * BN * LDK;   // SB = false: B has no lo part
     constexpr int kEpiHalfs = 4 * sf::kEpiScratchFloats * 2;
     __shared__ __attribute__((aligned(1024))) _Float16 smem[kMainHalfs > kEpiHalfs ? kMainHalfs : kEpiHalfs];
     _Float16 (*sA)[BM * LDK] = reinterpret_cast<_Float16 (*)[BM * LDK]>(smem);
@@ -161,7 +168,8 @@ __global__ __launch_bounds__(kThreads, (TM * TN >= 8) ? 2 : SF_GEMM_WAVES) void 
         const _Float16* pal = kDmaA ? pah + kAStage / 2 : sA[SA ? 1 : 0] + (wm * TM * 32 + l31) * LDK + khalf * 8;   // (SA only)
         constexpr int kATile = kDmaA ? 32 * 8 : 32 * LDK;        // halfs between the 32-row tiles of a wave
         constexpr int kAStep = kDmaA ? 2 * BM * 8 : 16;          // halfs per 16-deep k-step
-        const _Float16* pbh = sB[0] + (wn * TN * 32 + l31) * LDK + khalf * 8;
+        const int bbuf = kB2 ? ((kt - kt_beg) & 1) : 0;
+        const _Float16* pbh = sB[bbuf] + (wn * TN * 32 + l31) * LDK + khalf * 8;
         const _Float16* pbl = sB[SB ? 1 : 0] + (wn * TN * 32 + l31) * LDK + khalf * 8;
 #if SF_GEMM_FRAG_PREFETCH
         // all fragment reads of the k-tile are issued before its first MFMA (2 k-steps x 8 x ds_read_b128 = 64 VGPRs):
@@ -229,9 +237,9 @@ __global__ __launch_bounds__(kThreads, (TM * TN >= 8) ? 2 : SF_GEMM_WAVES) void 
 #endif
         __builtin_amdgcn_sched_barrier(0);
         if (kt + 1 < kt_end) {
-            __syncthreads();                       // every wave is done reading tile kt
+            if (!kB2) __syncthreads();             // every wave is done reading tile kt
             if (!kDmaA) opa.template store<SA>((kt + 1) * BK, sA[0], sA[SA ? 1 : 0], ra);
-            opb.template store<SB>((kt + 1) * BK, sB[0], sB[SB ? 1 : 0], rb, conv ? conv_tap((kt + 1) * BK) : -1);
+            opb.template store<SB>((kt + 1) * BK, sB[kB2 ? (bbuf ^ 1) : 0], sB[SB ? 1 : 0], rb, conv ? conv_tap((kt + 1) * BK) : -1);
             if (kDmaA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (already retired by the wait for rb)
             __syncthreads();
         }
