@@ -157,8 +157,10 @@ __global__ __launch_bounds__(kThreads, (TM * TN >= 8) ? 2 : SF_GEMM_WAVES) void 
             cb.advance();
             if (kDmaA) issue_a(kt + 1, abuf ^ 1);          // the other stage was last read one k-tile (two barriers) ago
             else opa.load((kt + 1) * BK, ca.off, ra);
+#ifndef SF_ABLATE_B          // timing ablation only (wrong results): B tile staged once, never refreshed
             if (conv) opb.load((kt + 1) * BK, conv_off((kt + 1) * BK), rb, conv_shift((kt + 1) * BK));
             else opb.load((kt + 1) * BK, cb.off, rb);
+#endif
         }
         // keep the staged loads in flight across the MFMA block: nothing below may be hoisted above it
         __builtin_amdgcn_sched_barrier(0);
@@ -239,7 +241,9 @@ __global__ __launch_bounds__(kThreads, (TM * TN >= 8) ? 2 : SF_GEMM_WAVES) void 
         if (kt + 1 < kt_end) {
             if (!kB2) __syncthreads();             // every wave is done reading tile kt
             if (!kDmaA) opa.template store<SA>((kt + 1) * BK, sA[0], sA[SA ? 1 : 0], ra);
+#ifndef SF_ABLATE_B
             opb.template store<SB>((kt + 1) * BK, sB[kB2 ? (bbuf ^ 1) : 0], sB[SB ? 1 : 0], rb, conv ? conv_tap((kt + 1) * BK) : -1);
+#endif
             if (kDmaA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (already retired by the wait for rb)
             __syncthreads();
         }

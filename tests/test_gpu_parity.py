@@ -324,25 +324,34 @@ def test_engine_on_non_current_device():
         assert max(orc.epe(u.cpu(), o) for u, o in zip(ups, ups_o)) <= 1e-3
 
 
-def test_kitti_shape_T2_vs_oracle(dev):
-    """BASELINE config 3: KITTI shape 376x1248 -> 47x156 grid (odd height, width not a multiple of 32), T=2
-    (one pair, single-token temporal block, 128->2 flow head), corr build + lookup + 2 iterations vs the oracle."""
+@pytest.mark.parametrize("preset", ["fp32_class", "config2_fp16"])
+def test_kitti_shape_T2_vs_oracle(dev, preset):
+    """BASELINE config 3: KITTI shape 376x1248 -> 47x156 grid (odd height, width not a multiple of 32, pooled levels of
+    odd width 39 / 19), T=2 (one pair, single-token temporal block, 128->2 flow head), corr build + lookup + 2 iterations
+    vs the oracle, in both presets (fp32 volumes: tight; fp16 volumes: one fp16 rounding of each stored cell)."""
     from oracle import streamflow_oracle as orc
-    from streamflow_amd import synthetic as syn
+    from streamflow_amd import presets, synthetic as syn
     from streamflow_amd.engine import HotPathEngine
     B, T, h, w = 1, 2, 47, 156
     P = syn.make_params(13, T)
     fmaps, cnets = syn.make_features(13, B, T, h, w)
-    eng = HotPathEngine(P, device=dev, T=T)
+    eng = HotPathEngine(P, device=dev, T=T, **presets.engine_kwargs(preset))
     ups, low = eng.forward(fmaps.to(dev), cnets.to(dev), iters=2)
     pl = eng.plan(B, h, w, 256)
-    pyr = orc.corr_pyramid(fmaps[:, 0], fmaps[:, 1])
-    for l in range(4):
-        got = pl.lvls[l].view(pyr[l].shape).cpu()
-        assert (got - pyr[l]).abs().max().item() < 5e-5, f"level {l}"
+    if preset == "fp32_class":
+        pyr = orc.corr_pyramid(fmaps[:, 0], fmaps[:, 1])
+        for l in range(4):
+            got = pl.lvls[l].view(pyr[l].shape).cpu()
+            assert (got - pyr[l]).abs().max().item() < 5e-5, f"level {l}"
+    else:
+        pyr = orc.corr_pyramid(fmaps[:, 0].half().float(), fmaps[:, 1].half().float())
+        for l in range(4):
+            got = pl.lvls[l].view(pyr[l].shape).float().cpu()
+            assert pl.lvls[l].dtype == torch.float16
+            assert ((got - pyr[l]).abs() <= 2.0 ** -11 * pyr[l].abs() + 3e-5).all(), f"level {l}"
     ups_o, _ = orc.hotpath_forward(fmaps, cnets, P, 2)
     e = orc.epe(ups[0].cpu(), ups_o[0])
-    print(f"kitti-shape T=2: EPE vs oracle = {e:.3e}")
+    print(f"kitti-shape T=2 [{preset}]: EPE vs oracle = {e:.3e}")
     assert ups[0].shape == (1, 2, 376, 1248) and e <= 1e-3
 
 
