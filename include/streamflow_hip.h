@@ -99,6 +99,12 @@ enum { SF_LAYOUT_K_MAJOR = 0,   /* A[k*lda + m]   /  B[k*ldb + n]   (rows of k) 
        SF_LAYOUT_F16_K_MINOR = 3,  /* B only, split precisions: B points to IEEE fp16 values B[n*ldb + k]
                                     (ldb, strideB in halfs; ldb % 2 == 0); used as they are, no lo part:
                                     a*b = ah*b + al*b.  The stored attention matrix (sf_softmax_rows).   */
+       SF_LAYOUT_F16_KOCT = 5,   /* B only, F16X2 / F16 with a SPLIT_F16 A and M > 96 (the 128-row tile): IEEE fp16 in k-octet
+                                    planes, element (k, n) at ((k/8)*ldb + n)*8 + k%8 (ldb = pixels per plane, strideB in
+                                    halves; 16-byte aligned) -- what a producing sf_gemm stores with c_f16 = 2.  16 bytes =
+                                    one MFMA operand octet of one pixel: the consumer moves its B tiles HBM/L2 -> LDS with
+                                    buffer_load ... lds like the weights (no registers, no conversion, no ds_write).
+                                    Octets past ceil(K/8) read as zero; rows K..8*ceil(K/8)-1 must be finite.          */
        SF_LAYOUT_F16_K_MAJOR = 4 };/* B only, SF_PRECISION_F16X2 with a SPLIT_F16 A: IEEE fp16 rows B[k*ldb + n]
                                     (ldb, strideB in halfs; N, ldb, strideB even) -- what a producing sf_gemm stores
                                     with c_f16 = 1.  Bit-identical to handing the fp32 values over (F16X2 rounds a
@@ -152,7 +158,9 @@ typedef struct SfGemm {
        products go to the scratch and a second kernel applies bias / epilogue.  Results are deterministic. */
     float* split_ws; int64_t split_ws_floats;
     /* c_f16 = 1 (split precisions, 16-byte-aligned C, N % 4 == 0, ldc % 4 == 0): C points to IEEE fp16 storage, results are
-       rounded to nearest and stored as halves (ldc, strideC in halves): the K-major fp16 operand of the next sf_gemm. */
+       rounded to nearest and stored as halves (ldc, strideC in halves): the K-major fp16 operand of the next sf_gemm.
+       c_f16 = 2: the same values in k-octet planes (SF_LAYOUT_F16_KOCT; ldc = pixels per plane, strideC in halves,
+       8*ceil(M/8) rows are written: the caller provides room for them). */
     int32_t c_f16;
 } SfGemm;
 

@@ -269,6 +269,88 @@ __device__ __forceinline__ void gemm_epilogue_vec_impl(const SfGemm& g, f32x16 (
     }
 }
 
+// ---- k-octet epilogue (c_f16 = 2): the result leaves as the NEXT GEMM's LDS image ------------------------------------------
+// Output element (m, n) -> IEEE fp16 at ((m / 8) * ldc + n) * 8 + m % 8 (SF_LAYOUT_F16_KOCT).  Each 32x32 accumulator
+// tile goes through the per-wave scratch like the vector epilogue, but is read back with a lane owning ONE pixel and the
+// 8 channels of one k-octet (lane = (octet half, pixel)): eight ds_read_b32, the epilogue arithmetic on packed pairs,
+// one 16-byte store; 32 consecutive lanes = 32 consecutive pixels = 512 contiguous bytes.  Rows past M inside the last
+// octet are written too (finite values from clamped parameters; the consumer's weights are zero there).
+template <int EPI, int WM, int WN, int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue_koct_impl(const SfGemm& g, f32x16 (&acc)[TM][TN], int m0, int n0, int z,
+                                                        int wm, int wn, int lane, float* scratch) {
+    constexpr bool kNeedsR = (EPI == SF_EPI_RES || EPI == SF_EPI_RES_GELU || EPI == SF_EPI_RES_GELU_DW1 ||
+                              EPI == SF_EPI_AXPY);
+    const int khalf = lane >> 5, l31 = lane & 31;
+    const int moct = (g.M + 7) / 8;
+    const int c_bytes = (int)((int64_t)moct * g.ldc * 16);
+    __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<char*>(g.C) + (int64_t)z * g.strideC * 2, 0, c_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rr = rc;
+    if (kNeedsR) {
+        const int mr = g.M - 1;
+        const int64_t last = (g.r_group > 0) ? (int64_t)(mr / g.r_group) * g.r_group_stride + (int64_t)(mr % g.r_group) * g.ldr
+                                             : (int64_t)mr * g.ldr;
+        rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.R) + (int64_t)z * g.strideR, 0,
+                                               (int)((last + g.N) * 4), 0x00020000);
+    }
+    const float gam = (EPI == SF_EPI_AXPY) ? g.gamma[0] : 0.f;
+    const bool has_bias = g.bias != nullptr;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int mt0 = m0 + (wm * TM + i) * 32;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                scratch[((r & 3) + 8 * (r >> 2) + 4 * khalf) * kEpiStride + l31] = acc[i][j][r];
+            const int n = n0 + (wn * TN + j) * 32 + l31;
+            const int nc = n < g.N ? n : g.N - 1;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {                         // octets (2q + khalf) of the 32-row tile
+                const int mo = mt0 + (2 * q + khalf) * 8;         // first row of this lane's octet
+                epi_u32x4 o;
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) {
+                    f32x2 v, r;
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int m = mo + e + u, mc = m < g.M ? m : g.M - 1;
+                        const float a = scratch[((2 * q + khalf) * 8 + e + u) * kEpiStride + l31];
+                        v[u] = g.alpha * (a + (has_bias ? g.bias[mc] : 0.f));
+                        r[u] = 0.f;
+                        if (kNeedsR) {
+                            const int rro = (g.r_group > 0)
+                                ? (int)(((int64_t)(mc / g.r_group) * g.r_group_stride + (int64_t)(mc % g.r_group) * g.ldr) * 4)
+                                : mc * (int)g.ldr * 4;
+                            r[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, rro + nc * 4, 0, 0));
+                        }
+                    }
+                    const int mc0 = (mo + e < g.M) ? mo + e : g.M - 1;
+                    const f32x2 res = epi_apply2<EPI>(v, r, EPI == SF_EPI_RES_GELU_DW1 ? g.dw_w[mc0] : 0.f,
+                                                      EPI == SF_EPI_RES_GELU_DW1 ? g.dw_b[mc0] : 0.f, gam);
+                    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                    h2 hv;
+                    hv[0] = (_Float16)res[0];
+                    hv[1] = (_Float16)res[1];
+                    o[e >> 1] = __builtin_bit_cast(unsigned, hv);
+                }
+                const bool ok = n < g.N && mo < g.M;
+                __builtin_amdgcn_raw_buffer_store_b128(o, rc, ok ? ((mo >> 3) * (int)g.ldc + n) * 16 : kOobTerm, 0, SF_EPI_STORE_AUX);
+            }
+        }
+    }
+}
+
+template <int WM, int WN, int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue_koct(const SfGemm& g, f32x16 (&acc)[TM][TN], int m0, int n0, int z, int wm,
+                                                   int wn, int lane, float* scratch) {
+    switch (g.epilogue) {     // wave-uniform; the hand-over tensors are produced with these three epilogues only
+        case SF_EPI_GELU: gemm_epilogue_koct_impl<SF_EPI_GELU, WM, WN, TM, TN>(g, acc, m0, n0, z, wm, wn, lane, scratch); break;
+        case SF_EPI_RES_GELU: gemm_epilogue_koct_impl<SF_EPI_RES_GELU, WM, WN, TM, TN>(g, acc, m0, n0, z, wm, wn, lane, scratch); break;
+        default: gemm_epilogue_koct_impl<SF_EPI_NONE, WM, WN, TM, TN>(g, acc, m0, n0, z, wm, wn, lane, scratch); break;
+    }
+}
+
 template <int WM, int WN, int TM, int TN>
 __device__ __forceinline__ void gemm_epilogue_vec(const SfGemm& g, f32x16 (&acc)[TM][TN], int m0, int n0, int z, int wm,
                                                   int wn, int lane, float* scratch) {
@@ -295,7 +377,7 @@ __device__ __forceinline__ bool epilogue_vec_ok(const SfGemm& g, int z) {
 
 // host-side guard for the 32-bit buffer offsets used above
 inline bool epilogue_spans_ok(const SfGemm& g) {
-    const int64_t c = ((int64_t)(g.M - 1) * g.ldc + g.N) * (g.c_f16 ? 2 : 4);
+    const int64_t c = (g.c_f16 == 2) ? (int64_t)((g.M + 7) / 8) * g.ldc * 16 : ((int64_t)(g.M - 1) * g.ldc + g.N) * (g.c_f16 ? 2 : 4);
     int64_t r = 0;
     if (g.R) {
         const int mr = g.M - 1;

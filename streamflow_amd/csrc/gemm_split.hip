@@ -68,8 +68,12 @@ __global__ __launch_bounds__(kThreads, (TM * TN >= 8) ? 2 : SF_GEMM_WAVES) void 
     // kB2: B double-buffered in LDS.  The staged registers of tile kt+1 are written to the OTHER stage right after the
     // MFMAs of tile kt (nobody reads that stage: it was last read in tile kt-1, a barrier ago), so the barrier that
     // separated "everyone is done reading" from the store disappears.
-    constexpr bool kB2 = SF_GEMM_B2 && !SB && kDmaA;
-    constexpr int kMainHalfs = kAHalfs + (SB ? 2 : (kB2 ? 2 : 1)) * BN * LDK;   // SB = false: B has no lo part
+    // kDmaB: B arrives as fp16 k-octet planes (SF_LAYOUT_F16_KOCT) and is DMA-fed like A: two stages [4 k-octets][BN][8]
+    constexpr bool kDmaB = (BLAY == SF_LAYOUT_F16_KOCT);
+    static_assert(!kDmaB || (kDmaA && !SB), "KOCT B needs the DMA-fed 128-row tile and no lo plane");
+    constexpr int kBStage = (BK / 8) * BN * 8;                                   // halfs of one DMA stage of B
+    constexpr bool kB2 = SF_GEMM_B2 && !SB && kDmaA && !kDmaB;
+    constexpr int kMainHalfs = kAHalfs + (kDmaB ? 2 * kBStage : (SB ? 2 : (kB2 ? 2 : 1)) * BN * LDK);   // SB = false: no lo part
     constexpr int kEpiHalfs = 4 * sf::kEpiScratchFloats * 2;
     __shared__ __attribute__((aligned(1024))) _Float16 smem[kMainHalfs > kEpiHalfs ? kMainHalfs : kEpiHalfs];
     _Float16 (*sA)[BM * LDK] = reinterpret_cast<_Float16 (*)[BM * LDK]>(smem);
@@ -135,10 +139,24 @@ __global__ __launch_bounds__(kThreads, (TM * TN >= 8) ? 2 : SF_GEMM_WAVES) void 
         }
     };
 
+    // ---- B by LDS-DMA (kDmaB): slot = k-octet * BN + pixel = j * 256 + tid; pixels past N are clamped (never stored) ----
+    const int b_plane = (int)(args.b_bytes);
+    const __amdgpu_buffer_rsrc_t rbd = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(g.B)) + (int64_t)z * g.strideB * 2, 0, b_plane, 0x00020000);
+    const int bpx = min(n0 + (tid & (BN - 1)), g.N - 1);
+    const int vob0 = ((tid / BN) * (int)g.ldb + bpx) * 16, vob1 = vob0 + (kThreads / BN) * (int)g.ldb * 16;
+    auto issue_b = [&](int kt, int buf) {
+        char* dst = reinterpret_cast<char*>(smem + kAHalfs) + buf * kBStage * 2 + wave_u * 1024;
+        const int so = kt * (BK / 8) * (int)g.ldb * 16;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rbd, (lds_ptr)(dst), 16, vob0, so, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rbd, (lds_ptr)(dst + 4096), 16, vob1, so, 0, 0);
+    };
+
     // the A piece is requested BEFORE the B loads of the same k-tile: vmcnt retires in order, so the wait that the B
     // registers need also covers the DMA
     if (kDmaA) issue_a(kt_beg, 0);
     else opa.load(kt_beg * BK, ca.off, ra);
+    if (kDmaB) issue_b(kt_beg, 0);
     if (conv) opb.load(kt_beg * BK, conv_off(kt_beg * BK), rb, conv_shift(kt_beg * BK));
     else opb.load(kt_beg * BK, cb.off, rb);
     if (!kDmaA) opa.template store<SA>(kt_beg * BK, sA[0], sA[SA ? 1 : 0], ra);
@@ -157,6 +175,7 @@ __global__ __launch_bounds__(kThreads, (TM * TN >= 8) ? 2 : SF_GEMM_WAVES) void 
             cb.advance();
             if (kDmaA) issue_a(kt + 1, abuf ^ 1);          // the other stage was last read one k-tile (two barriers) ago
             else opa.load((kt + 1) * BK, ca.off, ra);
+            if (kDmaB) issue_b(kt + 1, abuf ^ 1);
 #ifndef SF_ABLATE_B          // timing ablation only (wrong results): B tile staged once, never refreshed
             if (conv) opb.load((kt + 1) * BK, conv_off((kt + 1) * BK), rb, conv_shift((kt + 1) * BK));
             else opb.load((kt + 1) * BK, cb.off, rb);
@@ -171,7 +190,10 @@ __global__ __launch_bounds__(kThreads, (TM * TN >= 8) ? 2 : SF_GEMM_WAVES) void 
         constexpr int kATile = kDmaA ? 32 * 8 : 32 * LDK;        // halfs between the 32-row tiles of a wave
         constexpr int kAStep = kDmaA ? 2 * BM * 8 : 16;          // halfs per 16-deep k-step
         const int bbuf = kB2 ? ((kt - kt_beg) & 1) : 0;
-        const _Float16* pbh = sB[bbuf] + (wn * TN * 32 + l31) * LDK + khalf * 8;
+        constexpr int kBTile = kDmaB ? 32 * 8 : 32 * LDK;        // halfs between the 32-column tiles of a wave
+        constexpr int kBStep = kDmaB ? 2 * BN * 8 : 16;          // halfs per 16-deep k-step
+        const _Float16* pbh = kDmaB ? smem + kAHalfs + abuf * kBStage + (khalf * BN + wn * TN * 32 + l31) * 8
+                                    : sB[bbuf] + (wn * TN * 32 + l31) * LDK + khalf * 8;
         const _Float16* pbl = sB[SB ? 1 : 0] + (wn * TN * 32 + l31) * LDK + khalf * 8;
 #if SF_GEMM_FRAG_PREFETCH
         // all fragment reads of the k-tile are issued before its first MFMA (2 k-steps x 8 x ds_read_b128 = 64 VGPRs):
@@ -187,7 +209,7 @@ __global__ __launch_bounds__(kThreads, (TM * TN >= 8) ? 2 : SF_GEMM_WAVES) void 
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                bh[ks][j] = *reinterpret_cast<const f16x8*>(pbh + j * 32 * LDK + ks * 16);
+                bh[ks][j] = *reinterpret_cast<const f16x8*>(pbh + j * kBTile + ks * kBStep);
                 if (SB) bl[ks][j] = *reinterpret_cast<const f16x8*>(pbl + j * 32 * LDK + ks * 16);
             }
         }
@@ -223,7 +245,7 @@ __global__ __launch_bounds__(kThreads, (TM * TN >= 8) ? 2 : SF_GEMM_WAVES) void 
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                bh[j] = *reinterpret_cast<const f16x8*>(pbh + j * 32 * LDK + ks * 16);
+                bh[j] = *reinterpret_cast<const f16x8*>(pbh + j * kBTile + ks * kBStep);
                 if (SB) bl[j] = *reinterpret_cast<const f16x8*>(pbl + j * 32 * LDK + ks * 16);
             }
 #pragma unroll
@@ -239,7 +261,7 @@ __global__ __launch_bounds__(kThreads, (TM * TN >= 8) ? 2 : SF_GEMM_WAVES) void 
 #endif
         __builtin_amdgcn_sched_barrier(0);
         if (kt + 1 < kt_end) {
-            if (!kB2) __syncthreads();             // every wave is done reading tile kt
+            if (!kB2 && !kDmaB) __syncthreads();   // every wave is done reading tile kt
             if (!kDmaA) opa.template store<SA>((kt + 1) * BK, sA[0], sA[SA ? 1 : 0], ra);
 #ifndef SF_ABLATE_B
             opb.template store<SB>((kt + 1) * BK, sB[kB2 ? (bbuf ^ 1) : 0], sB[SB ? 1 : 0], rb, conv ? conv_tap((kt + 1) * BK) : -1);
@@ -253,7 +275,11 @@ __global__ __launch_bounds__(kThreads, (TM * TN >= 8) ? 2 : SF_GEMM_WAVES) void 
 #endif
     SfGemm gs = g;
     if (ksp > 1) gs.C = g.C + (int64_t)split * g.split_stride;   // partial product of this K slice: its own slab
-    if (sf::epilogue_vec_ok(gs, z)) {
+    if (gs.c_f16 == 2) {
+        __syncthreads();                                         // the main-loop LDS becomes the transpose scratch
+        sf::gemm_epilogue_koct<WM, WN, TM, TN>(gs, acc, m0, n0, z, wm, wn, lane,
+                                               reinterpret_cast<float*>(smem) + wave * sf::kEpiScratchFloats);
+    } else if (sf::epilogue_vec_ok(gs, z)) {
         __syncthreads();                                         // the main-loop LDS becomes the transpose scratch
         sf::gemm_epilogue_vec<WM, WN, TM, TN>(gs, acc, m0, n0, z, wm, wn, lane,
                                               reinterpret_cast<float*>(smem) + wave * sf::kEpiScratchFloats);
@@ -285,6 +311,13 @@ int launch_cfg(const SplitArgs& a, hipStream_t st) {
             return sf::check_launch("sf_gemm(f16x3)");
         }
         return sf::fail(SF_ERR_UNSUPPORTED, "sf_gemm(f16x3): SF_LAYOUT_F16_K_MINOR B not built for this tile");
+    }
+    if (lay == 13) {                                     // split weights x fp16 k-octet activations: both operands by LDS-DMA
+        if constexpr (!SB && WM * TM * 32 == 128) {
+            hipLaunchKernelGGL((gemm_f16x3_mfma<WM, WN, TM, TN, 2, 5, PM>), grid, dim3(kThreads), 0, st, a);
+            return sf::check_launch("sf_gemm(f16x2, k-octet B)");
+        }
+        return sf::fail(SF_ERR_UNSUPPORTED, "sf_gemm: SF_LAYOUT_F16_KOCT B needs the 128-row tile (M > 96) and F16X2 / F16");
     }
     if (lay == 12) {                                     // split weights x stored-fp16 K-major activations (F16X2 only)
         if constexpr (!SB) {
@@ -329,6 +362,7 @@ int pick_tile(const SplitArgs& a, hipStream_t st) {
 int64_t span_bytes(int layout, int X, int K, int64_t ld, int group, int64_t group_stride) {
     if (layout == SF_LAYOUT_F16_K_MINOR) return ((int64_t)(X - 1) * ld + K) * 2;
     if (layout == SF_LAYOUT_F16_K_MAJOR) return ((int64_t)(K - 1) * ld + X) * 2;
+    if (layout == SF_LAYOUT_F16_KOCT) return (int64_t)((K + 7) / 8) * ld * 16;
     if (layout == SF_LAYOUT_K_MINOR) return ((int64_t)(X - 1) * ld + K) * 4;
     if (group > 0) return ((int64_t)((K - 1) / group) * group_stride + (int64_t)((K - 1) % group) * ld + X) * 4;
     return ((int64_t)(K - 1) * ld + X) * 4;
@@ -450,6 +484,13 @@ int gemm_split_dispatch_inner(const SfGemm& g, hipStream_t st) {
         return fail(SF_ERR_UNSUPPORTED, "sf_gemm(f16x3): operand image larger than 2 GiB (32-bit buffer offsets)");
     // tile choice: the 128-row tile moves the fewest bytes per MAC; drop to 64/32 rows when padding M would
     // waste more than a quarter of the MFMAs
+    if (g.b_layout == SF_LAYOUT_F16_KOCT) {
+        if (g.a_layout != SF_LAYOUT_SPLIT_F16 || (g.precision != SF_PRECISION_F16X2 && g.precision != SF_PRECISION_F16) ||
+            g.b_group || g.conv3x3 || (g.strideB & 7) || (reinterpret_cast<uintptr_t>(g.B) & 15) || g.ldb < g.N)
+            return fail(SF_ERR_UNSUPPORTED, "sf_gemm: SF_LAYOUT_F16_KOCT B needs F16X2 / F16, a SPLIT_F16 A, no grouping, 16-byte "
+                                            "aligned B and strideB, ldb >= N");
+        return (g.precision == SF_PRECISION_F16) ? pick_tile<1>(a, st) : pick_tile<2>(a, st);
+    }
     if (g.b_layout == SF_LAYOUT_F16_K_MAJOR) {
         if (g.a_layout != SF_LAYOUT_SPLIT_F16 || (g.precision != SF_PRECISION_F16X2 && g.precision != SF_PRECISION_F16) || (g.N & 1) || (g.ldb & 1) || (g.strideB & 1) ||
             g.b_group || g.conv3x3 || (reinterpret_cast<uintptr_t>(g.B) & 3))
@@ -457,8 +498,12 @@ int gemm_split_dispatch_inner(const SfGemm& g, hipStream_t st) {
                                             "strideB, no grouping, 4-byte aligned B");
         return (g.precision == SF_PRECISION_F16) ? pick_tile<1>(a, st) : pick_tile<2>(a, st);
     }
-    if (g.c_f16 && ((g.N & 3) || (g.ldc & 3) || (g.strideC & 3) || (reinterpret_cast<uintptr_t>(g.C) & 15) || g.k_splits > 1))
+    if (g.c_f16 == 1 && ((g.N & 3) || (g.ldc & 3) || (g.strideC & 3) || (reinterpret_cast<uintptr_t>(g.C) & 15) || g.k_splits > 1))
         return fail(SF_ERR_UNSUPPORTED, "sf_gemm: c_f16 needs N %% 4 == 0, ldc %% 4 == 0, strideC %% 4 == 0, 16-byte aligned C, no split-K");
+    if (g.c_f16 == 2 && (g.ldc < g.N || (g.strideC & 7) || (reinterpret_cast<uintptr_t>(g.C) & 15) || g.k_splits > 1 ||
+                         (g.epilogue != SF_EPI_NONE && g.epilogue != SF_EPI_GELU && g.epilogue != SF_EPI_RES_GELU)))
+        return fail(SF_ERR_UNSUPPORTED, "sf_gemm: c_f16 = 2 (k-octet output) needs ldc >= N, strideC %% 8 == 0, 16-byte aligned C, "
+                                        "no split-K, epilogue NONE / GELU / RES_GELU");
     if (g.b_layout == SF_LAYOUT_F16_K_MINOR) {
         if (g.a_layout != SF_LAYOUT_K_MINOR || (g.ldb & 1) || g.b_group || g.conv3x3 || (reinterpret_cast<uintptr_t>(g.B) & 3))
             return fail(SF_ERR_UNSUPPORTED, "sf_gemm(f16x3): SF_LAYOUT_F16_K_MINOR B needs a K-minor A, even ldb, 4-byte aligned B");

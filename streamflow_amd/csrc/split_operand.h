@@ -263,8 +263,21 @@ struct OperandF16KMajor {
     }
 };
 
+// SF_LAYOUT_F16_KOCT: the producer already wrote the consumer's LDS image (k-octet planes of fp16), tiles go by
+// buffer_load ... lds inside the kernel: nothing is staged through registers, this stand-in only keeps the code shape.
+struct OperandDma {
+    struct Regs {};
+    __device__ __forceinline__ void init(const void*, const void*, int64_t, int, int, int, int, int, int64_t, int) {}
+    __device__ __forceinline__ void set_conv3x3(int, int, int, int) {}
+    __device__ __forceinline__ void load(int, int, Regs&, int = 0) const {}
+    template <bool kLo = false>
+    __device__ __forceinline__ void store(int, _Float16*, _Float16*, Regs&, int = -1) const {}
+};
+
 template <int BX, int LAY>
 struct OperandSel { typedef Operand<BX, LAY> type; };
+template <int BX>
+struct OperandSel<BX, SF_LAYOUT_F16_KOCT> { typedef OperandDma type; };
 template <int BX>
 struct OperandSel<BX, SF_LAYOUT_F16_K_MAJOR> { typedef OperandF16KMajor<BX> type; };
 

@@ -49,10 +49,21 @@ class SKBlockWeights:
         self.dwk_b = f32(g("conv_list.1.bias"))
 
 
-def _scratch(buf: Planes, n_img: int, rows: int, f16: bool = False) -> Planes:
-    """Reinterpret a scratch allocation as contiguous [n_img][rows][P] planes (fp32, or fp16 values in the same memory)."""
-    assert n_img * rows <= buf.n_img * buf.rows, "scratch too small"
-    return Planes(buf.base, buf.off, rows * buf.P, n_img, rows, buf.P, f16=f16)
+def _scratch(buf: Planes, n_img: int, rows: int, f16: bool = False, koct: bool = False) -> Planes:
+    """Reinterpret a scratch allocation as contiguous [n_img][rows][P] planes (fp32, or fp16 values in the same memory;
+    koct: fp16 k-octet planes [ceil(rows/8)][P][8], the DMA-able image of the consuming GEMM)."""
+    rows_alloc = (rows + 7) // 8 * 8 if koct else rows
+    assert n_img * rows_alloc * (1 if not f16 else 0.5) <= buf.n_img * buf.rows, "scratch too small"
+    return Planes(buf.base, buf.off, rows_alloc * buf.P, n_img, rows, buf.P, f16=f16, koct=f16 and koct)
+
+
+def _handover(buf: Planes, n_img: int, rows: int, P: int, consumer_rows: int, allow_koct: bool = True) -> Planes:
+    """Scratch view for a tensor that is written by one GEMM and read only as the B operand of the next: fp32 planes in
+    the exact / f16x3 modes; in f16x2 fp16 values -- as k-octet planes when the consumer runs on the DMA-fed 128-row tile
+    (both of its operands then go HBM/L2 -> LDS without touching registers), as fp16 rows otherwise."""
+    f16 = hidden_f16_ok(P)
+    koct = f16 and allow_koct and ops.uses_dma_tile(consumer_rows) and os.environ.get("SF_HIDDEN_KOCT", "1") != "0"
+    return _scratch(buf, n_img, rows, f16=f16, koct=koct)
 
 
 def hidden_f16_ok(P: int) -> bool:
@@ -69,15 +80,18 @@ def run_skblock(W: SKBlockWeights, X: Planes, Y: Planes, hid: Planes, xa: Planes
     y = ffn2(x4).  hid/xa/xb are scratch allocations (capacity >= n_img*c_mid / n_img*c_in rows)."""
     C = W.c_in
     assert X.rows == C and Y.rows == W.c_out and X.n_img == Y.n_img
-    hidden = _scratch(hid, X.n_img, W.c_mid, f16=hidden_f16_ok(X.P))
     a, b = _scratch(xa, X.n_img, C), _scratch(xb, X.n_img, C)
+    hidden = _handover(hid, X.n_img, W.c_mid, X.P, consumer_rows=C)                 # ffn1.0 -> ffn1.2
     ops.gemm(W.ffn1_0, X, hidden, EPI_GELU)
     # x1 = gelu(x + ffn1(x)); x2 = gelu(x1 + dw1x1(x1))  (both fused in the epilogue)
     ops.gemm(W.ffn1_2, hidden, a, EPI_RES_GELU_DW1, R=X, dw_w=W.dw1_w, dw_b=W.dw1_b)
     ops.dwconv_res_gelu(a, W.dwk_w, W.dwk_b, b, h, w, W.k)                     # x3 = gelu(x2 + dwKxK(x2))
     # x4 is read by ffn2.0 only: the same GEMM-to-GEMM hand-over as the hidden activations (x2 in `xa` is dead by now)
-    a4 = _scratch(xa, X.n_img, C, f16=hidden_f16_ok(X.P))
+    # (fp16 ROWS, not k-octets: the k-octet epilogue fetches its residual with 8 dword loads per octet and made the pw
+    # GEMMs 15-20 % slower -- more than their consumers gained)
+    a4 = _handover(xa, X.n_img, C, X.P, consumer_rows=W.c_mid, allow_koct=False)
     ops.gemm(W.pw, b, a4, EPI_RES_GELU, R=b)                                    # x4 = gelu(x3 + pw(x3))
+    hidden = _handover(hid, X.n_img, W.c_mid, X.P, consumer_rows=W.c_out)           # ffn2.0 -> ffn2.2
     ops.gemm(W.ffn2_0, a4, hidden, EPI_GELU)
     ops.gemm(W.ffn2_2, hidden, Y, EPI_GELU if final_gelu else EPI_NONE)
 
@@ -340,7 +354,7 @@ class HotPathEngine:
             ops.temporal_attn(pl.qkv, pl.att128, Bc, Pn, HDIM)
             ops.gemm(W.proj, pl.att128, pl.tx128, EPI_RES, R=pl.mf)
             ops.layernorm_cm(pl.tx128, W.ln2_w, W.ln2_b, pl.ln128)
-            h256 = _scratch(pl.h256, pl.n, 256, f16=hidden_f16_ok(P))             # fc1 -> fc2 only
+            h256 = _handover(pl.h256, pl.n, 256, P, consumer_rows=HDIM)            # fc1 -> fc2 only
             ops.gemm(W.fc1, pl.ln128, h256, EPI_GELU)
             ops.gemm(W.fc2, h256, pl.mft, EPI_RES, R=pl.tx128)
         # a7: global aggregation  mfg = mf + gamma * attn @ to_v(mf)   (gma.py:91-104), main stream

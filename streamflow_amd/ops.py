@@ -136,6 +136,8 @@ class Planes:
     group_stride: int = 0
     f16: bool = False       # the planes hold IEEE fp16 values (img_stride then counts halves; `off` stays in floats of
                             # the underlying fp32 allocation): GEMM-to-GEMM hand-over in the f16x2 mode (SfGemm.c_f16)
+    koct: bool = False      # (with f16) k-octet planes [ceil(rows/8)][P][8] instead of rows [rows][P]: the consumer GEMM's
+                            # LDS image, moved there by DMA (SF_LAYOUT_F16_KOCT / c_f16 = 2)
 
     @staticmethod
     def of(t: torch.Tensor) -> "Planes":
@@ -156,6 +158,12 @@ class Planes:
     def tensor(self) -> torch.Tensor:
         """Materialise as a [n_img, rows, P] torch view (only for contiguous-row, ungrouped views)."""
         assert self.group == 0
+        if self.f16 and self.koct:                     # logical [n_img, rows, P] copy out of the octet planes (tests only)
+            h = self.base.view(torch.float16)
+            oc = (self.rows + 7) // 8
+            t = torch.as_strided(h, (self.n_img, oc, self.P, 8), (self.img_stride, self.P * 8, 8, 1),
+                                 2 * (self.base.storage_offset() + self.off))
+            return t.permute(0, 1, 3, 2).reshape(self.n_img, oc * 8, self.P)[:, : self.rows]
         if self.f16:
             h = self.base.view(torch.float16)
             return torch.as_strided(h, (self.n_img, self.rows, self.P), (self.img_stride, self.P, 1),
@@ -227,6 +235,12 @@ class PackedLinear:
         self.split_error = float(((hi.float() + lo.float()) - wm).abs().max() / max(wmax * self.split_scale, 1e-30))
 
 
+def uses_dma_tile(M: int) -> bool:
+    """Does sf_gemm run an M-row problem on the 128-row, DMA-fed tile (gemm_split.hip pick_tile)?  Only that kernel takes
+    a k-octet fp16 B operand."""
+    return (M + 127) // 128 * 128 * 4 <= M * 5
+
+
 def gemm(A: PackedLinear, X: Planes, Y: Planes, epilogue: int = EPI_NONE, R: Optional[Planes] = None,
          dw_w: Optional[torch.Tensor] = None, dw_b: Optional[torch.Tensor] = None, alpha: float = 1.0,
          hw: Optional[Sequence[int]] = None) -> None:
@@ -246,9 +260,9 @@ def gemm(A: PackedLinear, X: Planes, Y: Planes, epilogue: int = EPI_NONE, R: Opt
         if prec not in (PRECISION_F16X2, PRECISION_F16):
             raise RuntimeError("fp16 activation planes are a hand-over format of the f16x2 / f16 modes only")
         if X.f16:
-            g.b_layout = _lib.LAYOUT_F16_K_MAJOR
+            g.b_layout = _lib.LAYOUT_F16_KOCT if X.koct else _lib.LAYOUT_F16_K_MAJOR
         if Y.f16:
-            g.c_f16 = 1
+            g.c_f16 = 2 if Y.koct else 1
     if prec != PRECISION_FP32:
         g.a_layout = LAYOUT_SPLIT_F16
         g.A_hi, g.A_lo, g.lda_h = A.hi.data_ptr(), A.lo.data_ptr(), A.lda_h

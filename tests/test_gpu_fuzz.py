@@ -185,7 +185,7 @@ def test_split_gemm_weight_magnitudes(dev, wscale):
     assert err < 3e-6, (wscale, err)
 
 
-@pytest.mark.parametrize("seed", range(4))
+@pytest.mark.parametrize("seed", range(8))
 def test_fp16_hidden_handover_is_bit_identical(dev, seed):
     """In the f16x2 mode a B operand is rounded to fp16 when it is staged, so a producer that already stores the rounded
     value (SfGemm.c_f16 -> SF_LAYOUT_F16_K_MAJOR in the consumer) must give BIT-IDENTICAL results to the fp32 hand-over,
@@ -213,8 +213,20 @@ def test_fp16_hidden_handover_is_bit_identical(dev, seed):
         y16 = torch.full((n, Cout, P), float("nan"), device=dev)
         ops.gemm(W1, X, hid16, ops.EPI_GELU)
         ops.gemm(W2, hid16, Planes.of(y16), ops.EPI_NONE)
+        # k-octet planes: the producer writes the consumer's LDS image, the consumer DMAs it (128-row tile only)
+        yko = None
+        if ops.uses_dma_tile(Cout):
+            Ha = (H + 7) // 8 * 8
+            store2 = torch.zeros(n, Ha, P, device=dev)
+            hidko = Planes(store2.view(-1), 0, Ha * P, n, H, P, f16=True, koct=True)
+            yko = torch.full((n, Cout, P), float("nan"), device=dev)
+            ops.gemm(W1, X, hidko, ops.EPI_GELU)
+            ops.gemm(W2, hidko, Planes.of(yko), ops.EPI_NONE)
         torch.cuda.synchronize()
     finally:
         ops.set_precision(prev)
+    if yko is not None:
+        assert torch.equal(hidko.tensor().float(), hid32.tensor().half().float())
+        assert torch.equal(yko, y32), (C, H, Cout, P, (yko - y32).abs().max().item())
     assert torch.equal(hid16.tensor().float(), hid32.tensor().half().float())
     assert torch.equal(y16, y32), (C, H, Cout, P, (y16 - y32).abs().max().item())
