@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SF_VERSION 101
+#define SF_VERSION 102
 
 enum {
     SF_OK = 0,
@@ -207,9 +207,13 @@ int sf_softmax_rows(float* x, int64_t rows, int cols, void* out_f16, void* strea
  * precision SF_PRECISION_FP32: fp32 FMA stencil on the VALU.  Split precisions: every kernel row is a banded
  * Toeplitz GEMM on the matrix cores with (hi, lo) fp16 operands and fp32 accumulation (same arithmetic as sf_gemm's
  * SF_PRECISION_F16X3; F16X2 is treated as F16X3 here: a two-product form with one staged plane measured 12 % SLOWER,
- * its exact residual has to be re-read from global memory). */
-int sf_dwconv_res_gelu(const float* x, int64_t x_img_stride, const float* wgt, const float* bias, float* y,
-                       int64_t y_img_stride, int n_img, int C, int h, int w, int ksize, int precision, void* stream);
+ * its exact residual has to be re-read from global memory).
+ * y_f16 = 1: y receives IEEE fp16 planes of the same [img][c][h][w] order, y_img_stride counted in halves -- the
+ * hand-over to a GEMM that reads them as SF_LAYOUT_F16_K_MAJOR (the engine's pw layer in the f16x2 mode, whose
+ * residual is folded into its weights so that x3 has no other reader). */
+int sf_dwconv_res_gelu(const float* x, int64_t x_img_stride, const float* wgt, const float* bias, void* y,
+                       int64_t y_img_stride, int y_f16, int n_img, int C, int h, int w, int ksize, int precision,
+                       void* stream);
 
 /* ---- LayerNorm over channels of channel-major planes (update.py:462-463,481-483) --------------
  * x,y [n_img][C][P] (image strides given in floats), normalises each (img,p) column over C. */

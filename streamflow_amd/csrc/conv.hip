@@ -28,10 +28,10 @@ struct DwArgs {
     int strip_h;      // output rows per strip (multiple of TY)
     int tiles_x;      // ceil(w / TX)
     int wp4;          // LDS row stride in float4 units
-    int vec_store;
+    int vec_store;    // rows of y are 16-byte (fp32) / 8-byte (fp16) aligned: one store per 4 outputs
 };
 
-template <int KS>
+template <int KS, bool kOutF16>
 __global__ __launch_bounds__(kMaxThreads) void dwconv_res_gelu_kernel(const DwArgs g) {
     constexpr int R = KS / 2;
     constexpr int IN_W = TX + KS - 1;               // window columns a thread needs (18 / 10)
@@ -92,7 +92,9 @@ __global__ __launch_bounds__(kMaxThreads) void dwconv_res_gelu_kernel(const DwAr
     }
 
     const float bv = g.bias[c];
+    // kOutF16: y holds IEEE fp16 planes (strides in halves) -- the fp16 hand-over to the pw GEMM (streamflow_hip.h)
     float* yp = g.y + img * g.y_img_stride + (int64_t)c * g.h * g.w;
+    _Float16* yh = reinterpret_cast<_Float16*>(g.y) + img * g.y_img_stride + (int64_t)c * g.h * g.w;
 #pragma unroll
     for (int oy = 0; oy < TY; ++oy) {
         const int gy = ys + ty * TY + oy;
@@ -110,7 +112,17 @@ __global__ __launch_bounds__(kMaxThreads) void dwconv_res_gelu_kernel(const DwAr
             o[ox + 1] = a[1];
         }
         const int gx = tx * TX;
-        if (g.vec_store && gx + 3 < g.w) {
+        if constexpr (kOutF16) {
+            if (g.vec_store && gx + 3 < g.w) {
+                typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+                *reinterpret_cast<f16x4*>(yh + gy * g.w + gx) =
+                    f16x4{(_Float16)o[0], (_Float16)o[1], (_Float16)o[2], (_Float16)o[3]};
+            } else {
+#pragma unroll
+                for (int ox = 0; ox < TX; ++ox)
+                    if (gx + ox < g.w) yh[gy * g.w + gx + ox] = (_Float16)o[ox];
+            }
+        } else if (g.vec_store && gx + 3 < g.w) {
             *reinterpret_cast<float4*>(yp + gy * g.w + gx) = make_float4(o[0], o[1], o[2], o[3]);
         } else {
 #pragma unroll
@@ -163,7 +175,7 @@ struct DwmArgs {
 #ifndef SF_DW_FU
 #define SF_DW_FU 6      // octets a thread stages at a time: 6 x 256 >= the 1404 octets of a 55x128 strip, ONE global round trip
 #endif
-template <int KS>
+template <int KS, bool kOutF16>
 __global__ __launch_bounds__(256, 2) void dwconv_mfma_kernel(const DwmArgs g) {
     using namespace sf_split;
     constexpr int R = KS / 2;
@@ -208,8 +220,10 @@ __global__ __launch_bounds__(256, 2) void dwconv_mfma_kernel(const DwmArgs g) {
     const int img_end = min(img0 + g.imgs_per_wg, g.n_img);
     for (int img = img0; img < img_end; ++img) {
         const float* __restrict__ xp = g.x + img * g.x_img_stride + (int64_t)c * g.h * g.w;
-        float* __restrict__ yp = g.y + img * g.y_img_stride + (int64_t)c * g.h * g.w;
-        const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(yp, 0, g.h * g.w * 4, 0x00020000);
+        // kOutF16: y holds fp16 planes, its strides count halves
+        void* yp = kOutF16 ? (void*)(reinterpret_cast<_Float16*>(g.y) + img * g.y_img_stride + (int64_t)c * g.h * g.w)
+                           : (void*)(g.y + img * g.y_img_stride + (int64_t)c * g.h * g.w);
+        const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(yp, 0, g.h * g.w * (kOutF16 ? 2 : 4), 0x00020000);
         // LDS-only barriers: the previous image's output stores stay in flight (a __syncthreads would drain them)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                           // previous image's tiles are done with the LDS planes
@@ -271,7 +285,8 @@ __global__ __launch_bounds__(256, 2) void dwconv_mfma_kernel(const DwmArgs g) {
             // output cell (j, r) of this lane: row gy0 + r, column gx0 + 16 j.  Stores are buffer ops with 32-bit offsets;
             // a cell outside the plane gets an out-of-range offset that the buffer unit drops (no branches).
             const int gy0 = ys + ty * 16 + 4 * kg, gx0 = tx0 * 16 + n;
-            const int off0 = (gy0 * g.w + gx0) * 4;
+            constexpr int EB = kOutF16 ? 2 : 4;                 // bytes per output element
+            const int off0 = (gy0 * g.w + gx0) * EB;
             // software pipeline: the fragments of kernel row ky + 1 are requested before the MFMAs of row ky
             f16x8 ah[2][TG], al[2][TG];
 #pragma unroll
@@ -316,9 +331,14 @@ __global__ __launch_bounds__(256, 2) void dwconv_mfma_kernel(const DwmArgs g) {
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
                         const bool ok = (gx0 + j * 16 < g.w) && (gy0 + r + u < g.h);
-                        const float o = a[u];
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), ry,
-                                                              ok ? off0 + ((r + u) * g.w + j * 16) * 4 : (int)0x80000000u, 0, 0);
+                        const int so = ok ? off0 + ((r + u) * g.w + j * 16) * EB : (int)0x80000000u;
+                        if constexpr (kOutF16) {
+                            const _Float16 o = (_Float16)a[u];
+                            __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, o), ry, so, 0, 0);
+                        } else {
+                            const float o = a[u];
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), ry, so, 0, 0);
+                        }
                     }
                 }
         }
@@ -336,10 +356,12 @@ __global__ __launch_bounds__(256, 2) void dwconv_mfma_kernel(const DwmArgs g) {
 
 }  // namespace
 
-extern "C" int sf_dwconv_res_gelu(const float* x, int64_t x_img_stride, const float* wgt, const float* bias, float* y,
-                                  int64_t y_img_stride, int n_img, int C, int h, int w, int ksize, int precision,
-                                  void* stream) {
+extern "C" int sf_dwconv_res_gelu(const float* x, int64_t x_img_stride, const float* wgt, const float* bias, void* y_,
+                                  int64_t y_img_stride, int y_f16, int n_img, int C, int h, int w, int ksize,
+                                  int precision, void* stream) {
+    float* y = static_cast<float*>(y_);
     SF_REQUIRE(x && wgt && bias && y, "sf_dwconv_res_gelu: null pointer");
+    SF_REQUIRE(y_f16 == 0 || y_f16 == 1, "sf_dwconv_res_gelu: y_f16 must be 0 or 1");
     SF_REQUIRE(n_img > 0 && C > 0 && h > 0 && w > 0, "sf_dwconv_res_gelu: bad dims");
     SF_REQUIRE(ksize == 15 || ksize == 7, "sf_dwconv_res_gelu: kernel size %d not built (7, 15)", ksize);
     SF_REQUIRE(precision >= SF_PRECISION_FP32 && precision <= SF_PRECISION_F16X2, "sf_dwconv_res_gelu: bad precision");
@@ -372,7 +394,10 @@ extern "C" int sf_dwconv_res_gelu(const float* x, int64_t x_img_stride, const fl
 #endif
         dim3 grid(C, strips, sf::ceil_div(n_img, m.imgs_per_wg));
         SF_REQUIRE(strips <= 65535 && grid.z <= 65535, "sf_dwconv_res_gelu: grid too large");
-        hipLaunchKernelGGL(dwconv_mfma_kernel<15>, grid, dim3(256), lds, (hipStream_t)stream, m);
+        if (y_f16)
+            hipLaunchKernelGGL((dwconv_mfma_kernel<15, true>), grid, dim3(256), lds, (hipStream_t)stream, m);
+        else
+            hipLaunchKernelGGL((dwconv_mfma_kernel<15, false>), grid, dim3(256), lds, (hipStream_t)stream, m);
         return sf::check_launch("sf_dwconv_res_gelu(mfma)");
     }
     DwArgs g;
@@ -384,15 +409,19 @@ extern "C" int sf_dwconv_res_gelu(const float* x, int64_t x_img_stride, const fl
     if (tiles_y * g.tiles_x > kMaxThreads) tiles_y = kMaxThreads / g.tiles_x;
     g.strip_h = tiles_y * TY;
     g.wp4 = (g.tiles_x * TX + ksize - 1 + 3) / 4;
-    g.vec_store = ((w & 3) == 0) && ((y_img_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
+    g.vec_store = ((w & 3) == 0) && ((y_img_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(y) & (y_f16 ? 7 : 15)) == 0);
     const int rows = g.strip_h + ksize - 1;
     const size_t lds = ((size_t)rows * g.wp4 * 4 + 8 + ksize * ksize + 8) * sizeof(float);
     SF_REQUIRE(lds <= 64 * 1024, "sf_dwconv_res_gelu: strip needs %zu bytes of LDS", lds);
     const int threads = ((tiles_y * g.tiles_x + 63) / 64) * 64;
     dim3 grid(n_img * C, sf::ceil_div(h, g.strip_h));
-    if (ksize == 15)
-        hipLaunchKernelGGL(dwconv_res_gelu_kernel<15>, grid, dim3(threads), lds, (hipStream_t)stream, g);
+    if (ksize == 15 && y_f16)
+        hipLaunchKernelGGL((dwconv_res_gelu_kernel<15, true>), grid, dim3(threads), lds, (hipStream_t)stream, g);
+    else if (ksize == 15)
+        hipLaunchKernelGGL((dwconv_res_gelu_kernel<15, false>), grid, dim3(threads), lds, (hipStream_t)stream, g);
+    else if (y_f16)
+        hipLaunchKernelGGL((dwconv_res_gelu_kernel<7, true>), grid, dim3(threads), lds, (hipStream_t)stream, g);
     else
-        hipLaunchKernelGGL(dwconv_res_gelu_kernel<7>, grid, dim3(threads), lds, (hipStream_t)stream, g);
+        hipLaunchKernelGGL((dwconv_res_gelu_kernel<7, false>), grid, dim3(threads), lds, (hipStream_t)stream, g);
     return sf::check_launch("sf_dwconv_res_gelu");
 }

@@ -34,6 +34,11 @@ class SKBlockWeights:
         self.ffn1_0 = PackedLinear(g("ffn1.0.weight"), g("ffn1.0.bias"), device)
         self.ffn1_2 = PackedLinear(g("ffn1.2.weight"), g("ffn1.2.bias"), device)
         self.pw = PackedLinear(g("pw.weight"), g("pw.bias"), device)
+        # x4 = gelu(x3 + pw(x3)) = gelu((W + I) x3 + b): with the residual folded into the weights x3 has ONE reader and
+        # can be handed over in fp16 like the FFN hiddens (run_skblock, f16x2 / f16 modes only)
+        wpw = g("pw.weight")
+        eye = torch.eye(wpw.shape[0], dtype=wpw.dtype, device=wpw.device).reshape(wpw.shape[0], wpw.shape[0], *wpw.shape[2:])
+        self.pw_res = PackedLinear(wpw + eye, g("pw.bias"), device)
         self.ffn2_0 = PackedLinear(g("ffn2.0.weight"), g("ffn2.0.bias"), device)
         self.ffn2_2 = PackedLinear(g("ffn2.2.weight"), g("ffn2.2.bias"), device)
         self.c_in, self.c_mid, self.c_out = self.ffn1_0.K, self.ffn1_0.M, self.ffn2_2.M
@@ -85,12 +90,20 @@ def run_skblock(W: SKBlockWeights, X: Planes, Y: Planes, hid: Planes, xa: Planes
     ops.gemm(W.ffn1_0, X, hidden, EPI_GELU)
     # x1 = gelu(x + ffn1(x)); x2 = gelu(x1 + dw1x1(x1))  (both fused in the epilogue)
     ops.gemm(W.ffn1_2, hidden, a, EPI_RES_GELU_DW1, R=X, dw_w=W.dw1_w, dw_b=W.dw1_b)
-    ops.dwconv_res_gelu(a, W.dwk_w, W.dwk_b, b, h, w, W.k)                     # x3 = gelu(x2 + dwKxK(x2))
     # x4 is read by ffn2.0 only: the same GEMM-to-GEMM hand-over as the hidden activations (x2 in `xa` is dead by now)
-    # (fp16 ROWS, not k-octets: the k-octet epilogue fetches its residual with 8 dword loads per octet and made the pw
-    # GEMMs 15-20 % slower -- more than their consumers gained)
-    a4 = _handover(xa, X.n_img, C, X.P, consumer_rows=W.c_mid, allow_koct=False)
-    ops.gemm(W.pw, b, a4, EPI_RES_GELU, R=b)                                    # x4 = gelu(x3 + pw(x3))
+    if hidden_f16_ok(X.P) and os.environ.get("SF_PW_FOLD", "1") != "0":
+        # x3 in fp16 rows straight out of the depthwise kernel, residual folded into the pw weights: the pw GEMM reads half
+        # the bytes, has a residual-free epilogue and may therefore write k-octets
+        b16 = _scratch(xb, X.n_img, C, f16=True)
+        ops.dwconv_res_gelu(a, W.dwk_w, W.dwk_b, b16, h, w, W.k)               # x3 = gelu(x2 + dwKxK(x2))
+        a4 = _handover(xa, X.n_img, C, X.P, consumer_rows=W.c_mid)
+        ops.gemm(W.pw_res, b16, a4, EPI_GELU)                                   # x4 = gelu((pw + I) x3)
+    else:
+        ops.dwconv_res_gelu(a, W.dwk_w, W.dwk_b, b, h, w, W.k)                 # x3 = gelu(x2 + dwKxK(x2))
+        # (fp16 ROWS, not k-octets: the k-octet epilogue fetches its residual with 8 dword loads per octet and made the
+        # pw GEMMs 15-20 % slower -- more than their consumers gained)
+        a4 = _handover(xa, X.n_img, C, X.P, consumer_rows=W.c_mid, allow_koct=False)
+        ops.gemm(W.pw, b, a4, EPI_RES_GELU, R=b)                                # x4 = gelu(x3 + pw(x3))
     hidden = _handover(hid, X.n_img, W.c_mid, X.P, consumer_rows=W.c_out)           # ffn2.0 -> ffn2.2
     ops.gemm(W.ffn2_0, a4, hidden, EPI_GELU)
     ops.gemm(W.ffn2_2, hidden, Y, EPI_GELU if final_gelu else EPI_NONE)

@@ -316,10 +316,11 @@ def splitk_combine(partial: torch.Tensor, split_stride: int, k_splits: int, part
 
 @on_tensor_device
 def dwconv_res_gelu(X: Planes, wgt: torch.Tensor, bias: torch.Tensor, Y: Planes, h: int, w: int, k: int) -> None:
-    assert X.rows == Y.rows == wgt.shape[0] and X.P == h * w
-    _launch("dwconv%d" % k, 2.0 * k * k * X.n_img * X.rows * h * w, 8.0 * X.n_img * X.rows * h * w,
+    """Y = gelu(X + dwconv_KxK(X) + bias).  Y may be fp16 row planes (Planes.f16, not koct): the hand-over to a GEMM."""
+    assert X.rows == Y.rows == wgt.shape[0] and X.P == h * w and not X.f16 and not Y.koct
+    _launch("dwconv%d" % k, 2.0 * k * k * X.n_img * X.rows * h * w, (6.0 if Y.f16 else 8.0) * X.n_img * X.rows * h * w,
             lambda: _lib.check(_lib.load().sf_dwconv_res_gelu(X.ptr, X.img_stride, wgt.data_ptr(), bias.data_ptr(),
-                                                              Y.ptr, Y.img_stride, X.n_img, X.rows, h, w, k,
+                                                              Y.ptr, Y.img_stride, int(Y.f16), X.n_img, X.rows, h, w, k,
                                                               min(PRECISION, PRECISION_F16X3), _lib.stream()),
                                "sf_dwconv_res_gelu"))
 

@@ -535,6 +535,71 @@ def test_dwconv_vs_torch(dev, precision, k, hw):
     got = Y.tensor().view(n_img, C, h, w).double().cpu()
     err = (got - ref).abs().max().item()
     assert err < (2e-5 if precision != "fp32" else 2e-5), (precision, err)
+    # fp16 row output (the hand-over to the folded pw GEMM): the same values, rounded ONCE to fp16 (the compiler may fold
+    # the last multiply of the GELU into the conversion, so this is within half an fp16 ulp of the fp32 result, not
+    # necessarily the rounding of the rounded fp32 value; and the two instantiations contract the erf polynomial
+    # differently: ~1e-7 absolute in the far negative tail where gelu is ~1e-6)
+    store = torch.zeros(n_img, C, h * w, device=dev)
+    Y16 = Planes(store.view(-1), 0, C * h * w, n_img, C, h * w, f16=True)
+    ops.dwconv_res_gelu(X, wgt.to(dev).contiguous(), b.to(dev), Y16, h, w, k)
+    torch.cuda.synchronize()
+    y32 = Y.tensor()
+    assert bool(((Y16.tensor().float() - y32).abs() <= 2.0 ** -11 * y32.abs() * (1 + 1e-3) + 3e-7).all())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,C,hw", [(15, 256, (55, 128)), (7, 640, (55, 128)), (15, 324, (22, 36))])
+def test_skblock_pw_fold_vs_float64(dev, k, C, hw):
+    """f16x2 mode: x4 = gelu(x3 + pw(x3)) is computed as gelu((W + I) x3) with x3 handed over in fp16 rows by the
+    depthwise kernel (engine.run_skblock).  The whole block against torch in float64, with the fold and without
+    (SF_PW_FOLD=0): both within the mode's error, and the fold no worse than 2x the plain path."""
+    import os
+    import torch.nn.functional as F
+    from streamflow_amd import ops
+    from streamflow_amd.engine import SKBlockWeights, run_skblock
+    from streamflow_amd.ops import Planes
+    h, w = hw
+    P, n, Cm, Co = h * w, 2, C * 3 // 2, 128
+    g = torch.Generator().manual_seed(C + k)
+    r = lambda *s: torch.randn(*s, generator=g)
+    sd = {"b.ffn1.0.weight": r(Cm, C, 1, 1) / C ** 0.5, "b.ffn1.0.bias": r(Cm) * 0.1,
+          "b.ffn1.2.weight": r(C, Cm, 1, 1) / Cm ** 0.5, "b.ffn1.2.bias": r(C) * 0.1,
+          "b.conv_list.0.weight": r(C, 1, 1, 1) * 0.3, "b.conv_list.0.bias": r(C) * 0.1,
+          "b.conv_list.1.weight": r(C, 1, k, k) / k, "b.conv_list.1.bias": r(C) * 0.1,
+          "b.pw.weight": r(C, C, 1, 1) / C ** 0.5, "b.pw.bias": r(C) * 0.1,
+          "b.ffn2.0.weight": r(Cm, C, 1, 1) / C ** 0.5, "b.ffn2.0.bias": r(Cm) * 0.1,
+          "b.ffn2.2.weight": r(Co, Cm, 1, 1) / Cm ** 0.5, "b.ffn2.2.bias": r(Co) * 0.1}
+    x = r(n, C, h, w)
+    d = {kk: v.double() for kk, v in sd.items()}
+    xd = x.double()
+    c1 = lambda t, nm: F.conv2d(t, d["b." + nm + ".weight"], d["b." + nm + ".bias"])
+    t = F.gelu(xd + c1(F.gelu(c1(xd, "ffn1.0")), "ffn1.2"))
+    t = F.gelu(t + F.conv2d(t, d["b.conv_list.0.weight"], d["b.conv_list.0.bias"], groups=C))
+    t = F.gelu(t + F.conv2d(t, d["b.conv_list.1.weight"], d["b.conv_list.1.bias"], padding=k // 2, groups=C))
+    t = F.gelu(t + c1(t, "pw"))
+    ref = c1(F.gelu(c1(t, "ffn2.0")), "ffn2.2").view(n, Co, P)
+    W = SKBlockWeights(sd, "b", dev)
+    X = Planes.of(x.view(n, C, P).to(dev))
+    mk = lambda rows: Planes.of(torch.zeros(n, rows + 8, P, device=dev))
+    errs = {}
+    prev = ops.set_precision("f16x2")
+    keep = os.environ.get("SF_PW_FOLD")
+    try:
+        for fold in ("1", "0"):
+            os.environ["SF_PW_FOLD"] = fold
+            y = torch.full((n, Co, P), float("nan"), device=dev)
+            run_skblock(W, X, Planes.of(y), mk(Cm), mk(C), mk(C), h, w)
+            torch.cuda.synchronize()
+            errs[fold] = (y.double().cpu() - ref).abs().max().item()
+    finally:
+        ops.set_precision(prev)
+        if keep is None:
+            os.environ.pop("SF_PW_FOLD", None)
+        else:
+            os.environ["SF_PW_FOLD"] = keep
+    scale = ref.abs().max().item()
+    assert errs["0"] < 4e-3 * scale and errs["1"] < 4e-3 * scale, (errs, scale)
+    assert errs["1"] < 2.0 * errs["0"] + 1e-6, errs
 
 
 @pytest.mark.gpu
