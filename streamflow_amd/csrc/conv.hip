@@ -175,7 +175,10 @@ struct DwmArgs {
 #ifndef SF_DW_FU
 #define SF_DW_FU 6      // octets a thread stages at a time: 6 x 256 >= the 1404 octets of a 55x128 strip, ONE global round trip
 #endif
-template <int KS, bool kOutF16>
+// kProd = 3: x = hi + lo on both sides (f16x3).  kProd = 2 (the GEMMs' f16x2 arithmetic): the ACTIVATION enters the
+// products as its hi half only (weights stay hi + lo) -- two MFMAs and one fragment read per kernel row and tile instead
+// of three and two; both planes are still staged, the residual stays exact.
+template <int KS, bool kOutF16, int kProd>
 __global__ __launch_bounds__(256, 2) void dwconv_mfma_kernel(const DwmArgs g) {
     using namespace sf_split;
     constexpr int R = KS / 2;
@@ -258,7 +261,7 @@ __global__ __launch_bounds__(256, 2) void dwconv_mfma_kernel(const DwmArgs g) {
 #pragma unroll
             for (int u = 0; u < FU; ++u) {
                 if (off[u] < 0) continue;
-                const Split8 s8 = split8(v[u]);
+                const Split8 s8 = (kProd == 2) ? split8_rn(v[u]) : split8(v[u]);
                 *reinterpret_cast<f16x8*>(hi + off[u]) = s8.hi;
                 *reinterpret_cast<f16x8*>(lo + off[u]) = s8.lo;
             }
@@ -292,7 +295,7 @@ __global__ __launch_bounds__(256, 2) void dwconv_mfma_kernel(const DwmArgs g) {
 #pragma unroll
             for (int j = 0; j < TG; ++j) {
                 ah[0][j] = *reinterpret_cast<const f16x8*>(hi + offj[j]);
-                al[0][j] = *reinterpret_cast<const f16x8*>(lo + offj[j]);
+                if constexpr (kProd == 3) al[0][j] = *reinterpret_cast<const f16x8*>(lo + offj[j]);
             }
 #pragma unroll
             for (int ky = 0; ky < KS; ++ky) {
@@ -301,11 +304,13 @@ __global__ __launch_bounds__(256, 2) void dwconv_mfma_kernel(const DwmArgs g) {
 #pragma unroll
                     for (int j = 0; j < TG; ++j) {
                         ah[nxt][j] = *reinterpret_cast<const f16x8*>(hi + offj[j] + (ky + 1) * row_step);
-                        al[nxt][j] = *reinterpret_cast<const f16x8*>(lo + offj[j] + (ky + 1) * row_step);
+                        if constexpr (kProd == 3) al[nxt][j] = *reinterpret_cast<const f16x8*>(lo + offj[j] + (ky + 1) * row_step);
                     }
                 }
+                if constexpr (kProd == 3) {
 #pragma unroll
-                for (int j = 0; j < TG; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[cur][j], bh[ky], acc[j], 0, 0, 0);
+                    for (int j = 0; j < TG; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[cur][j], bh[ky], acc[j], 0, 0, 0);
+                }
 #pragma unroll
                 for (int j = 0; j < TG; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[cur][j], bl[ky], acc[j], 0, 0, 0);
 #pragma unroll
@@ -364,7 +369,7 @@ extern "C" int sf_dwconv_res_gelu(const float* x, int64_t x_img_stride, const fl
     SF_REQUIRE(y_f16 == 0 || y_f16 == 1, "sf_dwconv_res_gelu: y_f16 must be 0 or 1");
     SF_REQUIRE(n_img > 0 && C > 0 && h > 0 && w > 0, "sf_dwconv_res_gelu: bad dims");
     SF_REQUIRE(ksize == 15 || ksize == 7, "sf_dwconv_res_gelu: kernel size %d not built (7, 15)", ksize);
-    SF_REQUIRE(precision >= SF_PRECISION_FP32 && precision <= SF_PRECISION_F16X2, "sf_dwconv_res_gelu: bad precision");
+    SF_REQUIRE(precision >= SF_PRECISION_FP32 && precision <= SF_PRECISION_F16, "sf_dwconv_res_gelu: bad precision");
     SF_REQUIRE((int64_t)h * w < (1 << 30), "sf_dwconv_res_gelu: plane too large");
     // K = 7: only 7/32 of the Toeplitz entries are non-zero and the stencil is the faster kernel (65 vs 87 us at
     // 128 channels x 24 images); K = 15 runs 1.45x faster on the matrix cores
@@ -394,10 +399,16 @@ extern "C" int sf_dwconv_res_gelu(const float* x, int64_t x_img_stride, const fl
 #endif
         dim3 grid(C, strips, sf::ceil_div(n_img, m.imgs_per_wg));
         SF_REQUIRE(strips <= 65535 && grid.z <= 65535, "sf_dwconv_res_gelu: grid too large");
-        if (y_f16)
-            hipLaunchKernelGGL((dwconv_mfma_kernel<15, true>), grid, dim3(256), lds, (hipStream_t)stream, m);
+        static const bool force3 = getenv("SF_DW_PRODUCTS") && atoi(getenv("SF_DW_PRODUCTS")) == 3;   // A/B knob
+        const bool two = precision != SF_PRECISION_F16X3 && !force3;
+        if (y_f16 && two)
+            hipLaunchKernelGGL((dwconv_mfma_kernel<15, true, 2>), grid, dim3(256), lds, (hipStream_t)stream, m);
+        else if (y_f16)
+            hipLaunchKernelGGL((dwconv_mfma_kernel<15, true, 3>), grid, dim3(256), lds, (hipStream_t)stream, m);
+        else if (two)
+            hipLaunchKernelGGL((dwconv_mfma_kernel<15, false, 2>), grid, dim3(256), lds, (hipStream_t)stream, m);
         else
-            hipLaunchKernelGGL((dwconv_mfma_kernel<15, false>), grid, dim3(256), lds, (hipStream_t)stream, m);
+            hipLaunchKernelGGL((dwconv_mfma_kernel<15, false, 3>), grid, dim3(256), lds, (hipStream_t)stream, m);
         return sf::check_launch("sf_dwconv_res_gelu(mfma)");
     }
     DwArgs g;

@@ -39,6 +39,19 @@ __device__ __forceinline__ Split8 split8(const float (&x)[8]) {
     return s;
 }
 
+// The same split with hi = round-to-nearest(x) (lo = x - hi, exact, either sign): for kernels that use hi ALONE in some
+// products (conv.hip's two-product mode) -- a truncated hi would bias every such product towards zero by up to 2^-10.
+__device__ __forceinline__ Split8 split8_rn(const float (&x)[8]) {
+    Split8 s;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const _Float16 h = (_Float16)x[i];
+        s.hi[i] = h;
+        s.lo[i] = (_Float16)(x[i] - (float)h);
+    }
+    return s;
+}
+
 // One operand (A or B) of the GEMM as seen by one thread.
 template <int BX, int LAY>
 struct Operand {

@@ -321,7 +321,7 @@ def dwconv_res_gelu(X: Planes, wgt: torch.Tensor, bias: torch.Tensor, Y: Planes,
     _launch("dwconv%d" % k, 2.0 * k * k * X.n_img * X.rows * h * w, (6.0 if Y.f16 else 8.0) * X.n_img * X.rows * h * w,
             lambda: _lib.check(_lib.load().sf_dwconv_res_gelu(X.ptr, X.img_stride, wgt.data_ptr(), bias.data_ptr(),
                                                               Y.ptr, Y.img_stride, int(Y.f16), X.n_img, X.rows, h, w, k,
-                                                              min(PRECISION, PRECISION_F16X3), _lib.stream()),
+                                                              PRECISION, _lib.stream()),
                                "sf_dwconv_res_gelu"))
 
 

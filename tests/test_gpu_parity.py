@@ -548,6 +548,39 @@ def test_dwconv_vs_torch(dev, precision, k, hw):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("hw", [(55, 128), (23, 37)])
+def test_dwconv_two_product_mode(dev, hw):
+    """f16x2 / f16 modes: the activation enters the 15x15 products rounded to fp16 (weights hi + lo, residual exact).
+    Against float64 with the activation rounded the same way the error is the split's (1e-5); against the exact
+    convolution it is bounded by 2^-11 * sum|w||x|."""
+    import torch.nn.functional as F
+    from streamflow_amd import ops
+    from streamflow_amd.ops import Planes
+    h, w = hw
+    k, n_img, C = 15, 2, 6
+    g = torch.Generator().manual_seed(h)
+    x = torch.randn(n_img, C, h * w, generator=g)
+    wgt = torch.randn(C, k, k, generator=g) / k
+    b = torch.randn(C, generator=g) * 0.1
+    X, Y = Planes.of(x.to(dev)), Planes.of(torch.empty(n_img, C, h * w, device=dev))
+    prev = ops.set_precision("f16x2")
+    try:
+        ops.dwconv_res_gelu(X, wgt.to(dev).contiguous(), b.to(dev), Y, h, w, k)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_precision(prev)
+    xd = x.double().view(n_img, C, h, w)
+    xr = x.half().double().view(n_img, C, h, w)
+    conv = lambda t, ww: F.conv2d(t, ww.double().view(C, 1, k, k), None, padding=k // 2, groups=C)
+    got = Y.tensor().view(n_img, C, h, w).double().cpu()
+    ref_same = F.gelu(xd + conv(xr, wgt) + b.double().view(1, C, 1, 1))
+    assert (got - ref_same).abs().max().item() < 2e-5
+    ref = F.gelu(xd + conv(xd, wgt) + b.double().view(1, C, 1, 1))
+    bound = 2.0 ** -11 * conv(xd.abs(), wgt.abs()) * 1.13 + 2e-5          # |gelu'| <= 1.13
+    assert bool(((got - ref).abs() <= bound).all())
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("k,C,hw", [(15, 256, (55, 128)), (7, 640, (55, 128)), (15, 324, (22, 36))])
 def test_skblock_pw_fold_vs_float64(dev, k, C, hw):
     """f16x2 mode: x4 = gelu(x3 + pw(x3)) is computed as gelu((W + I) x3) with x3 handed over in fp16 rows by the
