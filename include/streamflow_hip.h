@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SF_VERSION 102
+#define SF_VERSION 103
 
 enum {
     SF_OK = 0,
@@ -78,11 +78,14 @@ int64_t sf_corr_build_ws_bytes(int B, int pairs, int D, int h, int w);
  * out image img starts at out + img*out_img_stride (floats), channel stride h*w, so the caller can
  * write straight into a wider concatenation buffer.  Volumes are addressed as in
  * sf_corr_build_pyramid.  radius must be 4, num_levels 4.  vol_precision: the precision the volumes were built
- * with -- SF_PRECISION_F16 means lvl0..lvl3 hold fp16 cells (taps are blended in fp32), anything else fp32 cells. */
+ * with -- SF_PRECISION_F16 means lvl0..lvl3 hold fp16 cells (taps are blended in fp32), anything else fp32 cells.
+ * out_koct (optional, fp16 volumes only): the same 324 channels a second time, rounded to fp16, as k-octet planes
+ * [41][h*w][8] per image (SF_LAYOUT_F16_KOCT, image stride out_koct_img_stride halves, rows 324..327 zero): the
+ * B operand of the first sf_gemm of the correlation encoder. */
 int sf_corr_lookup(const float* lvl0, const float* lvl1, const float* lvl2, const float* lvl3,
-                   const int64_t* lvl_pair_stride, const float* coords, float* out,
-                   int64_t out_img_stride, int B, int pairs, int h, int w, int num_levels, int radius,
-                   int vol_precision, void* stream);
+                   const int64_t* lvl_pair_stride, const float* coords, float* out, int64_t out_img_stride,
+                   void* out_koct, int64_t out_koct_img_stride, int B, int pairs, int h, int w, int num_levels,
+                   int radius, int vol_precision, void* stream);
 
 /* ---- generic fused GEMM: every 1x1 conv / nn.Linear / einsum on the path ------------------------
  * C[z][m][n] = epilogue( alpha * ( sum_k A[z][m][k] * B[z][k][n] + bias[m] ) )
@@ -160,8 +163,12 @@ typedef struct SfGemm {
     /* c_f16 = 1 (split precisions, 16-byte-aligned C, N % 4 == 0, ldc % 4 == 0): C points to IEEE fp16 storage, results are
        rounded to nearest and stored as halves (ldc, strideC in halves): the K-major fp16 operand of the next sf_gemm.
        c_f16 = 2: the same values in k-octet planes (SF_LAYOUT_F16_KOCT; ldc = pixels per plane, strideC in halves,
-       8*ceil(M/8) rows are written: the caller provides room for them). */
+       8*ceil(M/8) rows are written: the caller provides room for them).
+       c_f16 = 3: C is written in fp32 as usual AND a second time as fp16 k-octet planes at C16 (ldc pixels per plane,
+       strideC16 halves between images; same alignment rules as c_f16 = 1 for C and c_f16 = 2 for C16; every epilogue).
+       Only rows < M are written to C16: a last, partial octet keeps its other rows. */
     int32_t c_f16;
+    void* C16; int64_t strideC16;
 } SfGemm;
 
 /* floats of scratch that let sf_gemm auto-split a problem of this size (0 if it never would) */
@@ -186,6 +193,8 @@ int sf_splitk_combine(const float* partial, int64_t split_stride, int k_splits, 
  *       3 = split precision (q_hi k_hi + q_lo k_hi + q_hi k_lo, fp32-class logits), 2 = k rounded to fp16,
  *       1 = q and k rounded to fp16 (the arithmetic of the reference's fp16 flash-attn path).  Softmax weights and v
  *       enter the second contraction as fp16 (like the materialised matrix of sf_softmax_rows), accumulation is fp32.
+ *       out_koct (optional): `out` a second time, rounded to fp16, as k-octet planes [16][P][8] per image
+ *       (SF_LAYOUT_F16_KOCT, image stride in halves) -- the operand format of the GEMM that reads it next.
  * ws: caller-owned scratch of sf_gma_flash_ws_bytes(n_img, P) bytes, 16-byte aligned; must persist from pack_qk to the
  * last aggregate of the clip. */
 int64_t sf_gma_flash_ws_bytes(int n_img, int P);
@@ -193,7 +202,7 @@ int sf_gma_flash_pack_qk(const float* qk, int64_t qk_img_stride, void* ws, int64
                          float scale, void* stream);
 int sf_gma_flash_aggregate(void* ws, int64_t ws_bytes, const float* v, int64_t v_img_stride, const float* mf,
                            int64_t mf_img_stride, const float* gamma, float* out, int64_t out_img_stride,
-                           int n_img, int P, int qk_products, void* stream);
+                           void* out_koct, int64_t out_koct_img_stride, int n_img, int P, int qk_products, void* stream);
 
 /* ---- row softmax (gma.py:63): x [rows][cols] ----------------------------------------------------
  * out_f16 == NULL: in place.  Otherwise the weights are written as IEEE fp16 to out_f16 [rows][cols] (x is then
@@ -224,15 +233,26 @@ int sf_layernorm_cm(const float* x, int64_t x_img_stride, const float* gamma, co
  * qkv [B*TT][3*C][P] (rows [q|k|v]) -> out [B*TT][C][P]; softmax(q k^T / sqrt(C)) v over t. */
 int sf_temporal_attn(const float* qkv, float* out, int B, int TT, int C, int P, void* stream);
 
+/* ---- fp32 planes -> fp16 k-octet planes (no reference counterpart: an operand format of sf_gemm) -----------------
+ * x [n_img][rows][P] fp32 (x_img_stride in floats) -> y [n_img][ceil(rows/8)][P][8] IEEE fp16 (y_img_stride in halves),
+ * element (r, p) at ((r / 8) * P + p) * 8 + r % 8, rows past `rows` in the last octet zero: SF_LAYOUT_F16_KOCT, the
+ * image sf_gemm moves to LDS by DMA.  Used once per clip for the static context features; tensors produced inside
+ * the loop get their k-octet copy from the producing kernel (SfGemm.C16). */
+int sf_pack_koct(const float* x, int64_t x_img_stride, int n_img, int rows, int P, void* y, int64_t y_img_stride,
+                 void* stream);
+
 /* ---- context split (streamflow.py:119-122): cnets [n_img][2*hdim][P] ->
  * nets = tanh(first half) (written with nets_img_stride), inps = relu(second half). */
 int sf_context_split(const float* cnets, float* nets, int64_t nets_img_stride, float* inps,
                      int64_t inps_img_stride, int n_img, int hdim, int P, void* stream);
 
 /* ---- flow bookkeeping (streamflow.py:133,138) ----------------------------------------------------
- * coords1 += delta (if delta != NULL); flow = coords1 - grid; flow written to up to two places. */
+ * coords1 += delta (if delta != NULL); flow = coords1 - grid; flow written to up to two places, and (flow_koct != NULL)
+ * as fp16 into rows flow_koct_row (x), flow_koct_row + 1 (y) of k-octet planes (SF_LAYOUT_F16_KOCT, image stride in
+ * halves): the flow rows of the k-octet copy of the motion features. */
 int sf_flow_update(float* coords1, const float* delta, float* flow_a, int64_t flow_a_img_stride,
-                   float* flow_b, int64_t flow_b_img_stride, int n_img, int h, int w, void* stream);
+                   float* flow_b, int64_t flow_b_img_stride, void* flow_koct, int64_t flow_koct_img_stride,
+                   int flow_koct_row, int n_img, int h, int w, void* stream);
 
 /* ---- f1: Twins_CSC encoder (core/encoders/twins_csc.py:59-85 over timm's twins_svt_large stages 1-2) -----------------
  * Token planes [n_img][C][N]: N = H*W tokens of the (T*h) x w grid of a clip, channel = head*32 + d (head dim 32).

@@ -38,6 +38,7 @@ class SfGemm(C.Structure):
         ("k_splits", C.c_int32), ("split_stride", _i64),
         ("split_ws", _vp), ("split_ws_floats", _i64),
         ("c_f16", C.c_int32),
+        ("C16", _vp), ("strideC16", _i64),
     ]
 
 
@@ -50,19 +51,20 @@ SIGNATURES = {
     "sf_corr_build_pyramid": (_i, [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, C.POINTER(_i64), _i, _i, _i, _i, _i, _i, _i,
                                    _vp, _i64, _vp]),
     "sf_corr_build_ws_bytes": (_i64, [_i, _i, _i, _i, _i]),
-    "sf_corr_lookup": (_i, [_vp, _vp, _vp, _vp, C.POINTER(_i64), _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "sf_corr_lookup": (_i, [_vp, _vp, _vp, _vp, C.POINTER(_i64), _vp, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "sf_gemm": (_i, [C.POINTER(SfGemm), _vp]),
     "sf_gemm_split_ws_floats": (_i64, [_i, _i, _i, _i]),
     "sf_gma_flash_ws_bytes": (_i64, [_i, _i]),
     "sf_gma_flash_pack_qk": (_i, [_vp, _i64, _vp, _i64, _i, _i, _f, _vp]),
-    "sf_gma_flash_aggregate": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i, _i, _i, _vp]),
+    "sf_gma_flash_aggregate": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _i, _i, _i, _vp]),
     "sf_softmax_rows": (_i, [_vp, _i64, _i, _vp, _vp]),
     "sf_splitk_combine": (_i, [_vp, _i64, _i, _i64, _vp, _i64, _vp, _vp, _i64, _i, _i64, _vp]),
     "sf_dwconv_res_gelu": (_i, [_vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "sf_layernorm_cm": (_i, [_vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _i, _f, _vp]),
     "sf_temporal_attn": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "sf_pack_koct": (_i, [_vp, _i64, _i, _i, _i, _vp, _i64, _vp]),
     "sf_context_split": (_i, [_vp, _vp, _i64, _vp, _i64, _i, _i, _i, _vp]),
-    "sf_flow_update": (_i, [_vp, _vp, _vp, _i64, _vp, _i64, _i, _i, _i, _vp]),
+    "sf_flow_update": (_i, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _vp]),
     "sf_window_attn": (_i, [_vp, _i64, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _vp]),
     "sf_subsample_attn": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _vp]),
     "sf_dwconv3x3_res": (_i, [_vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp]),
@@ -93,7 +95,7 @@ def load() -> C.CDLL:
             raise RuntimeError(f"{LIB_PATH} does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
-    if lib.sf_version() < 102:
+    if lib.sf_version() < 103:
         raise RuntimeError("libstreamflow_hip.so is too old; rebuild")
     _lib = lib
     return lib

@@ -39,6 +39,7 @@ constexpr int VTILE = (BJ / 8) * HD * 16;       // bytes of a V tile: 8 key-octe
 struct FlashArgs {
     const char* ws;                 // per image: [Qh | Ql | Kh | Kl | Vp], each 256 * Ppad bytes
     const float* mf; const float* gamma; float* out;
+    _Float16* out16; int64_t out16_img_stride;      // optional fp16 k-octet copy of out (SF_LAYOUT_F16_KOCT), halves
     int64_t mf_img_stride, out_img_stride;
     int P, Ppad;
 };
@@ -255,12 +256,24 @@ __global__ __launch_bounds__(256, (QKP == 3) ? 1 : ((QKP == 1 && SF_FLASH_V1) ? 
     if (q < P) {
         const float* mf = g.mf + (int64_t)img * g.mf_img_stride + q;
         float* out = g.out + (int64_t)img * g.out_img_stride + q;
+        // k-octet copy: registers 4m..4m+3 of a lane are channels 8m + 4 khalf .. + 3 of octet td*4 + m -- one 8-byte
+        // store per octet; lanes l and l + 32 complete an octet, a wave instruction covers 512 contiguous bytes
+        _Float16* o16 = g.out16 ? g.out16 + (int64_t)img * g.out16_img_stride + (int64_t)q * 8 + khalf * 4 : nullptr;
 #pragma unroll
         for (int td = 0; td < HD / 32; ++td)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int d = td * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-                out[(int64_t)d * P] = mf[(int64_t)d * P] + w * o[td][r];
+            for (int m = 0; m < 4; ++m) {
+                typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                h4 hv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * m + e;
+                    const int d = td * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                    const float val = mf[(int64_t)d * P] + w * o[td][r];
+                    out[(int64_t)d * P] = val;
+                    hv[e] = (_Float16)val;
+                }
+                if (o16) *reinterpret_cast<h4*>(o16 + (int64_t)(td * 4 + m) * P * 8) = hv;
             }
     }
 }
@@ -288,7 +301,10 @@ extern "C" int sf_gma_flash_pack_qk(const float* qk, int64_t qk_img_stride, void
 
 extern "C" int sf_gma_flash_aggregate(void* ws, int64_t ws_bytes, const float* v, int64_t v_img_stride, const float* mf,
                                       int64_t mf_img_stride, const float* gamma, float* out, int64_t out_img_stride,
-                                      int n_img, int P, int qk_products, void* stream) {
+                                      void* out_koct, int64_t out_koct_img_stride, int n_img, int P, int qk_products,
+                                      void* stream) {
+    SF_REQUIRE(!out_koct || ((reinterpret_cast<uintptr_t>(out_koct) & 15) == 0 && (out_koct_img_stride & 7) == 0),
+               "sf_gma_flash_aggregate: out_koct must be 16-byte aligned, its image stride a multiple of 8 halves");
     SF_REQUIRE(ws && v && mf && gamma && out, "sf_gma_flash_aggregate: null pointer");
     SF_REQUIRE(n_img > 0 && P > 0 && n_img <= 65535, "sf_gma_flash_aggregate: bad dims");
     SF_REQUIRE(qk_products >= 1 && qk_products <= 3, "sf_gma_flash_aggregate: qk_products must be 1, 2 or 3");
@@ -300,6 +316,7 @@ extern "C" int sf_gma_flash_aggregate(void* ws, int64_t ws_bytes, const float* v
                        v, v_img_stride, (char*)ws, P, Ppad);
     FlashArgs g;
     g.ws = (const char*)ws; g.mf = mf; g.gamma = gamma; g.out = out;
+    g.out16 = static_cast<_Float16*>(out_koct); g.out16_img_stride = out_koct_img_stride;
     g.mf_img_stride = mf_img_stride; g.out_img_stride = out_img_stride; g.P = P; g.Ppad = Ppad;
     dim3 grid(Ppad / BQ, n_img);
     switch (qk_products) {

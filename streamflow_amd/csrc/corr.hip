@@ -647,6 +647,8 @@ struct LookupArgs {
     int64_t lvl_pair_stride[4];
     int B, pairs, h, w, N;
     int hl[4], wl[4];
+    _Float16* out16;             // optional fp16 k-octet copy of `out` ([41 octets][N][8] per image), fp16-volume kernel only
+    int64_t out16_img_stride;    // halves
 };
 
 __global__ __launch_bounds__(kThreads) void corr_lookup_kernel(const LookupArgs g) {
@@ -764,7 +766,13 @@ __global__ __launch_bounds__(kThreads) void corr_lookup_f16_kernel(const LookupA
     __syncthreads();
     // ---- taps: channel = l*81 + a*9 + bb (a moves x, corr.py:31-37) ----
     float* out = g.out + (int64_t)img * g.out_img_stride + p0;
-    for (int it = tid; it < 4 * WIN * 3 * LQ; it += kThreads) {
+    constexpr int kTapIt = (4 * WIN * 3 * LQ + kThreads - 1) / kThreads;          // 4 (the last one partial)
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    h4 keep[kTapIt][3];                                                            // fp16 copies for the k-octet output
+#pragma unroll
+    for (int ti = 0; ti < kTapIt; ++ti) {
+        const int it = tid + ti * kThreads;
+        if (it >= 4 * WIN * 3 * LQ) continue;
         const int pq = it % LQ, r1 = it / LQ, ag = r1 % 3, r2 = r1 / 3, bb = r2 % WIN, l = r2 / WIN;
         float res[3][4];
 #pragma unroll
@@ -789,7 +797,37 @@ __global__ __launch_bounds__(kThreads) void corr_lookup_f16_kernel(const LookupA
                 for (int e = 0; e < 4; ++e)
                     if (p0 + pq * 4 + e < g.N) o[e] = res[k][e];
             }
+            keep[ti][k] = h4{(_Float16)res[k][0], (_Float16)res[k][1], (_Float16)res[k][2], (_Float16)res[k][3]};
         }
+    }
+    // ---- optional second output: the same 324 x 32 values as fp16 k-octets (SF_LAYOUT_F16_KOCT), the DMA-able B operand
+    // of the first GEMM that reads the correlation features.  Transposed through LDS (the footprints are dead by now):
+    // [channel][32 pixels] halves in, one (octet, pixel) = 8 channels = 16 bytes out, 512 contiguous bytes per octet.
+    if (g.out16 == nullptr) return;                                                // workgroup-uniform
+    constexpr int NCH = 4 * WIN * WIN, NOCT = (NCH + 7) / 8;                       // 324 channels, 41 octets
+    static_assert(NOCT * 8 * LP <= 4 * LP * FSTR, "the transpose buffer aliases the footprints");
+    __syncthreads();
+    _Float16* tb = win;
+#pragma unroll
+    for (int ti = 0; ti < kTapIt; ++ti) {
+        const int it = tid + ti * kThreads;
+        if (it >= 4 * WIN * 3 * LQ) continue;
+        const int pq = it % LQ, r1 = it / LQ, ag = r1 % 3, r2 = r1 / 3, bb = r2 % WIN, l = r2 / WIN;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            *reinterpret_cast<h4*>(tb + (l * WIN * WIN + (ag * 3 + k) * WIN + bb) * LP + pq * 4) = keep[ti][k];
+    }
+    for (int i = tid; i < (NOCT * 8 - NCH) * LP; i += kThreads) tb[NCH * LP + i] = (_Float16)0.f;   // rows 324..327
+    __syncthreads();
+    _Float16* o16 = g.out16 + (int64_t)img * g.out16_img_stride;
+    for (int i = tid; i < NOCT * LP; i += kThreads) {
+        const int pix = i % LP, oc = i / LP;
+        if (p0 + pix >= g.N) continue;
+        typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+        h8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = tb[(oc * 8 + e) * LP + pix];
+        *reinterpret_cast<h8*>(o16 + ((int64_t)oc * g.N + p0 + pix) * 8) = v;
     }
 }
 
@@ -916,8 +954,8 @@ extern "C" int sf_corr_build_pyramid(const float* f1, const float* f2, int64_t f
 
 extern "C" int sf_corr_lookup(const float* lvl0, const float* lvl1, const float* lvl2, const float* lvl3,
                               const int64_t* lvl_pair_stride, const float* coords, float* out,
-                              int64_t out_img_stride, int B, int pairs, int h, int w, int num_levels, int radius,
-                              int vol_precision, void* stream) {
+                              int64_t out_img_stride, void* out_koct, int64_t out_koct_img_stride, int B, int pairs,
+                              int h, int w, int num_levels, int radius, int vol_precision, void* stream) {
     SF_REQUIRE(lvl0 && lvl1 && lvl2 && lvl3 && coords && out, "sf_corr_lookup: null pointer");
     SF_REQUIRE(B > 0 && pairs > 0 && h > 0 && w > 0, "sf_corr_lookup: bad dims");
     SF_REQUIRE(pairs == 1 || lvl_pair_stride, "sf_corr_lookup: pairs > 1 needs lvl_pair_stride");
@@ -927,6 +965,10 @@ extern "C" int sf_corr_lookup(const float* lvl0, const float* lvl1, const float*
     LookupArgs g;
     g.lvl[0] = lvl0; g.lvl[1] = lvl1; g.lvl[2] = lvl2; g.lvl[3] = lvl3;
     g.coords = coords; g.out = out; g.out_img_stride = out_img_stride;
+    g.out16 = static_cast<_Float16*>(out_koct); g.out16_img_stride = out_koct_img_stride;
+    SF_REQUIRE(!out_koct || (vol_precision == SF_PRECISION_F16 && (reinterpret_cast<uintptr_t>(out_koct) & 15) == 0 &&
+                             (out_koct_img_stride & 7) == 0),
+               "sf_corr_lookup: the k-octet copy needs fp16 volumes, a 16-byte aligned out_koct and stride %% 8 == 0");
     g.B = B; g.pairs = pairs; g.h = h; g.w = w; g.N = h * w;
     for (int l = 0; l < 4; ++l) {
         g.hl[l] = h >> l; g.wl[l] = w >> l;

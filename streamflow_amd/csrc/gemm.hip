@@ -302,7 +302,8 @@ extern "C" int sf_gemm(const SfGemm* gp, void* stream) {
     SF_REQUIRE((g.b_layout != SF_LAYOUT_F16_K_MAJOR && g.b_layout != SF_LAYOUT_F16_KOCT) ||
                    g.precision == SF_PRECISION_F16X2 || g.precision == SF_PRECISION_F16,
                "sf_gemm: a stored-fp16 activation operand needs SF_PRECISION_F16X2 or SF_PRECISION_F16");
-    SF_REQUIRE(g.c_f16 >= 0 && g.c_f16 <= 2, "sf_gemm: c_f16 must be 0, 1 or 2");
+    SF_REQUIRE(g.c_f16 >= 0 && g.c_f16 <= 3, "sf_gemm: c_f16 must be 0 .. 3");
+    SF_REQUIRE(g.c_f16 != 3 || g.C16, "sf_gemm: c_f16 = 3 needs C16");
     SF_REQUIRE(!g.c_f16 || g.precision != SF_PRECISION_FP32, "sf_gemm: c_f16 needs a split precision");
     SF_REQUIRE(g.b_layout != SF_LAYOUT_F16_K_MINOR || g.precision != SF_PRECISION_FP32,
                "sf_gemm: a stored-fp16 B operand needs a split precision");
@@ -320,7 +321,8 @@ extern "C" int sf_gemm(const SfGemm* gp, void* stream) {
         SF_REQUIRE(g.b_layout == SF_LAYOUT_K_MAJOR && g.b_group == 0, "sf_gemm: conv3x3 needs a plain K-major B");
         SF_REQUIRE(g.K % 9 == 0 && g.h > 0 && g.w > 0 && g.h * g.w == g.N, "sf_gemm: conv3x3 needs K=9*Cin, h*w=N");
     }
-    if (g.b_group) SF_REQUIRE(g.b_layout == SF_LAYOUT_K_MAJOR, "sf_gemm: b_group needs a K-major B");
+    if (g.b_group) SF_REQUIRE(g.b_layout == SF_LAYOUT_K_MAJOR || g.b_layout == SF_LAYOUT_F16_KOCT,
+                              "sf_gemm: b_group needs a K-major or k-octet B");
     SF_REQUIRE(g.k_splits <= 1 || g.precision != SF_PRECISION_FP32, "sf_gemm: split-K is only built for the split-precision modes");
     SF_REQUIRE(sf::epilogue_spans_ok(g), "sf_gemm: C / R image larger than 1 GiB (32-bit buffer offsets in the epilogue)");
     hipStream_t st = static_cast<hipStream_t>(stream);

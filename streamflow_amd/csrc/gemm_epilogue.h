@@ -179,7 +179,7 @@ __device__ __forceinline__ void gemm_epilogue_vec_impl(const SfGemm& g, f32x16 (
     const int khalf = lane >> 5, l31 = lane & 31;
     const int rrow = lane >> 3, rcol = (lane & 7) * 4;       // read-back coordinates inside a 32x32 tile
     // c_f16: C is IEEE fp16 storage (ldc / strideC in halves): four rounded values leave as one 8-byte store
-    const int ces = g.c_f16 ? 2 : 4;
+    const int ces = g.c_f16 == 1 ? 2 : 4;
     const int c_bytes = (int)(((int64_t)(g.M - 1) * g.ldc + g.N) * ces);
     __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(
         reinterpret_cast<char*>(g.C) + (int64_t)z * g.strideC * ces, 0, c_bytes, 0x00020000);
@@ -191,6 +191,11 @@ __device__ __forceinline__ void gemm_epilogue_vec_impl(const SfGemm& g, f32x16 (
         rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.R) + (int64_t)z * g.strideR, 0,
                                                (int)((last + g.N) * 4), 0x00020000);
     }
+    // c_f16 = 3: second, k-octet fp16 copy of C at C16 (same ldc, strideC16 in halves)
+    __amdgpu_buffer_rsrc_t rc16 = rc;
+    if (g.c_f16 == 3)
+        rc16 = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(g.C16) + (int64_t)z * g.strideC16 * 2, 0,
+                                                 (int)((int64_t)((g.M + 7) / 8) * g.ldc * 16), 0x00020000);
     const float gam = (EPI == SF_EPI_AXPY) ? g.gamma[0] : 0.f;
     const bool has_bias = g.bias != nullptr;
 #pragma unroll
@@ -248,7 +253,9 @@ __device__ __forceinline__ void gemm_epilogue_vec_impl(const SfGemm& g, f32x16 (
                     o[e] = __builtin_bit_cast(unsigned, r0);
                     o[e + 1] = __builtin_bit_cast(unsigned, r1);
                 }
-                if (g.c_f16) {                                   // wave-uniform
+                if (g.c_f16 == 3)                                // wave-uniform: final values back into the scratch
+                    *reinterpret_cast<epi_u32x4*>(scratch + (rrow + 8 * q) * kEpiStride + rcol) = o;
+                if (g.c_f16 == 1) {                              // wave-uniform
                     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
                     typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
                     u32x2 oh;
@@ -263,6 +270,37 @@ __device__ __forceinline__ void gemm_epilogue_vec_impl(const SfGemm& g, f32x16 (
                     __builtin_amdgcn_raw_buffer_store_b64(oh, rc, crow[q] + ccol, 0, SF_EPI_STORE_AUX);
                 } else {
                     __builtin_amdgcn_raw_buffer_store_b128(o, rc, crow[q] + ccol, 0, SF_EPI_STORE_AUX);
+                }
+            }
+            if (g.c_f16 == 3) {
+                // dual output: the finished tile (now in the scratch) leaves a second time as fp16 k-octets -- lane =
+                // (octet half, pixel) as in the k-octet epilogue below.  Rows >= M of a last, partial octet are NOT
+                // written (another producer may own them: the flow rows of StreamFlow's motion features).
+                const int n1 = n0 + (wn * TN + j) * 32 + l31;
+#pragma unroll
+                for (int q2 = 0; q2 < 2; ++q2) {
+                    const int mo = mt0 + (2 * q2 + khalf) * 8;
+                    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                    epi_u32x4 oh;
+#pragma unroll
+                    for (int e = 0; e < 8; e += 2) {
+                        h2 hv;
+                        hv[0] = (_Float16)scratch[((2 * q2 + khalf) * 8 + e) * kEpiStride + l31];
+                        hv[1] = (_Float16)scratch[((2 * q2 + khalf) * 8 + e + 1) * kEpiStride + l31];
+                        oh[e >> 1] = __builtin_bit_cast(unsigned, hv);
+                    }
+                    const int o16 = ((mo >> 3) * (int)g.ldc + n1) * 16;
+                    if (mo + 8 <= g.M) {                                           // wave-uniform per half
+                        __builtin_amdgcn_raw_buffer_store_b128(oh, rc16, n1 < g.N ? o16 : kOobTerm, 0, SF_EPI_STORE_AUX);
+                    } else if (mo < g.M) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const unsigned w = oh[e >> 1];
+                            const unsigned short hs = (unsigned short)((e & 1) ? (w >> 16) : (w & 0xffffu));
+                            __builtin_amdgcn_raw_buffer_store_b16(hs, rc16, (n1 < g.N && mo + e < g.M) ? o16 + e * 2 : kOobTerm,
+                                                                  0, SF_EPI_STORE_AUX);
+                        }
+                    }
                 }
             }
         }
@@ -377,7 +415,9 @@ __device__ __forceinline__ bool epilogue_vec_ok(const SfGemm& g, int z) {
 
 // host-side guard for the 32-bit buffer offsets used above
 inline bool epilogue_spans_ok(const SfGemm& g) {
-    const int64_t c = (g.c_f16 == 2) ? (int64_t)((g.M + 7) / 8) * g.ldc * 16 : ((int64_t)(g.M - 1) * g.ldc + g.N) * (g.c_f16 ? 2 : 4);
+    const int64_t c = (g.c_f16 == 2) ? (int64_t)((g.M + 7) / 8) * g.ldc * 16
+                                     : ((int64_t)(g.M - 1) * g.ldc + g.N) * (g.c_f16 == 1 ? 2 : 4);
+    if (g.c_f16 == 3 && (int64_t)((g.M + 7) / 8) * g.ldc * 16 >= kOobTerm) return false;
     int64_t r = 0;
     if (g.R) {
         const int mr = g.M - 1;

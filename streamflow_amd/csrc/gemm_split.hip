@@ -145,9 +145,13 @@ __global__ __launch_bounds__(kThreads, (TM * TN >= 8) ? 2 : SF_GEMM_WAVES) void 
         const_cast<char*>(reinterpret_cast<const char*>(g.B)) + (int64_t)z * g.strideB * 2, 0, b_plane, 0x00020000);
     const int bpx = min(n0 + (tid & (BN - 1)), g.N - 1);
     const int vob0 = ((tid / BN) * (int)g.ldb + bpx) * 16, vob1 = vob0 + (kThreads / BN) * (int)g.ldb * 16;
+    // b_group > 0 ('(B T) C -> B (T C)' views): rows come in groups of b_group (a multiple of 32, so a k-tile never
+    // straddles two), group gi starts b_group_stride halves after group gi - 1
+    const int b_goct = g.b_group > 0 ? g.b_group / 8 : 0;
     auto issue_b = [&](int kt, int buf) {
         char* dst = reinterpret_cast<char*>(smem + kAHalfs) + buf * kBStage * 2 + wave_u * 1024;
-        const int so = kt * (BK / 8) * (int)g.ldb * 16;
+        const int o = kt * (BK / 8), gi = b_goct ? o / b_goct : 0;
+        const int so = (o - gi * b_goct) * (int)g.ldb * 16 + gi * (int)(g.b_group_stride * 2);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rbd, (lds_ptr)(dst), 16, vob0, so, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rbd, (lds_ptr)(dst + 4096), 16, vob1, so, 0, 0);
     };
@@ -362,7 +366,9 @@ int pick_tile(const SplitArgs& a, hipStream_t st) {
 int64_t span_bytes(int layout, int X, int K, int64_t ld, int group, int64_t group_stride) {
     if (layout == SF_LAYOUT_F16_K_MINOR) return ((int64_t)(X - 1) * ld + K) * 2;
     if (layout == SF_LAYOUT_F16_K_MAJOR) return ((int64_t)(K - 1) * ld + X) * 2;
-    if (layout == SF_LAYOUT_F16_KOCT) return (int64_t)((K + 7) / 8) * ld * 16;
+    if (layout == SF_LAYOUT_F16_KOCT)
+        return (group > 0) ? ((int64_t)((K - 1) / group) * group_stride * 2 + (int64_t)(((K - 1) % group) / 8 + 1) * ld * 16)
+                           : (int64_t)((K + 7) / 8) * ld * 16;
     if (layout == SF_LAYOUT_K_MINOR) return ((int64_t)(X - 1) * ld + K) * 4;
     if (group > 0) return ((int64_t)((K - 1) / group) * group_stride + (int64_t)((K - 1) % group) * ld + X) * 4;
     return ((int64_t)(K - 1) * ld + X) * 4;
@@ -486,9 +492,10 @@ int gemm_split_dispatch_inner(const SfGemm& g, hipStream_t st) {
     // waste more than a quarter of the MFMAs
     if (g.b_layout == SF_LAYOUT_F16_KOCT) {
         if (g.a_layout != SF_LAYOUT_SPLIT_F16 || (g.precision != SF_PRECISION_F16X2 && g.precision != SF_PRECISION_F16) ||
-            g.b_group || g.conv3x3 || (g.strideB & 7) || (reinterpret_cast<uintptr_t>(g.B) & 15) || g.ldb < g.N)
-            return fail(SF_ERR_UNSUPPORTED, "sf_gemm: SF_LAYOUT_F16_KOCT B needs F16X2 / F16, a SPLIT_F16 A, no grouping, 16-byte "
-                                            "aligned B and strideB, ldb >= N");
+            (g.b_group & 31) || (g.b_group_stride & 7) || g.conv3x3 || (g.strideB & 7) ||
+            (reinterpret_cast<uintptr_t>(g.B) & 15) || g.ldb < g.N)
+            return fail(SF_ERR_UNSUPPORTED, "sf_gemm: SF_LAYOUT_F16_KOCT B needs F16X2 / F16, a SPLIT_F16 A, groups of a multiple of "
+                                            "32 rows, 16-byte aligned B, strideB and group stride, ldb >= N");
         return (g.precision == SF_PRECISION_F16) ? pick_tile<1>(a, st) : pick_tile<2>(a, st);
     }
     if (g.b_layout == SF_LAYOUT_F16_K_MAJOR) {
@@ -500,6 +507,16 @@ int gemm_split_dispatch_inner(const SfGemm& g, hipStream_t st) {
     }
     if (g.c_f16 == 1 && ((g.N & 3) || (g.ldc & 3) || (g.strideC & 3) || (reinterpret_cast<uintptr_t>(g.C) & 15) || g.k_splits > 1))
         return fail(SF_ERR_UNSUPPORTED, "sf_gemm: c_f16 needs N %% 4 == 0, ldc %% 4 == 0, strideC %% 4 == 0, 16-byte aligned C, no split-K");
+    if (g.c_f16 == 3) {
+        bool ok = (g.N & 3) == 0 && (g.ldc & 3) == 0 && (g.strideC & 3) == 0 && (reinterpret_cast<uintptr_t>(g.C) & 15) == 0 &&
+                  g.k_splits <= 1 && (g.strideC16 & 7) == 0 && (reinterpret_cast<uintptr_t>(g.C16) & 15) == 0 && g.ldc >= g.N;
+        if (g.R) ok = ok && (g.ldr & 3) == 0 && (g.strideR & 3) == 0 && (g.r_group_stride & 3) == 0 &&
+                      (reinterpret_cast<uintptr_t>(g.R) & 15) == 0;
+        if (!ok)
+            return fail(SF_ERR_UNSUPPORTED, "sf_gemm: c_f16 = 3 (fp32 + k-octet output) needs the vector epilogue (N, ldc, strideC, "
+                                            "ldr, strideR %% 4 == 0, 16-byte aligned C / R), 16-byte aligned C16, strideC16 %% 8 == 0, "
+                                            "no split-K");
+    }
     if (g.c_f16 == 2 && (g.ldc < g.N || (g.strideC & 7) || (reinterpret_cast<uintptr_t>(g.C) & 15) || g.k_splits > 1 ||
                          (g.epilogue != SF_EPI_NONE && g.epilogue != SF_EPI_GELU && g.epilogue != SF_EPI_RES_GELU)))
         return fail(SF_ERR_UNSUPPORTED, "sf_gemm: c_f16 = 2 (k-octet output) needs ldc >= N, strideC %% 8 == 0, 16-byte aligned C, "

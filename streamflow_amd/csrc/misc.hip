@@ -55,7 +55,7 @@ __global__ void context_split_kernel(const float* cnets, float* nets, int64_t ne
 
 // ---- coords1 += delta; flow = coords1 - grid ---------------------------------------------------------
 __global__ void flow_update_kernel(float* coords1, const float* delta, float* fa, int64_t fa_stride, float* fb,
-                                   int64_t fb_stride, int n_img, int h, int w) {
+                                   int64_t fb_stride, _Float16* fk, int64_t fk_stride, int fk_row, int n_img, int h, int w) {
     const int P = h * w;
     const int64_t total = (int64_t)n_img * 2 * P;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -70,6 +70,8 @@ __global__ void flow_update_kernel(float* coords1, const float* delta, float* fa
         const float f = v - (float)(c == 0 ? p % w : p / w);
         if (fa) fa[img * fa_stride + (int64_t)c * P + p] = f;
         if (fb) fb[img * fb_stride + (int64_t)c * P + p] = f;
+        // k-octet planes: rows fk_row (x) and fk_row + 1 (y) of the fp16 copy that shadows flow_b's tensor
+        if (fk) fk[img * fk_stride + ((int64_t)((fk_row + c) >> 3) * P + p) * 8 + ((fk_row + c) & 7)] = (_Float16)f;
     }
 }
 
@@ -442,6 +444,34 @@ extern "C" int sf_coords_grid(float* out, int batch, int ht, int wd, void* strea
     return sf::check_launch("sf_coords_grid");
 }
 
+
+namespace {
+// fp32 channel-major planes -> fp16 k-octet planes (SF_LAYOUT_F16_KOCT): one thread = one (octet, pixel) = eight
+// coalesced dword loads (one per row) and one 16-byte store.  Rows past `rows` inside the last octet become 0.
+__global__ __launch_bounds__(256) void pack_koct_kernel(const float* __restrict__ x, int64_t x_img_stride, int rows, int P,
+                                                         _Float16* __restrict__ y, int64_t y_img_stride) {
+    const int p = blockIdx.x * 256 + threadIdx.x, o = blockIdx.y, img = blockIdx.z;
+    if (p >= P) return;
+    const float* xp = x + img * x_img_stride + (int64_t)o * 8 * P + p;
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    h8 v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (o * 8 + i < rows) ? (_Float16)xp[(int64_t)i * P] : (_Float16)0.f;
+    *reinterpret_cast<h8*>(y + img * y_img_stride + ((int64_t)o * P + p) * 8) = v;
+}
+}  // namespace
+
+extern "C" int sf_pack_koct(const float* x, int64_t x_img_stride, int n_img, int rows, int P, void* y,
+                            int64_t y_img_stride, void* stream) {
+    SF_REQUIRE(x && y && n_img > 0 && rows > 0 && P > 0, "sf_pack_koct: bad args");
+    SF_REQUIRE((reinterpret_cast<uintptr_t>(y) & 15) == 0 && (y_img_stride & 7) == 0, "sf_pack_koct: y must be 16-byte aligned");
+    const int noct = (rows + 7) / 8;
+    SF_REQUIRE(noct <= 65535 && n_img <= 65535, "sf_pack_koct: grid too large");
+    hipLaunchKernelGGL(pack_koct_kernel, dim3((P + 255) / 256, noct, n_img), dim3(256), 0, (hipStream_t)stream, x,
+                       x_img_stride, rows, P, (_Float16*)y, y_img_stride);
+    return sf::check_launch("sf_pack_koct");
+}
+
 extern "C" int sf_context_split(const float* cnets, float* nets, int64_t nets_img_stride, float* inps,
                                 int64_t inps_img_stride, int n_img, int hdim, int P, void* stream) {
     SF_REQUIRE(cnets && nets && inps && n_img > 0 && hdim > 0 && P > 0, "sf_context_split: bad args");
@@ -451,11 +481,13 @@ extern "C" int sf_context_split(const float* cnets, float* nets, int64_t nets_im
 }
 
 extern "C" int sf_flow_update(float* coords1, const float* delta, float* flow_a, int64_t flow_a_img_stride,
-                              float* flow_b, int64_t flow_b_img_stride, int n_img, int h, int w, void* stream) {
+                              float* flow_b, int64_t flow_b_img_stride, void* flow_koct, int64_t flow_koct_img_stride,
+                              int flow_koct_row, int n_img, int h, int w, void* stream) {
     SF_REQUIRE(coords1 && n_img > 0 && h > 0 && w > 0, "sf_flow_update: bad args");
+    SF_REQUIRE(!flow_koct || flow_koct_row >= 0, "sf_flow_update: bad k-octet row");
     hipLaunchKernelGGL(flow_update_kernel, dim3(grid_for((int64_t)n_img * 2 * h * w)), dim3(kBlock), 0,
                        (hipStream_t)stream, coords1, delta, flow_a, flow_a_img_stride, flow_b, flow_b_img_stride,
-                       n_img, h, w);
+                       static_cast<_Float16*>(flow_koct), flow_koct_img_stride, flow_koct_row, n_img, h, w);
     return sf::check_launch("sf_flow_update");
 }
 

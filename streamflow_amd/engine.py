@@ -14,6 +14,7 @@ from __future__ import annotations
 
 import contextlib
 import os
+from dataclasses import replace
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -152,7 +153,7 @@ class _Plan:
     """Buffers for one (clips, pairs, h, w) shape."""
 
     def __init__(self, W: HotPathWeights, Bc: int, h: int, w: int, D: int, device, attn_chunk_rows: int = 0,
-                 attn_f16: bool = False, corr_f16: bool = False, flash: Optional[bool] = None):
+                 attn_f16: bool = False, corr_f16: bool = False, flash: Optional[bool] = None, shadows: bool = False):
         Pn = W.pairs
         n, P = Bc * Pn, h * w
         self.Bc, self.Pn, self.h, self.w, self.n, self.P, self.D = Bc, Pn, h, w, n, P, D
@@ -205,6 +206,12 @@ class _Plan:
         self.ws = ws
         for name, r in spec:
             setattr(self, name, ws.take(n, r, P))
+        # f16x2 mode: the SK blocks' INPUT tensors keep an fp16 k-octet copy next to the fp32 planes (ops.Planes.shadow):
+        # the first GEMM of a block reads the copy by LDS-DMA, its residual epilogue and every other kernel the planes
+        self.shadows = bool(shadows)
+        if self.shadows:
+            for name in ("corr", "cor256", "cat256", "concat"):
+                setattr(self, name, replace(getattr(self, name), shadow=ops.new_shadow(getattr(self, name), device)))
         self.nets = self.concat.slice(0, 128)
         self.inps = self.concat.slice(128, 256)
         self.mf = self.concat.slice(256, 384)
@@ -213,6 +220,11 @@ class _Plan:
         # flow-head view of nets: '(B T) C H W -> B (T C) H W' without a copy
         self.nets_grouped = Planes(self.concat.base, self.concat.off, Pn * self.concat.img_stride, Bc, HDIM * Pn, P,
                                    group=HDIM, group_stride=self.concat.img_stride)
+        if self.shadows:
+            sh = self.concat.shadow
+            self.nets_grouped = replace(self.nets_grouped, shadow=Planes(
+                sh.base, sh.off, Pn * sh.img_stride, Bc, HDIM * Pn, P, f16=True, koct=True, group=HDIM,
+                group_stride=sh.img_stride))
         self.delta_fh = Planes(self.delta.base, self.delta.off, 2 * Pn * P, Bc, 2 * Pn, P)
         self.up = torch.empty(n, 2, 8 * h, 8 * w, dtype=torch.float32, device=device)
         # static input staging (so a captured graph sees constant pointers)
@@ -284,7 +296,9 @@ class HotPathEngine:
                                    "the materialised / chunked attention path")
             flash = {"auto": None, "matrix": False, "flash": True}[self.gma_mode]
             pl = _Plan(self.W, Bc, h, w, D, self.device, self.attn_chunk_rows, attn_f16=split, corr_f16=self.corr_f16,
-                       flash=flash)
+                       flash=flash, shadows=(ops.SHADOWS and (h * w) % 4 == 0 and
+                                             self.precision in (ops.PRECISION_F16X2, ops.PRECISION_F16) and
+                                             os.environ.get("SF_HIDDEN_F16", "1") != "0"))
         self._plans[key] = pl                                        # (re)insert as most recent
         return pl
 
@@ -313,6 +327,8 @@ class HotPathEngine:
                        Bc, Pn, D, h, w, ws=pl.corr_ws)
         # streamflow.py:119-122: nets = tanh(.), inps = relu(.)
         ops.context_split(cnets, pl.nets, pl.inps, HDIM)
+        ops.refresh_shadow(pl.nets)
+        ops.refresh_shadow(pl.inps)
         # a6: attn = softmax(scale * q k^T) over the context features (gma.py:53-65), computed once
         ops.gemm(W.to_qk, pl.inps, pl.qk, EPI_NONE)
         if pl.flash:
@@ -401,6 +417,8 @@ class HotPathEngine:
                          M=HDIM, N=P, K=P, batch=n, lda=P, ldb=P, ldc=P, ldr=P, strideA=pl.v128.img_stride,
                          strideB=P * P, strideC=pl.mfg.img_stride, strideR=pl.mf.img_stride,
                          a_layout=LAYOUT_K_MINOR, b_layout=attn_lay, alpha=1.0, epilogue=EPI_AXPY)
+        if not pl.flash:
+            ops.refresh_shadow(pl.mfg)                              # (the flash kernel writes the k-octet copy itself)
         join()
         # "gru": SKBlock(640 -> 128) over cat[nets, inps, mf, mfg, mft]; new nets overwrite the nets slice
         sk(W.gru, pl.concat, pl.nets)
@@ -410,7 +428,8 @@ class HotPathEngine:
             ops.gemm(W.mask0, pl.nets, pl.m256, EPI_RELU, hw=(h, w))
             ops.gemm(W.mask2, pl.m256, pl.mask, EPI_NONE, alpha=0.25)
         # streamflow.py:138 + :133 for the next iteration
-        ops.flow_update(pl.coords1, pl.delta, pl.flow, pl.mf.slice(HDIM - 2, HDIM), n, h, w)
+        ops.flow_update(pl.coords1, pl.delta, pl.flow, pl.mf.slice(HDIM - 2, HDIM), n, h, w,
+                        koct=pl.mf.shadow, koct_row=HDIM - 2)       # (+ the flow rows of mf's k-octet copy)
 
     @contextlib.contextmanager
     def _kernel_context(self, pl: _Plan):
@@ -472,7 +491,8 @@ class HotPathEngine:
                 raise RuntimeError(f"flow_init needs {T - 1} tensors, got {len(flow_init)}")
             for i, f in enumerate(flow_init):
                 coords1.view(Bc, T - 1, 2, h, w)[:, i] += f.to(coords1)
-        ops.flow_update(pl.coords1, None, pl.flow, pl.mf.slice(HDIM - 2, HDIM), n, h, w)
+        ops.flow_update(pl.coords1, None, pl.flow, pl.mf.slice(HDIM - 2, HDIM), n, h, w,
+                        koct=pl.mf.shadow, koct_row=HDIM - 2)
         return pl
 
     @torch.no_grad()

@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from dataclasses import dataclass, replace
 from typing import Optional, Sequence
 
@@ -138,6 +139,9 @@ class Planes:
                             # the underlying fp32 allocation): GEMM-to-GEMM hand-over in the f16x2 mode (SfGemm.c_f16)
     koct: bool = False      # (with f16) k-octet planes [ceil(rows/8)][P][8] instead of rows [rows][P]: the consumer GEMM's
                             # LDS image, moved there by DMA (SF_LAYOUT_F16_KOCT / c_f16 = 2)
+    shadow: Optional["Planes"] = None   # fp16 k-octet COPY of these fp32 planes, kept current by every producer (f16x2 mode):
+                                        # a GEMM on the DMA-fed tile reads it as its B operand, everything else (residuals,
+                                        # element-wise kernels) keeps reading the fp32 planes
 
     @staticmethod
     def of(t: torch.Tensor) -> "Planes":
@@ -152,8 +156,12 @@ class Planes:
         return self.base.data_ptr() + 4 * self.off
 
     def slice(self, r0: int, r1: int) -> "Planes":
-        assert 0 <= r0 < r1 <= self.rows and self.group == 0 and not self.f16
-        return replace(self, off=self.off + r0 * self.P, rows=r1 - r0)
+        assert 0 <= r0 < r1 <= self.rows and self.group == 0
+        if self.f16:                                # k-octet planes: whole octets only
+            assert self.koct and r0 % 8 == 0 and self.shadow is None
+            return replace(self, off=self.off + (r0 // 8) * self.P * 4, rows=r1 - r0)
+        sh = self.shadow.slice(r0, r1) if (self.shadow is not None and r0 % 8 == 0) else None
+        return replace(self, off=self.off + r0 * self.P, rows=r1 - r0, shadow=sh)
 
     def tensor(self) -> torch.Tensor:
         """Materialise as a [n_img, rows, P] torch view (only for contiguous-row, ungrouped views)."""
@@ -235,6 +243,32 @@ class PackedLinear:
         self.split_error = float(((hi.float() + lo.float()) - wm).abs().max() / max(wmax * self.split_scale, 1e-30))
 
 
+SHADOWS = os.environ.get("SF_SHADOW", "1") != "0"     # use / maintain Planes.shadow (A/B knob)
+
+
+def new_shadow(X: Planes, device) -> Planes:
+    """Allocate the k-octet copy of fp32 planes X (zeroed: rows past X.rows in the last octet must stay finite)."""
+    assert not X.f16 and X.group == 0
+    noct = (X.rows + 7) // 8
+    base = torch.zeros(X.n_img * noct * X.P * 4, dtype=torch.float32, device=device)       # 8 halves = 4 floats
+    return Planes(base, 0, noct * X.P * 8, X.n_img, X.rows, X.P, f16=True, koct=True)
+
+
+@on_tensor_device
+def pack_koct(X: Planes, Y: Planes) -> None:
+    """fp32 planes -> their k-octet fp16 copy (sf_pack_koct)."""
+    assert Y.f16 and Y.koct and not X.f16 and X.group == 0 and (X.rows, X.P, X.n_img) == (Y.rows, Y.P, Y.n_img)
+    _launch("pack_koct", 0, 6.0 * X.n_img * X.rows * X.P,
+            lambda: _lib.check(_lib.load().sf_pack_koct(X.ptr, X.img_stride, X.n_img, X.rows, X.P, Y.ptr, Y.img_stride,
+                                                        _lib.stream()), "sf_pack_koct"))
+
+
+def refresh_shadow(X: Planes) -> None:
+    """After a producer without a fused k-octet output wrote X: bring X.shadow up to date."""
+    if X.shadow is not None and SHADOWS:
+        pack_koct(replace(X, shadow=None), X.shadow)
+
+
 def uses_dma_tile(M: int) -> bool:
     """Does sf_gemm run an M-row problem on the 128-row, DMA-fed tile (gemm_split.hip pick_tile)?  Only that kernel takes
     a k-octet fp16 B operand."""
@@ -247,6 +281,9 @@ def gemm(A: PackedLinear, X: Planes, Y: Planes, epilogue: int = EPI_NONE, R: Opt
     """Y[img] = epilogue(alpha * (W @ X[img] + bias)) for every image (batched over grid.z)."""
     assert X.rows * (9 if A.conv3x3 else 1) == A.K, (X.rows, A.K)
     assert Y.rows == A.M and X.n_img == Y.n_img and X.P == Y.P, (Y.rows, A.M)
+    if (X.shadow is not None and SHADOWS and PRECISION in (PRECISION_F16X2, PRECISION_F16) and not A.conv3x3 and
+            uses_dma_tile(A.M)):
+        X = X.shadow                                  # the fp16 k-octet copy: both operands by LDS-DMA
     g = SfGemm()
     g.A, g.B, g.C = A.wt.data_ptr(), X.ptr, Y.ptr
     g.bias = None if A.bias is None else A.bias.data_ptr()
@@ -263,6 +300,11 @@ def gemm(A: PackedLinear, X: Planes, Y: Planes, epilogue: int = EPI_NONE, R: Opt
             g.b_layout = _lib.LAYOUT_F16_KOCT if X.koct else _lib.LAYOUT_F16_K_MAJOR
         if Y.f16:
             g.c_f16 = 2 if Y.koct else 1
+    fused_shadow = False
+    if (Y.shadow is not None and SHADOWS and not Y.f16 and prec in (PRECISION_F16X2, PRECISION_F16) and Y.P % 4 == 0
+            and os.environ.get("SF_SHADOW_FUSED", "1") != "0"):
+        g.c_f16, g.C16, g.strideC16 = 3, Y.shadow.ptr, Y.shadow.img_stride       # fp32 planes + their k-octet copy
+        fused_shadow = True
     if prec != PRECISION_FP32:
         g.a_layout = LAYOUT_SPLIT_F16
         g.A_hi, g.A_lo, g.lda_h = A.hi.data_ptr(), A.lo.data_ptr(), A.lda_h
@@ -283,10 +325,12 @@ def gemm(A: PackedLinear, X: Planes, Y: Planes, epilogue: int = EPI_NONE, R: Opt
         g.split_ws, g.split_ws_floats = SPLIT_WS.data_ptr(), SPLIT_WS.numel()
     name = "gemm" if not PROFILE_SHAPES else f"gemm M{g.M} K{g.K} b{g.batch} e{g.epilogue}"
     # algorithmic bytes: activations in (each input row once) + result out (+ residual in) per image, weights once
-    nbytes = (g.batch * g.N * ((2.0 if X.f16 else 4.0) * X.rows + (2.0 if Y.f16 else 4.0) * g.M +
+    nbytes = (g.batch * g.N * ((2.0 if X.f16 else 4.0) * X.rows + (2.0 if Y.f16 else 6.0 if fused_shadow else 4.0) * g.M +
                                (4.0 * g.M if R is not None else 0.0)) + 4.0 * g.M * g.K)
     _launch(name, 2.0 * g.M * g.N * g.K * g.batch, nbytes,
             lambda: _lib.check(_lib.load().sf_gemm(C.byref(g), _lib.stream()), "sf_gemm"))
+    if not fused_shadow:
+        refresh_shadow(Y)
 
 
 def gemm_raw(**kw) -> None:
@@ -399,10 +443,14 @@ def gma_flash_aggregate(ws: torch.Tensor, V: Planes, MF: Planes, gamma: torch.Te
     assert V.rows == MF.rows == OUT.rows == 128 and V.n_img == MF.n_img == OUT.n_img
     n, P = V.n_img, V.P
     # algorithmic: the two contractions; bytes: v, mf in, out (q/k/v tiles are re-read from L2 by every query tile)
-    _launch("gma_flash", 4.0 * n * P * P * 128, 4.0 * n * 128 * P * 3 + 2.0 * n * 128 * P * 2,
+    sh = OUT.shadow if (OUT.shadow is not None and SHADOWS and os.environ.get("SF_SHADOW_FUSED", "1") != "0") else None
+    _launch("gma_flash", 4.0 * n * P * P * 128, 4.0 * n * 128 * P * 3 + 2.0 * n * 128 * P * (2 if sh is None else 3),
             lambda: _lib.check(_lib.load().sf_gma_flash_aggregate(
                 ws.data_ptr(), ws.numel(), V.ptr, V.img_stride, MF.ptr, MF.img_stride, gamma.data_ptr(), OUT.ptr,
-                OUT.img_stride, n, P, int(qk_products), _lib.stream()), "sf_gma_flash_aggregate"))
+                OUT.img_stride, None if sh is None else sh.ptr, 0 if sh is None else sh.img_stride, n, P,
+                int(qk_products), _lib.stream()), "sf_gma_flash_aggregate"))
+    if sh is None:
+        refresh_shadow(OUT)
 
 
 @on_tensor_device
@@ -423,12 +471,18 @@ def context_split(cnets: torch.Tensor, nets: Planes, inps: Planes, hdim: int) ->
 
 @on_tensor_device
 def flow_update(coords1: Planes, delta: Optional[Planes], flow_a: Optional[Planes], flow_b: Optional[Planes],
-                n_img: int, h: int, w: int) -> None:
+                n_img: int, h: int, w: int, koct: Optional[Planes] = None, koct_row: int = 0) -> None:
+    """koct / koct_row: k-octet planes (Planes.shadow of the tensor flow_b is a slice of) and the row the x component
+    goes to: keeps that copy's flow rows current."""
     assert coords1.img_stride == 2 * h * w and (delta is None or delta.img_stride == 2 * h * w)
+    if not SHADOWS:
+        koct = None
+    assert koct is None or (koct.f16 and koct.koct and koct_row + 2 <= (koct.rows + 7) // 8 * 8)
     _launch("flow_update", 0, 0, lambda: _lib.check(_lib.load().sf_flow_update(
         coords1.ptr, None if delta is None else delta.ptr,
         None if flow_a is None else flow_a.ptr, 0 if flow_a is None else flow_a.img_stride,
         None if flow_b is None else flow_b.ptr, 0 if flow_b is None else flow_b.img_stride,
+        None if koct is None else koct.ptr, 0 if koct is None else koct.img_stride, int(koct_row),
         n_img, h, w, _lib.stream()), "sf_flow_update"))
 
 
@@ -497,11 +551,17 @@ def corr_lookup(lvls: Sequence[torch.Tensor], lvl_pair_stride: Optional[Sequence
     N = h * w
     vol16 = lvls[0].dtype == torch.float16
     # algorithmic bytes per image: 10x10 footprint x 4 levels read + coords + 324 output channels
-    nbytes = B * pairs * (N * 4 * 100 * (2.0 if vol16 else 4.0) + N * 2 * 4.0 + N * 324 * 4.0)
+    # the k-octet copy of the output (Planes.shadow) comes out of the same kernel when the volumes are fp16
+    sh = out.shadow if (out.shadow is not None and SHADOWS and vol16 and
+                        os.environ.get("SF_SHADOW_FUSED", "1") != "0") else None
+    nbytes = B * pairs * (N * 4 * 100 * (2.0 if vol16 else 4.0) + N * 2 * 4.0 + N * 324 * (4.0 if sh is None else 6.0))
     _launch("corr_lookup", 0, nbytes, lambda: _lib.check(_lib.load().sf_corr_lookup(
         lvls[0].data_ptr(), lvls[1].data_ptr(), lvls[2].data_ptr(), lvls[3].data_ptr(),
-        pair_strides(lvl_pair_stride), coords.ptr, out.ptr, out.img_stride, B, pairs, h, w, 4, 4,
+        pair_strides(lvl_pair_stride), coords.ptr, out.ptr, out.img_stride,
+        None if sh is None else sh.ptr, 0 if sh is None else sh.img_stride, B, pairs, h, w, 4, 4,
         PRECISION_F16 if vol16 else PRECISION_FP32, _lib.stream()), "sf_corr_lookup"))
+    if sh is None:
+        refresh_shadow(out)
 
 
 @on_tensor_device

@@ -33,9 +33,9 @@ def test_every_declared_symbol_is_exported(lib):
 def test_struct_layout_matches_header():
     from streamflow_amd._lib import SfGemm
     # 8 pointers + 4 i32 + 8 i64 + 2 i32 + (i32,pad,i64)*2 + 3 i32 + f32 + 2 i32  (natural alignment)
-    assert ctypes.sizeof(SfGemm) == 272                         # ... + split-K fields + c_f16 (offset 264), padded to 8
+    assert ctypes.sizeof(SfGemm) == 288                         # ... + split-K fields + c_f16 (offset 264) + C16, strideC16
     assert SfGemm.lda.offset == 80 and SfGemm.b_group_stride.offset == 160 and SfGemm.alpha.offset == 196
-    assert SfGemm.c_f16.offset == 264
+    assert SfGemm.c_f16.offset == 264 and SfGemm.C16.offset == 272 and SfGemm.strideC16.offset == 280
 
 
 def test_bad_arguments_return_error_codes(lib):

@@ -230,3 +230,112 @@ def test_fp16_hidden_handover_is_bit_identical(dev, seed):
         assert torch.equal(yko, y32), (C, H, Cout, P, (yko - y32).abs().max().item())
     assert torch.equal(hid16.tensor().float(), hid32.tensor().half().float())
     assert torch.equal(y16, y32), (C, H, Cout, P, (y16 - y32).abs().max().item())
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_dual_output_koct_copy(dev, seed):
+    """SfGemm.c_f16 = 3 (f16x2 mode): the fp32 result is unchanged and its k-octet fp16 copy (Planes.shadow) equals the
+    rounded fp32 result, for every tile configuration, residual epilogues and a ragged M whose last octet is shared with
+    another producer (rows >= M of that octet must survive).  A grouped k-octet view then feeds a consumer GEMM."""
+    from dataclasses import replace
+    from streamflow_amd import ops
+    from streamflow_amd.ops import Planes, PackedLinear
+    rng = np.random.default_rng(9100 + seed)
+    K = int(rng.choice([64, 192, 384]))
+    M = int(rng.choice([6, 64, 126, 128, 256, 640]))
+    P = int(rng.choice([96, 1000, 7040]))
+    epi = [ops.EPI_NONE, ops.EPI_GELU, ops.EPI_RES][seed % 3]
+    n = 3
+    g = torch.Generator().manual_seed(seed)
+    W = PackedLinear(torch.randn(M, K, 1, 1, generator=g) / K ** 0.5, torch.randn(M, generator=g) * 0.1, dev)
+    X = Planes.of(torch.randn(n, K, P, generator=g).to(dev))
+    R = Planes.of(torch.randn(n, M, P, generator=g).to(dev)) if epi == ops.EPI_RES else None
+    Ma = (M + 7) // 8 * 8
+    prev = ops.set_precision("f16x2")
+    try:
+        y_plain = torch.full((n, M, P), float("nan"), device=dev)
+        ops.gemm(W, X, Planes.of(y_plain), epi, R=R)
+        y = torch.full((n, M, P), float("nan"), device=dev)
+        sh = ops.new_shadow(Planes.of(torch.empty(n, Ma, P, device=dev)), dev)
+        sh.base.view(torch.float16).fill_(7.0)                                    # sentinel in the rows past M
+        Y = replace(Planes.of(y), shadow=replace(sh, rows=M))
+        ops.gemm(W, X, Y, epi, R=R)
+        torch.cuda.synchronize()
+        assert torch.equal(y, y_plain)
+        full = replace(sh, rows=Ma).tensor().float()
+        assert torch.equal(full[:, :M], y.half().float())
+        assert bool((full[:, M:] == 7.0).all())
+        # consumer: the copy as B (k-octets by DMA) == the fp32 planes as B (rounded on load)
+        if M % 32 == 0:
+            W2 = PackedLinear(torch.randn(256, M, 1, 1, generator=g) / M ** 0.5, None, dev)
+            z0 = torch.empty(n, 256, P, device=dev)
+            z1 = torch.empty(n, 256, P, device=dev)
+            ops.gemm(W2, Planes.of(y), Planes.of(z0), ops.EPI_NONE)
+            ops.gemm(W2, Y, Planes.of(z1), ops.EPI_NONE)
+            # '(B T) C -> B (T C)' view of the copy: groups of M rows, one group per image
+            W3 = PackedLinear(torch.randn(256, n * M, 1, 1, generator=g) / (n * M) ** 0.5, None, dev)
+            yg = Planes(Y.base, 0, n * M * P, 1, n * M, P, group=M, group_stride=M * P)
+            shg = Planes(sh.base, 0, n * sh.img_stride, 1, n * M, P, f16=True, koct=True, group=M, group_stride=sh.img_stride)
+            z2 = torch.empty(1, 256, P, device=dev)
+            z3 = torch.empty(1, 256, P, device=dev)
+            ops.gemm(W3, yg, Planes.of(z2), ops.EPI_NONE)
+            ops.gemm(W3, replace(yg, shadow=shg), Planes.of(z3), ops.EPI_NONE)
+            torch.cuda.synchronize()
+            assert torch.equal(z0, z1)
+            assert torch.equal(z2, z3)
+    finally:
+        ops.set_precision(prev)
+
+
+@pytest.mark.parametrize("hw", [(55, 128), (16, 24), (47, 156)])
+def test_lookup_koct_copy(dev, hw):
+    """sf_corr_lookup's optional second output (fp16 volumes): the 324 correlation channels as fp16 k-octet planes equal
+    the rounded fp32 output, rows 324..327 of the last octet are zero, and the fp32 output itself is unchanged."""
+    from dataclasses import replace
+    from streamflow_amd import ops
+    from streamflow_amd.ops import Planes
+    h, w = hw
+    B, pairs, D, N = 2, 2, 64, h * w
+    g = torch.Generator().manual_seed(h)
+    f = torch.randn(B, pairs + 1, D, N, generator=g).to(dev) * 0.3
+    dims = [(h >> l, w >> l) for l in range(4)]
+    stride = [B * N * a * b for a, b in dims]
+    lvls = [torch.empty(pairs * s, dtype=torch.float16, device=dev) for s in stride]
+    wsb = torch.empty(max(ops.corr_build_ws_bytes(B, pairs, D, h, w), 16), dtype=torch.uint8, device=dev)
+    ops.corr_build(f.data_ptr(), f.data_ptr() + 4 * D * N, (pairs + 1) * D * N, D * N, lvls, stride, B, pairs, D, h, w, ws=wsb)
+    coords = torch.rand(B * pairs, 2, N, generator=g).to(dev) * torch.tensor([w * 1.2, h * 1.2], device=dev).view(1, 2, 1) - 3.0
+    cp = Planes.of(coords)
+    plain = torch.full((B * pairs, 324, N), float("nan"), device=dev)
+    ops.corr_lookup(lvls, stride, cp, Planes.of(plain), B, pairs, h, w)
+    out = torch.full((B * pairs, 324, N), float("nan"), device=dev)
+    sh = ops.new_shadow(Planes.of(torch.empty(B * pairs, 328, N, device=dev)), dev)
+    sh.base.view(torch.float16).fill_(5.0)
+    ops.corr_lookup(lvls, stride, cp, replace(Planes.of(out), shadow=replace(sh, rows=324)), B, pairs, h, w)
+    torch.cuda.synchronize()
+    assert torch.equal(out, plain)
+    full = sh.tensor().float()
+    assert torch.equal(full[:, :324], out.half().float())
+    assert bool((full[:, 324:] == 0).all())
+
+
+def test_flow_update_koct_rows(dev):
+    """sf_flow_update's k-octet output: rows 126 / 127 of a 128-row fp16 k-octet tensor receive the rounded flow, the
+    other rows of that octet are untouched."""
+    from streamflow_amd import ops
+    from streamflow_amd.ops import Planes
+    n, h, w = 3, 9, 20
+    P = h * w
+    g = torch.Generator().manual_seed(3)
+    coords = ops.coords_grid(n, h, w, dev).view(n, 2, P) + torch.randn(n, 2, P, generator=g).to(dev)
+    delta = torch.randn(n, 2, P, generator=g).to(dev)
+    mf = torch.zeros(n, 128, P, device=dev)
+    sh = ops.new_shadow(Planes.of(mf), dev)
+    sh.base.view(torch.float16).fill_(3.0)
+    flow = torch.empty(n, 2, P, device=dev)
+    cp = Planes.of(coords.clone())
+    ops.flow_update(cp, Planes.of(delta), Planes.of(flow), Planes.of(mf).slice(126, 128), n, h, w, koct=sh, koct_row=126)
+    torch.cuda.synchronize()
+    got = sh.tensor().float()
+    assert torch.equal(got[:, 126:128], flow.half().float())
+    assert torch.equal(mf[:, 126:128], flow)
+    assert bool((got[:, :126] == 3.0).all())

@@ -401,6 +401,15 @@ def test_gma_flash_kernel_vs_float64(dev, P, qkp):
     tol = {3: 4e-4, 2: 1.5e-3, 1: 3e-3}[qkp]                  # fp16 softmax weights / v: ~2^-11 relative on O(1) values
     print(f"flash P={P} qk_products={qkp}: max abs err vs float64 = {err:.2e}")
     assert err < tol, (P, qkp, err)
+    # optional k-octet fp16 copy of the result (the next GEMM's operand format): same fp32 output, copy = its rounding
+    from dataclasses import replace
+    out2 = torch.full((n, 128, P), float("nan"), device=dev)
+    sh = ops.new_shadow(Planes.of(out2), dev)
+    ops.gma_flash_aggregate(ws, Planes.of(v.to(dev)), Planes.of(mf.to(dev)), gamma.to(dev),
+                            replace(Planes.of(out2), shadow=sh), qkp)
+    torch.cuda.synchronize()
+    assert torch.equal(out2, out)
+    assert torch.equal(sh.tensor().float(), out.half().float())
 
 
 @pytest.mark.parametrize("qkp", [1, 2, 3])
