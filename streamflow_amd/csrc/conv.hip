@@ -373,7 +373,11 @@ extern "C" int sf_dwconv_res_gelu(const float* x, int64_t x_img_stride, const fl
     SF_REQUIRE((int64_t)h * w < (1 << 30), "sf_dwconv_res_gelu: plane too large");
     // K = 7: only 7/32 of the Toeplitz entries are non-zero and the stencil is the faster kernel (65 vs 87 us at
     // 128 channels x 24 images); K = 15 runs 1.45x faster on the matrix cores
-    if (precision != SF_PRECISION_FP32 && ksize == 15) {
+    static const bool force3 = getenv("SF_DW_PRODUCTS") && atoi(getenv("SF_DW_PRODUCTS")) == 3;   // A/B knob
+    const bool two = precision != SF_PRECISION_FP32 && precision != SF_PRECISION_F16X3 && !force3;
+    static const bool dw7_stencil = getenv("SF_DW7_MFMA") && atoi(getenv("SF_DW7_MFMA")) == 0;      // A/B knob
+    // K = 7 in the two-product modes also runs on the matrix cores (7 x 2 MFMAs per tile against 49 FMAs per output)
+    if (precision != SF_PRECISION_FP32 && (ksize == 15 || (two && !dw7_stencil))) {
         DwmArgs m;
         m.x = x; m.wgt = wgt; m.bias = bias; m.y = y; m.x_img_stride = x_img_stride; m.y_img_stride = y_img_stride;
         m.n_img = n_img; m.C = C; m.h = h; m.w = w;
@@ -399,8 +403,11 @@ extern "C" int sf_dwconv_res_gelu(const float* x, int64_t x_img_stride, const fl
 #endif
         dim3 grid(C, strips, sf::ceil_div(n_img, m.imgs_per_wg));
         SF_REQUIRE(strips <= 65535 && grid.z <= 65535, "sf_dwconv_res_gelu: grid too large");
-        static const bool force3 = getenv("SF_DW_PRODUCTS") && atoi(getenv("SF_DW_PRODUCTS")) == 3;   // A/B knob
-        const bool two = precision != SF_PRECISION_F16X3 && !force3;
+        if (ksize == 7) {
+            if (y_f16) hipLaunchKernelGGL((dwconv_mfma_kernel<7, true, 2>), grid, dim3(256), lds, (hipStream_t)stream, m);
+            else hipLaunchKernelGGL((dwconv_mfma_kernel<7, false, 2>), grid, dim3(256), lds, (hipStream_t)stream, m);
+            return sf::check_launch("sf_dwconv_res_gelu(mfma7)");
+        }
         if (y_f16 && two)
             hipLaunchKernelGGL((dwconv_mfma_kernel<15, true, 2>), grid, dim3(256), lds, (hipStream_t)stream, m);
         else if (y_f16)

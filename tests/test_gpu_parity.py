@@ -557,16 +557,17 @@ def test_dwconv_vs_torch(dev, precision, k, hw):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("k", [15, 7])
 @pytest.mark.parametrize("hw", [(55, 128), (23, 37)])
-def test_dwconv_two_product_mode(dev, hw):
-    """f16x2 / f16 modes: the activation enters the 15x15 products rounded to fp16 (weights hi + lo, residual exact).
+def test_dwconv_two_product_mode(dev, hw, k):
+    """f16x2 / f16 modes (K = 15 and K = 7 on the matrix cores): the activation enters the products rounded to fp16 (weights hi + lo, residual exact).
     Against float64 with the activation rounded the same way the error is the split's (1e-5); against the exact
     convolution it is bounded by 2^-11 * sum|w||x|."""
     import torch.nn.functional as F
     from streamflow_amd import ops
     from streamflow_amd.ops import Planes
     h, w = hw
-    k, n_img, C = 15, 2, 6
+    n_img, C = 2, 6
     g = torch.Generator().manual_seed(h)
     x = torch.randn(n_img, C, h * w, generator=g)
     wgt = torch.randn(C, k, k, generator=g) / k
