@@ -8,8 +8,9 @@
   non-interlaced) is included, which is all the KITTI devkit files need.
 * PFM (FlyingThings ground truth, frame_utils.py:48-83): 'PF' / 'Pf' header, rows stored bottom-up, sign of the scale
   = endianness.
-* ``.flo5`` (Spring: an HDF5 container with one gzip dataset, frame_utils.py:31-47,130-135) is NOT built: HDF5 needs
-  h5py, which the image lacks.
+* ``.flo5`` (Spring: an HDF5 container with one gzip dataset, frame_utils.py:31-47,130-135): ``flo5.py``, a codec for
+  the subset of the HDF5 file format h5py emits for such a file (re-exported here as read_flo5 / write_flo5; h5py itself
+  is not in this image, so that codec is checked against the format specification only).
 * Metrics: end-point error map, Sintel-style EPE / 1px / 3px / 5px (evaluate_mf.py:484-497) and the KITTI
   F1-all outlier rate: epe > 3 px and epe/|gt| > 5 % over valid pixels (evaluate_mf.py:124-133).
 """
@@ -20,6 +21,8 @@ import zlib
 from typing import Dict, Tuple
 
 import numpy as np
+
+from .flo5 import read_flo5, write_flo5  # noqa: F401  (Spring's .flo5)
 
 FLO_MAGIC = np.float32(202021.25)
 

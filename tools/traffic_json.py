@@ -10,10 +10,11 @@ import collections, csv, json, re, sys
 FAMILY = [(r"corr_build|split_pack|pack_f16", "corr_build"), (r"corr_lookup", "corr_lookup"),
           (r"gma_flash|flash_pack_v", "gma_flash"), (r"flash_pack_qk", "flash_pack_qk"),
           (r"gemm_f16x3_mfma<[^>]*, 1, [13], (true|false)>", "gemm_attn"), (r"gemm_f", "gemm"),
-          (r"splitk_epilogue", "gemm"), (r"splitk_combine", "splitk_combine"), (r"dwconv_mfma", "dwconv15"),
+          (r"splitk_epilogue", "gemm"), (r"splitk_combine", "splitk_combine"), (r"dwconv_mfma_kernel<7", "dwconv7"), (r"dwconv_mfma", "dwconv15"),
           (r"dwconv_res_gelu_kernel<15>", "dwconv15"), (r"dwconv_res_gelu_kernel<7>", "dwconv7"),
           (r"softmax_rows", "softmax_rows"), (r"layernorm", "layernorm"), (r"temporal_attn", "temporal_attn"),
-          (r"upsample", "upsample_flow"), (r"flow_update", "flow_update"), (r"context_split", "context_split")]
+          (r"upsample", "upsample_flow"), (r"flow_update", "flow_update"), (r"context_split", "context_split"),
+          (r"pack_koct", "pack_koct")]
 
 def family(name):
     for pat, fam in FAMILY:
