@@ -132,59 +132,109 @@ __device__ __forceinline__ void pyramid_store(const BuildArgs& g, f32x16 (&acc)[
 #ifndef SF_CORR_NT
 #define SF_CORR_NT 2
 #endif
+#ifndef SF_CORR_PACK
+#define SF_CORR_PACK 1      // fp16 level-0 cells leave as packed pairs (A/B knob)
+#endif
     constexpr int kNt = SF_CORR_NT;
+    // Store-instruction diet (the epilogue is bound by store ISSUE, not bytes: 240 instructions per wave in the plain
+    // form).  (a) After the DPP pooling the 2 / 4 / 4 lanes of a pooling group hold the SAME level-1 / 2 / 3 value, so
+    // lane k of a group stores source row ri + k: one instruction covers 2 / 4 / 4 source rows (112 -> 44).  (b) fp16
+    // cells, even width: lanes 2j and 2j+1 exchange one value over DPP so that the even lane owns columns (2j, 2j+1) of
+    // source row ri and the odd lane the same two columns of row ri + 1: one 4-byte store per lane and register PAIR
+    // (128 -> 64), same 64-byte runs.  Values and roundings are unchanged.
+    const bool pack0 = (ES == 2) && (g.wl[0] & 1) == 0 && SF_CORR_PACK;
+    const int odd = l31 & 1;
+    const int vo0p = (!kGuard || x < g.wl[0]) ? ((4 * khalf + odd) * P0 + (l31 & ~1)) * ES : kDrop;
+    const int k1 = l31 & 1, k2 = l31 & 3, k3 = l31 & 7;       // which source row of a group this lane stores (levels 1..3)
+    const int vo1r = (vo1 == kDrop) ? kDrop : vo1 + k1 * P1 * ES;
+    const int vo2r = (vo2 == kDrop) ? kDrop : vo2 + k2 * P2 * ES;
+    const int vo3r = (vo3 == kDrop || k3 > 3) ? kDrop : vo3 + k3 * P3 * ES;
 #pragma unroll
     for (int rq = 0; rq < 4; ++rq) {                        // register group: source pixels 8*rq + 4*khalf + (0..3)
-        float v1[4][PR / 2], v2[4][PR / 4], v3[4];
+        // the level-2 / level-3 value (and row guard) THIS lane will store: picked up as the rows go by (a select per
+        // value; an indexed pick at the end would put the per-row arrays into scratch memory)
+        float sel2[PR / 4], sel3 = 0.f;
+        bool rok2 = false, rok3 = false;
+#pragma unroll
+        for (int t = 0; t < PR / 4; ++t) sel2[t] = 0.f;
         bool iok[4];
 #pragma unroll
-        for (int ri = 0; ri < 4; ++ri) {
-            const int r = rq * 4 + ri, rr = ri + 8 * rq;
-            iok[ri] = !kGuard || (i0 + rr + 4 * khalf < g.N);
-            float v0[PR];
+        for (int ri = 0; ri < 4; ++ri) iok[ri] = !kGuard || (i0 + ri + 8 * rq + 4 * khalf < g.N);
 #pragma unroll
-            for (int t = 0; t < PR; ++t) {
-                v0[t] = acc[t][r] * g.scale;
-                const bool ok = !kGuard || (iok[ri] && py0 + t < g.hl[0]);
-                store_cell<OutT, kNt>(v0[t], r0, ok ? vo0 : kDrop, (rr * P0 + t * g.wl[0]) * ES);
+        for (int j = 0; j < 2; ++j) {                       // source-row pair (2j, 2j + 1) of the group
+            const int ri = 2 * j;
+            float v0[2][PR], sel1[PR / 2];
+            bool rok1 = false;
+#pragma unroll
+            for (int t = 0; t < PR / 2; ++t) sel1[t] = 0.f;
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int t = 0; t < PR; ++t) v0[u][t] = acc[t][rq * 4 + ri + u] * g.scale;
+            if (pack0) {                                    // wave-uniform
+                if constexpr (ES == 2) {
+                    const bool rok = odd ? iok[ri + 1] : iok[ri];
+#pragma unroll
+                    for (int t = 0; t < PR; ++t) {
+                        const float a = v0[0][t], c = v0[1][t];
+                        const float y = dpp_xor1(odd ? a : c);      // even lane: a of lane + 1; odd lane: c of lane - 1
+                        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                        h2 hv;
+                        hv[0] = (_Float16)(odd ? y : a);
+                        hv[1] = (_Float16)(odd ? c : y);
+                        const bool ok = !kGuard || (rok && py0 + t < g.hl[0]);
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, hv), r0, ok ? vo0p : kDrop,
+                                                              ((ri + 8 * rq) * P0 + t * g.wl[0]) * ES, kNt);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int t = 0; t < PR; ++t) {
+                        const bool ok = !kGuard || (iok[ri + u] && py0 + t < g.hl[0]);
+                        store_cell<OutT, kNt>(v0[u][t], r0, ok ? vo0 : kDrop, ((ri + u + 8 * rq) * P0 + t * g.wl[0]) * ES);
+                    }
             }
 #pragma unroll
-            for (int t = 0; t < PR / 2; ++t) {
-                const float s = v0[2 * t] + v0[2 * t + 1];
-                v1[ri][t] = 0.25f * (s + dpp_xor1(s));
-            }
-#pragma unroll
-            for (int t = 0; t < PR / 4; ++t) {
-                const float s = v1[ri][2 * t] + v1[ri][2 * t + 1];
-                v2[ri][t] = 0.25f * (s + dpp_xor2(s));
-            }
-            const float s = v2[ri][0] + v2[ri][1];
-            v3[ri] = 0.25f * (s + dpp_shl4(s));
-        }
-        if ((l31 & 1) == 0) {
-#pragma unroll
-            for (int ri = 0; ri < 4; ++ri)
+            for (int u = 0; u < 2; ++u) {
+                float v1[PR / 2];
 #pragma unroll
                 for (int t = 0; t < PR / 2; ++t) {
-                    const bool ok = !kGuard || (iok[ri] && (py0 >> 1) + t < g.hl[1]);
-                    store_cell<OutT, 0>(v1[ri][t], r1, ok ? vo1 : kDrop, ((ri + 8 * rq) * P1 + t * g.wl[1]) * ES);
+                    const float s = v0[u][2 * t] + v0[u][2 * t + 1];
+                    v1[t] = 0.25f * (s + dpp_xor1(s));
+                    sel1[t] = (k1 == u) ? v1[t] : sel1[t];
                 }
-        }
-        if ((l31 & 3) == 0) {
-#pragma unroll
-            for (int ri = 0; ri < 4; ++ri)
+                rok1 = (k1 == u) ? iok[ri + u] : rok1;
+                float v2[PR / 4];
 #pragma unroll
                 for (int t = 0; t < PR / 4; ++t) {
-                    const bool ok = !kGuard || (iok[ri] && (py0 >> 2) + t < g.hl[2]);
-                    store_cell<OutT, 0>(v2[ri][t], r2, ok ? vo2 : kDrop, ((ri + 8 * rq) * P2 + t * g.wl[2]) * ES);
+                    const float s = v1[2 * t] + v1[2 * t + 1];
+                    v2[t] = 0.25f * (s + dpp_xor2(s));
+                    sel2[t] = (k2 == ri + u) ? v2[t] : sel2[t];
                 }
-        }
-        if ((l31 & 7) == 0) {
-#pragma unroll
-            for (int ri = 0; ri < 4; ++ri) {
-                const bool ok = !kGuard || (iok[ri] && (py0 >> 3) < g.hl[3]);
-                store_cell<OutT, 0>(v3[ri], r3, ok ? vo3 : kDrop, ((ri + 8 * rq) * P3) * ES);
+                const float s = v2[0] + v2[1];
+                const float v3 = 0.25f * (s + dpp_shl4(s));
+                sel3 = (k3 == ri + u) ? v3 : sel3;
+                rok2 = (k2 == ri + u) ? iok[ri + u] : rok2;
+                rok3 = (k3 == ri + u) ? iok[ri + u] : rok3;
             }
+            // level 1: lane parity k1 stores source row 2j + k1
+#pragma unroll
+            for (int t = 0; t < PR / 2; ++t) {
+                const bool ok = !kGuard || (rok1 && (py0 >> 1) + t < g.hl[1]);
+                store_cell<OutT, 0>(sel1[t], r1, ok ? vo1r : kDrop, ((ri + 8 * rq) * P1 + t * g.wl[1]) * ES);
+            }
+        }
+        // level 2 / 3: lane k of a group of four stores source row k
+#pragma unroll
+        for (int t = 0; t < PR / 4; ++t) {
+            const bool ok = !kGuard || (rok2 && (py0 >> 2) + t < g.hl[2]);
+            store_cell<OutT, 0>(sel2[t], r2, ok ? vo2r : kDrop, ((8 * rq) * P2 + t * g.wl[2]) * ES);
+        }
+        {
+            const bool ok = !kGuard || (rok3 && (py0 >> 3) < g.hl[3]);
+            store_cell<OutT, 0>(sel3, r3, ok ? vo3r : kDrop, ((8 * rq) * P3) * ES);
         }
     }
 }
@@ -240,6 +290,9 @@ __device__ __forceinline__ void pyramid_store_vec(const BuildArgs& g, f32x16 (&a
     const int co3 = (!kGuard || (x >> 3) < g.wl[3]) ? (xq >> 3) * ES : kDrop;
 #ifndef SF_CORR_NT
 #define SF_CORR_NT 2
+#endif
+#ifndef SF_CORR_PACK
+#define SF_CORR_PACK 1      // fp16 level-0 cells leave as packed pairs (A/B knob)
 #endif
     constexpr int kNt = SF_CORR_NT;
     float l2s[PR / 4][4];                                       // level-2 values (one per lane and source row)
