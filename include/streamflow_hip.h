@@ -235,7 +235,8 @@ int sf_temporal_attn(const float* qkv, float* out, int B, int TT, int C, int P, 
 
 /* ---- fp32 planes -> fp16 k-octet planes (no reference counterpart: an operand format of sf_gemm) -----------------
  * x [n_img][rows][P] fp32 (x_img_stride in floats) -> y [n_img][ceil(rows/8)][P][8] IEEE fp16 (y_img_stride in halves),
- * element (r, p) at ((r / 8) * P + p) * 8 + r % 8, rows past `rows` in the last octet zero: SF_LAYOUT_F16_KOCT, the
+ * element (r, p) at ((r / 8) * P + p) * 8 + r % 8; rows past `rows` in a last, partial octet are left untouched (they
+ * must be finite: zero-initialise the planes once): SF_LAYOUT_F16_KOCT, the
  * image sf_gemm moves to LDS by DMA.  Used once per clip for the static context features; tensors produced inside
  * the loop get their k-octet copy from the producing kernel (SfGemm.C16). */
 int sf_pack_koct(const float* x, int64_t x_img_stride, int n_img, int rows, int P, void* y, int64_t y_img_stride,

@@ -447,7 +447,8 @@ extern "C" int sf_coords_grid(float* out, int batch, int ht, int wd, void* strea
 
 namespace {
 // fp32 channel-major planes -> fp16 k-octet planes (SF_LAYOUT_F16_KOCT): one thread = one (octet, pixel) = eight
-// coalesced dword loads (one per row) and one 16-byte store.  Rows past `rows` inside the last octet become 0.
+// coalesced dword loads (one per row) and one 16-byte store.  Rows past `rows` inside a last, partial octet are NOT
+// written (they may belong to another producer; the caller zero-initialises the planes once).
 __global__ __launch_bounds__(256) void pack_koct_kernel(const float* __restrict__ x, int64_t x_img_stride, int rows, int P,
                                                          _Float16* __restrict__ y, int64_t y_img_stride) {
     const int p = blockIdx.x * 256 + threadIdx.x, o = blockIdx.y, img = blockIdx.z;
@@ -457,7 +458,14 @@ __global__ __launch_bounds__(256) void pack_koct_kernel(const float* __restrict_
     h8 v;
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = (o * 8 + i < rows) ? (_Float16)xp[(int64_t)i * P] : (_Float16)0.f;
-    *reinterpret_cast<h8*>(y + img * y_img_stride + ((int64_t)o * P + p) * 8) = v;
+    _Float16* yp = y + img * y_img_stride + ((int64_t)o * P + p) * 8;
+    if (o * 8 + 8 <= rows) {
+        *reinterpret_cast<h8*>(yp) = v;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (o * 8 + i < rows) yp[i] = v[i];
+    }
 }
 }  // namespace
 
