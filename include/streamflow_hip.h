@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SF_VERSION 103
+#define SF_VERSION 104
 
 enum {
     SF_OK = 0,
@@ -225,13 +225,18 @@ int sf_dwconv_res_gelu(const float* x, int64_t x_img_stride, const float* wgt, c
                        void* stream);
 
 /* ---- LayerNorm over channels of channel-major planes (update.py:462-463,481-483) --------------
- * x,y [n_img][C][P] (image strides given in floats), normalises each (img,p) column over C. */
+ * x,y [n_img][C][P] (image strides given in floats), normalises each (img,p) column over C.
+ * y_koct (optional, C = 128 / 256): the result as fp16 k-octet planes (SF_LAYOUT_F16_KOCT, image stride in halves) for
+ * a consumer that is an sf_gemm; y may then be NULL. */
 int sf_layernorm_cm(const float* x, int64_t x_img_stride, const float* gamma, const float* beta,
-                    float* y, int64_t y_img_stride, int n_img, int C, int P, float eps, void* stream);
+                    float* y, int64_t y_img_stride, void* y_koct, int64_t y_koct_img_stride, int n_img, int C, int P,
+                    float eps, void* stream);
 
 /* ---- per-pixel attention over the T-1 tokens (timm Attention core, update.py:466-474) ----------
- * qkv [B*TT][3*C][P] (rows [q|k|v]) -> out [B*TT][C][P]; softmax(q k^T / sqrt(C)) v over t. */
-int sf_temporal_attn(const float* qkv, float* out, int B, int TT, int C, int P, void* stream);
+ * qkv [B*TT][3*C][P] (rows [q|k|v]) -> out [B*TT][C][P]; softmax(q k^T / sqrt(C)) v over t.
+ * out_koct (optional, C % 32 == 0): the result as fp16 k-octet planes [B*TT][C/8][P][8] (SF_LAYOUT_F16_KOCT); out may
+ * then be NULL. */
+int sf_temporal_attn(const float* qkv, float* out, void* out_koct, int B, int TT, int C, int P, void* stream);
 
 /* ---- fp32 planes -> fp16 k-octet planes (no reference counterpart: an operand format of sf_gemm) -----------------
  * x [n_img][rows][P] fp32 (x_img_stride in floats) -> y [n_img][ceil(rows/8)][P][8] IEEE fp16 (y_img_stride in halves),

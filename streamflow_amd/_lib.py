@@ -60,8 +60,8 @@ SIGNATURES = {
     "sf_softmax_rows": (_i, [_vp, _i64, _i, _vp, _vp]),
     "sf_splitk_combine": (_i, [_vp, _i64, _i, _i64, _vp, _i64, _vp, _vp, _i64, _i, _i64, _vp]),
     "sf_dwconv_res_gelu": (_i, [_vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _i, _vp]),
-    "sf_layernorm_cm": (_i, [_vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _i, _f, _vp]),
-    "sf_temporal_attn": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "sf_layernorm_cm": (_i, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _i, _i, _i, _f, _vp]),
+    "sf_temporal_attn": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "sf_pack_koct": (_i, [_vp, _i64, _i, _i, _i, _vp, _i64, _vp]),
     "sf_context_split": (_i, [_vp, _vp, _i64, _vp, _i64, _i, _i, _i, _vp]),
     "sf_flow_update": (_i, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _vp]),
@@ -95,7 +95,7 @@ def load() -> C.CDLL:
             raise RuntimeError(f"{LIB_PATH} does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
-    if lib.sf_version() < 103:
+    if lib.sf_version() < 104:
         raise RuntimeError("libstreamflow_hip.so is too old; rebuild")
     _lib = lib
     return lib

@@ -196,8 +196,8 @@ __global__ __launch_bounds__(kBlock) void layernorm_cm_kernel(const float* x, in
 constexpr int kLnPix = 64;
 template <int CPT>
 __global__ __launch_bounds__(kBlock) void layernorm_cm_split_kernel(const float* x, int64_t xs, const float* gamma,
-                                                                     const float* beta, float* y, int64_t ys, int P,
-                                                                     float eps) {
+                                                                     const float* beta, float* y, int64_t ys,
+                                                                     _Float16* y16, int64_t y16s, int P, float eps) {
     __shared__ float red[4][kLnPix];
     constexpr int C = 4 * CPT;
     const int px = threadIdx.x & (kLnPix - 1), cg = threadIdx.x >> 6;
@@ -226,11 +226,26 @@ __global__ __launch_bounds__(kBlock) void layernorm_cm_split_kernel(const float*
     const float var = ((red[0][px] + red[1][px]) + (red[2][px] + red[3][px])) * (1.0f / (float)C);
     const float rstd = 1.0f / sqrtf(var + eps);
     if (!ok) return;
-    float* yp = y + (int64_t)blockIdx.y * ys + (int64_t)cg * CPT * P + p;
     const float* gp = gamma + cg * CPT;
     const float* bp = beta + cg * CPT;
 #pragma unroll
-    for (int c = 0; c < CPT; ++c) yp[(int64_t)c * P] = (v[c] - mean) * rstd * gp[c] + bp[c];
+    for (int c = 0; c < CPT; ++c) v[c] = (v[c] - mean) * rstd * gp[c] + bp[c];
+    if (y) {
+        float* yp = y + (int64_t)blockIdx.y * ys + (int64_t)cg * CPT * P + p;
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) yp[(int64_t)c * P] = v[c];
+    }
+    if (y16) {      // fp16 k-octet planes (SF_LAYOUT_F16_KOCT): a thread owns CPT / 8 whole octets of its pixel, 16 bytes each
+        typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+        _Float16* yp = y16 + (int64_t)blockIdx.y * y16s + ((int64_t)cg * (CPT / 8) * P + p) * 8;
+#pragma unroll
+        for (int o = 0; o < CPT / 8; ++o) {
+            h8 hv;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) hv[i] = (_Float16)v[o * 8 + i];
+            *reinterpret_cast<h8*>(yp + (int64_t)o * P * 8) = hv;
+        }
+    }
 }
 
 // ---- attention over the TT tokens of one pixel ---------------------------------------------------------
@@ -240,7 +255,7 @@ __global__ __launch_bounds__(kBlock) void layernorm_cm_split_kernel(const float*
 // All global accesses are 256-byte rows (64 lanes x consecutive pixels of one channel plane).
 constexpr int kTaPix = 64;
 template <int TT>
-__global__ __launch_bounds__(kBlock) void temporal_attn_kernel(const float* qkv, float* out, int C, int P) {
+__global__ __launch_bounds__(kBlock) void temporal_attn_kernel(const float* qkv, float* out, _Float16* out16, int C, int P) {
     __shared__ float red[4][TT * TT][kTaPix];
     const int px = threadIdx.x & (kTaPix - 1), cg = threadIdx.x >> 6;
     const int p = blockIdx.x * kTaPix + px;
@@ -294,6 +309,29 @@ __global__ __launch_bounds__(kBlock) void temporal_attn_kernel(const float* qkv,
         for (int u = 0; u < TT; ++u) s[t][u] *= inv;
     }
     if (!ok) return;
+    if (out16) {    // fp16 k-octet planes (SF_LAYOUT_F16_KOCT, C % 32 == 0): 8 channels of a token = one 16-byte store
+        typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+        _Float16* ob = out16 + (int64_t)b * TT * C * P + (int64_t)p * 8;
+        for (int c8 = c0; c8 < c0 + cpt; c8 += 8) {
+            h8 hv[TT];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float v[TT];
+#pragma unroll
+                for (int u = 0; u < TT; ++u) v[u] = base[u * img + (int64_t)(2 * C + c8 + i) * P];
+#pragma unroll
+                for (int t = 0; t < TT; ++t) {
+                    float o = 0.f;
+#pragma unroll
+                    for (int u = 0; u < TT; ++u) o = fmaf(s[t][u], v[u], o);
+                    hv[t][i] = (_Float16)o;
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < TT; ++t) *reinterpret_cast<h8*>(ob + (int64_t)t * C * P + (int64_t)(c8 / 8) * P * 8) = hv[t];
+        }
+        if (!out) return;
+    }
     float* obase = out + (int64_t)b * TT * C * P + p;
 #pragma unroll 4
     for (int c = c0; c < c0 + cpt; ++c) {
@@ -512,33 +550,41 @@ extern "C" int sf_softmax_rows(float* x, int64_t rows, int cols, void* out_f16, 
 }
 
 extern "C" int sf_layernorm_cm(const float* x, int64_t x_img_stride, const float* gamma, const float* beta, float* y,
-                               int64_t y_img_stride, int n_img, int C, int P, float eps, void* stream) {
-    SF_REQUIRE(x && gamma && beta && y && n_img > 0 && C > 0 && P > 0, "sf_layernorm_cm: bad args");
+                               int64_t y_img_stride, void* y_koct, int64_t y_koct_img_stride, int n_img, int C, int P,
+                               float eps, void* stream) {
+    SF_REQUIRE(x && gamma && beta && (y || y_koct) && n_img > 0 && C > 0 && P > 0, "sf_layernorm_cm: bad args");
+    SF_REQUIRE(!y_koct || ((C == 128 || C == 256) && (reinterpret_cast<uintptr_t>(y_koct) & 15) == 0 &&
+                           (y_koct_img_stride & 7) == 0),
+               "sf_layernorm_cm: the k-octet output needs C = 128 or 256, a 16-byte aligned y_koct, stride %% 8 == 0");
+    _Float16* y16 = static_cast<_Float16*>(y_koct);
     if (C == 128)
         hipLaunchKernelGGL(layernorm_cm_split_kernel<32>, dim3(sf::ceil_div(P, kLnPix), n_img), dim3(kBlock), 0,
-                           (hipStream_t)stream, x, x_img_stride, gamma, beta, y, y_img_stride, P, eps);
+                           (hipStream_t)stream, x, x_img_stride, gamma, beta, y, y_img_stride, y16, y_koct_img_stride, P, eps);
     else if (C == 256)                                       // second stage of the Twins_CSC encoder
         hipLaunchKernelGGL(layernorm_cm_split_kernel<64>, dim3(sf::ceil_div(P, kLnPix), n_img), dim3(kBlock), 0,
-                           (hipStream_t)stream, x, x_img_stride, gamma, beta, y, y_img_stride, P, eps);
+                           (hipStream_t)stream, x, x_img_stride, gamma, beta, y, y_img_stride, y16, y_koct_img_stride, P, eps);
     else
         hipLaunchKernelGGL(layernorm_cm_kernel, dim3(sf::ceil_div(P, kBlock), n_img), dim3(kBlock), 0,
                            (hipStream_t)stream, x, x_img_stride, gamma, beta, y, y_img_stride, C, P, eps);
     return sf::check_launch("sf_layernorm_cm");
 }
 
-extern "C" int sf_temporal_attn(const float* qkv, float* out, int B, int TT, int C, int P, void* stream) {
-    SF_REQUIRE(qkv && out && B > 0 && C > 0 && P > 0, "sf_temporal_attn: bad args");
+extern "C" int sf_temporal_attn(const float* qkv, float* out, void* out_koct, int B, int TT, int C, int P, void* stream) {
+    SF_REQUIRE(qkv && (out || out_koct) && B > 0 && C > 0 && P > 0, "sf_temporal_attn: bad args");
     SF_REQUIRE(C % 4 == 0, "sf_temporal_attn: C must be a multiple of 4");
+    SF_REQUIRE(!out_koct || (C % 32 == 0 && (reinterpret_cast<uintptr_t>(out_koct) & 15) == 0),
+               "sf_temporal_attn: the k-octet output needs C %% 32 == 0 and a 16-byte aligned out_koct");
+    _Float16* out16 = static_cast<_Float16*>(out_koct);
     dim3 grid(sf::ceil_div(P, kTaPix), B), block(kBlock);
     hipStream_t st = (hipStream_t)stream;
     switch (TT) {
-        case 1: hipLaunchKernelGGL(temporal_attn_kernel<1>, grid, block, 0, st, qkv, out, C, P); break;
-        case 2: hipLaunchKernelGGL(temporal_attn_kernel<2>, grid, block, 0, st, qkv, out, C, P); break;
-        case 3: hipLaunchKernelGGL(temporal_attn_kernel<3>, grid, block, 0, st, qkv, out, C, P); break;
-        case 4: hipLaunchKernelGGL(temporal_attn_kernel<4>, grid, block, 0, st, qkv, out, C, P); break;
-        case 5: hipLaunchKernelGGL(temporal_attn_kernel<5>, grid, block, 0, st, qkv, out, C, P); break;
-        case 6: hipLaunchKernelGGL(temporal_attn_kernel<6>, grid, block, 0, st, qkv, out, C, P); break;
-        case 7: hipLaunchKernelGGL(temporal_attn_kernel<7>, grid, block, 0, st, qkv, out, C, P); break;
+        case 1: hipLaunchKernelGGL(temporal_attn_kernel<1>, grid, block, 0, st, qkv, out, out16, C, P); break;
+        case 2: hipLaunchKernelGGL(temporal_attn_kernel<2>, grid, block, 0, st, qkv, out, out16, C, P); break;
+        case 3: hipLaunchKernelGGL(temporal_attn_kernel<3>, grid, block, 0, st, qkv, out, out16, C, P); break;
+        case 4: hipLaunchKernelGGL(temporal_attn_kernel<4>, grid, block, 0, st, qkv, out, out16, C, P); break;
+        case 5: hipLaunchKernelGGL(temporal_attn_kernel<5>, grid, block, 0, st, qkv, out, out16, C, P); break;
+        case 6: hipLaunchKernelGGL(temporal_attn_kernel<6>, grid, block, 0, st, qkv, out, out16, C, P); break;
+        case 7: hipLaunchKernelGGL(temporal_attn_kernel<7>, grid, block, 0, st, qkv, out, out16, C, P); break;
         default: return sf::fail(SF_ERR_UNSUPPORTED, "sf_temporal_attn: T-1=%d tokens not supported (1..7)", TT);
     }
     return sf::check_launch("sf_temporal_attn");

@@ -378,13 +378,17 @@ class HotPathEngine:
         # a10: temporal transformer block over the T-1 tokens of each pixel (update.py:481-484,770), side stream
         fork()
         with on_side():
-            ops.layernorm_cm(pl.mf, W.ln1_w, W.ln1_b, pl.ln128)
-            ops.gemm(W.qkv, pl.ln128, pl.qkv, EPI_NONE)
-            ops.temporal_attn(pl.qkv, pl.att128, Bc, Pn, HDIM)
-            ops.gemm(W.proj, pl.att128, pl.tx128, EPI_RES, R=pl.mf)
-            ops.layernorm_cm(pl.tx128, W.ln2_w, W.ln2_b, pl.ln128)
+            # LayerNorm / attention outputs have ONE reader, a GEMM: in the f16x2 mode they leave as its k-octet operand
+            ko = lambda buf, M: (lambda t: t if t.koct else buf)(_handover(buf, pl.n, HDIM, P, consumer_rows=M))
+            ln, att = ko(pl.ln128, W.qkv.M), ko(pl.att128, W.proj.M)
+            ops.layernorm_cm(pl.mf, W.ln1_w, W.ln1_b, ln)
+            ops.gemm(W.qkv, ln, pl.qkv, EPI_NONE)
+            ops.temporal_attn(pl.qkv, att, Bc, Pn, HDIM)
+            ops.gemm(W.proj, att, pl.tx128, EPI_RES, R=pl.mf)
+            ln = ko(pl.ln128, W.fc1.M)
+            ops.layernorm_cm(pl.tx128, W.ln2_w, W.ln2_b, ln)
             h256 = _handover(pl.h256, pl.n, 256, P, consumer_rows=HDIM)            # fc1 -> fc2 only
-            ops.gemm(W.fc1, pl.ln128, h256, EPI_GELU)
+            ops.gemm(W.fc1, ln, h256, EPI_GELU)
             ops.gemm(W.fc2, h256, pl.mft, EPI_RES, R=pl.tx128)
         # a7: global aggregation  mfg = mf + gamma * attn @ to_v(mf)   (gma.py:91-104), main stream
         ops.gemm(W.to_v, pl.mf, pl.v128, EPI_NONE)

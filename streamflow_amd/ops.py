@@ -371,18 +371,24 @@ def dwconv_res_gelu(X: Planes, wgt: torch.Tensor, bias: torch.Tensor, Y: Planes,
 
 @on_tensor_device
 def layernorm_cm(X: Planes, gamma: torch.Tensor, beta: torch.Tensor, Y: Planes, eps: float = 1e-5) -> None:
-    _launch("layernorm", 0, 8.0 * X.n_img * X.rows * X.P,
+    """Y fp32 planes, or fp16 k-octet planes (Planes.koct: the hand-over to a GEMM on the DMA-fed tile)."""
+    assert not X.f16 and (not Y.f16 or Y.koct)
+    ko = Y.f16
+    _launch("layernorm", 0, (6.0 if ko else 8.0) * X.n_img * X.rows * X.P,
             lambda: _lib.check(_lib.load().sf_layernorm_cm(X.ptr, X.img_stride, gamma.data_ptr(), beta.data_ptr(),
-                                                           Y.ptr, Y.img_stride, X.n_img, X.rows, X.P, eps,
-                                                           _lib.stream()), "sf_layernorm_cm"))
+                                                           None if ko else Y.ptr, 0 if ko else Y.img_stride,
+                                                           Y.ptr if ko else None, Y.img_stride if ko else 0,
+                                                           X.n_img, X.rows, X.P, eps, _lib.stream()), "sf_layernorm_cm"))
 
 
 @on_tensor_device
 def temporal_attn(QKV: Planes, OUT: Planes, B: int, TT: int, C_: int) -> None:
     assert QKV.img_stride == 3 * C_ * QKV.P and OUT.img_stride == C_ * OUT.P and QKV.n_img == B * TT
-    _launch("temporal_attn", 0, 16.0 * QKV.n_img * C_ * QKV.P,
-            lambda: _lib.check(_lib.load().sf_temporal_attn(QKV.ptr, OUT.ptr, B, TT, C_, QKV.P, _lib.stream()),
-                               "sf_temporal_attn"))
+    assert not OUT.f16 or OUT.koct
+    ko = OUT.f16                                          # fp16 k-octet planes: the hand-over to the proj GEMM
+    _launch("temporal_attn", 0, (14.0 if ko else 16.0) * QKV.n_img * C_ * QKV.P,
+            lambda: _lib.check(_lib.load().sf_temporal_attn(QKV.ptr, None if ko else OUT.ptr, OUT.ptr if ko else None,
+                                                            B, TT, C_, QKV.P, _lib.stream()), "sf_temporal_attn"))
 
 
 @on_tensor_device

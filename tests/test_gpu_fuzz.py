@@ -339,3 +339,32 @@ def test_flow_update_koct_rows(dev):
     assert torch.equal(got[:, 126:128], flow.half().float())
     assert torch.equal(mf[:, 126:128], flow)
     assert bool((got[:, :126] == 3.0).all())
+
+
+@pytest.mark.parametrize("P", [7040, 1000, 323])
+def test_layernorm_and_temporal_attn_koct_outputs(dev, P):
+    """sf_layernorm_cm / sf_temporal_attn with the fp16 k-octet output (the hand-over to the qkv / fc1 / proj GEMMs in the
+    f16x2 mode): equal to the rounded fp32 output, fp32 output untouched when not requested."""
+    from streamflow_amd import ops
+    from streamflow_amd.ops import Planes
+    g = torch.Generator().manual_seed(P)
+    n, C, TT = 6, 128, 3
+    x = (torch.randn(n, C, P, generator=g) * 2 + 0.3).to(dev)
+    gam, bet = torch.randn(C, generator=g).to(dev), torch.randn(C, generator=g).to(dev)
+    y = torch.empty(n, C, P, device=dev)
+    ops.layernorm_cm(Planes.of(x), gam, bet, Planes.of(y))
+    sh = ops.new_shadow(Planes.of(y), dev)
+    ops.layernorm_cm(Planes.of(x), gam, bet, sh)
+    torch.cuda.synchronize()
+    ref = torch.nn.functional.layer_norm(x.double().permute(0, 2, 1), (C,), gam.double(), bet.double()).permute(0, 2, 1)
+    assert (y.double() - ref).abs().max().item() < 2e-5
+    # (the two instantiations may contract the final fma differently: equal up to one fp16 rounding of the fp32 result)
+    close = lambda a, b: bool(((a - b).abs() <= 2.0 ** -11 * b.abs() * 1.01 + 1e-6).all())
+    assert close(sh.tensor().float(), y)
+    qkv = torch.randn(n, 3 * C, P, generator=g).to(dev)
+    out = torch.empty(n, C, P, device=dev)
+    ops.temporal_attn(Planes.of(qkv), Planes.of(out), n // TT, TT, C)
+    sh2 = ops.new_shadow(Planes.of(out), dev)
+    ops.temporal_attn(Planes.of(qkv), sh2, n // TT, TT, C)
+    torch.cuda.synchronize()
+    assert close(sh2.tensor().float(), out)
