@@ -178,8 +178,11 @@ struct DwmArgs {
 // kProd = 3: x = hi + lo on both sides (f16x3).  kProd = 2 (the GEMMs' f16x2 arithmetic): the ACTIVATION enters the
 // products as its hi half only (weights stay hi + lo) -- two MFMAs and one fragment read per kernel row and tile instead
 // of three and two; both planes are still staged, the residual stays exact.
+#ifndef SF_DW_MINWG
+#define SF_DW_MINWG 2
+#endif
 template <int KS, bool kOutF16, int kProd>
-__global__ __launch_bounds__(256, 2) void dwconv_mfma_kernel(const DwmArgs g) {
+__global__ __launch_bounds__(256, (KS == 15 && kProd == 2) ? SF_DW_MINWG : 2) void dwconv_mfma_kernel(const DwmArgs g) {
     using namespace sf_split;
     constexpr int R = KS / 2;
     constexpr int WZ = 64;                                      // zero-padded weight row: w[ky][j - 24]
