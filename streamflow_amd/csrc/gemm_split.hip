@@ -143,8 +143,10 @@ __global__ __launch_bounds__(kThreads, (TM * TN >= 8) ? 2 : SF_GEMM_WAVES) void 
     const int b_plane = (int)(args.b_bytes);
     const __amdgpu_buffer_rsrc_t rbd = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char*>(reinterpret_cast<const char*>(g.B)) + (int64_t)z * g.strideB * 2, 0, b_plane, 0x00020000);
+    static_assert(!kDmaB || BN == 128 || BN == 256, "KOCT B: 128 or 256 pixel columns per workgroup");
+    constexpr int kBPieces = BN / 64;                      // 4 KB DMA pieces per stage: piece j = slots j*256 .. j*256+255
     const int bpx = min(n0 + (tid & (BN - 1)), g.N - 1);
-    const int vob0 = ((tid / BN) * (int)g.ldb + bpx) * 16, vob1 = vob0 + (kThreads / BN) * (int)g.ldb * 16;
+    const int vob0 = ((tid / BN) * (int)g.ldb + bpx) * 16, vobs = (kThreads / BN) * (int)g.ldb * 16;
     // b_group > 0 ('(B T) C -> B (T C)' views): rows come in groups of b_group (a multiple of 32, so a k-tile never
     // straddles two), group gi starts b_group_stride halves after group gi - 1
     const int b_goct = g.b_group > 0 ? g.b_group / 8 : 0;
@@ -152,8 +154,9 @@ __global__ __launch_bounds__(kThreads, (TM * TN >= 8) ? 2 : SF_GEMM_WAVES) void 
         char* dst = reinterpret_cast<char*>(smem + kAHalfs) + buf * kBStage * 2 + wave_u * 1024;
         const int o = kt * (BK / 8), gi = b_goct ? o / b_goct : 0;
         const int so = (o - gi * b_goct) * (int)g.ldb * 16 + gi * (int)(g.b_group_stride * 2);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rbd, (lds_ptr)(dst), 16, vob0, so, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rbd, (lds_ptr)(dst + 4096), 16, vob1, so, 0, 0);
+#pragma unroll
+        for (int j = 0; j < kBPieces; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rbd, (lds_ptr)(dst + j * 4096), 16, vob0 + j * vobs, so, 0, 0);
     };
 
     // the A piece is requested BEFORE the B loads of the same k-tile: vmcnt retires in order, so the wait that the B
@@ -358,6 +361,9 @@ int pick_tile(const SplitArgs& a, hipStream_t st) {
     }
     // (a wave-specialised producer/consumer variant of the 128x128 kernel was faster for K >= 768 early in the round;
     // after the cheaper split and epilogue it measured 2-25 % slower at every batch size and was removed)
+    // both operands by LDS-DMA (k-octet B): a 128 x 256 tile halves the weight bytes a CU pulls through its L1 per MAC
+    static const int wide = getenv("SF_GEMM_WIDE") ? atoi(getenv("SF_GEMM_WIDE")) : 0;
+    if (wide && g.b_layout == SF_LAYOUT_F16_KOCT && padded(128) * 4 <= M * 5 && M >= wide) return launch_cfg<2, 2, 2, 4, PM>(a, st);
     if (padded(128) * 4 <= M * 5) return launch_cfg<2, 2, 2, 2, PM>(a, st);
     if (padded(64) * 4 <= M * 5 || M > 32) return launch_cfg<1, 4, 2, 1, PM>(a, st);
     return launch_cfg<1, 4, 1, 1, PM>(a, st);
