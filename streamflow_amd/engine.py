@@ -542,4 +542,5 @@ class HotPathEngine:
             pl.coords1.tensor().copy_(state[0])
             pl.flow.tensor().copy_(state[1])
             pl.mf.tensor().copy_(state[2])
+            ops.refresh_shadow(pl.mf.slice(HDIM - 8, HDIM))       # ... and the flow rows of mf's k-octet copy
         pl.graph.replay()

@@ -368,3 +368,28 @@ def test_layernorm_and_temporal_attn_koct_outputs(dev, P):
     ops.temporal_attn(Planes.of(qkv), sh2, n // TT, TT, C)
     torch.cuda.synchronize()
     assert close(sh2.tensor().float(), out)
+
+
+@pytest.mark.parametrize("preset", ["config2_fp16", "fp32_class"])
+def test_graph_capture_call_equals_replays_and_eager(dev, preset):
+    """The call that captures the HIP graph (warm-up iteration outside capture, loop state restored, first replay) must
+    return exactly what later replays and the eager engine return -- with a warm-start flow_init, so that the restored
+    loop state (including the flow rows of the k-octet copy of the motion features) matters."""
+    from streamflow_amd import presets, synthetic as syn
+    from streamflow_amd.engine import HotPathEngine
+    B, T, h, w, iters = 2, 4, 24, 40, 4
+    P = syn.make_params(11, T)
+    fmaps, cnets = syn.make_features(11, B, T, h, w)
+    g = torch.Generator().manual_seed(1)
+    finit = [(torch.randn(B, 2, h, w, generator=g) * 2).to(dev) for _ in range(T - 1)]
+    kw = presets.engine_kwargs(preset)
+    eng_g = HotPathEngine(P, device=dev, T=T, use_graph=True, **kw)
+    eng_e = HotPathEngine(P, device=dev, T=T, use_graph=False, **kw)
+    fd, cd = fmaps.to(dev), cnets.to(dev)
+    first = [u.clone() for u in eng_g.forward(fd, cd, iters=iters, flow_init=finit)[0]]
+    second = [u.clone() for u in eng_g.forward(fd, cd, iters=iters, flow_init=finit)[0]]
+    eager = eng_e.forward(fd, cd, iters=iters, flow_init=finit)[0]
+    torch.cuda.synchronize()
+    for a, b2, c in zip(first, second, eager):
+        assert torch.equal(a, b2)
+        assert torch.equal(a, c)
