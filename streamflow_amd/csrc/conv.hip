@@ -1,8 +1,9 @@
 // Depthwise KxK convolution fused with bias, residual and exact GELU:
 //     y = gelu(x + dwconv_KxK(x) + b)            (reference core/update.py:33-34, kernels 15 and 7)
 //
-// Two kernels.  (1) fp32 stencil on the VALU, below (exact fp32 mode, and K = 7 in every mode).  (2) For K = 15 in the
-// split precisions, banded-Toeplitz GEMMs on the matrix cores: dwconv_mfma_kernel further down.
+// Two kernels.  (1) fp32 stencil on the VALU, below (exact fp32 mode, and K = 7 in the f16x3 mode).  (2) Banded-Toeplitz
+// GEMMs on the matrix cores, dwconv_mfma_kernel further down: K = 15 in every split precision (three products in f16x3,
+// two in f16x2 / f16), K = 7 in the two-product modes.  Either kernel can write y as fp16 rows (y_f16).
 //
 // (1) VALU-bound stencil (225 or 49 FMAs per output).  One workgroup owns one (image, channel) plane
 // strip: the strip plus its K/2 halo is staged once in LDS (zero padded, so the inner loop has no
@@ -374,7 +375,7 @@ extern "C" int sf_dwconv_res_gelu(const float* x, int64_t x_img_stride, const fl
     SF_REQUIRE(ksize == 15 || ksize == 7, "sf_dwconv_res_gelu: kernel size %d not built (7, 15)", ksize);
     SF_REQUIRE(precision >= SF_PRECISION_FP32 && precision <= SF_PRECISION_F16, "sf_dwconv_res_gelu: bad precision");
     SF_REQUIRE((int64_t)h * w < (1 << 30), "sf_dwconv_res_gelu: plane too large");
-    // K = 7: only 7/32 of the Toeplitz entries are non-zero and the stencil is the faster kernel (65 vs 87 us at
+    // K = 7, three products: only 7/32 of the Toeplitz entries are non-zero and the stencil is the faster kernel (65 vs 87 us at
     // 128 channels x 24 images); K = 15 runs 1.45x faster on the matrix cores
     static const bool force3 = getenv("SF_DW_PRODUCTS") && atoi(getenv("SF_DW_PRODUCTS")) == 3;   // A/B knob
     const bool two = precision != SF_PRECISION_FP32 && precision != SF_PRECISION_F16X3 && !force3;

@@ -21,6 +21,11 @@
 //    address arithmetic in the loop.  Columns n >= N (rows m >= M) of a tile may load anything: an output
 //    element only depends on its own row of A and column of B, and those outputs are never stored.  Rows
 //    k >= K are forced to zero (clamped row + select on a wave-uniform or per-lane compare).
+//  * template parameter PM = products per element: 3 (f16x3, above), 2 (f16x2: the activation is ONE fp16 -- rounded while
+//    staged, or already stored as fp16 rows SF_LAYOUT_F16_K_MAJOR / k-octets SF_LAYOUT_F16_KOCT by its producer; the
+//    k-octet form goes HBM/L2 -> LDS by DMA like the weights, so the loop has no VALU staging at all), 1 (f16);
+//  * c_f16: the epilogue can hand the result to the next GEMM as fp16 rows (1), k-octets (2) or fp32 planes plus a k-octet
+//    copy (3) -- see include/streamflow_hip.h and DESIGN.md section 5.
 #include "sf_common.h"
 #include "gemm_epilogue.h"
 #include "split_operand.h"
