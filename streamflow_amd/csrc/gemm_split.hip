@@ -359,16 +359,11 @@ int pick_tile(const SplitArgs& a, hipStream_t st) {
     if (const char* e = getenv("SF_GEMM_BM")) {          // experiment knob
         const int bm = atoi(e);
         if (bm == 128) return launch_cfg<2, 2, 2, 2, PM>(a, st);
-        if (bm == 256) return launch_cfg<2, 2, 4, 2, PM>(a, st);
-        if (bm == 257) return launch_cfg<2, 2, 2, 4, PM>(a, st);
         if (bm == 64) return launch_cfg<1, 4, 2, 1, PM>(a, st);
         if (bm == 32) return launch_cfg<1, 4, 1, 1, PM>(a, st);
     }
     // (a wave-specialised producer/consumer variant of the 128x128 kernel was faster for K >= 768 early in the round;
     // after the cheaper split and epilogue it measured 2-25 % slower at every batch size and was removed)
-    // both operands by LDS-DMA (k-octet B): a 128 x 256 tile halves the weight bytes a CU pulls through its L1 per MAC
-    static const int wide = getenv("SF_GEMM_WIDE") ? atoi(getenv("SF_GEMM_WIDE")) : 0;
-    if (wide && g.b_layout == SF_LAYOUT_F16_KOCT && padded(128) * 4 <= M * 5 && M >= wide) return launch_cfg<2, 2, 2, 4, PM>(a, st);
     if (padded(128) * 4 <= M * 5) return launch_cfg<2, 2, 2, 2, PM>(a, st);
     if (padded(64) * 4 <= M * 5 || M > 32) return launch_cfg<1, 4, 2, 1, PM>(a, st);
     return launch_cfg<1, 4, 1, 1, PM>(a, st);
