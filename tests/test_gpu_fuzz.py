@@ -393,3 +393,24 @@ def test_graph_capture_call_equals_replays_and_eager(dev, preset):
     for a, b2, c in zip(first, second, eager):
         assert torch.equal(a, b2)
         assert torch.equal(a, c)
+
+
+@pytest.mark.parametrize("case", [(2, 3, 16, 24, True), (1, 2, 17, 21, False), (3, 5, 16, 20, True), (1, 4, 17, 19, False),
+                                  (2, 2, 24, 36, True)])
+def test_config2_preset_shapes_vs_oracle(dev, case):
+    """The bench preset (f16x2 + fp16 volumes + fused GMA + fp16 / k-octet operand hand-over) over clip lengths T = 2..5,
+    batches, and grids whose pixel count is or is not a multiple of 4 (the fp16 hand-over formats need P % 4 == 0 and are
+    switched off otherwise), graph and eager: every flow against the CPU oracle after 4 iterations."""
+    from oracle import streamflow_oracle as orc
+    from streamflow_amd import presets, synthetic as syn
+    from streamflow_amd.engine import HotPathEngine
+    B, T, h, w, graph = case
+    P = syn.make_params(20 + T, T)
+    fmaps, cnets = syn.make_features(30 + h, B, T, h, w)
+    ups_o, _ = orc.hotpath_forward(fmaps, cnets, P, 4)
+    eng = HotPathEngine(P, device=dev, T=T, use_graph=graph, **presets.engine_kwargs("config2_fp16"))
+    for _ in range(2):
+        ups, _ = eng.forward(fmaps.to(dev), cnets.to(dev), iters=4)
+    assert eng.plan(B, h, w, 256).shadows == ((h * w) % 4 == 0)
+    e = max(orc.epe(u.cpu(), o) for u, o in zip(ups, ups_o))
+    assert e <= 1e-3, (case, e)
