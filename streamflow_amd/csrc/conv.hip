@@ -179,6 +179,9 @@ struct DwmArgs {
 // kProd = 3: x = hi + lo on both sides (f16x3).  kProd = 2 (the GEMMs' f16x2 arithmetic): the ACTIVATION enters the
 // products as its hi half only (weights stay hi + lo) -- two MFMAs and one fragment read per kernel row and tile instead
 // of three and two; both planes are still staged, the residual stays exact.
+#ifndef SF_GEMM_FAST_GELU
+#define SF_GEMM_FAST_GELU 1
+#endif
 #ifndef SF_DW_MINWG
 #define SF_DW_MINWG 2
 #endif
@@ -336,7 +339,7 @@ __global__ __launch_bounds__(256, (KS == 15 && kProd == 2) ? SF_DW_MINWG : 2) vo
                                          (float)*reinterpret_cast<const _Float16*>(lo + xo);
                         t[u] = xv + (acc[j][r + u] + bv);
                     }
-                    const sf::f32x2 a = sf::gelu_erf2(t);
+                    const sf::f32x2 a = sf::gelu2<(kProd == 2) && kOutF16 && SF_GEMM_FAST_GELU>(t);   // polynomial GELU where the result leaves as fp16
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
                         const bool ok = (gx0 + j * 16 < g.w) && (gy0 + r + u < g.h);

@@ -59,13 +59,14 @@ __device__ __forceinline__ float epi_apply(float v, float r, float dww, float dw
 }
 
 // the same for two values at once (packed fp32 GELU)
-template <int EPI>
+// kFast: the polynomial GELU of the two-product arithmetic modes (sf_common.h gelu_poly2)
+template <int EPI, bool kFast = false>
 __device__ __forceinline__ f32x2 epi_apply2(f32x2 v, f32x2 r, float dww, float dwb, float gam) {
-    if (EPI == SF_EPI_GELU) return gelu_erf2(v);
-    if (EPI == SF_EPI_RES_GELU) return gelu_erf2(r + v);
+    if (EPI == SF_EPI_GELU) return gelu2<kFast>(v);
+    if (EPI == SF_EPI_RES_GELU) return gelu2<kFast>(r + v);
     if (EPI == SF_EPI_RES_GELU_DW1) {
-        const f32x2 t = gelu_erf2(r + v);
-        return gelu_erf2(t + (splat2(dww) * t + splat2(dwb)));
+        const f32x2 t = gelu2<kFast>(r + v);
+        return gelu2<kFast>(t + (splat2(dww) * t + splat2(dwb)));
     }
     f32x2 o;
     o[0] = epi_apply<EPI>(v[0], r[0], dww, dwb, gam);
@@ -171,7 +172,7 @@ constexpr int kEpiScratchFloats = 32 * kEpiStride;          // per wave
 
 typedef unsigned int epi_u32x4 __attribute__((ext_vector_type(4)));
 
-template <int EPI, int WM, int WN, int TM, int TN>
+template <int EPI, int WM, int WN, int TM, int TN, bool kFast>
 __device__ __forceinline__ void gemm_epilogue_vec_impl(const SfGemm& g, f32x16 (&acc)[TM][TN], int m0, int n0, int z,
                                                        int wm, int wn, int lane, float* scratch) {
     constexpr bool kNeedsR = (EPI == SF_EPI_RES || EPI == SF_EPI_RES_GELU || EPI == SF_EPI_RES_GELU_DW1 ||
@@ -248,7 +249,7 @@ __device__ __forceinline__ void gemm_epilogue_vec_impl(const SfGemm& g, f32x16 (
                     const unsigned ru0 = kNeedsR ? rv[j][q][e] : 0u, ru1 = kNeedsR ? rv[j][q][e + 1] : 0u;
                     r[0] = __builtin_bit_cast(float, ru0);
                     r[1] = __builtin_bit_cast(float, ru1);
-                    const f32x2 res = epi_apply2<EPI>(v, r, dww[q], dwb[q], gam);
+                    const f32x2 res = epi_apply2<EPI, kFast>(v, r, dww[q], dwb[q], gam);
                     const float r0 = res[0], r1 = res[1];
                     o[e] = __builtin_bit_cast(unsigned, r0);
                     o[e + 1] = __builtin_bit_cast(unsigned, r1);
@@ -313,7 +314,7 @@ __device__ __forceinline__ void gemm_epilogue_vec_impl(const SfGemm& g, f32x16 (
 // 8 channels of one k-octet (lane = (octet half, pixel)): eight ds_read_b32, the epilogue arithmetic on packed pairs,
 // one 16-byte store; 32 consecutive lanes = 32 consecutive pixels = 512 contiguous bytes.  Rows past M inside the last
 // octet are written too (finite values from clamped parameters; the consumer's weights are zero there).
-template <int EPI, int WM, int WN, int TM, int TN>
+template <int EPI, int WM, int WN, int TM, int TN, bool kFast>
 __device__ __forceinline__ void gemm_epilogue_koct_impl(const SfGemm& g, f32x16 (&acc)[TM][TN], int m0, int n0, int z,
                                                         int wm, int wn, int lane, float* scratch) {
     constexpr bool kNeedsR = (EPI == SF_EPI_RES || EPI == SF_EPI_RES_GELU || EPI == SF_EPI_RES_GELU_DW1 ||
@@ -364,7 +365,7 @@ __device__ __forceinline__ void gemm_epilogue_koct_impl(const SfGemm& g, f32x16 
                         }
                     }
                     const int mc0 = (mo + e < g.M) ? mo + e : g.M - 1;
-                    const f32x2 res = epi_apply2<EPI>(v, r, EPI == SF_EPI_RES_GELU_DW1 ? g.dw_w[mc0] : 0.f,
+                    const f32x2 res = epi_apply2<EPI, kFast>(v, r, EPI == SF_EPI_RES_GELU_DW1 ? g.dw_w[mc0] : 0.f,
                                                       EPI == SF_EPI_RES_GELU_DW1 ? g.dw_b[mc0] : 0.f, gam);
                     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
                     h2 hv;
@@ -379,28 +380,28 @@ __device__ __forceinline__ void gemm_epilogue_koct_impl(const SfGemm& g, f32x16 
     }
 }
 
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, bool kFast = false>
 __device__ __forceinline__ void gemm_epilogue_koct(const SfGemm& g, f32x16 (&acc)[TM][TN], int m0, int n0, int z, int wm,
                                                    int wn, int lane, float* scratch) {
     switch (g.epilogue) {     // wave-uniform; the hand-over tensors are produced with these three epilogues only
-        case SF_EPI_GELU: gemm_epilogue_koct_impl<SF_EPI_GELU, WM, WN, TM, TN>(g, acc, m0, n0, z, wm, wn, lane, scratch); break;
-        case SF_EPI_RES_GELU: gemm_epilogue_koct_impl<SF_EPI_RES_GELU, WM, WN, TM, TN>(g, acc, m0, n0, z, wm, wn, lane, scratch); break;
-        default: gemm_epilogue_koct_impl<SF_EPI_NONE, WM, WN, TM, TN>(g, acc, m0, n0, z, wm, wn, lane, scratch); break;
+        case SF_EPI_GELU: gemm_epilogue_koct_impl<SF_EPI_GELU, WM, WN, TM, TN, kFast>(g, acc, m0, n0, z, wm, wn, lane, scratch); break;
+        case SF_EPI_RES_GELU: gemm_epilogue_koct_impl<SF_EPI_RES_GELU, WM, WN, TM, TN, kFast>(g, acc, m0, n0, z, wm, wn, lane, scratch); break;
+        default: gemm_epilogue_koct_impl<SF_EPI_NONE, WM, WN, TM, TN, kFast>(g, acc, m0, n0, z, wm, wn, lane, scratch); break;
     }
 }
 
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, bool kFast = false>
 __device__ __forceinline__ void gemm_epilogue_vec(const SfGemm& g, f32x16 (&acc)[TM][TN], int m0, int n0, int z, int wm,
                                                   int wn, int lane, float* scratch) {
     switch (g.epilogue) {     // wave-uniform
-        case SF_EPI_GELU: gemm_epilogue_vec_impl<SF_EPI_GELU, WM, WN, TM, TN>(g, acc, m0, n0, z, wm, wn, lane, scratch); break;
-        case SF_EPI_RELU: gemm_epilogue_vec_impl<SF_EPI_RELU, WM, WN, TM, TN>(g, acc, m0, n0, z, wm, wn, lane, scratch); break;
-        case SF_EPI_RES: gemm_epilogue_vec_impl<SF_EPI_RES, WM, WN, TM, TN>(g, acc, m0, n0, z, wm, wn, lane, scratch); break;
-        case SF_EPI_RES_GELU: gemm_epilogue_vec_impl<SF_EPI_RES_GELU, WM, WN, TM, TN>(g, acc, m0, n0, z, wm, wn, lane, scratch); break;
+        case SF_EPI_GELU: gemm_epilogue_vec_impl<SF_EPI_GELU, WM, WN, TM, TN, kFast>(g, acc, m0, n0, z, wm, wn, lane, scratch); break;
+        case SF_EPI_RELU: gemm_epilogue_vec_impl<SF_EPI_RELU, WM, WN, TM, TN, kFast>(g, acc, m0, n0, z, wm, wn, lane, scratch); break;
+        case SF_EPI_RES: gemm_epilogue_vec_impl<SF_EPI_RES, WM, WN, TM, TN, kFast>(g, acc, m0, n0, z, wm, wn, lane, scratch); break;
+        case SF_EPI_RES_GELU: gemm_epilogue_vec_impl<SF_EPI_RES_GELU, WM, WN, TM, TN, kFast>(g, acc, m0, n0, z, wm, wn, lane, scratch); break;
         case SF_EPI_RES_GELU_DW1:
-            gemm_epilogue_vec_impl<SF_EPI_RES_GELU_DW1, WM, WN, TM, TN>(g, acc, m0, n0, z, wm, wn, lane, scratch); break;
-        case SF_EPI_AXPY: gemm_epilogue_vec_impl<SF_EPI_AXPY, WM, WN, TM, TN>(g, acc, m0, n0, z, wm, wn, lane, scratch); break;
-        default: gemm_epilogue_vec_impl<SF_EPI_NONE, WM, WN, TM, TN>(g, acc, m0, n0, z, wm, wn, lane, scratch); break;
+            gemm_epilogue_vec_impl<SF_EPI_RES_GELU_DW1, WM, WN, TM, TN, kFast>(g, acc, m0, n0, z, wm, wn, lane, scratch); break;
+        case SF_EPI_AXPY: gemm_epilogue_vec_impl<SF_EPI_AXPY, WM, WN, TM, TN, kFast>(g, acc, m0, n0, z, wm, wn, lane, scratch); break;
+        default: gemm_epilogue_vec_impl<SF_EPI_NONE, WM, WN, TM, TN, kFast>(g, acc, m0, n0, z, wm, wn, lane, scratch); break;
     }
 }
 

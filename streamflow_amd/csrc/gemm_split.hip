@@ -47,6 +47,9 @@ struct SplitArgs {
 #endif
 };
 
+#ifndef SF_GEMM_FAST_GELU
+#define SF_GEMM_FAST_GELU 1      // A/B knob: 0 = the rational erf GELU in every mode
+#endif
 #ifndef SF_GEMM_FRAG_PREFETCH
 #define SF_GEMM_FRAG_PREFETCH 0
 #endif
@@ -285,11 +288,14 @@ __global__ __launch_bounds__(kThreads, (TM * TN >= 8) ? 2 : SF_GEMM_WAVES) void 
 #ifdef SF_GEMM_TIMERS
     const long long ts2 = __builtin_readcyclecounter();
 #endif
+    // the two-product modes evaluate GELU as a polynomial (sf_common.h) WHERE THE RESULT LEAVES AS fp16 (the k-octet
+    // epilogue): a tenth of the rounding it receives there; results kept in fp32 use the erf-rational form in every mode
+    constexpr bool kFastGelu = (PM <= 2) && SF_GEMM_FAST_GELU;
     SfGemm gs = g;
     if (ksp > 1) gs.C = g.C + (int64_t)split * g.split_stride;   // partial product of this K slice: its own slab
     if (gs.c_f16 == 2) {
         __syncthreads();                                         // the main-loop LDS becomes the transpose scratch
-        sf::gemm_epilogue_koct<WM, WN, TM, TN>(gs, acc, m0, n0, z, wm, wn, lane,
+        sf::gemm_epilogue_koct<WM, WN, TM, TN, kFastGelu>(gs, acc, m0, n0, z, wm, wn, lane,
                                                reinterpret_cast<float*>(smem) + wave * sf::kEpiScratchFloats);
     } else if (sf::epilogue_vec_ok(gs, z)) {
         __syncthreads();                                         // the main-loop LDS becomes the transpose scratch

@@ -75,6 +75,35 @@ __device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
     return splat2(0.5f) * x * (splat2(1.0f) + erf_fast2(x * splat2(0.70710678118654752440f)));
 }
 
+// GELU for results that leave as fp16 in the f16x2 / f16 arithmetic (kFast below: the k-octet GEMM epilogue, the fp16-row
+// output of the depthwise kernel): a pure polynomial -- erf(z) ~ z Q(z^2) on |z| <= 3 (degree-8 minimax
+// Q, |err| <= 2.2e-5, erf(3) = 1 - 2.2e-5 beyond), constants folded so that gelu(x) = h + h * (xc * D(xc^2)), h = x / 2,
+// xc = x clamped to +-3 sqrt 2: 14 issue slots per PAIR (2 v_med3, 10 v_pk_fma / v_pk_mul, no v_rcp) against 28 for the
+// rational form above.  |gelu error| <= 5.2e-5 absolute and <= 1.1e-5 relative for x > 0 -- a tenth of the fp16 rounding
+// (2^-11 relative) that every activation of these modes receives on its way into the next contraction.
+__device__ __forceinline__ f32x2 gelu_poly2(f32x2 x) {
+    f32x2 xc;
+    xc[0] = __builtin_amdgcn_fmed3f(x[0], -4.2426405f, 4.2426405f);
+    xc[1] = __builtin_amdgcn_fmed3f(x[1], -4.2426405f, 4.2426405f);
+    const f32x2 t = xc * xc;
+    f32x2 p = splat2(1.12535e-10f);
+    p = __builtin_elementwise_fma(p, t, splat2(-1.074371e-08f));
+    p = __builtin_elementwise_fma(p, t, splat2(4.5365834e-07f));
+    p = __builtin_elementwise_fma(p, t, splat2(-1.12924145e-05f));
+    p = __builtin_elementwise_fma(p, t, splat2(0.0001871811f));
+    p = __builtin_elementwise_fma(p, t, splat2(-0.0022188f));
+    p = __builtin_elementwise_fma(p, t, splat2(0.019636236f));
+    p = __builtin_elementwise_fma(p, t, splat2(-0.13269384f));
+    p = __builtin_elementwise_fma(p, t, splat2(0.79780626f));
+    const f32x2 h = splat2(0.5f) * x;
+    return __builtin_elementwise_fma(h, xc * p, h);
+}
+template <bool kFast>
+__device__ __forceinline__ f32x2 gelu2(f32x2 x) {
+    if constexpr (kFast) return gelu_poly2(x);
+    else return gelu_erf2(x);
+}
+
 __host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 // MI355X dispatches workgroup b of a 1-D grid to XCD b % 8 (8 XCDs with private 4 MiB L2s; observed, used for speed
