@@ -72,6 +72,21 @@ def _handover(buf: Planes, n_img: int, rows: int, P: int, consumer_rows: int, al
     return _scratch(buf, n_img, rows, f16=f16, koct=koct)
 
 
+def _sub(X: Planes, i0: int, cnt: int) -> Planes:
+    """Images i0 .. i0 + cnt - 1 of X (and of its k-octet copy)."""
+    assert 0 <= i0 and i0 + cnt <= X.n_img
+    step = X.img_stride // (2 if X.f16 else 1)                     # `off` counts floats of the underlying allocation
+    assert not X.f16 or X.img_stride % 2 == 0
+    sh = _sub(X.shadow, i0, cnt) if X.shadow is not None else None
+    return replace(X, off=X.off + i0 * step, n_img=cnt, shadow=sh)
+
+
+def _part(buf: Planes, which: int, parts: int) -> Planes:
+    """One of `parts` equal pieces of a scratch allocation (concurrent chains, each over 1 / parts of the images)."""
+    k = buf.n_img // parts
+    return replace(buf, off=buf.off + which * k * buf.img_stride, n_img=k)
+
+
 def hidden_f16_ok(P: int) -> bool:
     """FFN hidden activations are handed from GEMM to GEMM as fp16 in the f16x2 mode (bit-identical: that mode rounds a
     B operand to fp16 on load anyway) when the plane geometry allows 8-byte stores / dword loads."""
@@ -276,6 +291,11 @@ class HotPathEngine:
         if self.flash_qk_products not in (1, 2, 3):
             raise RuntimeError(f"flash_qk_products must be 1, 2 or 3, got {self.flash_qk_products}")
         self._side = torch.cuda.Stream(device=self.device)
+        self._chain_streams = [torch.cuda.Stream(device=self.device) for _ in range(3)]
+        # Where the main stream has no concurrent branch (corr encoder, motion-encoder tail, GRU + flow head) a batch of an
+        # even number of clips is cut in two halves that run as two chains on two streams: a dependent kernel boundary costs
+        # ~8 us on this part and each chain hides the other's.  SF_SPLIT_SOLO = 0 / 2 / 4 chains.
+        self.split_solo = int(os.environ.get("SF_SPLIT_SOLO", "2"))
         self.W = HotPathWeights(state_dict, self.device, T)
         self.use_graph = use_graph
         self._plans: Dict[Tuple[int, int, int, int], _Plan] = {}
@@ -371,10 +391,41 @@ class HotPathEngine:
             run_skblock(W.convf2, pl.f128, pl.cat256.slice(192, 256), pl.hid2, pl.xa2, pl.xb2, h, w)
         # ... while the main stream does a3 (correlation lookup for all pairs, streamflow.py:132) and the corr branch
         ops.corr_lookup(pl.lvls, pl.lvl_pair_stride, pl.coords1, pl.corr, Bc, Pn, h, w)
-        sk(W.convc1, pl.corr, pl.cor256, True)                     # cor = gelu(convc1(corr))
-        sk(W.convc2, pl.cor256, pl.cat256.slice(0, 192))
+        nch = self.split_solo if (self.split_solo in (2, 4) and side is not main and Bc % self.split_solo == 0) else 1
+        split = nch > 1
+        npc = n // nch                                              # images per chain (whole clips)
+
+        def two_chains(fn):
+            """fn(image0, count, scratch part): chain 0 on the main stream, the others on their own streams."""
+            keep = ops.SPLIT_WS
+            ops.SPLIT_WS = None                                    # (one scratch buffer: no automatic split-K while the chains run)
+            try:
+                for c in range(1, nch):
+                    sc = self._chain_streams[c - 1]
+                    sc.wait_stream(main)
+                    with torch.cuda.stream(sc):
+                        fn(c * npc, npc, c)
+                fn(0, npc, 0)
+            finally:
+                ops.SPLIT_WS = keep
+            for c in range(1, nch):
+                main.wait_stream(self._chain_streams[c - 1])
+
+        if split:
+            def corr_chain(i0, cnt, hf):
+                hid, xa, xb = _part(pl.hid, hf, nch), _part(pl.xa, hf, nch), _part(pl.xb, hf, nch)
+                run_skblock(W.convc1, _sub(pl.corr, i0, cnt), _sub(pl.cor256, i0, cnt), hid, xa, xb, h, w, True)
+                run_skblock(W.convc2, _sub(pl.cor256, i0, cnt), _sub(pl.cat256.slice(0, 192), i0, cnt), hid, xa, xb, h, w)
+            two_chains(corr_chain)
+        else:
+            sk(W.convc1, pl.corr, pl.cor256, True)                 # cor = gelu(convc1(corr))
+            sk(W.convc2, pl.cor256, pl.cat256.slice(0, 192))
         join()
-        sk(W.conv, pl.cat256, pl.mf.slice(0, HDIM - 2))            # mf = cat(out, flow); flow rows kept by flow_update
+        if split:                                                   # mf = cat(out, flow); flow rows kept by flow_update
+            two_chains(lambda i0, cnt, hf: run_skblock(W.conv, _sub(pl.cat256, i0, cnt), _sub(pl.mf.slice(0, HDIM - 2), i0, cnt),
+                                                       _part(pl.hid, hf, nch), _part(pl.xa, hf, nch), _part(pl.xb, hf, nch), h, w))
+        else:
+            sk(W.conv, pl.cat256, pl.mf.slice(0, HDIM - 2))
         # a10: temporal transformer block over the T-1 tokens of each pixel (update.py:481-484,770), side stream
         fork()
         with on_side():
@@ -425,9 +476,18 @@ class HotPathEngine:
             ops.refresh_shadow(pl.mfg)                              # (the flash kernel writes the k-octet copy itself)
         join()
         # "gru": SKBlock(640 -> 128) over cat[nets, inps, mf, mfg, mft]; new nets overwrite the nets slice
-        sk(W.gru, pl.concat, pl.nets)
-        # flow head sees all T-1 hidden states of a clip jointly (update.py:774)
-        sk(W.flow_head, pl.nets_grouped, pl.delta_fh)
+        if split:
+            def gru_chain(i0, cnt, hf):
+                hid, xa, xb = _part(pl.hid, hf, nch), _part(pl.xa, hf, nch), _part(pl.xb, hf, nch)
+                run_skblock(W.gru, _sub(pl.concat, i0, cnt), _sub(pl.nets, i0, cnt), hid, xa, xb, h, w)
+                # flow head sees all T-1 hidden states of a clip jointly (update.py:774): clips i0 / Pn ..
+                run_skblock(W.flow_head, _sub(pl.nets_grouped, i0 // Pn, cnt // Pn), _sub(pl.delta_fh, i0 // Pn, cnt // Pn),
+                            hid, xa, xb, h, w)
+            two_chains(gru_chain)
+        else:
+            sk(W.gru, pl.concat, pl.nets)
+            # flow head sees all T-1 hidden states of a clip jointly (update.py:774)
+            sk(W.flow_head, pl.nets_grouped, pl.delta_fh)
         if with_mask:                                               # update.py:756-759,777
             ops.gemm(W.mask0, pl.nets, pl.m256, EPI_RELU, hw=(h, w))
             ops.gemm(W.mask2, pl.m256, pl.mask, EPI_NONE, alpha=0.25)

@@ -463,3 +463,31 @@ def test_two_product_mode_gelu_accuracy(dev):
             # polynomial (<= 5.2e-5 absolute, 1.1e-5 relative) + the fp16 rounding of the stored value (2^-11 relative)
             assert bool((err <= 6e-5 + 2.0 ** -11 * ref.abs() * 1.01).all())
             assert (err[big] / ref[big]).max().item() < 2.0 ** -11 * 1.05
+
+
+@pytest.mark.parametrize("preset", ["config2_fp16", "fp32_class"])
+def test_two_chain_schedule_is_bitwise_the_one_chain_schedule(dev, preset, monkeypatch):
+    """The engine runs the sections without a concurrent branch as two half-batch chains on two streams (SF_SPLIT_SOLO,
+    default 2).  Clips are independent and a kernel's arithmetic does not depend on the batch it is launched with, so the
+    flows must be bit-identical to the single-chain schedule -- graph and eager, B = 2 and 4.  (The automatic split-K of
+    small grids is switched off for the comparison: it is not available inside the chains -- one scratch buffer -- and
+    changes the summation order of the GEMMs it applies to at this test's small shape.)"""
+    from streamflow_amd import presets, synthetic as syn
+    from streamflow_amd.engine import HotPathEngine
+    monkeypatch.setenv("SF_AUTO_SPLITK", "0")
+    T, h, w, iters = 3, 24, 32, 3
+    P = syn.make_params(7, T)
+    kw = presets.engine_kwargs(preset)
+    for B, graph in ((2, True), (4, False)):
+        fmaps, cnets = syn.make_features(40 + B, B, T, h, w)
+        outs = {}
+        for chains in ("0", "2", "4"):
+            monkeypatch.setenv("SF_SPLIT_SOLO", chains)
+            eng = HotPathEngine(P, device=dev, T=T, use_graph=graph, **kw)
+            for _ in range(2):
+                ups = eng.forward(fmaps.to(dev), cnets.to(dev), iters=iters)[0]
+            outs[chains] = [u.clone() for u in ups]
+        torch.cuda.synchronize()
+        for chains in ("2", "4"):
+            for a, b2 in zip(outs["0"], outs[chains]):
+                assert torch.equal(a, b2), (preset, B, graph, chains)
