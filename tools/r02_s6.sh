@@ -19,10 +19,13 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $P/$O/prof_s
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $P/$O/prof_sintel_serial -o prof -- python3 $P/bench.py $B --no-graph --serial-branches > $P/$O/prof_sintel_serial.log 2>&1; echo "prof sintel serial rc $?"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $P/$O/prof_kitti -o prof -- python3 $P/bench.py $B --workload kitti > $P/$O/prof_kitti.log 2>&1; echo "prof kitti rc $?"
 C="--steps 1 --warmup 0 --no-cpu-baseline --no-kernel-breakdown --no-graph"
+# (HBM-traffic passes on the ONE-chain schedule: bench.py prices its instrumented, unsplit step with these per-launch bytes)
+export SF_SPLIT_SOLO=0
 for w in sintel kitti; do
   timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $P/$O/pmc_${w}_fetch -o pmc -- python3 $P/bench.py $C --workload $w > $P/$O/pmc_${w}_fetch.log 2>&1; echo "pmc $w fetch rc $?"
   timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $P/$O/pmc_${w}_write -o pmc -- python3 $P/bench.py $C --workload $w > $P/$O/pmc_${w}_write.log 2>&1; echo "pmc $w write rc $?"
 done
+unset SF_SPLIT_SOLO
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $P/$O/pmc_sintel_mfma -o pmc -- python3 $P/bench.py $C > $P/$O/pmc_sintel_mfma.log 2>&1; echo "pmc mfma rc $?"
 cd $P
 # keep only stats / counter csv (small)
