@@ -81,10 +81,9 @@ def _sub(X: Planes, i0: int, cnt: int) -> Planes:
     return replace(X, off=X.off + i0 * step, n_img=cnt, shadow=sh)
 
 
-def _part(buf: Planes, which: int, parts: int) -> Planes:
-    """One of `parts` equal pieces of a scratch allocation (concurrent chains, each over 1 / parts of the images)."""
-    k = buf.n_img // parts
-    return replace(buf, off=buf.off + which * k * buf.img_stride, n_img=k)
+def _part(buf: Planes, i0: int, cnt: int) -> Planes:
+    """The piece of a scratch allocation that belongs to images i0 .. i0 + cnt - 1 (concurrent chains over disjoint images)."""
+    return replace(buf, off=buf.off + i0 * buf.img_stride, n_img=cnt)
 
 
 def hidden_f16_ok(P: int) -> bool:
@@ -391,29 +390,36 @@ class HotPathEngine:
             run_skblock(W.convf2, pl.f128, pl.cat256.slice(192, 256), pl.hid2, pl.xa2, pl.xb2, h, w)
         # ... while the main stream does a3 (correlation lookup for all pairs, streamflow.py:132) and the corr branch
         ops.corr_lookup(pl.lvls, pl.lvl_pair_stride, pl.coords1, pl.corr, Bc, Pn, h, w)
-        nch = self.split_solo if (self.split_solo in (2, 4) and side is not main and Bc % self.split_solo == 0) else 1
-        split = nch > 1
-        npc = n // nch                                              # images per chain (whole clips)
+        # image ranges of the chains: whole clips when the clip count divides, else (a single clip, an odd batch) two
+        # ranges of images -- every block but the flow head works image by image
+        nch = self.split_solo if (self.split_solo in (2, 4) and side is not main) else 1
+        if nch > 1 and Bc % nch == 0:
+            parts, by_clip = [(c * (n // nch), n // nch) for c in range(nch)], True
+        elif nch > 1 and n >= 2:
+            parts, by_clip = [(0, (n + 1) // 2), ((n + 1) // 2, n // 2)], False
+        else:
+            parts, by_clip = [(0, n)], True
+        split = len(parts) > 1
 
         def two_chains(fn):
-            """fn(image0, count, scratch part): chain 0 on the main stream, the others on their own streams."""
+            """fn(image0, count): chain 0 on the main stream, the others on their own streams."""
             keep = ops.SPLIT_WS
             ops.SPLIT_WS = None                                    # (one scratch buffer: no automatic split-K while the chains run)
             try:
-                for c in range(1, nch):
+                for c in range(1, len(parts)):
                     sc = self._chain_streams[c - 1]
                     sc.wait_stream(main)
                     with torch.cuda.stream(sc):
-                        fn(c * npc, npc, c)
-                fn(0, npc, 0)
+                        fn(*parts[c])
+                fn(*parts[0])
             finally:
                 ops.SPLIT_WS = keep
-            for c in range(1, nch):
+            for c in range(1, len(parts)):
                 main.wait_stream(self._chain_streams[c - 1])
 
         if split:
-            def corr_chain(i0, cnt, hf):
-                hid, xa, xb = _part(pl.hid, hf, nch), _part(pl.xa, hf, nch), _part(pl.xb, hf, nch)
+            def corr_chain(i0, cnt):
+                hid, xa, xb = _part(pl.hid, i0, cnt), _part(pl.xa, i0, cnt), _part(pl.xb, i0, cnt)
                 run_skblock(W.convc1, _sub(pl.corr, i0, cnt), _sub(pl.cor256, i0, cnt), hid, xa, xb, h, w, True)
                 run_skblock(W.convc2, _sub(pl.cor256, i0, cnt), _sub(pl.cat256.slice(0, 192), i0, cnt), hid, xa, xb, h, w)
             two_chains(corr_chain)
@@ -422,8 +428,8 @@ class HotPathEngine:
             sk(W.convc2, pl.cor256, pl.cat256.slice(0, 192))
         join()
         if split:                                                   # mf = cat(out, flow); flow rows kept by flow_update
-            two_chains(lambda i0, cnt, hf: run_skblock(W.conv, _sub(pl.cat256, i0, cnt), _sub(pl.mf.slice(0, HDIM - 2), i0, cnt),
-                                                       _part(pl.hid, hf, nch), _part(pl.xa, hf, nch), _part(pl.xb, hf, nch), h, w))
+            two_chains(lambda i0, cnt: run_skblock(W.conv, _sub(pl.cat256, i0, cnt), _sub(pl.mf.slice(0, HDIM - 2), i0, cnt),
+                                                   _part(pl.hid, i0, cnt), _part(pl.xa, i0, cnt), _part(pl.xb, i0, cnt), h, w))
         else:
             sk(W.conv, pl.cat256, pl.mf.slice(0, HDIM - 2))
         # a10: temporal transformer block over the T-1 tokens of each pixel (update.py:481-484,770), side stream
@@ -477,13 +483,15 @@ class HotPathEngine:
         join()
         # "gru": SKBlock(640 -> 128) over cat[nets, inps, mf, mfg, mft]; new nets overwrite the nets slice
         if split:
-            def gru_chain(i0, cnt, hf):
-                hid, xa, xb = _part(pl.hid, hf, nch), _part(pl.xa, hf, nch), _part(pl.xb, hf, nch)
+            def gru_chain(i0, cnt):
+                hid, xa, xb = _part(pl.hid, i0, cnt), _part(pl.xa, i0, cnt), _part(pl.xb, i0, cnt)
                 run_skblock(W.gru, _sub(pl.concat, i0, cnt), _sub(pl.nets, i0, cnt), hid, xa, xb, h, w)
-                # flow head sees all T-1 hidden states of a clip jointly (update.py:774): clips i0 / Pn ..
-                run_skblock(W.flow_head, _sub(pl.nets_grouped, i0 // Pn, cnt // Pn), _sub(pl.delta_fh, i0 // Pn, cnt // Pn),
-                            hid, xa, xb, h, w)
+                if by_clip:     # flow head sees all T-1 hidden states of a clip jointly (update.py:774): clips i0 / Pn ..
+                    run_skblock(W.flow_head, _sub(pl.nets_grouped, i0 // Pn, cnt // Pn),
+                                _sub(pl.delta_fh, i0 // Pn, cnt // Pn), hid, xa, xb, h, w)
             two_chains(gru_chain)
+            if not by_clip:
+                sk(W.flow_head, pl.nets_grouped, pl.delta_fh)
         else:
             sk(W.gru, pl.concat, pl.nets)
             # flow head sees all T-1 hidden states of a clip jointly (update.py:774)

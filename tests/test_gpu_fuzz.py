@@ -478,7 +478,7 @@ def test_two_chain_schedule_is_bitwise_the_one_chain_schedule(dev, preset, monke
     T, h, w, iters = 3, 24, 32, 3
     P = syn.make_params(7, T)
     kw = presets.engine_kwargs(preset)
-    for B, graph in ((2, True), (4, False)):
+    for B, graph in ((2, True), (4, False), (1, True), (3, False)):     # (odd batches: two chains over IMAGE ranges)
         fmaps, cnets = syn.make_features(40 + B, B, T, h, w)
         outs = {}
         for chains in ("0", "2", "4"):
