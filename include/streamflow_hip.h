@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SF_VERSION 104
+#define SF_VERSION 105
 
 enum {
     SF_OK = 0,
@@ -86,6 +86,34 @@ int sf_corr_lookup(const float* lvl0, const float* lvl1, const float* lvl2, cons
                    const int64_t* lvl_pair_stride, const float* coords, float* out, int64_t out_img_stride,
                    void* out_koct, int64_t out_koct_img_stride, int B, int pairs, int h, int w, int num_levels,
                    int radius, int vol_precision, void* stream);
+
+/* ---- a1 + a2 + a3 in the BLOCKED fp16 volume layout (core/corr.py:7-54; csrc/corr_blocked.hip) --------------------------
+ * Same mathematics as sf_corr_build_pyramid(SF_PRECISION_F16) / sf_corr_lookup, different memory layout: ONE buffer per
+ * launch; image img = b*pairs + t starts at vol + img * vol_img_stride_bytes and holds one RECORD of rec_bytes per source
+ * pixel (src_rows = h*w rounded up to 128 records; the padding records are written by the build and never read):
+ *     record = [level 0 | level 1 | level 2 | level 3], level l = nby[l] x nbx[l] blocks of 8 x 8 cells (nb = ceil(size/8)),
+ *     block (by, bx) at lvl_off[l] + (by*nbx[l] + bx)*128, cell (ty, tx) at byte ((tx%8)*8 + ty%8)*2 of block (ty/8, tx/8).
+ * A 128-byte block is one cache line: a 10 x 10 lookup footprint touches ~4.5 lines per level instead of ~11 in the
+ * row-major volume, and the build stores a level-0 block column (16 bytes) per lane and accumulator register.
+ * Cells of a block outside the level (hl, wl not multiples of 8) have UNSPECIFIED contents; the lookup ignores them.
+ *   sf_corr_blocked_geometry: the numbers above for an h x w feature grid (any output pointer may be NULL).
+ *   sf_corr_blocked_bytes: n_img * src_rows * rec_bytes.
+ *   sf_corr_build_blocked: features as in sf_corr_build_pyramid; ws = scratch of sf_corr_build_blocked_ws_bytes() bytes
+ *       (fp16 k-octet repack of the features, 16-byte aligned); vol 128-byte aligned, vol_img_stride_bytes % 128 == 0.
+ *   sf_corr_lookup_blocked: coords / channel order / sampling rule exactly as sf_corr_lookup.  out_koct: the 324 channels
+ *       rounded to fp16 as k-octet planes [41][h*w][8] per image (SF_LAYOUT_F16_KOCT, rows 324..327 zero) -- the operand
+ *       (and, through SfGemm.r_f16, the residual) of the correlation encoder's first block: no fp32 copy is written.
+ *       out: optional fp32 planes [324][h*w] per image (un-rounded taps; API parity and tests).  At least one of the two. */
+int sf_corr_blocked_geometry(int h, int w, int64_t* rec_bytes, int64_t* lvl_off, int32_t* nby, int32_t* nbx,
+                             int64_t* src_rows);
+int64_t sf_corr_blocked_bytes(int n_img, int h, int w);
+int64_t sf_corr_build_blocked_ws_bytes(int n_img, int D, int h, int w);
+int sf_corr_build_blocked(const float* f1, const float* f2, int64_t f_clip_stride, int64_t f_pair_stride,
+                          void* vol, int64_t vol_img_stride_bytes, int B, int pairs, int D, int h, int w,
+                          void* ws, int64_t ws_bytes, void* stream);
+int sf_corr_lookup_blocked(const void* vol, int64_t vol_img_stride_bytes, const float* coords, float* out,
+                           int64_t out_img_stride, void* out_koct, int64_t out_koct_img_stride, int B, int pairs,
+                           int h, int w, void* stream);
 
 /* ---- generic fused GEMM: every 1x1 conv / nn.Linear / einsum on the path ------------------------
  * C[z][m][n] = epilogue( alpha * ( sum_k A[z][m][k] * B[z][k][n] + bias[m] ) )
@@ -169,6 +197,11 @@ typedef struct SfGemm {
        Only rows < M are written to C16: a last, partial octet keeps its other rows. */
     int32_t c_f16;
     void* C16; int64_t strideC16;
+    /* r_f16 = 2 (split precisions, vector epilogue: the alignment rules of c_f16 = 1 for C): the residual R is not fp32
+       planes but an fp16 k-octet image (SF_LAYOUT_F16_KOCT: element (m, n) at ((m/8)*ldr + n)*8 + m%8, ldr = pixels per
+       plane, strideR in halves, 16-byte aligned, no grouping) -- e.g. the tensor that was this block's GEMM operand, read
+       a second time as the residual without an fp32 copy of it ever having been written (correlation features). */
+    int32_t r_f16;
 } SfGemm;
 
 /* floats of scratch that let sf_gemm auto-split a problem of this size (0 if it never would) */

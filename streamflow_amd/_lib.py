@@ -39,6 +39,7 @@ class SfGemm(C.Structure):
         ("split_ws", _vp), ("split_ws_floats", _i64),
         ("c_f16", C.c_int32),
         ("C16", _vp), ("strideC16", _i64),
+        ("r_f16", C.c_int32),
     ]
 
 
@@ -52,6 +53,12 @@ SIGNATURES = {
                                    _vp, _i64, _vp]),
     "sf_corr_build_ws_bytes": (_i64, [_i, _i, _i, _i, _i]),
     "sf_corr_lookup": (_i, [_vp, _vp, _vp, _vp, C.POINTER(_i64), _vp, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "sf_corr_blocked_geometry": (_i, [_i, _i, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                      C.POINTER(_i64)]),
+    "sf_corr_blocked_bytes": (_i64, [_i, _i, _i]),
+    "sf_corr_build_blocked_ws_bytes": (_i64, [_i, _i, _i, _i]),
+    "sf_corr_build_blocked": (_i, [_vp, _vp, _i64, _i64, _vp, _i64, _i, _i, _i, _i, _i, _vp, _i64, _vp]),
+    "sf_corr_lookup_blocked": (_i, [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _vp]),
     "sf_gemm": (_i, [C.POINTER(SfGemm), _vp]),
     "sf_gemm_split_ws_floats": (_i64, [_i, _i, _i, _i]),
     "sf_gma_flash_ws_bytes": (_i64, [_i, _i]),
@@ -95,7 +102,7 @@ def load() -> C.CDLL:
             raise RuntimeError(f"{LIB_PATH} does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
-    if lib.sf_version() < 104:
+    if lib.sf_version() < 105:
         raise RuntimeError("libstreamflow_hip.so is too old; rebuild")
     _lib = lib
     return lib

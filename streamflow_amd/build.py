@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libstreamflow_hip.so")
-SOURCES = ["misc.hip", "corr.hip", "conv.hip", "gemm.hip", "gemm_split.hip", "attn.hip", "encoder.hip"]
+SOURCES = ["misc.hip", "corr.hip", "corr_blocked.hip", "conv.hip", "gemm.hip", "gemm_split.hip", "attn.hip", "encoder.hip"]
 HEADERS = [os.path.join(CSRC, "sf_common.h"), os.path.join(CSRC, "gemm_epilogue.h"), os.path.join(CSRC, "split_operand.h"),
            os.path.join(HERE, "..", "include", "streamflow_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-Wall",

@@ -17,11 +17,13 @@ class CorrBlock:
     ``blk(coords)`` returns ``[B, 4*81, h, w]`` float32 contiguous (corr.py:23-44).
     ``dtype=torch.float16`` (an extension; the reference always keeps fp32 volumes) stores the pyramid as fp16
     cells built with single f16 MFMA products -- the bf16/fp16 volume configurations of BASELINE.json.
+    ``layout="blocked"`` (fp16 only) keeps them in the 8 x 8-cell block layout of csrc/corr_blocked.hip -- what the fused
+    engine uses; ``corr_pyramid`` is then a row-major COPY made on first access.
     """
 
     @ops.on_tensor_device
     def __init__(self, fmap1: torch.Tensor, fmap2: torch.Tensor, num_levels: int = 4, radius: int = 4,
-                 dtype: torch.dtype = torch.float32):
+                 dtype: torch.dtype = torch.float32, layout: str = "rows"):
         if num_levels != 4 or radius != 4:
             raise RuntimeError("CorrBlock: the HIP path is built for num_levels=4, radius=4 "
                                "(the only values the StreamFlow model uses, streamflow.py:38-39)")
@@ -35,10 +37,25 @@ class CorrBlock:
         N = h * w
         if dtype not in (torch.float32, torch.float16):
             raise RuntimeError(f"CorrBlock: volume dtype must be float32 or float16, got {dtype}")
+        if layout not in ("rows", "blocked") or (layout == "blocked" and dtype != torch.float16):
+            raise RuntimeError("CorrBlock: layout must be 'rows' or 'blocked' (blocked: float16 volumes only)")
+        self._keep = (f1, f2)
+        self.vol = None
+        if layout == "blocked":
+            self.vol = ops.new_blocked_volume(B, h, w, f1.device)
+            ops.corr_build_blocked(f1.data_ptr(), f2.data_ptr(), D * N, 0, self.vol, B, 1, D)
+            self._pyr = None
+            return
         lv = [torch.empty(B * N, 1, h >> l, w >> l, dtype=dtype, device=f1.device) for l in range(4)]
         ops.corr_build(f1.data_ptr(), f2.data_ptr(), D * N, 0, lv, None, B, 1, D, h, w)
-        self._keep = (f1, f2)
-        self.corr_pyramid = lv
+        self._pyr = lv
+
+    @property
+    def corr_pyramid(self):
+        if self._pyr is None:                                  # blocked volumes: row-major copy, reference shapes
+            B, h, w = self.shape
+            self._pyr = [t.reshape(B * h * w, 1, h >> l, w >> l) for l, t in enumerate(self.vol.levels())]
+        return self._pyr
 
     @ops.on_tensor_device
     def __call__(self, coords: torch.Tensor) -> torch.Tensor:
@@ -47,7 +64,10 @@ class CorrBlock:
         ops._dev_check(c)
         assert tuple(c.shape) == (B, 2, h, w), (c.shape, self.shape)
         out = torch.empty(B, 4 * 81, h, w, dtype=torch.float32, device=c.device)
-        ops.corr_lookup(self.corr_pyramid, None, Planes.of(c), Planes.of(out), B, 1, h, w)
+        if self.vol is not None:
+            ops.corr_lookup_blocked(self.vol, Planes.of(c), Planes.of(out), None, B, 1)
+        else:
+            ops.corr_lookup(self.corr_pyramid, None, Planes.of(c), Planes.of(out), B, 1, h, w)
         return out
 
     @staticmethod

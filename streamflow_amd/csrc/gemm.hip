@@ -305,6 +305,7 @@ extern "C" int sf_gemm(const SfGemm* gp, void* stream) {
     SF_REQUIRE(g.c_f16 >= 0 && g.c_f16 <= 3, "sf_gemm: c_f16 must be 0 .. 3");
     SF_REQUIRE(g.c_f16 != 3 || g.C16, "sf_gemm: c_f16 = 3 needs C16");
     SF_REQUIRE(!g.c_f16 || g.precision != SF_PRECISION_FP32, "sf_gemm: c_f16 needs a split precision");
+    SF_REQUIRE(!g.r_f16 || g.precision != SF_PRECISION_FP32, "sf_gemm: r_f16 needs a split precision");
     SF_REQUIRE(g.b_layout != SF_LAYOUT_F16_K_MINOR || g.precision != SF_PRECISION_FP32,
                "sf_gemm: a stored-fp16 B operand needs a split precision");
     SF_REQUIRE(g.a_layout != SF_LAYOUT_SPLIT_F16 || g.precision != SF_PRECISION_FP32,

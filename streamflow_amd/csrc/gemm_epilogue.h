@@ -172,11 +172,15 @@ constexpr int kEpiScratchFloats = 32 * kEpiStride;          // per wave
 
 typedef unsigned int epi_u32x4 __attribute__((ext_vector_type(4)));
 
-template <int EPI, int WM, int WN, int TM, int TN, bool kFast>
+// kRK (SfGemm.r_f16 = 2): the residual is an fp16 k-octet image.  In the accumulator layout a lane holds rows
+// 8o + 4 khalf + (0..3) of pixel l31 for o = 0..3 -- half an octet of one pixel, 8 contiguous bytes -- so the residual is
+// fetched with four 8-byte loads per 32x32 tile (lanes l and l + 32 share a 16-byte piece) and added to the accumulators
+// BEFORE the transpose, scaled by 1 / alpha (v = alpha * (acc + R / alpha + bias) = alpha * (acc + bias) + R).
+template <int EPI, int WM, int WN, int TM, int TN, bool kFast, bool kRK = false>
 __device__ __forceinline__ void gemm_epilogue_vec_impl(const SfGemm& g, f32x16 (&acc)[TM][TN], int m0, int n0, int z,
                                                        int wm, int wn, int lane, float* scratch) {
-    constexpr bool kNeedsR = (EPI == SF_EPI_RES || EPI == SF_EPI_RES_GELU || EPI == SF_EPI_RES_GELU_DW1 ||
-                              EPI == SF_EPI_AXPY);
+    constexpr bool kNeedsR = !kRK && (EPI == SF_EPI_RES || EPI == SF_EPI_RES_GELU || EPI == SF_EPI_RES_GELU_DW1 ||
+                                      EPI == SF_EPI_AXPY);
     const int khalf = lane >> 5, l31 = lane & 31;
     const int rrow = lane >> 3, rcol = (lane & 7) * 4;       // read-back coordinates inside a 32x32 tile
     // c_f16: C is IEEE fp16 storage (ldc / strideC in halves): four rounded values leave as one 8-byte store
@@ -202,6 +206,37 @@ __device__ __forceinline__ void gemm_epilogue_vec_impl(const SfGemm& g, f32x16 (
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int mt0 = m0 + (wm * TM + i) * 32;
+        if constexpr (kRK) {
+            typedef unsigned int epi_u32x2 __attribute__((ext_vector_type(2)));
+            typedef _Float16 epi_h2 __attribute__((ext_vector_type(2)));
+            const int moct = (g.M + 7) / 8;
+            const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<char*>(reinterpret_cast<const char*>(g.R)) + (int64_t)z * g.strideR * 2, 0,
+                (int)((int64_t)moct * g.ldr * 16), 0x00020000);
+            const float inv_alpha = 1.0f / g.alpha;
+            epi_u32x2 rh[TN][4];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n1 = n0 + (wn * TN + j) * 32 + l31;
+                const int nc = n1 < g.N ? n1 : g.N - 1;
+#pragma unroll
+                for (int o = 0; o < 4; ++o) {
+                    const int oc = min((mt0 >> 3) + o, moct - 1);        // octets past M: clamped, their rows are never stored
+                    rh[j][o] = __builtin_amdgcn_raw_buffer_load_b64(rk, (oc * (int)g.ldr + nc) * 16 + khalf * 8, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int o = 0; o < 4; ++o)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const unsigned u = rh[j][o][e];
+                        const epi_h2 hv = __builtin_bit_cast(epi_h2, u);
+                        acc[i][j][4 * o + 2 * e] += (float)hv[0] * inv_alpha;
+                        acc[i][j][4 * o + 2 * e + 1] += (float)hv[1] * inv_alpha;
+                    }
+        }
         // per-row parameters and residuals of this row of tiles (all loads issued before any arithmetic)
         float bias[4], dww[4], dwb[4];
         int crow[4];
@@ -399,7 +434,11 @@ __device__ __forceinline__ void gemm_epilogue_vec(const SfGemm& g, f32x16 (&acc)
         case SF_EPI_RES: gemm_epilogue_vec_impl<SF_EPI_RES, WM, WN, TM, TN, kFast>(g, acc, m0, n0, z, wm, wn, lane, scratch); break;
         case SF_EPI_RES_GELU: gemm_epilogue_vec_impl<SF_EPI_RES_GELU, WM, WN, TM, TN, kFast>(g, acc, m0, n0, z, wm, wn, lane, scratch); break;
         case SF_EPI_RES_GELU_DW1:
-            gemm_epilogue_vec_impl<SF_EPI_RES_GELU_DW1, WM, WN, TM, TN, kFast>(g, acc, m0, n0, z, wm, wn, lane, scratch); break;
+            if (g.r_f16 == 2)   // wave-uniform; the one epilogue built for a k-octet residual (host-checked)
+                gemm_epilogue_vec_impl<SF_EPI_RES_GELU_DW1, WM, WN, TM, TN, kFast, true>(g, acc, m0, n0, z, wm, wn, lane, scratch);
+            else
+                gemm_epilogue_vec_impl<SF_EPI_RES_GELU_DW1, WM, WN, TM, TN, kFast>(g, acc, m0, n0, z, wm, wn, lane, scratch);
+            break;
         case SF_EPI_AXPY: gemm_epilogue_vec_impl<SF_EPI_AXPY, WM, WN, TM, TN, kFast>(g, acc, m0, n0, z, wm, wn, lane, scratch); break;
         default: gemm_epilogue_vec_impl<SF_EPI_NONE, WM, WN, TM, TN, kFast>(g, acc, m0, n0, z, wm, wn, lane, scratch); break;
     }
@@ -409,8 +448,9 @@ __device__ __forceinline__ void gemm_epilogue_vec(const SfGemm& g, f32x16 (&acc)
 __device__ __forceinline__ bool epilogue_vec_ok(const SfGemm& g, int z) {
     bool ok = (g.N & 3) == 0 && (g.ldc & 3) == 0 && (g.strideC & 3) == 0 &&
               ((reinterpret_cast<uintptr_t>(g.C) & 15) == 0);
-    if (g.R) ok = ok && (g.ldr & 3) == 0 && (g.strideR & 3) == 0 && (g.r_group_stride & 3) == 0 &&
-                  ((reinterpret_cast<uintptr_t>(g.R) & 15) == 0);
+    if (g.R && g.r_f16 == 2) ok = ok && (g.strideR & 7) == 0 && ((reinterpret_cast<uintptr_t>(g.R) & 15) == 0);
+    else if (g.R) ok = ok && (g.ldr & 3) == 0 && (g.strideR & 3) == 0 && (g.r_group_stride & 3) == 0 &&
+                       ((reinterpret_cast<uintptr_t>(g.R) & 15) == 0);
     return ok;
 }
 
@@ -420,7 +460,9 @@ inline bool epilogue_spans_ok(const SfGemm& g) {
                                      : ((int64_t)(g.M - 1) * g.ldc + g.N) * (g.c_f16 == 1 ? 2 : 4);
     if (g.c_f16 == 3 && (int64_t)((g.M + 7) / 8) * g.ldc * 16 >= kOobTerm) return false;
     int64_t r = 0;
-    if (g.R) {
+    if (g.R && g.r_f16 == 2) {
+        r = (int64_t)((g.M + 7) / 8) * g.ldr * 16;
+    } else if (g.R) {
         const int mr = g.M - 1;
         r = (g.r_group > 0) ? (int64_t)(mr / g.r_group) * g.r_group_stride + (int64_t)(mr % g.r_group) * g.ldr
                             : (int64_t)mr * g.ldr;

@@ -448,6 +448,41 @@ int auto_splits(int M, int N, int K, int batch) {
     return ks < 2 ? 1 : ks;
 }
 
+// c_f16 / r_f16 rules of the vector and k-octet epilogues.  The kernel picks the vector epilogue only when
+// epilogue_vec_ok() holds and would otherwise fall back to the scalar one, which knows neither format: reject here.
+int check_output_formats(const SfGemm& g) {
+    using sf::fail;
+    const bool vec_c = (g.N & 3) == 0 && (g.ldc & 3) == 0 && (g.strideC & 3) == 0 && (reinterpret_cast<uintptr_t>(g.C) & 15) == 0;
+    bool vec_r = true;
+    if (g.R && g.r_f16 != 2)
+        vec_r = (g.ldr & 3) == 0 && (g.strideR & 3) == 0 && (g.r_group_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(g.R) & 15) == 0;
+    if (g.c_f16 == 1 && (!vec_c || !vec_r || g.k_splits > 1))
+        return fail(SF_ERR_UNSUPPORTED, "sf_gemm: c_f16 = 1 needs the vector epilogue (N, ldc, strideC, ldr, strideR %% 4 == 0, "
+                                        "16-byte aligned C / R), no split-K");
+    if (g.c_f16 == 3) {
+        const bool ok = vec_c && vec_r && g.k_splits <= 1 && (g.strideC16 & 7) == 0 &&
+                        (reinterpret_cast<uintptr_t>(g.C16) & 15) == 0 && g.ldc >= g.N;
+        if (!ok)
+            return fail(SF_ERR_UNSUPPORTED, "sf_gemm: c_f16 = 3 (fp32 + k-octet output) needs the vector epilogue (N, ldc, strideC, "
+                                            "ldr, strideR %% 4 == 0, 16-byte aligned C / R), 16-byte aligned C16, strideC16 %% 8 == 0, "
+                                            "no split-K");
+    }
+    if (g.c_f16 == 2 && (g.ldc < g.N || (g.strideC & 7) || (reinterpret_cast<uintptr_t>(g.C) & 15) || g.k_splits > 1 ||
+                         (g.epilogue != SF_EPI_NONE && g.epilogue != SF_EPI_GELU && g.epilogue != SF_EPI_RES_GELU)))
+        return fail(SF_ERR_UNSUPPORTED, "sf_gemm: c_f16 = 2 (k-octet output) needs ldc >= N, strideC %% 8 == 0, 16-byte aligned C, "
+                                        "no split-K, epilogue NONE / GELU / RES_GELU");
+    if (g.r_f16 != 0 && g.r_f16 != 2) return fail(SF_ERR_BAD_ARG, "sf_gemm: r_f16 must be 0 or 2");
+    if (g.r_f16 == 2) {
+        const bool ok = g.R && g.epilogue == SF_EPI_RES_GELU_DW1 && g.c_f16 != 2 && vec_c && g.r_group == 0 && g.ldr >= g.N &&
+                        (g.strideR & 7) == 0 && (reinterpret_cast<uintptr_t>(g.R) & 15) == 0 && g.k_splits <= 1 && g.alpha != 0.f;
+        if (!ok)
+            return fail(SF_ERR_UNSUPPORTED, "sf_gemm: r_f16 = 2 (k-octet residual) needs epilogue RES_GELU_DW1, the vector epilogue "
+                                            "(N, ldc, strideC %% 4 == 0, 16-byte aligned C), c_f16 != 2, no grouping, ldr >= N, "
+                                            "16-byte aligned R, strideR %% 8 == 0, no split-K");
+    }
+    return SF_OK;
+}
+
 }  // namespace
 
 namespace sf {
@@ -462,7 +497,7 @@ int gemm_split_dispatch_inner(const SfGemm& g, hipStream_t st);
 
 int gemm_split_dispatch(const SfGemm& g, hipStream_t st) {
     // automatic split-K through caller-provided scratch
-    if (g.k_splits == 0 && g.split_ws && !g.conv3x3 && !g.c_f16) {  // (no split-K form for the 3x3 conv / fp16 output)
+    if (g.k_splits == 0 && g.split_ws && !g.conv3x3 && !g.c_f16 && !g.r_f16) {  // (no split-K form for the 3x3 conv / fp16 output)
         const int ks = auto_splits(g.M, g.N, g.K, g.batch);
         const int64_t slab = (int64_t)g.batch * g.M * g.N;
         if (ks > 1 && g.split_ws_floats >= ks * slab) {
@@ -502,6 +537,8 @@ int gemm_split_dispatch_inner(const SfGemm& g, hipStream_t st) {
         return fail(SF_ERR_UNSUPPORTED, "sf_gemm(f16x3): operand image larger than 2 GiB (32-bit buffer offsets)");
     // tile choice: the 128-row tile moves the fewest bytes per MAC; drop to 64/32 rows when padding M would
     // waste more than a quarter of the MFMAs
+    // output / residual format rules: checked for EVERY operand layout (the fp16-in -> fp16-out hand-over is the common case)
+    if (const int rc = check_output_formats(g); rc != SF_OK) return rc;
     if (g.b_layout == SF_LAYOUT_F16_KOCT) {
         if (g.a_layout != SF_LAYOUT_SPLIT_F16 || (g.precision != SF_PRECISION_F16X2 && g.precision != SF_PRECISION_F16) ||
             (g.b_group & 31) || (g.b_group_stride & 7) || g.conv3x3 || (g.strideB & 7) ||
@@ -517,22 +554,6 @@ int gemm_split_dispatch_inner(const SfGemm& g, hipStream_t st) {
                                             "strideB, no grouping, 4-byte aligned B");
         return (g.precision == SF_PRECISION_F16) ? pick_tile<1>(a, st) : pick_tile<2>(a, st);
     }
-    if (g.c_f16 == 1 && ((g.N & 3) || (g.ldc & 3) || (g.strideC & 3) || (reinterpret_cast<uintptr_t>(g.C) & 15) || g.k_splits > 1))
-        return fail(SF_ERR_UNSUPPORTED, "sf_gemm: c_f16 needs N %% 4 == 0, ldc %% 4 == 0, strideC %% 4 == 0, 16-byte aligned C, no split-K");
-    if (g.c_f16 == 3) {
-        bool ok = (g.N & 3) == 0 && (g.ldc & 3) == 0 && (g.strideC & 3) == 0 && (reinterpret_cast<uintptr_t>(g.C) & 15) == 0 &&
-                  g.k_splits <= 1 && (g.strideC16 & 7) == 0 && (reinterpret_cast<uintptr_t>(g.C16) & 15) == 0 && g.ldc >= g.N;
-        if (g.R) ok = ok && (g.ldr & 3) == 0 && (g.strideR & 3) == 0 && (g.r_group_stride & 3) == 0 &&
-                      (reinterpret_cast<uintptr_t>(g.R) & 15) == 0;
-        if (!ok)
-            return fail(SF_ERR_UNSUPPORTED, "sf_gemm: c_f16 = 3 (fp32 + k-octet output) needs the vector epilogue (N, ldc, strideC, "
-                                            "ldr, strideR %% 4 == 0, 16-byte aligned C / R), 16-byte aligned C16, strideC16 %% 8 == 0, "
-                                            "no split-K");
-    }
-    if (g.c_f16 == 2 && (g.ldc < g.N || (g.strideC & 7) || (reinterpret_cast<uintptr_t>(g.C) & 15) || g.k_splits > 1 ||
-                         (g.epilogue != SF_EPI_NONE && g.epilogue != SF_EPI_GELU && g.epilogue != SF_EPI_RES_GELU)))
-        return fail(SF_ERR_UNSUPPORTED, "sf_gemm: c_f16 = 2 (k-octet output) needs ldc >= N, strideC %% 8 == 0, 16-byte aligned C, "
-                                        "no split-K, epilogue NONE / GELU / RES_GELU");
     if (g.b_layout == SF_LAYOUT_F16_K_MINOR) {
         if (g.a_layout != SF_LAYOUT_K_MINOR || (g.ldb & 1) || g.b_group || g.conv3x3 || (reinterpret_cast<uintptr_t>(g.B) & 3))
             return fail(SF_ERR_UNSUPPORTED, "sf_gemm(f16x3): SF_LAYOUT_F16_K_MINOR B needs a K-minor A, even ldb, 4-byte aligned B");

@@ -167,7 +167,8 @@ class _Plan:
     """Buffers for one (clips, pairs, h, w) shape."""
 
     def __init__(self, W: HotPathWeights, Bc: int, h: int, w: int, D: int, device, attn_chunk_rows: int = 0,
-                 attn_f16: bool = False, corr_f16: bool = False, flash: Optional[bool] = None, shadows: bool = False):
+                 attn_f16: bool = False, corr_f16: bool = False, flash: Optional[bool] = None, shadows: bool = False,
+                 corr_blocked: bool = False):
         Pn = W.pairs
         n, P = Bc * Pn, h * w
         self.Bc, self.Pn, self.h, self.w, self.n, self.P, self.D = Bc, Pn, h, w, n, P, D
@@ -179,12 +180,21 @@ class _Plan:
                                "is undefined there (needs images >= 128 px per side)")
         dims = [(h >> l, w >> l) for l in range(4)]
         self.lvl_pair_stride = [Bc * P * hl * wl for hl, wl in dims]
-        # correlation pyramids of all pairs: fp32 cells, or fp16 cells (corr_dtype='f16': half the bytes of the
-        # HBM-bound build and lookups; BASELINE.json configs 2 and 5)
-        self.lvls = [torch.empty(Pn * s, dtype=torch.float16 if corr_f16 else torch.float32, device=device)
-                     for s in self.lvl_pair_stride]
-        # scratch of the split-precision volume build: (hi, lo) fp16 planes of every f1 / f2 image
-        self.corr_ws = torch.empty(max(ops.corr_build_ws_bytes(Bc, Pn, D, h, w), 16), dtype=torch.uint8, device=device)
+        # blocked fp16 volumes (csrc/corr_blocked.hip): one buffer, 8 x 8-cell blocks = cache lines; the lookup then hands
+        # the correlation features over as fp16 k-octets ONLY (operand and residual of convc1's first block)
+        self.corr_blocked = bool(corr_blocked and corr_f16 and shadows)
+        if self.corr_blocked:
+            self.vol = ops.new_blocked_volume(n, h, w, device)
+            self.lvls = None
+            self.corr_ws = torch.empty(max(ops.corr_build_blocked_ws_bytes(n, D, h, w), 16), dtype=torch.uint8, device=device)
+        else:
+            self.vol = None
+            # correlation pyramids of all pairs: fp32 cells, or fp16 cells (corr_dtype='f16': half the bytes of the
+            # HBM-bound build and lookups; BASELINE.json configs 2 and 5)
+            self.lvls = [torch.empty(Pn * s, dtype=torch.float16 if corr_f16 else torch.float32, device=device)
+                         for s in self.lvl_pair_stride]
+            # scratch of the split-precision volume build: (hi, lo) fp16 planes of every f1 / f2 image
+            self.corr_ws = torch.empty(max(ops.corr_build_ws_bytes(Bc, Pn, D, h, w), 16), dtype=torch.uint8, device=device)
         # GMA attention: materialise the N x N matrix once (reference core/gma.py) when an image's matrix fits the
         # kernels' 32-bit offsets; otherwise (high resolution, e.g. 1080p: N = 32400 -> 4.2 GB per image) recompute
         # softmax(q k^T) v in row chunks every iteration, which is what the reference's demo does through
@@ -216,15 +226,19 @@ class _Plan:
                 ("hid2", 192), ("xa2", 128), ("xb2", 128),       # scratch of the flow branch (runs concurrently)
                 ("part", 128 * 4),                               # split-K slabs of attn @ v: [4][n][128][P]
                 ("splitws", 1024)]                                # scratch for sf_gemm's automatic split-K
+        if self.corr_blocked:
+            spec = [(nm, r) for nm, r in spec if nm != "corr"]          # no fp32 planes of the correlation features at all
         ws = Workspace(sum(n * r * P + 64 for _, r in spec), device)
         self.ws = ws
         for name, r in spec:
             setattr(self, name, ws.take(n, r, P))
+        if self.corr_blocked:
+            self.corr = ops.new_shadow(Planes(ws.buf, 0, COR_PLANES * P, n, COR_PLANES, P), device)   # k-octet planes only
         # f16x2 mode: the SK blocks' INPUT tensors keep an fp16 k-octet copy next to the fp32 planes (ops.Planes.shadow):
         # the first GEMM of a block reads the copy by LDS-DMA, its residual epilogue and every other kernel the planes
         self.shadows = bool(shadows)
         if self.shadows:
-            for name in ("corr", "cor256", "cat256", "concat"):
+            for name in ("cor256", "cat256", "concat") + (() if self.corr_blocked else ("corr",)):
                 setattr(self, name, replace(getattr(self, name), shadow=ops.new_shadow(getattr(self, name), device)))
         self.nets = self.concat.slice(0, 128)
         self.inps = self.concat.slice(128, 256)
@@ -268,6 +282,9 @@ class HotPathEngine:
         if corr_dtype not in ("f32", "f16"):
             raise RuntimeError(f"corr_dtype must be 'f32' or 'f16', got {corr_dtype!r}")
         self.corr_f16 = corr_dtype == "f16"
+        # fp16 volumes in the blocked layout (+ k-octet-only hand-over of the correlation features) wherever the f16x2 / f16
+        # hand-over formats are active; SF_CORR_BLOCKED=0 keeps the row-major fp16 volumes (A/B knob)
+        self.corr_blocked = self.corr_f16 and os.environ.get("SF_CORR_BLOCKED", "1") != "0"
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("HotPathEngine needs an MI355X device (cuda:N); there is no CPU fallback")
@@ -317,7 +334,8 @@ class HotPathEngine:
             pl = _Plan(self.W, Bc, h, w, D, self.device, self.attn_chunk_rows, attn_f16=split, corr_f16=self.corr_f16,
                        flash=flash, shadows=(ops.SHADOWS and (h * w) % 4 == 0 and
                                              self.precision in (ops.PRECISION_F16X2, ops.PRECISION_F16) and
-                                             os.environ.get("SF_HIDDEN_F16", "1") != "0"))
+                                             os.environ.get("SF_HIDDEN_F16", "1") != "0"),
+                       corr_blocked=self.corr_blocked)
         self._plans[key] = pl                                        # (re)insert as most recent
         return pl
 
@@ -342,8 +360,12 @@ class HotPathEngine:
         Bc, Pn, h, w, P, n, D = pl.Bc, pl.Pn, pl.h, pl.w, pl.P, pl.n, pl.D
         T = Pn + 1
         # a1+a2: all pairs, one launch.  pair t = (frame t, frame t+1)
-        ops.corr_build(fmaps.data_ptr(), fmaps.data_ptr() + 4 * D * P, T * D * P, D * P, pl.lvls, pl.lvl_pair_stride,
-                       Bc, Pn, D, h, w, ws=pl.corr_ws)
+        if pl.corr_blocked:
+            ops.corr_build_blocked(fmaps.data_ptr(), fmaps.data_ptr() + 4 * D * P, T * D * P, D * P, pl.vol, Bc, Pn, D,
+                                   ws=pl.corr_ws)
+        else:
+            ops.corr_build(fmaps.data_ptr(), fmaps.data_ptr() + 4 * D * P, T * D * P, D * P, pl.lvls, pl.lvl_pair_stride,
+                           Bc, Pn, D, h, w, ws=pl.corr_ws)
         # streamflow.py:119-122: nets = tanh(.), inps = relu(.)
         ops.context_split(cnets, pl.nets, pl.inps, HDIM)
         ops.refresh_shadow(pl.nets)
@@ -389,7 +411,10 @@ class HotPathEngine:
             ops.gemm(W.convf1, pl.flow, pl.f128, EPI_NONE)
             run_skblock(W.convf2, pl.f128, pl.cat256.slice(192, 256), pl.hid2, pl.xa2, pl.xb2, h, w)
         # ... while the main stream does a3 (correlation lookup for all pairs, streamflow.py:132) and the corr branch
-        ops.corr_lookup(pl.lvls, pl.lvl_pair_stride, pl.coords1, pl.corr, Bc, Pn, h, w)
+        if pl.corr_blocked:
+            ops.corr_lookup_blocked(pl.vol, pl.coords1, None, pl.corr, Bc, Pn)
+        else:
+            ops.corr_lookup(pl.lvls, pl.lvl_pair_stride, pl.coords1, pl.corr, Bc, Pn, h, w)
         # image ranges of the chains: whole clips when the clip count divides, else (a single clip, an odd batch) two
         # ranges of images -- every block but the flow head works image by image
         nch = self.split_solo if (self.split_solo in (2, 4) and side is not main) else 1

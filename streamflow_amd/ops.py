@@ -99,6 +99,8 @@ def on_tensor_device(fn):
             return a.device if a.is_cuda else None
         if isinstance(a, Planes):
             return a.base.device
+        if isinstance(a, BlockedVolume):
+            return a.buf.device
         if isinstance(a, torch.device):
             return a if a.type == "cuda" else None
         if isinstance(a, (list, tuple)) and a:
@@ -316,6 +318,9 @@ def gemm(A: PackedLinear, X: Planes, Y: Planes, epilogue: int = EPI_NONE, R: Opt
         assert R.rows == A.M and R.n_img == Y.n_img
         g.R, g.ldr, g.strideR = R.ptr, R.P, R.img_stride
         g.r_group, g.r_group_stride = R.group, R.group_stride
+        if R.f16:                                     # the block input exists only as fp16 k-octets (correlation features)
+            assert R.koct and R.group == 0
+            g.r_f16 = 2
     if dw_w is not None:
         g.dw_w, g.dw_b = dw_w.data_ptr(), dw_b.data_ptr()
     if A.conv3x3:
@@ -326,7 +331,7 @@ def gemm(A: PackedLinear, X: Planes, Y: Planes, epilogue: int = EPI_NONE, R: Opt
     name = "gemm" if not PROFILE_SHAPES else f"gemm M{g.M} K{g.K} b{g.batch} e{g.epilogue}"
     # algorithmic bytes: activations in (each input row once) + result out (+ residual in) per image, weights once
     nbytes = (g.batch * g.N * ((2.0 if X.f16 else 4.0) * X.rows + (2.0 if Y.f16 else 6.0 if fused_shadow else 4.0) * g.M +
-                               (4.0 * g.M if R is not None else 0.0)) + 4.0 * g.M * g.K)
+                               ((2.0 if R.f16 else 4.0) * g.M if R is not None else 0.0)) + 4.0 * g.M * g.K)
     _launch(name, 2.0 * g.M * g.N * g.K * g.batch, nbytes,
             lambda: _lib.check(_lib.load().sf_gemm(C.byref(g), _lib.stream()), "sf_gemm"))
     if not fused_shadow:
@@ -560,7 +565,8 @@ def corr_lookup(lvls: Sequence[torch.Tensor], lvl_pair_stride: Optional[Sequence
     # the k-octet copy of the output (Planes.shadow) comes out of the same kernel when the volumes are fp16
     sh = out.shadow if (out.shadow is not None and SHADOWS and vol16 and
                         os.environ.get("SF_SHADOW_FUSED", "1") != "0") else None
-    nbytes = B * pairs * (N * 4 * 100 * (2.0 if vol16 else 4.0) + N * 2 * 4.0 + N * 324 * (4.0 if sh is None else 6.0))
+    # (footprints + coords + the 324 fp32 output channels; the k-octet copy is extra traffic)
+    nbytes = B * pairs * (N * 4 * 100 * (2.0 if vol16 else 4.0) + N * 2 * 4.0 + N * 324 * 4.0)
     _launch("corr_lookup", 0, nbytes, lambda: _lib.check(_lib.load().sf_corr_lookup(
         lvls[0].data_ptr(), lvls[1].data_ptr(), lvls[2].data_ptr(), lvls[3].data_ptr(),
         pair_strides(lvl_pair_stride), coords.ptr, out.ptr, out.img_stride,
@@ -568,6 +574,87 @@ def corr_lookup(lvls: Sequence[torch.Tensor], lvl_pair_stride: Optional[Sequence
         PRECISION_F16 if vol16 else PRECISION_FP32, _lib.stream()), "sf_corr_lookup"))
     if sh is None:
         refresh_shadow(out)
+
+
+@dataclass(frozen=True)
+class BlockedVolume:
+    """Correlation pyramids of `n_img` images in the blocked fp16 layout of csrc/corr_blocked.hip (one buffer)."""
+    buf: torch.Tensor          # uint8
+    img_stride: int            # bytes
+    n_img: int
+    h: int
+    w: int
+    rec: int                   # bytes per source pixel
+    off: tuple                 # byte offset of each level inside a record
+    nby: tuple
+    nbx: tuple
+    src_rows: int              # records per image (h*w rounded up to 128)
+
+    def levels(self):
+        """The four levels as [n_img, h*w, hl, wl] fp16 tensors (copies; tests and API parity only)."""
+        N = self.h * self.w
+        recs = torch.as_strided(self.buf, (self.n_img, N, self.rec), (self.img_stride, self.rec, 1)).contiguous()
+        out = []
+        for l in range(4):
+            hl, wl, nby, nbx = self.h >> l, self.w >> l, self.nby[l], self.nbx[l]
+            blk = recs[:, :, self.off[l]: self.off[l] + nby * nbx * 128].contiguous().view(torch.float16)
+            blk = blk.view(self.n_img, N, nby, nbx, 8, 8)                 # [by][bx][tx % 8][ty % 8]
+            out.append(blk.permute(0, 1, 2, 5, 3, 4).reshape(self.n_img, N, nby * 8, nbx * 8)[:, :, :hl, :wl].contiguous())
+        return out
+
+
+def blocked_geometry(h: int, w: int):
+    rec, src = C.c_int64(), C.c_int64()
+    off, nby, nbx = (C.c_int64 * 4)(), (C.c_int32 * 4)(), (C.c_int32 * 4)()
+    _lib.check(_lib.load().sf_corr_blocked_geometry(h, w, C.byref(rec), off, nby, nbx, C.byref(src)),
+               "sf_corr_blocked_geometry")
+    return int(rec.value), tuple(int(v) for v in off), tuple(int(v) for v in nby), tuple(int(v) for v in nbx), int(src.value)
+
+
+def new_blocked_volume(n_img: int, h: int, w: int, device) -> BlockedVolume:
+    rec, off, nby, nbx, src = blocked_geometry(h, w)
+    stride = src * rec                                      # a multiple of 128 (rec is)
+    buf = torch.empty(n_img * stride + 128, dtype=torch.uint8, device=device)
+    pad = (-buf.data_ptr()) % 128
+    return BlockedVolume(buf[pad: pad + n_img * stride], stride, n_img, h, w, rec, off, nby, nbx, src)
+
+
+def corr_build_blocked_ws_bytes(n_img: int, D: int, h: int, w: int) -> int:
+    return int(_lib.load().sf_corr_build_blocked_ws_bytes(n_img, D, h, w))
+
+
+@on_tensor_device
+def corr_build_blocked(f1_ptr: int, f2_ptr: int, clip_stride: int, pair_stride: int, vol: BlockedVolume, B: int,
+                       pairs: int, D: int, ws: Optional[torch.Tensor] = None) -> None:
+    """a1 + a2 into a BlockedVolume (fp16 cells, single f16 MFMA products, fp32 accumulation)."""
+    h, w = vol.h, vol.w
+    N = h * w
+    assert vol.n_img == B * pairs
+    need = corr_build_blocked_ws_bytes(B * pairs, D, h, w)
+    if ws is None or ws.numel() * ws.element_size() < need:
+        ws = torch.empty(need, dtype=torch.uint8, device=vol.buf.device)
+    cells = sum((h >> l) * (w >> l) for l in range(4))
+    nbytes = B * pairs * (2.0 * N * D * 4 + 2.0 * N * cells)          # SURVEY.md section 8d, e = 2
+    _launch("corr_build", 2.0 * N * N * D * B * pairs, nbytes, lambda: _lib.check(
+        _lib.load().sf_corr_build_blocked(f1_ptr, f2_ptr, clip_stride, pair_stride, vol.buf.data_ptr(), vol.img_stride,
+                                          B, pairs, D, h, w, ws.data_ptr(), need, _lib.stream()),
+        "sf_corr_build_blocked"))
+
+
+@on_tensor_device
+def corr_lookup_blocked(vol: BlockedVolume, coords: Planes, out: Optional[Planes], out_koct: Optional[Planes], B: int,
+                        pairs: int) -> None:
+    """a3 from a BlockedVolume: `out_koct` (fp16 k-octet planes of the 324 features) and / or `out` (fp32 planes)."""
+    h, w = vol.h, vol.w
+    N = h * w
+    assert coords.img_stride == 2 * N and vol.n_img == B * pairs
+    assert out is None or (out.rows == 324 and out.n_img == B * pairs and not out.f16)
+    assert out_koct is None or (out_koct.rows == 324 and out_koct.n_img == B * pairs and out_koct.koct)
+    nbytes = B * pairs * (N * 4 * 100 * 2.0 + N * 2 * 4.0 + N * 324 * 4.0)      # SURVEY.md section 8d, e = 2
+    _launch("corr_lookup", 0, nbytes, lambda: _lib.check(_lib.load().sf_corr_lookup_blocked(
+        vol.buf.data_ptr(), vol.img_stride, coords.ptr, None if out is None else out.ptr,
+        0 if out is None else out.img_stride, None if out_koct is None else out_koct.ptr,
+        0 if out_koct is None else out_koct.img_stride, B, pairs, h, w, _lib.stream()), "sf_corr_lookup_blocked"))
 
 
 @on_tensor_device

@@ -33,9 +33,58 @@ def test_every_declared_symbol_is_exported(lib):
 def test_struct_layout_matches_header():
     from streamflow_amd._lib import SfGemm
     # 8 pointers + 4 i32 + 8 i64 + 2 i32 + (i32,pad,i64)*2 + 3 i32 + f32 + 2 i32  (natural alignment)
-    assert ctypes.sizeof(SfGemm) == 288                         # ... + split-K fields + c_f16 (offset 264) + C16, strideC16
+    assert ctypes.sizeof(SfGemm) == 296                         # ... + split-K fields + c_f16 (offset 264) + C16, strideC16, r_f16
     assert SfGemm.lda.offset == 80 and SfGemm.b_group_stride.offset == 160 and SfGemm.alpha.offset == 196
     assert SfGemm.c_f16.offset == 264 and SfGemm.C16.offset == 272 and SfGemm.strideC16.offset == 280
+    assert SfGemm.r_f16.offset == 288
+
+
+def test_blocked_volume_geometry(lib):
+    """sf_corr_blocked_geometry (host-only): records of 8 x 8-cell blocks, levels floor-halved (corr.py:19-21)."""
+    from streamflow_amd import ops
+    rec, off, nby, nbx, src = ops.blocked_geometry(55, 128)                  # Sintel 440 x 1024
+    assert (nby, nbx) == ((7, 4, 2, 1), (16, 8, 4, 2)) and rec == 128 * (112 + 32 + 8 + 2) == 19712
+    assert off == (0, 112 * 128, 144 * 128, 152 * 128) and src == 7040
+    rec, off, nby, nbx, src = ops.blocked_geometry(47, 156)                  # KITTI 376 x 1248: 23x78, 11x39, 5x19
+    assert (nby, nbx) == ((6, 3, 2, 1), (20, 10, 5, 3)) and rec == 128 * (120 + 30 + 10 + 3) and src == 7424
+    assert lib.sf_corr_blocked_bytes(3, 55, 128) == 3 * 7040 * 19712
+    assert lib.sf_corr_blocked_geometry(7, 64, None, None, None, None, None) == -1
+    assert b"too small" in lib.sf_last_error()
+    assert lib.sf_corr_build_blocked_ws_bytes(2, 256, 55, 128) == 2 * 2 * 32 * 7048 * 16
+
+
+def test_gemm_output_format_rules_hold_for_every_b_layout(lib):
+    """the c_f16 rules were skipped for fp16 B operands (the common hand-over case): a K-major fp16 B with
+    c_f16 = 1 and N = 6 would have run the scalar fp32 epilogue into a buffer sized for halves.  Validation happens
+    before any launch, so this runs without a GPU (dummy, never dereferenced pointers)."""
+    from streamflow_amd import _lib
+    from streamflow_amd._lib import SfGemm
+
+    def desc(**kw):
+        g = SfGemm()
+        g.A, g.B, g.C, g.A_hi, g.A_lo = 4096, 4096, 4096, 4096, 8192
+        g.M, g.N, g.K, g.batch = 128, 6, 64, 1
+        g.lda, g.ldb, g.ldc, g.lda_h = 128, 6, 6, 128
+        g.a_layout, g.alpha, g.precision = _lib.LAYOUT_SPLIT_F16, 1.0, _lib.PRECISION_F16X2
+        for k, v in kw.items():
+            setattr(g, k, v)
+        return g
+
+    for blay in (_lib.LAYOUT_F16_K_MAJOR, _lib.LAYOUT_F16_KOCT):
+        for cf in (1, 3):
+            g = desc(b_layout=blay, c_f16=cf, C16=4096)
+            assert lib.sf_gemm(ctypes.byref(g), None) == -2, (blay, cf)
+            assert b"c_f16" in lib.sf_last_error()
+    g = desc(b_layout=_lib.LAYOUT_F16_KOCT, c_f16=2, N=8, ldb=8, ldc=8, epilogue=_lib.EPI_RELU)
+    assert lib.sf_gemm(ctypes.byref(g), None) == -2 and b"c_f16 = 2" in lib.sf_last_error()
+    g = desc(b_layout=_lib.LAYOUT_F16_KOCT, N=8, ldb=8, ldc=8, k_splits=2, c_f16=1)
+    assert lib.sf_gemm(ctypes.byref(g), None) == -2
+    # k-octet residual: only with the RES_GELU_DW1 vector epilogue
+    g = desc(b_layout=_lib.LAYOUT_F16_KOCT, N=8, ldb=8, ldc=8, ldr=8, R=4096, r_f16=2, epilogue=_lib.EPI_RES_GELU)
+    assert lib.sf_gemm(ctypes.byref(g), None) == -2 and b"r_f16" in lib.sf_last_error()
+    g = desc(b_layout=_lib.LAYOUT_F16_KOCT, N=6, ldb=6, ldc=6, ldr=6, R=4096, r_f16=2, epilogue=_lib.EPI_RES_GELU_DW1,
+             dw_w=4096, dw_b=4096)
+    assert lib.sf_gemm(ctypes.byref(g), None) == -2 and b"r_f16" in lib.sf_last_error()
 
 
 def test_bad_arguments_return_error_codes(lib):

@@ -1,0 +1,137 @@
+"""Blocked fp16 correlation volumes (csrc/corr_blocked.hip; reference core/corr.py:7-54) through the C ABI:
+build vs the oracle pyramid of the fp16-rounded features, lookup vs the oracle lookup on the stored cells, the k-octet
+hand-over, robustness against garbage in the padding cells, and the k-octet residual of sf_gemm (SfGemm.r_f16)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need an MI355X; torch.cuda.is_available() is False")
+    return torch.device("cuda:0")
+
+
+def _coords(orc, B, h, w, g, scale=4.0):
+    c = orc.coords_grid(B, h, w) + torch.randn(B, 2, h, w, generator=g) * scale
+    c[:, :, 0, 0] = torch.tensor([-6.0, 2.0])                        # window partly outside
+    c[:, :, 1, 1] = torch.tensor([float(w + 9), float(h + 9)])       # fully outside
+    c[:, :, 2, 2] = torch.tensor([3.0, 4.0])                         # exactly integer
+    c[:, :, 3, 3] = torch.tensor([float(w - 1), float(h - 1)])       # last cell
+    c[:, :, 4, 4] = torch.tensor([float("nan"), 1.0])                # swallowed: samples zero padding
+    c[:, :, 5, 5] = torch.tensor([3.0, float(h) - 0.5])              # footprint crosses the padded last block row
+    return c
+
+
+# shapes: block-aligned, ragged in both dims, minimal (16 x 16: a 1-pixel coarsest level is NaN in the reference, utils.py:69-70), odd pooled sizes (KITTI-like 47 x 156 levels 23x78 / 11x39 / 5x19)
+SHAPES = [(1, 32, 16, 24), (2, 16, 17, 19), (1, 40, 16, 16), (1, 256, 47, 156), (3, 16, 9, 40), (1, 64, 33, 65), (2, 256, 24, 41)]
+
+
+@pytest.mark.parametrize("B,D,h,w", SHAPES)
+def test_blocked_build_and_lookup_vs_oracle(dev, B, D, h, w):
+    from oracle import streamflow_oracle as orc
+    import streamflow_amd as sfa
+    g = torch.Generator().manual_seed(B * 1000 + h * 10 + w)
+    f1, f2 = torch.randn(B, D, h, w, generator=g), torch.randn(B, D, h, w, generator=g)
+    coords = _coords(orc, B, h, w, g)
+    blk = sfa.CorrBlock(f1.to(dev), f2.to(dev), num_levels=4, radius=4, dtype=torch.float16, layout="blocked")
+    out = blk(coords.to(dev)).cpu()
+    lv = [t.cpu() for t in blk.corr_pyramid]
+    pyr = orc.corr_pyramid(f1.half().float(), f2.half().float(), 4)
+    for l, (a, b_) in enumerate(zip(lv, pyr)):
+        assert a.dtype == torch.float16 and a.shape == b_.shape, (l, a.shape, b_.shape)
+        err = (a.float() - b_).abs()
+        tol = 2.0 ** -11 * b_.abs() + 3e-5
+        assert (err <= tol).all(), (l, (err - tol).max().item())
+    cc = coords.clone()
+    cc[torch.isnan(cc)] = -1.0e6
+    ref = orc.corr_lookup([t.float() for t in lv], cc, 4)
+    assert torch.isfinite(out).all()
+    assert (out - ref).abs().max().item() < 5e-5
+
+
+@pytest.mark.parametrize("B,pairs,D,h,w", [(2, 3, 32, 17, 28), (1, 1, 16, 47, 156), (1, 3, 256, 55, 128)])
+def test_blocked_koct_output_and_padding_garbage(dev, B, pairs, D, h, w):
+    """The k-octet product is the fp16 rounding of the fp32 planes of the same launch, bit for bit; rows 324..327 are
+    zero; and neither output changes when the volume buffer was full of NaN bit patterns before the build (padding cells
+    of partial blocks are never read as data)."""
+    from oracle import streamflow_oracle as orc
+    from streamflow_amd import ops
+    from streamflow_amd.ops import Planes
+    n, N = B * pairs, h * w
+    g = torch.Generator().manual_seed(7 + h)
+    fm = torch.randn(B, pairs + 1, D, h, w, generator=g).to(dev)
+    coords = _coords(orc, n, h, w, g, 3.0).to(dev).contiguous()
+    outs = []
+    for fill in (0x00, 0xFF):
+        vol = ops.new_blocked_volume(n, h, w, dev)
+        vol.buf.fill_(fill)
+        ops.corr_build_blocked(fm.data_ptr(), fm.data_ptr() + 4 * D * N, (pairs + 1) * D * N, D * N, vol, B, pairs, D)
+        out = torch.full((n, 324, N), float("nan"), device=dev)
+        ko = ops.new_shadow(Planes.of(out), dev)
+        ko.base.fill_(float("nan"))
+        ops.corr_lookup_blocked(vol, Planes.of(coords), Planes.of(out), ko, B, pairs)
+        torch.cuda.synchronize()
+        raw = ko.base.view(torch.float16).view(n, 41, N, 8)
+        assert (raw[:, 40, :, 4:] == 0).all()
+        outs.append((out.cpu(), ko.tensor().cpu(), [t.cpu() for t in vol.levels()]))
+    a, b = outs
+    assert torch.isfinite(a[0]).all() and torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert torch.equal(a[1], a[0].half())
+    for x, y in zip(a[2], b[2]):
+        assert torch.equal(x, y)
+    # per-pair addressing: image (clip b, pair t) is the volume of frames (t, t + 1) of clip b
+    lv = a[2]
+    fmc = fm.cpu()
+    for (b_, t) in ((0, 0), (B - 1, pairs - 1)):
+        pyr = orc.corr_pyramid(fmc[b_:b_ + 1, t].half().float(), fmc[b_:b_ + 1, t + 1].half().float(), 4)
+        for l in range(4):
+            got = lv[l][b_ * pairs + t].float().reshape(pyr[l].shape)
+            assert ((got - pyr[l]).abs() <= 2.0 ** -11 * pyr[l].abs() + 3e-5).all(), (b_, t, l)
+
+
+def test_blocked_matches_row_major_fp16_path(dev):
+    """Same arithmetic, two layouts: the cells of the blocked build equal the row-major fp16 build bit for bit."""
+    import streamflow_amd as sfa
+    g = torch.Generator().manual_seed(3)
+    f1, f2 = torch.randn(2, 256, 23, 37, generator=g).to(dev), torch.randn(2, 256, 23, 37, generator=g).to(dev)
+    a = sfa.CorrBlock(f1, f2, dtype=torch.float16)
+    b = sfa.CorrBlock(f1, f2, dtype=torch.float16, layout="blocked")
+    for x, y in zip(a.corr_pyramid, b.corr_pyramid):
+        assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("M,K,P,n", [(324, 486, 7040, 2), (200, 96, 300, 3), (128, 64, 36, 1)])
+def test_gemm_koct_residual(dev, M, K, P, n):
+    """SfGemm.r_f16 = 2: C = gelu(t + dw_w t + dw_b), t = gelu(R + W X + b), with R an fp16 k-octet image (here: the
+    k-octet copy of X's block input, as in convc1's ffn1.2) -- against float64 on the same fp16 residual values."""
+    import torch.nn.functional as F
+    from streamflow_amd import ops
+    from streamflow_amd.ops import Planes, PackedLinear
+    g = torch.Generator().manual_seed(M + K)
+    Wt, bias = torch.randn(M, K, generator=g) / K ** 0.5, torch.randn(M, generator=g) * 0.1
+    dw_w, dw_b = torch.randn(M, generator=g) * 0.3, torch.randn(M, generator=g) * 0.1
+    X, R = torch.randn(n, K, P, generator=g), torch.randn(n, M, P, generator=g)
+    prev = ops.set_precision("f16x2")
+    try:
+        A = PackedLinear(Wt.reshape(M, K, 1, 1), bias, dev)
+        Rp = Planes.of(R.to(dev))
+        Rk = ops.new_shadow(Rp, dev)
+        ops.pack_koct(Rp, Rk)
+        Y = torch.full((n, M, P), float("nan"), device=dev)
+        ops.gemm(A, Planes.of(X.to(dev)), Planes.of(Y), ops.EPI_RES_GELU_DW1, R=Rk, dw_w=dw_w.to(dev), dw_b=dw_b.to(dev))
+        Y2 = torch.full((n, M, P), float("nan"), device=dev)
+        ops.gemm(A, Planes.of(X.to(dev)), Planes.of(Y2), ops.EPI_RES_GELU_DW1, R=Planes.of(R.half().float().to(dev)),
+                 dw_w=dw_w.to(dev), dw_b=dw_b.to(dev))
+        torch.cuda.synchronize()
+    finally:
+        ops.set_precision(prev)
+    ge = lambda t: F.gelu(t)
+    t = ge(R.half().double() + torch.einsum("mk,nkp->nmp", Wt.double(), X.half().double()) + bias.double()[None, :, None])
+    ref = ge(t + dw_w.double()[None, :, None] * t + dw_b.double()[None, :, None])
+    assert (Y.double().cpu() - ref).abs().max().item() < 2e-4
+    # and within fp32 rounding of the fp32-residual epilogue fed the same (fp16-representable) residual values
+    assert (Y - Y2).abs().max().item() < 2e-5

@@ -345,9 +345,11 @@ def test_kitti_shape_T2_vs_oracle(dev, preset):
             assert (got - pyr[l]).abs().max().item() < 5e-5, f"level {l}"
     else:
         pyr = orc.corr_pyramid(fmaps[:, 0].half().float(), fmaps[:, 1].half().float())
+        assert pl.corr_blocked                                   # the preset's fp16 volumes live in the blocked layout
+        lv = pl.vol.levels()
         for l in range(4):
-            got = pl.lvls[l].view(pyr[l].shape).float().cpu()
-            assert pl.lvls[l].dtype == torch.float16
+            got = lv[l].reshape(pyr[l].shape).float().cpu()
+            assert lv[l].dtype == torch.float16
             assert ((got - pyr[l]).abs() <= 2.0 ** -11 * pyr[l].abs() + 3e-5).all(), f"level {l}"
     ups_o, _ = orc.hotpath_forward(fmaps, cnets, P, 2)
     e = orc.epe(ups[0].cpu(), ups_o[0])
