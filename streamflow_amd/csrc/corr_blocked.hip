@@ -24,6 +24,7 @@
 // image of the first GEMM of the correlation encoder; fp32 planes are optional (API parity / tests).
 #include "sf_common.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -79,21 +80,25 @@ __device__ __forceinline__ float dpp_shl1(float v) {     // lane + 1 inside a ro
 // ------------------------------------------------------------------------------------------------
 // build
 // ------------------------------------------------------------------------------------------------
-constexpr int BM = 128;           // source pixels per workgroup (4 waves x 32)
 constexpr int PR = 8, PC = 32;    // target patch: 8 rows x 32 columns = one block row of four blocks
-constexpr int BN = PR * PC;
-constexpr int FK = 32;            // k per stage
-constexpr int FST_A = (FK / 8) * BM * 16;
-constexpr int FST_B = (FK / 8) * BN * 16;
-constexpr int FSTAGE = FST_A + FST_B;          // 24 KB, two stages, three workgroups per CU
+constexpr int BN = PR * PC;       // 256 target cells
+constexpr int KD = 256;           // feature depth the resident-patch kernel is built for (the StreamFlow encoders: 256)
+#ifndef SF_CORRB_NW
+#define SF_CORRB_NW 8
+#endif
+constexpr int NW = SF_CORRB_NW;   // waves per workgroup: 8 = 2 per SIMD with a 256-register budget, 12 = 3 per SIMD with 168
+constexpr int kBuildThreads = NW * 64;
+constexpr int kPatchBytes = (KD / 8) * BN * 16;          // 128 KB: the whole patch, all k, resident in LDS
+constexpr int kTilesPerItem = 60;                         // 32-source tiles per work item (~5 per wave)
 
 struct BuildArgs {
     const char* ws;               // packed features: image (img, side) = [Dp / 8][Np][8] halves, pixel N.. = zeros
     char* vol;
     int64_t vol_img_stride;       // bytes
-    int n_img, Dp, h, w, N, Np;
+    int n_img, h, w, N, Np;
     VolGeom g;
-    int pcols, np, mt, pblk;      // patch columns, patches per image, m-tiles, patches per L2-resident block
+    int pcols, np;                // patch columns, patches per image
+    int ntiles, nchunks, tpc;     // 32-source tiles per image, chunks per image, tiles per chunk
     float scale;
 #ifdef SF_CORR_TIMERS
     long long* ts;
@@ -116,184 +121,206 @@ __global__ __launch_bounds__(256) void pack_f16z_kernel(const float* f1, const f
     *reinterpret_cast<f16x8*>(ws + (int64_t)blockIdx.z * plane + ((int64_t)kq * Np + px) * 16) = hv;
 }
 
-struct TileId { int img, m_tile, patch; };
-// 1-D grid in XCD-aware order [image][patch block][m-tile][patch in block]: the `pblk` target patches of a block stay in
-// the XCD's L2 while all m-tiles stream past them
-__device__ __forceinline__ TileId build_tile(const BuildArgs& g, int id) {
-    const int per_img = g.np * g.mt;
-    TileId t;
-    t.img = id / per_img;
-    int r = id % per_img;
-    const int full = g.np / g.pblk;
-    if (r < full * g.pblk * g.mt) {
-        const int blk = r / (g.pblk * g.mt), r2 = r % (g.pblk * g.mt);
-        t.m_tile = r2 / g.pblk;
-        t.patch = blk * g.pblk + r2 % g.pblk;
-    } else {
-        r -= full * g.pblk * g.mt;
-        const int rem = g.np - full * g.pblk;
-        t.m_tile = r / rem;
-        t.patch = full * g.pblk + r % rem;
-    }
-    return t;
-}
-
 #ifndef SF_CORRB_NT
 #define SF_CORRB_NT 2            // cache policy of the level-0 stores (2 = non-temporal)
 #endif
-#ifndef SF_CORRB_WG
-#define SF_CORRB_WG 3            // workgroups per CU the register budget is sized for
-#endif
 
-__global__ __launch_bounds__(kThreads, SF_CORRB_WG) void corr_build_blocked_kernel(const BuildArgs g) {
-    __shared__ __attribute__((aligned(1024))) char smem[2 * FSTAGE];
+// BUILD, resident-patch form.  Work item = (image, chunk of source tiles, target patch); one workgroup of 12 waves per
+// item and CU.  The patch's features for ALL 256 k (128 KB) are DMA'd into LDS once; after ONE barrier every wave is on
+// its own: it draws 32-source tiles from a workgroup counter, streams that tile's A fragments straight from L2 into
+// registers (a lane's fragment is one 16-byte k-octet of one pixel: no LDS, no DMA, ring of four in flight), reads B
+// fragments from the resident patch, and runs its epilogue while the other two waves of its SIMD keep the matrix pipe
+// busy.  No barrier, no DMA and no shared staging buffer inside the loop.
+// (The first blocked kernel kept round 2's structure -- 128 x 256 tile per workgroup, both operands staged through a
+// 2- or 3-stage LDS ring -- and measured 27k cycles of k-loop per tile of which 4.1k were MFMA issue: every wave sat
+// ~190 cycles in each of its 48 LDS-DMA instructions and ~0.5k cycles per stage at the barrier; interleaving the DMA
+// instructions with the MFMAs moved that time, it did not remove it.  tools/corrb_bench.py)
+__global__ __launch_bounds__(kBuildThreads, NW / 4) void corr_build_blocked_kernel(const BuildArgs g) {
+    __shared__ __attribute__((aligned(1024))) char smem[kPatchBytes + 16];
 #ifdef SF_CORR_TIMERS
     const long long ts0 = __builtin_readcyclecounter();
     const long long rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int khalf = lane >> 5, l31 = lane & 31;
-    const TileId tile = build_tile(g, sf::xcd_linear_id(blockIdx.x, gridDim.x));
-    const int m0 = tile.m_tile * BM;
-    const int by0 = tile.patch / g.pcols, pxb = tile.patch % g.pcols;
+    const int khalf = lane >> 5, l31_ = lane & 31;
+    // item order [image][chunk][patch]: the workgroups that run side by side on an XCD share the chunk's source features
+    const int item = sf::xcd_linear_id(blockIdx.x, gridDim.x);
+    const int patch = item % g.np, chunk = (item / g.np) % g.nchunks, img = item / (g.np * g.nchunks);
+    const int by0 = patch / g.pcols, pxb = patch % g.pcols;
     const int py0 = by0 * PR, px0 = pxb * PC;
-    const int plane = (g.Dp / 8) * g.Np * 16;                     // bytes of one packed image (< 2 GiB, host-checked)
+    const int plane = (KD / 8) * g.Np * 16;                       // bytes of one packed image (< 2 GiB, host-checked)
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char*>(g.ws) + (int64_t)(tile.img * 2 + 0) * plane, 0, plane, 0x00020000);
+        const_cast<char*>(g.ws) + (int64_t)(img * 2 + 0) * plane, 0, plane, 0x00020000);
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char*>(g.ws) + (int64_t)(tile.img * 2 + 1) * plane, 0, plane, 0x00020000);
-    // A slot = kq*128 + source pixel: a piece of 256 threads covers two k-octets; B slot = kq*256 + cell (cell = patch
-    // row * 32 + patch column): one k-octet per piece.  Source pixels past N are clamped (their records are padding);
-    // patch cells outside the image read the zero pixel.
-    const int voa = ((tid >> 7) * g.Np + min(m0 + (tid & 127), g.N - 1)) * 16;
-    const int ty = py0 + tid / PC, tx = px0 + tid % PC;
-    const int vob = ((ty < g.h && tx < g.w) ? ty * g.w + tx : g.N) * 16;
+        const_cast<char*>(g.ws) + (int64_t)(img * 2 + 1) * plane, 0, plane, 0x00020000);
     const int kq_step = g.Np * 16;
-
-    auto issue = [&](int kt, int buf) {
-        char* sb = smem + buf * FSTAGE + wave * 1024;
-        const int so = kt * (FK / 8) * kq_step;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)(sb), 16, voa, so, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)(sb + 4096), 16, voa, so + 2 * kq_step, 0, 0);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr)(sb + FST_A + j * 4096), 16, vob, so + j * kq_step, 0, 0);
-    };
-
-    f32x16 acc[PR];
-#pragma unroll
-    for (int t = 0; t < PR; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-
-#if defined(SF_CORRB_ABLATE) && SF_CORRB_ABLATE == 2      // timing ablation: one k-stage only
-    const int nk = 1;
-#else
-    const int nk = g.Dp / FK;
-#endif
-    const int offa = (khalf * BM + wave * 32 + l31) * 16;
-    const int offb = FST_A + (khalf * BN + l31) * 16;
-    issue(0, 0);
-    for (int kt = 0; kt < nk; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's pieces of stage kt have landed ...
-        __builtin_amdgcn_s_barrier();                            // ... everyone's; the other slot is no longer read
-        if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
-        const char* sb = smem + (kt & 1) * FSTAGE;
-#pragma unroll
-        for (int ks = 0; ks < FK / 16; ++ks) {
-            const f16x8 a = *reinterpret_cast<const f16x8*>(sb + offa + ks * 2 * BM * 16);
-#pragma unroll
-            for (int t = 0; t < PR; ++t) {
-                const f16x8 bv = *reinterpret_cast<const f16x8*>(sb + offb + ks * 2 * BN * 16 + t * PC * 16);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bv, acc[t], 0, 0, 0);
-            }
-        }
+    int* const counter = reinterpret_cast<int*>(smem + kPatchBytes);
+    if (tid == 0) *counter = 0;
+    // ---- the patch: LDS slot = k-octet * 256 + cell (cell = patch row * 32 + patch column), 128 pieces of 1 KB; piece p
+    // covers k-octet p / 4, cells (p % 4) * 64 + lane.  Wave w takes pieces w, w + 12, ...: always cell group w % 4.
+    // Cells outside the image read the zero pixel. ----
+    {
+        const int cell = (wave & 3) * 64 + lane;
+        const int ty = py0 + cell / PC, tx = px0 + cell % PC;
+        const int vob = ((ty < g.h && tx < g.w) ? ty * g.w + tx : g.N) * 16;
+        static_assert(NW % 4 == 0, "a wave keeps its cell group");
+        for (int p = wave; p < (KD / 8) * 4; p += NW)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr)(smem + p * 1024), 16, vob, (p >> 2) * kq_step, 0, 0);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
 #ifdef SF_CORR_TIMERS
     const long long ts1 = __builtin_readcyclecounter();
+    long long t_k = 0, t_e = 0;
+    int n_t = 0;
 #endif
 
-    // ---- epilogue: C/D layout = lane (target column l31, k-half), register r = source row (r&3) + 8(r>>2) + 4 khalf,
-    // acc[t] = patch row t.  A lane's eight values of one register are one block column of level 0. ----
     const int rec = g.g.rec;
-    const int i0 = m0 + wave * 32;
-    char* const base = g.vol + (int64_t)tile.img * g.vol_img_stride + (int64_t)i0 * rec;
-    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(base, 0, 32 * rec, 0x00020000);
-    const int rowh = 4 * khalf * rec;
-    // level 0: four consecutive blocks of block row by0 -> 512 contiguous bytes per source row
-    const int vo0_ = ((px0 >> 3) + (l31 >> 3) < g.g.nbx[0])
-                        ? rowh + g.g.off[0] + (by0 * g.g.nbx[0] + (px0 >> 3)) * 128 + l31 * 16 : kDrop;
-    // level 1: lane pair (2j, 2j+1) holds cell column j of the patch's 4 x 16 level-1 cells: rows 4 (by0 & 1) .. +3 of
-    // block row by0 >> 1, an 8-byte piece; lane parity k1 stores source row (2 j2 + k1) of a register pair
-    const int j1 = l31 >> 1, k1 = l31 & 1;
-    const int by1 = by0 >> 1, bx1 = 2 * pxb + (j1 >> 3);
-    const int vo1_ = (by1 < g.g.nby[1] && bx1 < g.g.nbx[1])
-                        ? rowh + k1 * rec + g.g.off[1] + (by1 * g.g.nbx[1] + bx1) * 128 + (j1 & 7) * 16 + (by0 & 1) * 8 : kDrop;
-    // level 2: lane quad = cell column l31 >> 2 of 2 x 8 cells: rows 2 (by0 & 3) .. +1 of block row by0 >> 2 (4 bytes);
-    // lane k2 of the quad stores source row k2 of a register group
-    const int j2c = l31 >> 2, k2 = l31 & 3;
-    const int by2 = by0 >> 2;
-    const int vo2_ = (by2 < g.g.nby[2] && pxb < g.g.nbx[2])
-                        ? rowh + k2 * rec + g.g.off[2] + (by2 * g.g.nbx[2] + pxb) * 128 + j2c * 16 + (by0 & 3) * 4 : kDrop;
-    // level 3: lanes 0..3 of an octet hold cell column 4 pxb + (l31 >> 3), row by0 & 7 of block row by0 >> 3 (2 bytes)
-    const int k3 = l31 & 7, tx3 = 4 * pxb + (l31 >> 3);
-    const int by3 = by0 >> 3;
-    const int vo3_ = (k3 < 4 && by3 < g.g.nby[3] && (tx3 >> 3) < g.g.nbx[3])
-                        ? rowh + k3 * rec + g.g.off[3] + (by3 * g.g.nbx[3] + (tx3 >> 3)) * 128 + (tx3 & 7) * 16 + (by0 & 7) * 2 : kDrop;
-    constexpr int kNt = SF_CORRB_NT;
-#if defined(SF_CORRB_ABLATE) && SF_CORRB_ABLATE == 1      // timing ablation: no stores leave the CU
-    const int vo0 = kDrop | (vo0_ & 0), vo1 = kDrop | (vo1_ & 0), vo2 = kDrop | (vo2_ & 0), vo3 = kDrop | (vo3_ & 0);
+    const int t_begin = chunk * g.tpc, t_count = min(g.tpc, g.ntiles - t_begin);
+    char* const img_base = g.vol + (int64_t)img * g.vol_img_stride;
+    const char* const sbB = smem + (khalf * BN + l31_) * 16;       // + (2 ks * 256 + t * 32) * 16
+
+    for (;;) {
+        int tile = 0;
+        if (lane == 0) tile = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        tile = __builtin_amdgcn_readfirstlane(tile);
+        if (tile >= t_count) break;
+#ifdef SF_CORR_TIMERS
+        const long long tt0 = __builtin_readcyclecounter();
+#endif
+        const int i0 = (t_begin + tile) * 32;                     // first source pixel of the tile
+        // A fragment of k-step ks: k-octet 2 ks + khalf of source pixel i0 + l31 (pixels past N clamped: padding records)
+        const int voa = (khalf * g.Np + min(i0 + l31_, g.N - 1)) * 16;
+        f32x16 acc[PR];
+#pragma unroll
+        for (int t = 0; t < PR; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        constexpr int kSteps = KD / 16, kRing = (NW <= 8) ? 4 : 2;
+        u32x4 af[kRing];
+#pragma unroll
+        for (int s = 0; s < kRing; ++s) af[s] = __builtin_amdgcn_raw_buffer_load_b128(ra, voa, s * 2 * kq_step, 0);
+#if defined(SF_CORRB_ABLATE) && SF_CORRB_ABLATE == 2      // timing ablation: four k-steps only
+        constexpr int kRun = 4;
 #else
-    const int vo0 = vo0_, vo1 = vo1_, vo2 = vo2_, vo3 = vo3_;
+        constexpr int kRun = kSteps;
 #endif
 #pragma unroll
-    for (int rq = 0; rq < 4; ++rq) {                       // register group: source rows 8 rq + 4 khalf + (0..3)
-        float sel2[2] = {0.f, 0.f}, sel3 = 0.f;
+        for (int ks = 0; ks < kRun; ++ks) {
+            const f16x8 a = __builtin_bit_cast(f16x8, af[ks % kRing]);
 #pragma unroll
-        for (int jp = 0; jp < 2; ++jp) {                   // register pair (2 jp, 2 jp + 1) of the group
-            float sel1[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int ri = 2 * jp + u, r = 4 * rq + ri;
-                float v0[PR];
-#pragma unroll
-                for (int t = 0; t < PR; ++t) v0[t] = acc[t][r] * g.scale;
-                u32x4 o;
-#pragma unroll
-                for (int t = 0; t < 4; ++t) o[t] = pack_h2(v0[2 * t], v0[2 * t + 1]);
-                __builtin_amdgcn_raw_buffer_store_b128(o, rv, vo0, (ri + 8 * rq) * rec, kNt);
-                float v1[4], v2[2];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const float s = v0[2 * t] + v0[2 * t + 1];
-                    v1[t] = 0.25f * (s + dpp_xor1(s));
-                    sel1[t] = (k1 == u) ? v1[t] : sel1[t];
-                }
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const float s = v1[2 * t] + v1[2 * t + 1];
-                    v2[t] = 0.25f * (s + dpp_xor2(s));
-                    sel2[t] = (k2 == ri) ? v2[t] : sel2[t];
-                }
-                const float s = v2[0] + v2[1];
-                const float v3 = 0.25f * (s + dpp_shl4(s));
-                sel3 = (k3 == ri) ? v3 : sel3;
+            for (int t = 0; t < PR; ++t) {
+                const f16x8 bv = *reinterpret_cast<const f16x8*>(sbB + (ks * 2 * BN + t * PC) * 16);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bv, acc[t], 0, 0, 0);
             }
-            u32x2 o1;
-            o1[0] = pack_h2(sel1[0], sel1[1]);
-            o1[1] = pack_h2(sel1[2], sel1[3]);
-            __builtin_amdgcn_raw_buffer_store_b64(o1, rv, vo1, (2 * jp + 8 * rq) * rec, 0);
+            if (ks + kRing < kRun) af[ks % kRing] = __builtin_amdgcn_raw_buffer_load_b128(ra, voa, (ks + kRing) * 2 * kq_step, 0);
         }
-        __builtin_amdgcn_raw_buffer_store_b32(pack_h2(sel2[0], sel2[1]), rv, vo2, (8 * rq) * rec, 0);
-        const _Float16 h3 = (_Float16)sel3;
-        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, h3), rv, vo3, (8 * rq) * rec, 0);
+        // Issue order of the whole (fully unrolled) k-loop, pinned: the four A loads of the ring first, then B fragment
+        // reads running kAhead MFMAs ahead of their use, one A refill behind every eighth MFMA.  Left to itself hipcc sinks
+        // every load next to its use (vmcnt(0) / lgkmcnt(0) in front of each MFMA: 28k cycles per tile for 4.1k of MFMA).
+        {
+            constexpr int kAhead = (NW <= 8) ? 8 : 4, kMfma = kRun * PR;
+            __builtin_amdgcn_sched_group_barrier(0x020, kRing, 0);               // VMEM reads
+            __builtin_amdgcn_sched_group_barrier(0x100, kAhead, 0);              // DS reads
+#pragma unroll
+            for (int i = 0; i < kMfma; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);               // one MFMA
+                if (i + kAhead < kMfma) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                if (i % PR == PR - 1 && i / PR + kRing < kRun) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+        }
+#ifdef SF_CORR_TIMERS
+        const long long tt1 = __builtin_readcyclecounter();
+#endif
+        // ---- epilogue ----
+        // ---- per-lane store offsets, recomputed per tile from a laundered lane id: as loop invariants they would sit in
+            // ~10 VGPRs through the k-loop, which needs every register it can get for B fragments in flight ----
+            int l31 = l31_;
+            asm volatile("" : "+v"(l31));
+            const int khalf = lane >> 5;
+        // C/D layout: lane = (target column l31, k-half), register r = source row (r&3) + 8(r>>2) + 4 khalf, acc[t] = patch row
+        // t.  A lane's eight values of one register are one block column of level 0.
+        const int rowh = 4 * khalf * rec;
+        // level 0: four consecutive blocks of block row by0 -> 512 contiguous bytes per source row
+        const int vo0_ = ((px0 >> 3) + (l31 >> 3) < g.g.nbx[0])
+                             ? rowh + g.g.off[0] + (by0 * g.g.nbx[0] + (px0 >> 3)) * 128 + l31 * 16 : kDrop;
+        // level 1: lane pair (2j, 2j+1) holds cell column j of the patch's 4 x 16 level-1 cells: rows 4 (by0 & 1) .. +3 of
+        // block row by0 >> 1, an 8-byte piece; lane parity k1 stores source row (2 jp + k1) of a register pair
+        const int j1 = l31 >> 1, k1 = l31 & 1;
+        const int by1 = by0 >> 1, bx1 = 2 * pxb + (j1 >> 3);
+        const int vo1_ = (by1 < g.g.nby[1] && bx1 < g.g.nbx[1])
+                             ? rowh + k1 * rec + g.g.off[1] + (by1 * g.g.nbx[1] + bx1) * 128 + (j1 & 7) * 16 + (by0 & 1) * 8 : kDrop;
+        // level 2: lane quad = cell column l31 >> 2 of 2 x 8 cells: rows 2 (by0 & 3) .. +1 of block row by0 >> 2 (4 bytes);
+        // lane k2 of the quad stores source row k2 of a register group
+        const int j2c = l31 >> 2, k2 = l31 & 3;
+        const int by2 = by0 >> 2;
+        const int vo2_ = (by2 < g.g.nby[2] && pxb < g.g.nbx[2])
+                             ? rowh + k2 * rec + g.g.off[2] + (by2 * g.g.nbx[2] + pxb) * 128 + j2c * 16 + (by0 & 3) * 4 : kDrop;
+        // level 3: lanes 0..3 of an octet hold cell column 4 pxb + (l31 >> 3), row by0 & 7 of block row by0 >> 3 (2 bytes)
+        const int k3 = l31 & 7, tx3 = 4 * pxb + (l31 >> 3);
+        const int by3 = by0 >> 3;
+        const int vo3_ = (k3 < 4 && by3 < g.g.nby[3] && (tx3 >> 3) < g.g.nbx[3])
+                             ? rowh + k3 * rec + g.g.off[3] + (by3 * g.g.nbx[3] + (tx3 >> 3)) * 128 + (tx3 & 7) * 16 + (by0 & 7) * 2 : kDrop;
+        constexpr int kNt = SF_CORRB_NT;
+#if defined(SF_CORRB_ABLATE) && SF_CORRB_ABLATE == 1      // timing ablation: no stores leave the CU
+        const int vo0 = kDrop | (vo0_ & 0), vo1 = kDrop | (vo1_ & 0), vo2 = kDrop | (vo2_ & 0), vo3 = kDrop | (vo3_ & 0);
+#else
+        const int vo0 = vo0_, vo1 = vo1_, vo2 = vo2_, vo3 = vo3_;
+#endif
+        const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(img_base + (int64_t)i0 * rec, 0, 32 * rec, 0x00020000);
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {                       // register group: source rows 8 rq + 4 khalf + (0..3)
+            float sel2[2] = {0.f, 0.f}, sel3 = 0.f;
+#pragma unroll
+            for (int jp = 0; jp < 2; ++jp) {                   // register pair (2 jp, 2 jp + 1) of the group
+                float sel1[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int ri = 2 * jp + u, r = 4 * rq + ri;
+                    float v0[PR];
+#pragma unroll
+                    for (int t = 0; t < PR; ++t) v0[t] = acc[t][r] * g.scale;
+                    u32x4 o;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) o[t] = pack_h2(v0[2 * t], v0[2 * t + 1]);
+                    __builtin_amdgcn_raw_buffer_store_b128(o, rv, vo0, (ri + 8 * rq) * rec, kNt);
+                    float v1[4], v2[2];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const float sm = v0[2 * t] + v0[2 * t + 1];
+                        v1[t] = 0.25f * (sm + dpp_xor1(sm));
+                        sel1[t] = (k1 == u) ? v1[t] : sel1[t];
+                    }
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const float sm = v1[2 * t] + v1[2 * t + 1];
+                        v2[t] = 0.25f * (sm + dpp_xor2(sm));
+                        sel2[t] = (k2 == ri) ? v2[t] : sel2[t];
+                    }
+                    const float sm = v2[0] + v2[1];
+                    const float v3 = 0.25f * (sm + dpp_shl4(sm));
+                    sel3 = (k3 == ri) ? v3 : sel3;
+                }
+                u32x2 o1;
+                o1[0] = pack_h2(sel1[0], sel1[1]);
+                o1[1] = pack_h2(sel1[2], sel1[3]);
+                __builtin_amdgcn_raw_buffer_store_b64(o1, rv, vo1, (2 * jp + 8 * rq) * rec, 0);
+            }
+            __builtin_amdgcn_raw_buffer_store_b32(pack_h2(sel2[0], sel2[1]), rv, vo2, (8 * rq) * rec, 0);
+            const _Float16 h3 = (_Float16)sel3;
+            __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, h3), rv, vo3, (8 * rq) * rec, 0);
+        }
+#ifdef SF_CORR_TIMERS
+        t_k += tt1 - tt0; t_e += __builtin_readcyclecounter() - tt1; ++n_t;
+#endif
     }
 #ifdef SF_CORR_TIMERS
-    if (g.ts && tid == 0) {
+    if (g.ts && lane == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        long long* d = g.ts + (int64_t)blockIdx.x * 8;
+        long long* d = g.ts + ((int64_t)blockIdx.x * NW + wave) * 8;
         d[0] = ts0; d[1] = ts1; d[2] = __builtin_readcyclecounter(); d[3] = rt0; d[4] = __builtin_amdgcn_s_memrealtime();
+        d[5] = t_k; d[6] = t_e; d[7] = n_t;
     }
 #endif
 }
@@ -493,8 +520,8 @@ extern "C" int64_t sf_corr_blocked_bytes(int n_img, int h, int w) {
 
 extern "C" int64_t sf_corr_build_blocked_ws_bytes(int n_img, int D, int h, int w) {
     if (n_img <= 0 || D <= 0 || h <= 0 || w <= 0) return 0;
-    const int Dp = sf::ceil_div(D, FK) * FK, Np = (h * w + 8) / 8 * 8;
-    return (int64_t)2 * n_img * (Dp / 8) * Np * 16;
+    const int Np = (h * w + 8) / 8 * 8;
+    return (int64_t)2 * n_img * (KD / 8) * Np * 16;
 }
 
 extern "C" int sf_corr_build_blocked(const float* f1, const float* f2, int64_t f_clip_stride, int64_t f_pair_stride,
@@ -502,14 +529,14 @@ extern "C" int sf_corr_build_blocked(const float* f1, const float* f2, int64_t f
                                      void* ws, int64_t ws_bytes, void* stream) {
     SF_REQUIRE(f1 && f2 && vol && ws, "sf_corr_build_blocked: null pointer");
     SF_REQUIRE(B > 0 && pairs > 0 && D > 0 && h > 0 && w > 0, "sf_corr_build_blocked: bad dims");
+    SF_REQUIRE(D <= KD, "sf_corr_build_blocked: feature depth %d > %d (the resident-patch kernel holds all k of a patch in LDS)", D, KD);
     SF_REQUIRE((h >> 3) >= 1 && (w >> 3) >= 1, "sf_corr_build_blocked: feature grid %dx%d too small for 4 levels", h, w);
     const int n_img = B * pairs;
     BuildArgs g;
     g.g = make_geom(h, w);
     g.N = h * w;
     g.Np = (g.N + 8) / 8 * 8;
-    g.Dp = sf::ceil_div(D, FK) * FK;
-    SF_REQUIRE((int64_t)(g.Dp / 8) * g.Np * 16 < ((int64_t)1 << 31), "sf_corr_build_blocked: feature image larger than 2 GiB");
+    SF_REQUIRE((int64_t)(KD / 8) * g.Np * 16 < ((int64_t)1 << 31), "sf_corr_build_blocked: feature image larger than 2 GiB");
     SF_REQUIRE((int64_t)32 * g.g.rec < ((int64_t)1 << 31), "sf_corr_build_blocked: feature grid %dx%d too large", h, w);
     SF_REQUIRE(ws_bytes >= sf_corr_build_blocked_ws_bytes(n_img, D, h, w) && (reinterpret_cast<uintptr_t>(ws) & 15) == 0,
                "sf_corr_build_blocked: needs a 16-byte aligned workspace of sf_corr_build_blocked_ws_bytes() bytes");
@@ -524,20 +551,19 @@ extern "C" int sf_corr_build_blocked(const float* f1, const float* f2, int64_t f
     g.n_img = n_img; g.h = h; g.w = w;
     g.pcols = sf::ceil_div(w, PC);
     g.np = g.pcols * sf::ceil_div(h, PR);
-    g.mt = sf::ceil_div(g.N, BM);
+    g.ntiles = sf::ceil_div(g.N, 32);
+    g.nchunks = sf::ceil_div(g.ntiles, kTilesPerItem);
+    g.tpc = sf::ceil_div(g.ntiles, g.nchunks);
+    g.nchunks = sf::ceil_div(g.ntiles, g.tpc);
     g.scale = 1.0f / sqrtf((float)D);
-    // patches per L2-resident block: ~1.75 MB of packed target features (of the 4 MiB L2 of an XCD)
-    const int patch_bytes = BN * g.Dp * 2;
-    g.pblk = (7 << 18) / patch_bytes;
-    g.pblk = g.pblk < 1 ? 1 : (g.pblk > g.np ? g.np : g.pblk);
 #ifdef SF_CORR_TIMERS
     g.ts = getenv("SF_CORR_TS_BUF") ? (long long*)strtoull(getenv("SF_CORR_TS_BUF"), nullptr, 0) : nullptr;
 #endif
-    const int64_t n_wg = (int64_t)g.np * g.mt * n_img;
+    const int64_t n_wg = (int64_t)g.np * g.nchunks * n_img;
     SF_REQUIRE(n_wg < ((int64_t)1 << 31), "sf_corr_build_blocked: grid too large");
-    hipLaunchKernelGGL(pack_f16z_kernel, dim3(sf::ceil_div(g.Np, 256), g.Dp / 8, 2 * n_img), dim3(256), 0,
-                       (hipStream_t)stream, f1, f2, f_clip_stride, f_pair_stride, (char*)ws, pairs, D, g.Dp, g.N, g.Np);
-    hipLaunchKernelGGL(corr_build_blocked_kernel, dim3((unsigned)n_wg), dim3(kThreads), 0, (hipStream_t)stream, g);
+    hipLaunchKernelGGL(pack_f16z_kernel, dim3(sf::ceil_div(g.Np, 256), KD / 8, 2 * n_img), dim3(256), 0,
+                       (hipStream_t)stream, f1, f2, f_clip_stride, f_pair_stride, (char*)ws, pairs, D, KD, g.N, g.Np);
+    hipLaunchKernelGGL(corr_build_blocked_kernel, dim3((unsigned)n_wg), dim3(kBuildThreads), 0, (hipStream_t)stream, g);
     return sf::check_launch("sf_corr_build_blocked");
 }
 

@@ -68,8 +68,12 @@ if "blocked" in which:
         os.environ.pop("SF_CORR_TS_BUF")
         t = ts.view(-1, 8).cpu().double()
         t = t[t[:, 0] > 0]
-        for name, v in (("k-loop", t[:, 1] - t[:, 0]), ("epilogue", t[:, 2] - t[:, 1])):
-            print(f"# {name:9s} mean {v.mean().item():9.0f} median {v.median().item():9.0f} min {v.min().item():9.0f} max {v.max().item():9.0f} cycles")
+        nt = t[:, 7].clamp(min=1)
+        for name, v in (("patch load", t[:, 1] - t[:, 0]), ("wave life", t[:, 2] - t[:, 0]), ("tiles/wave", t[:, 7]),
+                        ("k-loop/tile", t[:, 5] / nt), ("epilogue/tile", t[:, 6] / nt)):
+            print(f"# {name:13s} mean {v.mean().item():9.0f} median {v.median().item():9.0f} min {v.min().item():9.0f} max {v.max().item():9.0f}")
+        dt_c, dt_r = t[:, 2] - t[:, 0], t[:, 4] - t[:, 3]
+        print(f"# clock: {(dt_c.sum() / dt_r.sum()).item() * 100:.0f} MHz")
 for k, (tb, tl) in res.items():
     it = 15
     frac = (b_bytes + it * l_bytes) / ((tb + it * tl) * 1e-6) / 8e12
