@@ -92,31 +92,44 @@ constexpr int kPatchBytes = (KD / 8) * BN * 16;          // 128 KB: the whole pa
 constexpr int kTilesPerItem = 60;                         // 32-source tiles per work item (~5 per wave)
 
 struct BuildArgs {
-    const char* ws;               // packed features: image (img, side) = [Dp / 8][Np][8] halves, pixel N.. = zeros
+    const char* ws;               // packed features: image (img, side) = [KD / 8][Np][8] halves, pixel N.. = zeros
     char* vol;
     int64_t vol_img_stride;       // bytes
     int n_img, h, w, N, Np;
+    int pairs, shared;            // shared: packed planes are per frame (see pack_f16z_kernel)
     VolGeom g;
-    int pcols, np;                // patch columns, patches per image
+    // target patches: np16 patches of 16 rows x 16 columns (two block rows x two blocks) cover block rows 0 .. 2 * rows16 - 1;
+    // an odd last block row is covered by np32 patches of 8 rows x 32 columns
+    int pcols16, np16, pcols32, np32, rows16;
     int ntiles, nchunks, tpc;     // 32-source tiles per image, chunks per image, tiles per chunk
-    float scale;
+    float scale;                  // applied in the epilogue (1 when folded into the packed source features)
 #ifdef SF_CORR_TIMERS
     long long* ts;
 #endif
 };
 
 // features fp32 [D][N] -> fp16 k-octet planes [(k / 8)][Np][8]; pixels N .. Np-1 are zero (the target of every patch
-// cell that lies outside the image: its products are exactly 0)
+// cell that lies outside the image: its products are exactly 0).
+// shared = 0: plane 2 i = the source side (f1) of image i = b * pairs + t, multiplied by `pre`; plane 2 i + 1 = its f2.
+// shared = 1 (f2 == f1 + f_pair_stride: consecutive frames of a clip, the engine's call): every FRAME is packed once,
+//             plane b * (pairs + 1) + j = frame j of clip b times `pre`; image (b, t) uses planes (b, t) and (b, t + 1).
 __global__ __launch_bounds__(256) void pack_f16z_kernel(const float* f1, const float* f2, int64_t f_clip_stride,
                                                         int64_t f_pair_stride, char* ws, int pairs, int D, int Dp, int N,
-                                                        int Np) {
+                                                        int Np, float pre, int shared) {
     const int px = blockIdx.x * 256 + threadIdx.x, kq = blockIdx.y;
-    const int side = blockIdx.z & 1, img = blockIdx.z >> 1;             // img = b * pairs + pair
     if (px >= Np) return;
-    const float* f = (side ? f2 : f1) + (int64_t)(img / pairs) * f_clip_stride + (int64_t)(img % pairs) * f_pair_stride;
+    const float* f;
+    float m = pre;
+    if (shared) {
+        f = f1 + (int64_t)(blockIdx.z / (pairs + 1)) * f_clip_stride + (int64_t)(blockIdx.z % (pairs + 1)) * f_pair_stride;
+    } else {
+        const int side = blockIdx.z & 1, img = blockIdx.z >> 1;         // img = b * pairs + pair
+        f = (side ? f2 : f1) + (int64_t)(img / pairs) * f_clip_stride + (int64_t)(img % pairs) * f_pair_stride;
+        if (side) m = 1.0f;
+    }
     f16x8 hv;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) hv[i] = (_Float16)((px < N && kq * 8 + i < D) ? f[(int64_t)(kq * 8 + i) * N + px] : 0.f);
+    for (int i = 0; i < 8; ++i) hv[i] = (_Float16)((px < N && kq * 8 + i < D) ? m * f[(int64_t)(kq * 8 + i) * N + px] : 0.f);
     const int64_t plane = (int64_t)(Dp / 8) * Np * 16;
     *reinterpret_cast<f16x8*>(ws + (int64_t)blockIdx.z * plane + ((int64_t)kq * Np + px) * 16) = hv;
 }
@@ -125,87 +138,111 @@ __global__ __launch_bounds__(256) void pack_f16z_kernel(const float* f1, const f
 #define SF_CORRB_NT 2            // cache policy of the level-0 stores (2 = non-temporal)
 #endif
 
-// BUILD, resident-patch form.  Work item = (image, chunk of source tiles, target patch); one workgroup of 12 waves per
+// BUILD, resident-patch form.  Work item = (image, chunk of source tiles, target patch); one workgroup of 8 waves per
 // item and CU.  The patch's features for ALL 256 k (128 KB) are DMA'd into LDS once; after ONE barrier every wave is on
-// its own: it draws 32-source tiles from a workgroup counter, streams that tile's A fragments straight from L2 into
-// registers (a lane's fragment is one 16-byte k-octet of one pixel: no LDS, no DMA, ring of four in flight), reads B
-// fragments from the resident patch, and runs its epilogue while the other two waves of its SIMD keep the matrix pipe
-// busy.  No barrier, no DMA and no shared staging buffer inside the loop.
-// (The first blocked kernel kept round 2's structure -- 128 x 256 tile per workgroup, both operands staged through a
-// 2- or 3-stage LDS ring -- and measured 27k cycles of k-loop per tile of which 4.1k were MFMA issue: every wave sat
-// ~190 cycles in each of its 48 LDS-DMA instructions and ~0.5k cycles per stage at the barrier; interleaving the DMA
-// instructions with the MFMAs moved that time, it did not remove it.  tools/corrb_bench.py)
-__global__ __launch_bounds__(kBuildThreads, NW / 4) void corr_build_blocked_kernel(const BuildArgs g) {
-    __shared__ __attribute__((aligned(1024))) char smem[kPatchBytes + 16];
+// its own: it draws 32-source tiles from a workgroup counter, gets that tile's sixteen A fragments straight from L2 into
+// registers (a lane's fragment is one 16-byte k-octet of one pixel: no LDS, no DMA), reads B fragments from the resident
+// patch eight MFMAs ahead of their use, and runs its epilogue while the other wave of its SIMD keeps the matrix pipe busy.
+// No barrier, no DMA and no staging buffer inside the loop.
+//  * The A fragments of the NEXT tile are requested before the epilogue's stores: vmcnt retires in issue order, so a load
+//    issued behind the 32 stores of a tile would wait for their HBM acknowledgement (~16k cycles when the chip writes at
+//    full rate) -- the first version of this kernel did, and its waves spent as long draining as computing.
+//  * kShape16: the patch is 16 rows x 16 columns, lane = (block row l31 >> 4, column l31 & 15), so that a tile produces a
+//    COMPLETE 8 x 8 level-1 block (a full 128-byte line).  With 8 x 32 patches the level-1 cells of a block come from two
+//    work items at different times: partial-line writes, which HBM3 (no data mask) serves as read-modify-write -- the
+//    store-only rate of that pattern measured 3.9 TB/s against 5.5 for full lines.  8 x 32 is used for an odd last block
+//    row only (no wasted MFMA rows).
+// (History: the first blocked kernel kept round 2's structure -- 128 x 256 tile per workgroup, both operands staged
+// through a 2- or 3-stage LDS ring -- and measured 27k cycles of k-loop per tile of which 4.1k were MFMA issue: every
+// wave sat ~190 cycles in each of its 48 LDS-DMA instructions and ~0.5k cycles per stage at the barrier; interleaving the
+// DMA instructions with the MFMAs moved that time, it did not remove it.  DESIGN.md section 10.)
+#ifdef SF_CORR_TIMERS
+#define SF_TIMER_ARGS , long long& t_load, long long& t_k, long long& t_e, int& n_t
+#define SF_TIMER_PASS , t_load, t_k, t_e, n_t
+#else
+#define SF_TIMER_ARGS
+#define SF_TIMER_PASS
+#endif
+template <bool kShape16, bool kScale>
+__device__ __forceinline__ void build_item(const BuildArgs& g, char* smem, int item SF_TIMER_ARGS) {
 #ifdef SF_CORR_TIMERS
     const long long ts0 = __builtin_readcyclecounter();
-    const long long rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int khalf = lane >> 5, l31_ = lane & 31;
     // item order [image][chunk][patch]: the workgroups that run side by side on an XCD share the chunk's source features
-    const int item = sf::xcd_linear_id(blockIdx.x, gridDim.x);
-    const int patch = item % g.np, chunk = (item / g.np) % g.nchunks, img = item / (g.np * g.nchunks);
-    const int by0 = patch / g.pcols, pxb = patch % g.pcols;
-    const int py0 = by0 * PR, px0 = pxb * PC;
+    const int np = kShape16 ? g.np16 : g.np32, pcols = kShape16 ? g.pcols16 : g.pcols32;
+    const int patch = item % np, chunk = (item / np) % g.nchunks, img = item / (np * g.nchunks);
+    // patch origin in blocks: kShape16: block rows 2 pyb, 2 pyb + 1, blocks 2 pxb, 2 pxb + 1; else block row pyb, blocks 4 pxb ..
+    const int pyb = kShape16 ? patch / pcols : 2 * g.rows16 + patch / pcols, pxb = patch % pcols;
     const int plane = (KD / 8) * g.Np * 16;                       // bytes of one packed image (< 2 GiB, host-checked)
+    const int pa = g.shared ? (img / g.pairs) * (g.pairs + 1) + img % g.pairs : 2 * img;    // packed plane of the source side
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char*>(g.ws) + (int64_t)(img * 2 + 0) * plane, 0, plane, 0x00020000);
+        const_cast<char*>(g.ws) + (int64_t)pa * plane, 0, plane, 0x00020000);
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char*>(g.ws) + (int64_t)(img * 2 + 1) * plane, 0, plane, 0x00020000);
+        const_cast<char*>(g.ws) + (int64_t)(pa + 1) * plane, 0, plane, 0x00020000);
     const int kq_step = g.Np * 16;
     int* const counter = reinterpret_cast<int*>(smem + kPatchBytes);
     if (tid == 0) *counter = 0;
-    // ---- the patch: LDS slot = k-octet * 256 + cell (cell = patch row * 32 + patch column), 128 pieces of 1 KB; piece p
-    // covers k-octet p / 4, cells (p % 4) * 64 + lane.  Wave w takes pieces w, w + 12, ...: always cell group w % 4.
-    // Cells outside the image read the zero pixel. ----
+    // ---- the patch: LDS slot = k-octet * 256 + cell, cell = t * 32 + l (t = accumulator / row inside a block row, l = the
+    // MFMA column lane), 128 pieces of 1 KB; piece p covers k-octet p / 4, cells (p % 4) * 64 + lane.  Wave w takes pieces
+    // w, w + 8, ...: always cell group w % 4.  Cells outside the image read the zero pixel. ----
     {
-        const int cell = (wave & 3) * 64 + lane;
-        const int ty = py0 + cell / PC, tx = px0 + cell % PC;
+        const int cell = (wave & 3) * 64 + lane, t = cell >> 5, l = cell & 31;
+        const int ty = kShape16 ? 16 * pyb + 8 * (l >> 4) + t : 8 * pyb + t;
+        const int tx = kShape16 ? 16 * pxb + (l & 15) : 32 * pxb + l;
         const int vob = ((ty < g.h && tx < g.w) ? ty * g.w + tx : g.N) * 16;
         static_assert(NW % 4 == 0, "a wave keeps its cell group");
         for (int p = wave; p < (KD / 8) * 4; p += NW)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr)(smem + p * 1024), 16, vob, (p >> 2) * kq_step, 0, 0);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    const int t_begin = chunk * g.tpc, t_count = min(g.tpc, g.ntiles - t_begin);
+    // (vmcnt is in order: this also drains the wave's stores.  The BUILTIN, not inline asm: hipcc tracks LDS-DMA as a pending
+    // write to LDS and, unless it sees this wait itself, puts its own vmcnt(0) in front of the first LDS access of every
+    // trip of the tile loop -- i.e. a full drain of the previous tile's stores at the top of each tile.)
+    __builtin_amdgcn_s_waitcnt(0x0070);                           // vmcnt(0) expcnt(7) lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();
 #ifdef SF_CORR_TIMERS
     const long long ts1 = __builtin_readcyclecounter();
-    long long t_k = 0, t_e = 0;
-    int n_t = 0;
+    t_load += ts1 - ts0;
 #endif
-
     const int rec = g.g.rec;
-    const int t_begin = chunk * g.tpc, t_count = min(g.tpc, g.ntiles - t_begin);
     char* const img_base = g.vol + (int64_t)img * g.vol_img_stride;
-    const char* const sbB = smem + (khalf * BN + l31_) * 16;       // + (2 ks * 256 + t * 32) * 16
-
+    const char* const sbB = smem + (khalf * BN + l31_) * 16;      // + (2 ks * 256 + t * 32) * 16
+    constexpr int kSteps = KD / 16;
+#if defined(SF_CORRB_ABLATE) && SF_CORRB_ABLATE == 2      // timing ablation: four k-steps only
+    constexpr int kRun = 4;
+#else
+    constexpr int kRun = kSteps;
+#endif
+    auto grab = [&]() {
+        int t = 0;
+        if (lane == 0) t = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return __builtin_amdgcn_readfirstlane(t);
+    };
+    int tile = grab();
+    if (tile >= t_count) return;
     for (;;) {
-        int tile = 0;
-        if (lane == 0) tile = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        tile = __builtin_amdgcn_readfirstlane(tile);
-        if (tile >= t_count) break;
 #ifdef SF_CORR_TIMERS
         const long long tt0 = __builtin_readcyclecounter();
 #endif
-        const int i0 = (t_begin + tile) * 32;                     // first source pixel of the tile
-        // A fragment of k-step ks: k-octet 2 ks + khalf of source pixel i0 + l31 (pixels past N clamped: padding records)
+        const int next = grab();                                  // (LDS atomic: its latency hides behind the k-loop)
+        const int i0 = (t_begin + tile) * 32;                     // first source pixel of this tile
+        // A fragment of k-step ks: k-octet 2 ks + khalf of source pixel i0 + l31 (pixels past N clamped: padding records);
+        // a ring of four loads in flight.  (vmcnt retires in issue order, so the first of them also waits for the HBM
+        // acknowledgement of the previous tile's stores; requesting the fragments before those stores changes nothing --
+        // measured -- and costs 64 registers.)
         const int voa = (khalf * g.Np + min(i0 + l31_, g.N - 1)) * 16;
+        constexpr int kRing = (NW <= 8) ? 4 : 2;
+        u32x4 af[kRing];
+#pragma unroll
+        for (int s = 0; s < kRing; ++s) af[s] = __builtin_amdgcn_raw_buffer_load_b128(ra, voa, s * 2 * kq_step, 0);
         f32x16 acc[PR];
 #pragma unroll
         for (int t = 0; t < PR; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-        constexpr int kSteps = KD / 16, kRing = (NW <= 8) ? 4 : 2;
-        u32x4 af[kRing];
-#pragma unroll
-        for (int s = 0; s < kRing; ++s) af[s] = __builtin_amdgcn_raw_buffer_load_b128(ra, voa, s * 2 * kq_step, 0);
-#if defined(SF_CORRB_ABLATE) && SF_CORRB_ABLATE == 2      // timing ablation: four k-steps only
-        constexpr int kRun = 4;
-#else
-        constexpr int kRun = kSteps;
-#endif
 #pragma unroll
         for (int ks = 0; ks < kRun; ++ks) {
             const f16x8 a = __builtin_bit_cast(f16x8, af[ks % kRing]);
@@ -216,11 +253,11 @@ __global__ __launch_bounds__(kBuildThreads, NW / 4) void corr_build_blocked_kern
             }
             if (ks + kRing < kRun) af[ks % kRing] = __builtin_amdgcn_raw_buffer_load_b128(ra, voa, (ks + kRing) * 2 * kq_step, 0);
         }
-        // Issue order of the whole (fully unrolled) k-loop, pinned: the four A loads of the ring first, then B fragment
-        // reads running kAhead MFMAs ahead of their use, one A refill behind every eighth MFMA.  Left to itself hipcc sinks
-        // every load next to its use (vmcnt(0) / lgkmcnt(0) in front of each MFMA: 28k cycles per tile for 4.1k of MFMA).
+        // Issue order of the whole (fully unrolled) k-loop, pinned: the ring's loads first, then B fragment reads running
+        // kAhead MFMAs ahead of their use, one A refill behind every eighth MFMA.  Left to itself hipcc sinks every load
+        // next to its use (vmcnt(0) / lgkmcnt(0) in front of each MFMA: 28k cycles per tile for 4.1k of MFMA issue).
         {
-            constexpr int kAhead = (NW <= 8) ? 8 : 4, kMfma = kRun * PR;
+            constexpr int kAhead = (NW <= 8) ? 8 : 3, kMfma = kRun * PR;
             __builtin_amdgcn_sched_group_barrier(0x020, kRing, 0);               // VMEM reads
             __builtin_amdgcn_sched_group_barrier(0x100, kAhead, 0);              // DS reads
 #pragma unroll
@@ -230,41 +267,47 @@ __global__ __launch_bounds__(kBuildThreads, NW / 4) void corr_build_blocked_kern
                 if (i % PR == PR - 1 && i / PR + kRing < kRun) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
 #ifdef SF_CORR_TIMERS
         const long long tt1 = __builtin_readcyclecounter();
 #endif
-        // ---- epilogue ----
-        // ---- per-lane store offsets, recomputed per tile from a laundered lane id: as loop invariants they would sit in
-            // ~10 VGPRs through the k-loop, which needs every register it can get for B fragments in flight ----
-            int l31 = l31_;
-            asm volatile("" : "+v"(l31));
-            const int khalf = lane >> 5;
-        // C/D layout: lane = (target column l31, k-half), register r = source row (r&3) + 8(r>>2) + 4 khalf, acc[t] = patch row
-        // t.  A lane's eight values of one register are one block column of level 0.
+        // ---- epilogue.  C/D layout: lane = (MFMA column l31, k-half), register r = source row (r&3) + 8(r>>2) + 4 khalf,
+        // acc[t] = row t of the lane's block row: a lane's eight values of one register are one block column of level 0.
+        // Per-lane store offsets are recomputed per tile from a laundered lane id: as loop invariants they would occupy
+        // ~10 VGPRs through the k-loop. ----
+        int l31 = l31_;
+        asm volatile("" : "+v"(l31));
         const int rowh = 4 * khalf * rec;
-        // level 0: four consecutive blocks of block row by0 -> 512 contiguous bytes per source row
-        const int vo0_ = ((px0 >> 3) + (l31 >> 3) < g.g.nbx[0])
-                             ? rowh + g.g.off[0] + (by0 * g.g.nbx[0] + (px0 >> 3)) * 128 + l31 * 16 : kDrop;
-        // level 1: lane pair (2j, 2j+1) holds cell column j of the patch's 4 x 16 level-1 cells: rows 4 (by0 & 1) .. +3 of
-        // block row by0 >> 1, an 8-byte piece; lane parity k1 stores source row (2 jp + k1) of a register pair
-        const int j1 = l31 >> 1, k1 = l31 & 1;
-        const int by1 = by0 >> 1, bx1 = 2 * pxb + (j1 >> 3);
+        const int br = kShape16 ? l31 >> 4 : 0, c = kShape16 ? l31 & 15 : l31;     // block row of the lane, column in the patch
+        const int by0 = kShape16 ? 2 * pyb + br : pyb, bxp = kShape16 ? 2 * pxb : 4 * pxb;   // level-0 block row / first block
+        // level 0: lanes of one block row = consecutive 16-byte block columns (256 or 512 contiguous bytes per source row)
+        const int vo0_ = (by0 < g.g.nby[0] && bxp + (c >> 3) < g.g.nbx[0])
+                             ? rowh + g.g.off[0] + (by0 * g.g.nbx[0] + bxp) * 128 + c * 16 : kDrop;
+        // level 1: lane pair (2j, 2j+1) holds level-1 column j, four rows (block row by0: rows 4 (by0 & 1) .. +3 of level-1
+        // block row by0 >> 1): an 8-byte piece; lane parity k1 stores source row (2 jp + k1) of a register pair.
+        // kShape16: the two block rows of the patch supply both halves of every block column: 128 full bytes per source row.
+        const int j1 = c >> 1, k1 = c & 1;
+        const int by1 = by0 >> 1, bx1 = (bxp >> 1) + (j1 >> 3);
         const int vo1_ = (by1 < g.g.nby[1] && bx1 < g.g.nbx[1])
                              ? rowh + k1 * rec + g.g.off[1] + (by1 * g.g.nbx[1] + bx1) * 128 + (j1 & 7) * 16 + (by0 & 1) * 8 : kDrop;
-        // level 2: lane quad = cell column l31 >> 2 of 2 x 8 cells: rows 2 (by0 & 3) .. +1 of block row by0 >> 2 (4 bytes);
+        // level 2: lane quad = level-2 column (bxp * 2 + (c >> 2)), rows 2 (by0 & 3) .. +1 of block row by0 >> 2 (4 bytes);
         // lane k2 of the quad stores source row k2 of a register group
-        const int j2c = l31 >> 2, k2 = l31 & 3;
+        const int k2 = c & 3, tx2 = bxp * 2 + (c >> 2);
         const int by2 = by0 >> 2;
-        const int vo2_ = (by2 < g.g.nby[2] && pxb < g.g.nbx[2])
-                             ? rowh + k2 * rec + g.g.off[2] + (by2 * g.g.nbx[2] + pxb) * 128 + j2c * 16 + (by0 & 3) * 4 : kDrop;
-        // level 3: lanes 0..3 of an octet hold cell column 4 pxb + (l31 >> 3), row by0 & 7 of block row by0 >> 3 (2 bytes)
-        const int k3 = l31 & 7, tx3 = 4 * pxb + (l31 >> 3);
+        const int vo2_ = (by2 < g.g.nby[2] && (tx2 >> 3) < g.g.nbx[2])
+                             ? rowh + k2 * rec + g.g.off[2] + (by2 * g.g.nbx[2] + (tx2 >> 3)) * 128 + (tx2 & 7) * 16 + (by0 & 3) * 4 : kDrop;
+        // level 3: lanes 0..3 of an octet hold level-3 column bxp + (c >> 3), row by0 & 7 of block row by0 >> 3 (2 bytes)
+        const int k3 = c & 7, tx3 = bxp + (c >> 3);
         const int by3 = by0 >> 3;
         const int vo3_ = (k3 < 4 && by3 < g.g.nby[3] && (tx3 >> 3) < g.g.nbx[3])
                              ? rowh + k3 * rec + g.g.off[3] + (by3 * g.g.nbx[3] + (tx3 >> 3)) * 128 + (tx3 & 7) * 16 + (by0 & 7) * 2 : kDrop;
         constexpr int kNt = SF_CORRB_NT;
 #if defined(SF_CORRB_ABLATE) && SF_CORRB_ABLATE == 1      // timing ablation: no stores leave the CU
         const int vo0 = kDrop | (vo0_ & 0), vo1 = kDrop | (vo1_ & 0), vo2 = kDrop | (vo2_ & 0), vo3 = kDrop | (vo3_ & 0);
+#elif defined(SF_CORRB_ABLATE) && SF_CORRB_ABLATE == 3    // only the level-0 stores leave the CU
+        const int vo0 = vo0_, vo1 = kDrop | (vo1_ & 0), vo2 = kDrop | (vo2_ & 0), vo3 = kDrop | (vo3_ & 0);
+#elif defined(SF_CORRB_ABLATE) && SF_CORRB_ABLATE == 4    // only the pooled levels' stores leave the CU
+        const int vo0 = kDrop | (vo0_ & 0), vo1 = vo1_, vo2 = vo2_, vo3 = vo3_;
 #else
         const int vo0 = vo0_, vo1 = vo1_, vo2 = vo2_, vo3 = vo3_;
 #endif
@@ -280,11 +323,16 @@ __global__ __launch_bounds__(kBuildThreads, NW / 4) void corr_build_blocked_kern
                     const int ri = 2 * jp + u, r = 4 * rq + ri;
                     float v0[PR];
 #pragma unroll
-                    for (int t = 0; t < PR; ++t) v0[t] = acc[t][r] * g.scale;
+                    for (int t = 0; t < PR; ++t) v0[t] = kScale ? acc[t][r] * g.scale : acc[t][r];
                     u32x4 o;
 #pragma unroll
                     for (int t = 0; t < 4; ++t) o[t] = pack_h2(v0[2 * t], v0[2 * t + 1]);
                     __builtin_amdgcn_raw_buffer_store_b128(o, rv, vo0, (ri + 8 * rq) * rec, kNt);
+                    // HARDWARE HAZARD (gfx950, measured): a VALU write to the data registers of a >64-bit buffer store in the
+                    // very next issue slots corrupts the stored data for the last lanes of each 16-lane group (sporadic wrong
+                    // level-0 cells in columns 12..15 / 28..31).  hipcc only pads this hazard when soffset is an immediate
+                    // (GCNHazardRecognizer::createsVALUHazard); here it is an SGPR, so pad by hand.
+                    asm volatile("s_nop 1" : "+v"(o) : : "memory");      // (tied to the data registers: they stay live until here)
                     float v1[4], v2[2];
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
@@ -314,12 +362,32 @@ __global__ __launch_bounds__(kBuildThreads, NW / 4) void corr_build_blocked_kern
 #ifdef SF_CORR_TIMERS
         t_k += tt1 - tt0; t_e += __builtin_readcyclecounter() - tt1; ++n_t;
 #endif
+        if (next >= t_count) break;
+        tile = next;
     }
+}
+
+// One workgroup per work item.  (A persistent form -- one workgroup per CU looping over items -- measured the same
+// 1.13 ms and, inlined into that loop, hipcc no longer honours the pinned issue order of the k-loop: DESIGN.md section 10.)
+template <bool kScale, bool kMixed>
+__global__ __launch_bounds__(kBuildThreads, NW / 4) void corr_build_blocked_kernel(const BuildArgs g) {
+    __shared__ __attribute__((aligned(1024))) char smem[kPatchBytes + 16];
 #ifdef SF_CORR_TIMERS
-    if (g.ts && lane == 0) {
+    const long long ts0 = __builtin_readcyclecounter();
+    const long long rt0 = __builtin_amdgcn_s_memrealtime();
+    long long t_load = 0, t_k = 0, t_e = 0;
+    int n_t = 0;
+#endif
+    // 16 x 16 patches first (if any), then the 8 x 32 patches
+    const int n16 = g.np16 * g.nchunks * g.n_img;                 // workgroup-uniform
+    const int id = sf::xcd_linear_id(blockIdx.x, gridDim.x);
+    if (kMixed && id < n16) build_item<true, kScale>(g, smem, id SF_TIMER_PASS);
+    else build_item<false, kScale>(g, smem, id - n16 SF_TIMER_PASS);
+#ifdef SF_CORR_TIMERS
+    if (g.ts && (threadIdx.x & 63) == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        long long* d = g.ts + ((int64_t)blockIdx.x * NW + wave) * 8;
-        d[0] = ts0; d[1] = ts1; d[2] = __builtin_readcyclecounter(); d[3] = rt0; d[4] = __builtin_amdgcn_s_memrealtime();
+        long long* d = g.ts + ((int64_t)blockIdx.x * NW + (threadIdx.x >> 6)) * 8;
+        d[0] = ts0; d[1] = t_load; d[2] = __builtin_readcyclecounter(); d[3] = rt0; d[4] = __builtin_amdgcn_s_memrealtime();
         d[5] = t_k; d[6] = t_e; d[7] = n_t;
     }
 #endif
@@ -549,21 +617,46 @@ extern "C" int sf_corr_build_blocked(const float* f1, const float* f2, int64_t f
     g.vol = static_cast<char*>(vol);
     g.vol_img_stride = vol_img_stride_bytes;
     g.n_img = n_img; g.h = h; g.w = w;
-    g.pcols = sf::ceil_div(w, PC);
-    g.np = g.pcols * sf::ceil_div(h, PR);
+#ifndef SF_CORRB_SHAPE16
+#define SF_CORRB_SHAPE16 0       // 1: 16 x 16 patches for the even block rows (full-line level-1 writes, 256-byte level-0 runs).
+#endif                           // Measured slower than 8 x 32 everywhere (Sintel 1177 vs 1131 us): off.
+    g.rows16 = SF_CORRB_SHAPE16 ? g.g.nby[0] / 2 : 0;             // full pairs of block rows
+    g.pcols16 = sf::ceil_div(w, 16);
+    g.np16 = g.rows16 * g.pcols16;
+    g.pcols32 = sf::ceil_div(w, 32);
+    g.np32 = (g.g.nby[0] - 2 * g.rows16) * g.pcols32;
     g.ntiles = sf::ceil_div(g.N, 32);
     g.nchunks = sf::ceil_div(g.ntiles, kTilesPerItem);
     g.tpc = sf::ceil_div(g.ntiles, g.nchunks);
     g.nchunks = sf::ceil_div(g.ntiles, g.tpc);
-    g.scale = 1.0f / sqrtf((float)D);
+    // 1 / sqrt(D) is folded into the packed features where that is exact (a power of two): into the source side, or -- when
+    // f2 is f1 one frame on, so that every frame is packed ONCE and serves both sides -- as sqrt(scale) into every frame
+    // (D = 256: 1/4 each).  Otherwise the epilogue multiplies.
+    const float scale = 1.0f / sqrtf((float)D), root = sqrtf(scale);
+    int e2 = 0;
+    const bool pow2 = frexpf(scale, &e2) == 0.5f, root_pow2 = frexpf(root, &e2) == 0.5f;
+    g.pairs = pairs;
+    g.shared = (pairs > 1 && f2 == f1 + f_pair_stride && (root_pow2 || !pow2)) ? 1 : 0;
+    const bool fold = g.shared ? root_pow2 : pow2;
+    const float pre = !fold ? 1.0f : (g.shared ? root : scale);
+    g.scale = fold ? 1.0f : scale;
 #ifdef SF_CORR_TIMERS
     g.ts = getenv("SF_CORR_TS_BUF") ? (long long*)strtoull(getenv("SF_CORR_TS_BUF"), nullptr, 0) : nullptr;
 #endif
-    const int64_t n_wg = (int64_t)g.np * g.nchunks * n_img;
-    SF_REQUIRE(n_wg < ((int64_t)1 << 31), "sf_corr_build_blocked: grid too large");
-    hipLaunchKernelGGL(pack_f16z_kernel, dim3(sf::ceil_div(g.Np, 256), KD / 8, 2 * n_img), dim3(256), 0,
-                       (hipStream_t)stream, f1, f2, f_clip_stride, f_pair_stride, (char*)ws, pairs, D, KD, g.N, g.Np);
-    hipLaunchKernelGGL(corr_build_blocked_kernel, dim3((unsigned)n_wg), dim3(kBuildThreads), 0, (hipStream_t)stream, g);
+    const int64_t n_items = (int64_t)(g.np16 + g.np32) * g.nchunks * n_img;
+    SF_REQUIRE(n_items < ((int64_t)1 << 31), "sf_corr_build_blocked: too many work items");
+    const int64_t n_wg = n_items;
+    hipLaunchKernelGGL(pack_f16z_kernel, dim3(sf::ceil_div(g.Np, 256), KD / 8, g.shared ? B * (pairs + 1) : 2 * n_img), dim3(256), 0,
+                       (hipStream_t)stream, f1, f2, f_clip_stride, f_pair_stride, (char*)ws, pairs, D, KD, g.N, g.Np, pre, g.shared);
+    const dim3 grid((unsigned)n_wg), block(kBuildThreads);
+    hipStream_t st = (hipStream_t)stream;
+    if (g.np16 > 0) {
+        if (fold) hipLaunchKernelGGL((corr_build_blocked_kernel<false, true>), grid, block, 0, st, g);
+        else hipLaunchKernelGGL((corr_build_blocked_kernel<true, true>), grid, block, 0, st, g);
+    } else {
+        if (fold) hipLaunchKernelGGL((corr_build_blocked_kernel<false, false>), grid, block, 0, st, g);
+        else hipLaunchKernelGGL((corr_build_blocked_kernel<true, false>), grid, block, 0, st, g);
+    }
     return sf::check_launch("sf_corr_build_blocked");
 }
 

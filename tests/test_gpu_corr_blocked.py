@@ -94,14 +94,17 @@ def test_blocked_koct_output_and_padding_garbage(dev, B, pairs, D, h, w):
 
 
 def test_blocked_matches_row_major_fp16_path(dev):
-    """Same arithmetic, two layouts: the cells of the blocked build equal the row-major fp16 build bit for bit."""
+    """Same arithmetic, two layouts: the cells of the blocked build equal the row-major fp16 build to one fp16 ulp (the
+    blocked build folds 1 / sqrt(D) = 2^-4 into the packed source features: exact except where a scaled feature becomes
+    an fp16 subnormal)."""
     import streamflow_amd as sfa
     g = torch.Generator().manual_seed(3)
     f1, f2 = torch.randn(2, 256, 23, 37, generator=g).to(dev), torch.randn(2, 256, 23, 37, generator=g).to(dev)
     a = sfa.CorrBlock(f1, f2, dtype=torch.float16)
     b = sfa.CorrBlock(f1, f2, dtype=torch.float16, layout="blocked")
     for x, y in zip(a.corr_pyramid, b.corr_pyramid):
-        assert torch.equal(x, y)
+        assert ((x.float() - y.float()).abs() <= 2.0 ** -10 * x.float().abs() + 1e-6).all()
+        assert (x != y).float().mean().item() < 0.01
 
 
 @pytest.mark.parametrize("M,K,P,n", [(324, 486, 7040, 2), (200, 96, 300, 3), (128, 64, 36, 1)])

@@ -69,7 +69,7 @@ if "blocked" in which:
         t = ts.view(-1, 8).cpu().double()
         t = t[t[:, 0] > 0]
         nt = t[:, 7].clamp(min=1)
-        for name, v in (("patch load", t[:, 1] - t[:, 0]), ("wave life", t[:, 2] - t[:, 0]), ("tiles/wave", t[:, 7]),
+        for name, v in (("wave life", t[:, 2] - t[:, 0]), ("patch loads", t[:, 1]), ("tiles/wave", t[:, 7]), ("k-loops", t[:, 5]), ("epilogues", t[:, 6]),
                         ("k-loop/tile", t[:, 5] / nt), ("epilogue/tile", t[:, 6] / nt)):
             print(f"# {name:13s} mean {v.mean().item():9.0f} median {v.median().item():9.0f} min {v.min().item():9.0f} max {v.max().item():9.0f}")
         dt_c, dt_r = t[:, 2] - t[:, 0], t[:, 4] - t[:, 3]
