@@ -112,6 +112,22 @@ def cpu_baseline(fmaps, cnets, params, iters: int, pairs: int, runs: int = 3):
             "s_per_clip": clip}, ups
 
 
+def mfma_busy_from_profiles(kernel_family):
+    """SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 128 SIMD-cycles per count) of the dominant family from the newest
+    committed profiles/rNN*mfma_busy*.json (written by tools/pmc_mfma_json.py from a rocprofv3 --pmc pass), or None."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*mfma_busy*.json")))
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as f:
+            d = json.load(f)
+        v = d.get(kernel_family)
+        return {"value": v, "source": os.path.relpath(files[-1], ROOT)} if v is not None else None
+    except (OSError, ValueError):
+        return None
+
+
 def newest_traffic_file():
     """profiles/rNN*_traffic.json of the latest round (names sort by round); None if there is none."""
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]*traffic.json")))
@@ -168,7 +184,7 @@ def main():
     ap.add_argument("--all-masks", action="store_true",
                     help="run the mask head every iteration as the reference literally does (outputs identical; "
                          "the default skips the 14 mask heads whose results test_mode discards)")
-    ap.add_argument("--preset", default=None, choices=["config2_fp16", "fp32_class"],
+    ap.add_argument("--preset", default=None, choices=["config2_mixed", "config2_fp16", "fp32_class"],
                     help="named arithmetic configuration (streamflow_amd/presets.py); default config2_fp16 = BASELINE.json "
                          "configuration 2 ('bf16'): activations fp16 into split-precision weights, fp16 correlation "
                          "volumes, fused fp16 GMA aggregation, fp32 accumulation everywhere.  fp32_class = the library "
@@ -298,7 +314,9 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": {"fp32": "fp32", "f16x3": "f16x3-split (fp32 accumulate)",
-                  "f16x2": "f16x2 (weights hi+lo, activations fp16; fp32 accumulate)",
+                  "f16x2": ("f16x2 (weights hi+lo, activations fp16; fp32 accumulate)" if not cfg.get("single_layers") else
+                            f"f16x2 / f16 mixed (activations fp16, weights hi+lo in {39 - len(cfg['single_layers'])} layers and "
+                            f"fp16 in {len(cfg['single_layers'])}; fp32 accumulate)"),
                   "f16": "f16 (weights and activations fp16; fp32 accumulate)"}[args.precision] +
                  ("; fp16 correlation volumes" if args.corr_dtype == "f16" else ""), "data": "synthetic",
         "config": {"workload": f"{args.workload}_{H}x{W}_T{T}_iters{iters}", "clips_per_gpu_per_step": B,
@@ -312,7 +330,9 @@ def main():
                                                 if eng.gma_mode == "flash" else ""),
                    "precision": {"fp32": "exact fp32 (v_mfma_f32_32x32x2_f32)",
                                  "f16x3": "split fp16x3 (x=hi+lo, 3x v_mfma_f32_32x32x16_f16, fp32 accumulate)",
-                                 "f16x2": "weights hi+lo fp16, activations fp16 (2x v_mfma_f32_32x32x16_f16)",
+                                 "f16x2": "weights hi+lo fp16, activations fp16 (2x v_mfma_f32_32x32x16_f16)" +
+                                          (f"; single fp16 weights (1x) in {len(cfg['single_layers'])} of 39 layers"
+                                           if cfg.get("single_layers") else ""),
                                  "f16": "weights fp16, activations fp16 (1x v_mfma_f32_32x32x16_f16)"}[args.precision]},
     }
 
@@ -378,7 +398,11 @@ def main():
             gbps = alg_bytes / (ms * 1e-3) / 1e9 if ms else 0.0
             result["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": round(gbps, 1), "peak": PEAK_HBM_GBPS,
                                   "unit": "GB/s", "frac": round(gbps / PEAK_HBM_GBPS, 4)}
+        mfma_fl = (summ[dom]["mfma_flops"] if dom in summ else sum(summ[k]["mfma_flops"] for k in summ if k.startswith("gemm M"))) / reps
         result["roofline"].update({
+            "frac_mfma": round(mfma_fl / (ms * 1e-3) / (PEAK_F16_MFMA_TFLOPS * 1e12), 4) if args.precision != "fp32" else None,
+            "mfma_tflops_issued": round(mfma_fl / (ms * 1e-3) / 1e12, 1),
+            "mfma_busy": mfma_busy_from_profiles(dom),
             "traffic": pmc_bytes, "launches_per_step": n_launch, "avg_launch_us": round(1e3 * ms / n_launch, 2),
             "algorithmic_bytes_per_launch": int(alg_bytes / n_launch), "algorithmic_tflops": d["tflops"],
             "floor_ms_per_step": {"mfma": round(1e3 * t_mfma, 2), "hbm": round(1e3 * t_hbm, 2)},
@@ -413,6 +437,24 @@ def main():
                                            "sequence, last clip of the batch) vs CPU oracle, full shape, all iterations"}
 
     if rank == 0 and world == 1 and not args.no_kernel_breakdown and cfg == presets.engine_kwargs(presets.BENCH_PRESET):
+        for other in ("config2_fp16",):
+            # the all-split-weights form of the same arithmetic class (round 2's headline preset), same run, same box
+            try:
+                o_eng = HotPathEngine(params, device=dev, T=T, use_graph=not args.no_graph, **presets.engine_kwargs(other))
+                for _ in range(2):
+                    o_eng.forward(fmaps, cnets, iters=iters, all_masks=args.all_masks)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(5):
+                    o_eng.forward(fmaps, cnets, iters=iters, all_masks=args.all_masks)
+                torch.cuda.synchronize()
+                dto = (time.perf_counter() - t0) / 5
+                result[other + "_mode"] = {"value": B * pairs / dto, "unit": "flow-fields/s", "ms_per_step": 1e3 * dto,
+                                           "note": "same workload, split (hi + lo) weights in every layer"}
+                del o_eng
+                torch.cuda.empty_cache()
+            except RuntimeError as e:
+                result[other + "_mode"] = {"error": str(e)[:200]}
         # the same workload in the library's fp32-class arithmetic (split precision everywhere, fp32 volumes), so that
         # both named configurations are on record from one run on one box
         try:

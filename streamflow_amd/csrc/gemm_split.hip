@@ -316,6 +316,150 @@ __global__ __launch_bounds__(kThreads, (TM * TN >= 8) ? 2 : SF_GEMM_WAVES) void 
 }
 
 
+// ---- "B-direct" kernel: split weights x fp16 k-octet activations (SF_LAYOUT_SPLIT_F16 x SF_LAYOUT_F16_KOCT) ----------------
+// 128 (rows) x 256 (pixels) tile, 8 waves as 2 (rows) x 4 (pixels), each 64 x 64 = 2 x 2 MFMA tiles.
+//  * WEIGHTS (shared by all waves) go L2 -> LDS by DMA into a ring of three 32-deep stages: ONE 1-KB piece per plane
+//    (hi, lo) per wave and stage, requested two stages ahead, waited for with a counted vmcnt;
+//  * ACTIVATIONS are private to a wave column, and in the k-octet planes a lane's MFMA B fragment (8 consecutive k of one
+//    pixel) is one aligned 16-byte piece: every wave loads its own fragments straight from L2 into REGISTERS with plain
+//    buffer loads, one stage ahead.  No LDS, no DMA, no ds_read for them.
+// Why: the 128 x 128 kernel above moves BOTH operands by LDS-DMA -- 6 pieces per wave per 16 MFMAs -- and a wave sits
+// ~190 cycles in each such instruction in a busy CU (measured in the correlation build): more
+// than the MFMAs take.  Here it is 2 pieces and 4 plain loads per 16 MFMAs, a third of the LDS reads, one barrier per
+// 16 MFMAs of EIGHT waves, and 16 waves per CU (128 registers) instead of 12.
+// Same epilogues (gemm_epilogue.h) as the 128 x 128 kernel.
+constexpr int kBdThreads = 512;
+// wave grid WM x (8 / WM): 2 x 4 (64 x 64 per wave: every activation fragment is loaded by two waves) or 1 x 8 (each wave all
+// 128 rows x 32 pixels: no duplicate activation loads, but every wave re-reads all weight fragments from LDS)
+template <int PM, int WM>
+__global__ __launch_bounds__(kBdThreads, 4) void gemm_bdirect_kernel(const SplitArgs args) {
+    const SfGemm& g = args.g;
+    constexpr int BM = 128, BN = 256, WN = 8 / WM, TM = 4 / WM, TN = WM, NST = 3;
+    constexpr int kPlane = (BK / 8) * BM * 16;                       // bytes of one plane (hi or lo) of a stage: 8 KB
+    constexpr int kStage = PM * kPlane;
+    constexpr int kEpiBytes = 8 * sf::kEpiScratchFloats * 4;
+    __shared__ __attribute__((aligned(1024))) char smem[NST * kStage > kEpiBytes ? NST * kStage : kEpiBytes];
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int khalf = lane >> 5, l31 = lane & 31;
+    const int mt = (g.M + BM - 1) / BM, nt = (g.N + BN - 1) / BN;
+    const sf::TileCoord tc = sf::xcd_tile(blockIdx.x, gridDim.x, mt, nt);
+    const int n0 = tc.n_tile * BN, m0 = tc.m_tile * BM, z = tc.z;
+    const int nk = (g.K + BK - 1) / BK;
+
+    // ---- weights by DMA: slot = k-octet * 128 + row = tid (512 slots = one 8-KB plane of a stage) ----
+    const int a_plane = (int)(args.a_bytes);
+    const __amdgpu_buffer_rsrc_t rah = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.A_hi), 0, a_plane, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ral = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.A_lo), 0, a_plane, 0x00020000);
+    const int voa = ((tid >> 7) * (int)g.lda_h + m0 + (tid & 127)) * 16;
+    auto issue_a = [&](int kt, int slot) {
+        char* dst = smem + slot * kStage + wave * 1024;
+        const int so = kt * (BK / 8) * (int)g.lda_h * 16;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rah, (lds_ptr)(dst), 16, voa, so, 0, 0);
+        if (PM == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(ral, (lds_ptr)(dst + kPlane), 16, voa, so, 0, 0);
+    };
+    // ---- activations straight into registers: fragment (j, k-step ks) of stage kt = k-octet 4 kt + 2 ks + khalf of pixel
+    // n0 + (wn * 2 + j) * 32 + l31 (pixels past N clamped: never stored) ----
+    const __amdgpu_buffer_rsrc_t rbd = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(g.B)) + (int64_t)z * g.strideB * 2, 0, (int)args.b_bytes, 0x00020000);
+    int vob[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) vob[j] = (khalf * (int)g.ldb + min(n0 + (wn * TN + j) * 32 + l31, g.N - 1)) * 16;
+    const int b_goct = g.b_group > 0 ? g.b_group / 8 : 0;           // grouped rows: see the 128 x 128 kernel
+    // (two explicit register sets, the k-loop unrolled by two stages: indexed by kt & 1 the set becomes a dynamically indexed
+    // register array -- s_set_gpr_idx + v_mov behind a vmcnt(0) after every single load)
+    u32x4 bq0[BK / 16][TN], bq1[BK / 16][TN];
+    auto load_b = [&](int kt, u32x4 (&bq)[BK / 16][TN]) {
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            const int o = kt * (BK / 8) + ks * 2, gi = b_goct ? o / b_goct : 0;
+            const int so = (o - gi * b_goct) * (int)g.ldb * 16 + gi * (int)(g.b_group_stride * 2);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bq[ks][j] = __builtin_amdgcn_raw_buffer_load_b128(rbd, vob[j], so, 0);
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // issue order matters (vmcnt retires in order): B(0), DMA(0), DMA(1); then per stage kt: B(kt + 1), DMA(kt + 2)
+    load_b(0, bq0);
+    issue_a(0, 0);
+    issue_a(1, 1);
+    const int offa = (khalf * BM + wm * TM * 32 + l31) * 16;
+    int slot = 0, slot2 = 2;
+#ifdef SF_GEMM_TIMERS
+    const long long ts0 = __builtin_readcyclecounter(), rt0 = __builtin_amdgcn_s_memrealtime();
+    long long tw = 0, tb = 0, ti = 0, tm = 0, tprev = ts0;
+#define SF_BD_STAMP(acc_) { const long long t_ = __builtin_readcyclecounter(); acc_ += t_ - tprev; tprev = t_; }
+#else
+#define SF_BD_STAMP(acc_)
+#endif
+    auto stage = [&](int kt, u32x4 (&bcur)[BK / 16][TN], u32x4 (&bnext)[BK / 16][TN]) {
+        SF_BD_STAMP(tm)
+        // stage kt of the weights has landed (this wave's pieces; the barrier makes it everyone's): behind it in the queue
+        // are only B(kt) -- needed now anyway -- and the PM pieces of DMA(kt + 1)
+        __builtin_amdgcn_s_waitcnt(PM == 2 ? 0x0F72 : 0x0F71);                       // vmcnt(PM)
+        SF_BD_STAMP(tw)
+        __builtin_amdgcn_s_barrier();                       // ... and slot2 (stage kt - 1) is no longer read by anyone
+        SF_BD_STAMP(tb)
+        // (unconditional, also past the last stage -- out-of-range buffer reads return zeros into registers / a slot nobody
+        // reads: with the same number of memory operations behind every load on every path, hipcc's vmcnt waits are exact;
+        // with `if (kt + 1 < nk)` around them it sizes them for the shortest path, i.e. vmcnt(1) and (0))
+        load_b(kt + 1, bnext);
+        issue_a(kt + 2, slot2);
+        SF_BD_STAMP(ti)
+        const char* sa = smem + slot * kStage + offa;
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            f16x8 ah[TM], al[TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                ah[i] = *reinterpret_cast<const f16x8*>(sa + ks * 2 * BM * 16 + i * 32 * 16);
+                if (PM == 2) al[i] = *reinterpret_cast<const f16x8*>(sa + kPlane + ks * 2 * BM * 16 + i * 32 * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const f16x8 b = __builtin_bit_cast(f16x8, bcur[ks][j]);
+                    if (PM == 2) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], b, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], b, acc[i][j], 0, 0, 0);
+                }
+        }
+        slot = (slot == NST - 1) ? 0 : slot + 1;
+        slot2 = (slot2 == NST - 1) ? 0 : slot2 + 1;
+    };
+    for (int kt = 0; kt < nk; kt += 2) {                     // (an odd last stage multiplies zeros: nk is rounded up to even)
+        stage(kt, bq0, bq1);
+        stage(kt + 1, bq1, bq0);
+    }
+    constexpr bool kFastGelu = SF_GEMM_FAST_GELU;
+    __syncthreads();                                         // the stage ring becomes the epilogues' transpose scratch
+#ifdef SF_GEMM_TIMERS
+    const long long ts2 = __builtin_readcyclecounter();
+#endif
+    float* scratch = reinterpret_cast<float*>(smem) + wave * sf::kEpiScratchFloats;
+    if (g.c_f16 == 2) sf::gemm_epilogue_koct<WM, WN, TM, TN, kFastGelu>(g, acc, m0, n0, z, wm, wn, lane, scratch);
+    else if (sf::epilogue_vec_ok(g, z)) sf::gemm_epilogue_vec<WM, WN, TM, TN>(g, acc, m0, n0, z, wm, wn, lane, scratch);
+    else gemm_epilogue<WM, WN, TM, TN>(g, acc, m0, n0, z, wm, wn, lane);
+#ifdef SF_GEMM_TIMERS
+    if (args.ts && lane == 0 && blockIdx.x < 8192) {
+        long long* d = args.ts + ((int64_t)blockIdx.x * 8 + wave) * 8;
+        d[0] = ts0; d[1] = tw; d[2] = tb; d[3] = ti; d[4] = tm; d[5] = ts2 - ts0; d[6] = __builtin_readcyclecounter() - ts2;
+        d[7] = __builtin_amdgcn_s_memrealtime() - rt0;
+    }
+#endif
+}
+
+
 template <int WM, int WN, int TM, int TN, int PM>
 int launch_cfg(const SplitArgs& a, hipStream_t st) {
     constexpr bool SB = (PM == 3);
@@ -332,6 +476,17 @@ int launch_cfg(const SplitArgs& a, hipStream_t st) {
     }
     if (lay == 13) {                                     // split weights x fp16 k-octet activations: both operands by LDS-DMA
         if constexpr (!SB && WM * TM * 32 == 128) {
+            // B-direct kernel (128 x 256 tile, activations straight into registers): SF_GEMM_BDIRECT=0 keeps the 128 x 128 one
+            static const bool bdirect = !(getenv("SF_GEMM_BDIRECT") && atoi(getenv("SF_GEMM_BDIRECT")) == 0);
+            // measured per shape (tools/gemm_koct_bench.py, 24 x 7040 pixels): 2 x 4 waves win for M >= 512 (+7..9 %), 1 x 8 for
+            // 192 <= M < 512 (+0..15 %); M <= 128 stays on the 128 x 128 kernel (-10 % otherwise)
+            static const int bd_min_m = getenv("SF_GEMM_BD_MIN_M") ? atoi(getenv("SF_GEMM_BD_MIN_M")) : 192;
+            if (bdirect && g.M >= bd_min_m && g.k_splits <= 1 && (int64_t)g.ldb * 16 * 2 < ((int64_t)1 << 31)) {
+                dim3 grid2(sf::ceil_div(g.N, 256) * sf::ceil_div(g.M, 128) * g.batch);
+                if (g.M >= 512) hipLaunchKernelGGL((gemm_bdirect_kernel<PM, 2>), grid2, dim3(kBdThreads), 0, st, a);
+                else hipLaunchKernelGGL((gemm_bdirect_kernel<PM, 1>), grid2, dim3(kBdThreads), 0, st, a);
+                return sf::check_launch("sf_gemm(B-direct)");
+            }
             hipLaunchKernelGGL((gemm_f16x3_mfma<WM, WN, TM, TN, 2, 5, PM>), grid, dim3(kThreads), 0, st, a);
             return sf::check_launch("sf_gemm(f16x2, k-octet B)");
         }

@@ -159,6 +159,30 @@ class HotPathWeights:
         self.fc1 = PackedLinear(sd[tb + ".mlp.fc1.weight"], sd[tb + ".mlp.fc1.bias"], device)
         self.fc2 = PackedLinear(sd[tb + ".mlp.fc2.weight"], sd[tb + ".mlp.fc2.bias"], device)
 
+    SK_BLOCKS = ("convc1", "convc2", "convf2", "conv", "gru", "flow_head")
+    SK_LAYERS = ("ffn1_0", "ffn1_2", "pw", "ffn2_0", "ffn2_2")
+    PLAIN_LAYERS = ("to_qk", "convf1", "to_v", "qkv", "proj", "fc1", "fc2", "mask0", "mask2")
+
+    def layers(self) -> Dict[str, PackedLinear]:
+        """Every contraction's packed weights by name ('gru.ffn1_0', 'qkv', ...; 'X.pw' covers both forms of the pw layer)."""
+        out = {n: getattr(self, n) for n in self.PLAIN_LAYERS}
+        for b in self.SK_BLOCKS:
+            for l in self.SK_LAYERS:
+                out[f"{b}.{l}"] = getattr(getattr(self, b), l)
+        return out
+
+    def set_single(self, names) -> None:
+        """Mark the named layers (or 'all') as single-product in the f16x2 mode (ops.PackedLinear.single)."""
+        lay = self.layers()
+        names = list(lay) if names == "all" else list(names or [])
+        unknown = [n for n in names if n not in lay]
+        if unknown:
+            raise RuntimeError(f"unknown layer name(s) {unknown}; have {sorted(lay)}")
+        for n, pl in lay.items():
+            pl.single = n in names
+            if n.endswith(".pw"):
+                getattr(self, n.split(".")[0]).pw_res.single = pl.single
+
 
 ATTN_ROW_LIMIT = 1 << 28          # floats per image the GEMM epilogue can address with 32-bit offsets (1 GiB)
 
@@ -267,7 +291,8 @@ class HotPathEngine:
 
     def __init__(self, state_dict: Dict[str, torch.Tensor], device="cuda:0", T: Optional[int] = None,
                  use_graph: bool = False, precision: Optional[str] = None, corr_dtype: str = "f32",
-                 gma_mode: Optional[str] = None, flash_qk_products: Optional[int] = None):
+                 gma_mode: Optional[str] = None, flash_qk_products: Optional[int] = None,
+                 single_layers: Optional[Sequence[str]] = None):
         """precision: 'f16x3' (split fp16, fp32-class accuracy, default), 'fp32' (exact fp32 MFMA), 'f16x2'
         (weights split, activations rounded to fp16: ~1e-4 px EPE, faster) or 'f16' (weights and activations fp16);
         None = the package-wide setting (streamflow_amd.ops.PRECISION).
@@ -313,6 +338,9 @@ class HotPathEngine:
         # ~8 us on this part and each chain hides the other's.  SF_SPLIT_SOLO = 0 / 2 / 4 chains.
         self.split_solo = int(os.environ.get("SF_SPLIT_SOLO", "2"))
         self.W = HotPathWeights(state_dict, self.device, T)
+        # layers whose weights are used as ONE fp16 value in the f16x2 mode (see presets.py: chosen by measured EPE)
+        self.single_layers = tuple(single_layers or ())
+        self.W.set_single("all" if self.single_layers == ("all",) else self.single_layers)
         self.use_graph = use_graph
         self._plans: Dict[Tuple[int, int, int, int], _Plan] = {}
         self.max_plans = int(os.environ.get("SF_MAX_PLANS", "4"))

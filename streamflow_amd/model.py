@@ -30,7 +30,7 @@ def default_args(T: int = 4, Encoder: str = "Twins_CSC", **kw) -> Namespace:
     a = Namespace(model_name="SKFlow_MF8", Encoder=Encoder, UpdateBlock="SKUpdateBlock_TAM_v3",
                   MotionEncoder="SKMotionEncoder6_Deep_nopool_res", use_gma=True, k_conv=[1, 15],
                   PCUpdater_conv=[1, 7], T=T, num_heads=1, decoder_dim=256, mixed_precision=False, dropout=0,
-                  corr_levels=4, corr_radius=4, use_graph=False)
+                  corr_levels=4, corr_radius=4, use_graph=False, preset=None)
     for k, v in kw.items():
         setattr(a, k, v)
     return a
@@ -65,12 +65,28 @@ class SKFlow_MF8(nn.Module):
     def _hot_state(self):
         return {k: v for k, v in self.state_dict().items() if k.startswith(("att.", "update_block."))}
 
+    def preset_name(self) -> str:
+        """Arithmetic configuration of the refinement loop, chosen the way the reference chooses its own: `args.preset`
+        names one of streamflow_amd.presets explicitly; otherwise `args.mixed_precision` (the reference's autocast switch,
+        evaluate_mf.py:1106, streamflow.py:106,118,135) selects the reduced-precision class (`config2_mixed`) and its absence
+        the fp32-class arithmetic (`fp32_class`)."""
+        from . import presets
+        name = getattr(self.args, "preset", None)
+        if name is None:
+            name = presets.BENCH_PRESET if getattr(self.args, "mixed_precision", False) else "fp32_class"
+        if name not in presets.PRESETS:
+            raise RuntimeError(f"unknown preset {name!r} (have {list(presets.PRESETS)})")
+        return name
+
     def engine(self, device) -> HotPathEngine:
+        from . import presets
         params = [p for n, p in self.named_parameters() if n.startswith(("att.", "update_block."))]
-        key = (str(device),) + tuple((p.data_ptr(), p._version) for p in params)
+        name = self.preset_name()
+        key = (str(device), name) + tuple((p.data_ptr(), p._version) for p in params)
         if self._engine is None or self._engine_key != key:
             self._engine = HotPathEngine(self._hot_state(), device=device, T=self.args.T,
-                                         use_graph=bool(getattr(self.args, "use_graph", False)))
+                                         use_graph=bool(getattr(self.args, "use_graph", False)),
+                                         **presets.engine_kwargs(name))
             self._engine_key = key
         return self._engine
 
@@ -113,8 +129,9 @@ class StreamFlowT4(SKFlow_MF8):
     bare dict, keys optionally prefixed 'module.').  With the default Twins_CSC encoder the whole checkpoint is loaded
     strictly (demo.py:388-389); with a stand-in encoder only the hot-path keys are (and must match exactly)."""
 
-    def __init__(self, ckpt=None, Encoder: str = "Twins_CSC", use_graph: bool = True):
-        super().__init__(default_args(T=4, Encoder=Encoder, use_graph=use_graph))
+    def __init__(self, ckpt=None, Encoder: str = "Twins_CSC", use_graph: bool = True, preset: Optional[str] = None):
+        # the reference's demo hard-wires autocast(enabled=True) (demo.py:427,439,456): reduced-precision class by default
+        super().__init__(default_args(T=4, Encoder=Encoder, use_graph=use_graph, mixed_precision=True, preset=preset))
         if ckpt is not None:
             obj = torch.load(ckpt, map_location="cpu") if isinstance(ckpt, (str, bytes)) or hasattr(ckpt, "read") else ckpt
             sd = obj["model"] if isinstance(obj, dict) and "model" in obj else obj

@@ -55,23 +55,26 @@ class Profiler:
     def __init__(self):
         self.records = []
 
-    def launch(self, name, flops, nbytes, fn):
+    def launch(self, name, flops, nbytes, fn, products=1.0):
         s = torch.cuda.Event(enable_timing=True)
         e = torch.cuda.Event(enable_timing=True)
         s.record()
         fn()
         e.record()
-        self.records.append((name, float(flops), float(nbytes), s, e))
+        self.records.append((name, float(flops), float(nbytes), s, e, float(flops) * float(products)))
 
     def summary(self):
+        """per name: launches, ms, algorithmic flops and bytes, and mfma_flops = flops x MFMA products per algorithmic
+        product (3 / 2 / 1 in f16x3 / f16x2 / f16 or a single-product layer; fp32 MFMA counts as 1)."""
         torch.cuda.synchronize()
         out = {}
-        for name, fl, by, s, e in self.records:
-            d = out.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+        for name, fl, by, s, e, mf in self.records:
+            d = out.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0, "mfma_flops": 0.0})
             d["launches"] += 1
             d["ms"] += s.elapsed_time(e)
             d["flops"] += fl
             d["bytes"] += by
+            d["mfma_flops"] += mf
         return out
 
 
@@ -81,11 +84,15 @@ PROFILER: Optional[Profiler] = None
 PROFILE_SHAPES = False      # tag GEMM launches with their shape in the profiler (bench.py --gemm-shapes)
 
 
-def _launch(name: str, flops: float, nbytes: float, fn) -> None:
+def _launch(name: str, flops: float, nbytes: float, fn, products: float = 1.0) -> None:
     if PROFILER is None:
         fn()
     else:
-        PROFILER.launch(name, flops, nbytes, fn)
+        PROFILER.launch(name, flops, nbytes, fn, products)
+
+
+def _products(prec: int) -> float:
+    return {PRECISION_FP32: 1.0, PRECISION_F16X3: 3.0, PRECISION_F16X2: 2.0, PRECISION_F16: 1.0}[prec]
 
 
 def on_tensor_device(fn):
@@ -209,6 +216,9 @@ class PackedLinear:
     """A 1x1-conv / Linear weight [Cout, Cin(,1,1)] repacked K-major ([Cin][Cout padded to 4]) for sf_gemm."""
 
     def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor], device, conv3x3: bool = False):
+        # single: in the f16x2 mode this layer's weights enter the products as their round-to-nearest fp16 `hi` image alone
+        # (ONE MFMA per product instead of two, no `lo` plane read): set per layer by HotPathEngine(single_layers=...)
+        self.single = False
         w = weight.detach().to(device=device, dtype=torch.float32)
         if conv3x3:                                   # [Cout, Cin, 3, 3] -> k = (ky*3+kx)*Cin + c
             cout = w.shape[0]
@@ -295,6 +305,8 @@ def gemm(A: PackedLinear, X: Planes, Y: Planes, epilogue: int = EPI_NONE, R: Opt
     g.a_layout, g.b_layout = LAYOUT_K_MAJOR, LAYOUT_K_MAJOR
     g.a_padded = 1
     prec = PRECISION
+    if A.single and prec == PRECISION_F16X2:
+        prec = PRECISION_F16                          # per-layer single-product weights (same operand formats)
     if X.f16 or Y.f16:
         if prec not in (PRECISION_F16X2, PRECISION_F16):
             raise RuntimeError("fp16 activation planes are a hand-over format of the f16x2 / f16 modes only")
@@ -333,7 +345,7 @@ def gemm(A: PackedLinear, X: Planes, Y: Planes, epilogue: int = EPI_NONE, R: Opt
     nbytes = (g.batch * g.N * ((2.0 if X.f16 else 4.0) * X.rows + (2.0 if Y.f16 else 6.0 if fused_shadow else 4.0) * g.M +
                                ((2.0 if R.f16 else 4.0) * g.M if R is not None else 0.0)) + 4.0 * g.M * g.K)
     _launch(name, 2.0 * g.M * g.N * g.K * g.batch, nbytes,
-            lambda: _lib.check(_lib.load().sf_gemm(C.byref(g), _lib.stream()), "sf_gemm"))
+            lambda: _lib.check(_lib.load().sf_gemm(C.byref(g), _lib.stream()), "sf_gemm"), products=_products(prec))
     if not fused_shadow:
         refresh_shadow(Y)
 
@@ -350,7 +362,7 @@ def gemm_raw(**kw) -> None:
     nbytes = g.batch * (4.0 * g.M * g.K + eb * g.K * g.N + 4.0 * g.M * g.N * (2 if g.R else 1) *
                         (g.k_splits if g.k_splits > 1 else 1))
     _launch(name, 2.0 * g.M * g.N * g.K * g.batch, nbytes,
-            lambda: _lib.check(_lib.load().sf_gemm(C.byref(g), _lib.stream()), "sf_gemm"))
+            lambda: _lib.check(_lib.load().sf_gemm(C.byref(g), _lib.stream()), "sf_gemm"), products=_products(PRECISION))
 
 
 @on_tensor_device
@@ -371,7 +383,10 @@ def dwconv_res_gelu(X: Planes, wgt: torch.Tensor, bias: torch.Tensor, Y: Planes,
             lambda: _lib.check(_lib.load().sf_dwconv_res_gelu(X.ptr, X.img_stride, wgt.data_ptr(), bias.data_ptr(),
                                                               Y.ptr, Y.img_stride, int(Y.f16), X.n_img, X.rows, h, w, k,
                                                               PRECISION, _lib.stream()),
-                               "sf_dwconv_res_gelu"))
+                               "sf_dwconv_res_gelu"),
+            # matrix-core work: banded Toeplitz GEMMs (32 / 15 of the algorithmic flops) for K = 15 in the split modes, 2 or 3
+            # products; the fp32 and 7 x 7 stencils run on the VALU
+            products=((32.0 / 15.0) * (3.0 if PRECISION == PRECISION_F16X3 else 2.0)) if (k == 15 and PRECISION != PRECISION_FP32) else 0.0)
 
 
 @on_tensor_device
@@ -459,7 +474,7 @@ def gma_flash_aggregate(ws: torch.Tensor, V: Planes, MF: Planes, gamma: torch.Te
             lambda: _lib.check(_lib.load().sf_gma_flash_aggregate(
                 ws.data_ptr(), ws.numel(), V.ptr, V.img_stride, MF.ptr, MF.img_stride, gamma.data_ptr(), OUT.ptr,
                 OUT.img_stride, None if sh is None else sh.ptr, 0 if sh is None else sh.img_stride, n, P,
-                int(qk_products), _lib.stream()), "sf_gma_flash_aggregate"))
+                int(qk_products), _lib.stream()), "sf_gma_flash_aggregate"), products=(qk_products + 1) / 2.0)
     if sh is None:
         refresh_shadow(OUT)
 
@@ -552,7 +567,7 @@ def corr_build(f1_ptr: int, f2_ptr: int, clip_stride: int, pair_stride: int, lvl
             f1_ptr, f2_ptr, clip_stride, pair_stride, lvls[0].data_ptr(), lvls[1].data_ptr(), lvls[2].data_ptr(),
             lvls[3].data_ptr(), pair_strides(lvl_pair_stride), B, pairs, D, h, w, 4, prec,
             ws.data_ptr() if need else None, need, _lib.stream()),
-        "sf_corr_build_pyramid"))
+        "sf_corr_build_pyramid"), products=_products(prec))
 
 
 @on_tensor_device

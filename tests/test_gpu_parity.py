@@ -247,7 +247,7 @@ def test_sintel_shape_vs_oracle(dev, precision):
 _HEADLINE_ORACLE = {}
 
 
-@pytest.mark.parametrize("preset", ["config2_fp16", "fp32_class"])
+@pytest.mark.parametrize("preset", ["config2_mixed", "config2_fp16", "fp32_class"])
 def test_headline_config_batched_vs_oracle(dev, preset):
     """BASELINE.json's headline configuration exactly as bench.py times it: 440x1024 (55x128 grid), T=4, ALL 15
     iterations, 8 clips batched through every launch (the per-GPU share of config 4's batch 64), HIP-graph replay, in
@@ -283,6 +283,52 @@ def test_headline_config_batched_vs_oracle(dev, preset):
     ups2, _ = eng.forward(fd2, cd2, iters=iters)
     for i in range(T - 1):
         assert orc.epe(ups2[i][3:4].cpu(), ups[i][B - 1:B]) <= 1e-4
+
+
+def test_preset_selected_through_reference_args(dev):
+    """The arithmetic preset is chosen the way the reference chooses its own (args.mixed_precision, evaluate_mf.py:1106)
+    or by name (args.preset); the engine the model builds carries exactly that preset's settings."""
+    import streamflow_amd as sfa
+    from streamflow_amd import ops, presets, synthetic as syn
+    P = syn.make_params(2, 4)
+    for kw, want in ((dict(), "fp32_class"), (dict(mixed_precision=True), presets.BENCH_PRESET),
+                     (dict(preset="config2_fp16"), "config2_fp16")):
+        m = sfa.SKFlow_MF8(sfa.default_args(T=4, Encoder="InjectEncoder", **kw))
+        m.load_state_dict(dict(P), strict=True)
+        assert m.preset_name() == want
+        eng = m.engine(dev)
+        cfg = presets.engine_kwargs(want)
+        assert eng.precision == ops._PRECISION_NAMES[cfg["precision"]] and eng.corr_f16 == (cfg["corr_dtype"] == "f16")
+        assert eng.single_layers == tuple(cfg.get("single_layers", ()))
+        assert sum(pl.single for pl in eng.W.layers().values()) == len(cfg.get("single_layers", ()))
+    assert sfa.StreamFlowT4(None, Encoder="InjectEncoder").preset_name() == presets.BENCH_PRESET
+    with pytest.raises(RuntimeError, match="unknown preset"):
+        sfa.SKFlow_MF8(sfa.default_args(T=4, Encoder="InjectEncoder", preset="nope")).engine(dev)
+
+
+def test_single_product_layers_are_what_they_say(dev):
+    """A layer marked single-product multiplies by the round-to-nearest fp16 image of its (scaled) weights alone: equal to
+    the two-product GEMM run on weights that ARE fp16-representable, and different from the split-weight result."""
+    from streamflow_amd import ops
+    from streamflow_amd.ops import Planes, PackedLinear
+    g = torch.Generator().manual_seed(5)
+    M, K, P_, n = 384, 256, 512, 2
+    Wt = torch.randn(M, K, generator=g) / K ** 0.5
+    X = torch.randn(n, K, P_, generator=g).to(dev)
+    prev = ops.set_precision("f16x2")
+    try:
+        A = PackedLinear(Wt.reshape(M, K, 1, 1), None, dev)
+        Y2, Y1, Yr = (torch.empty(n, M, P_, device=dev) for _ in range(3))
+        ops.gemm(A, Planes.of(X), Planes.of(Y2))
+        A.single = True
+        ops.gemm(A, Planes.of(X), Planes.of(Y1))
+        Ar = PackedLinear((A.hi.float().permute(1, 0, 2).reshape(A.lda_h, -1)[:M, :K] / A.split_scale).reshape(M, K, 1, 1), None, dev)
+        ops.gemm(Ar, Planes.of(X), Planes.of(Yr))
+        torch.cuda.synchronize()
+    finally:
+        ops.set_precision(prev)
+    assert (Y1 - Yr).abs().max().item() < 1e-5
+    assert (Y1 - Y2).abs().max().item() > 1e-5
 
 
 def test_fp16_volume_mode_within_parity_budget(dev):

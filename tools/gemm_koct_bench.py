@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""f16x2 GEMMs with a k-octet fp16 B operand (the hand-over format of the conv stack) at the shapes that hold the GEMM time,
+24 images of 7040 pixels.  Prints us and algorithmic TF per shape; SF_GEMM_BDIRECT=0/1 selects the kernel.
+usage: gemm_koct_bench.py [epi: none|gelu|koct]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from streamflow_amd import ops
+from streamflow_amd.ops import Planes, PackedLinear
+mode = sys.argv[1] if len(sys.argv) > 1 else "none"
+n, P = int(os.environ.get("SF_N_IMG", "24")), 7040
+dev = torch.device("cuda:0")
+ops.set_precision("f16x2")
+shapes = [(960, 640), (640, 960), (640, 640), (128, 960), (486, 324), (324, 486), (384, 256), (256, 384), (256, 256), (192, 128), (128, 192), (128, 128)]
+tot = 0.0
+for M, K in shapes:
+    W = PackedLinear(torch.randn(M, K, 1, 1) / K ** 0.5, torch.randn(M) * 0.1, dev)
+    Ka = (K + 7) // 8 * 8
+    xs = torch.randn(n, Ka, P, device=dev)
+    X = Planes(torch.zeros(n * Ka * P // 2, device=dev), 0, Ka * P, n, K, P, f16=True, koct=True)
+    ops.pack_koct(Planes.of(xs[:, :K].contiguous()) if Ka != K else Planes.of(xs), X)
+    if mode == "koct":
+        Ma = (M + 7) // 8 * 8
+        Y = Planes(torch.zeros(n * Ma * P // 2, device=dev), 0, Ma * P, n, M, P, f16=True, koct=True)
+        epi = ops.EPI_GELU
+    else:
+        Y = Planes.of(torch.empty(n, M, P, device=dev))
+        epi = ops.EPI_GELU if mode == "gelu" else ops.EPI_NONE
+    if mode == "koct" and not ops.uses_dma_tile(M):
+        continue
+    for _ in range(3):
+        ops.gemm(W, X, Y, epi)
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(10):
+        ops.gemm(W, X, Y, epi)
+    e.record(); torch.cuda.synchronize()
+    us = s.elapsed_time(e) * 100
+    tot += us
+    print(f"M{M:4d} K{K:4d} {mode:5s}: {us:7.1f} us  {2.0 * M * K * P * n / us / 1e6:6.1f} TF", flush=True)
+print(f"sum {tot:.1f} us")

@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Per-layer sensitivity of the final flows to SINGLE-product weights (weights rounded once to fp16) in the f16x2 arithmetic:
+headline shape (55 x 128 grid, T = 4, 15 iterations, one clip), EPE vs the fp32 CPU oracle, one layer at a time, then the
+cumulative set in order of increasing damage.  Writes JSON lines.  usage: layer_ablation.py [seed]"""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from oracle import streamflow_oracle as orc
+from streamflow_amd import presets, synthetic as syn
+from streamflow_amd.engine import HotPathEngine, HotPathWeights
+seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+dev = torch.device("cuda:0")
+B, T, h, w, iters = 1, 4, 55, 128, 15
+P = syn.make_params(seed, T)
+fmaps, cnets = syn.make_features(1000 + seed, B, T, h, w)
+t0 = time.time()
+ups_o, _ = orc.hotpath_forward(fmaps, cnets, P, iters)
+print(json.dumps({"oracle_s": round(time.time() - t0, 1)}), flush=True)
+fd, cd = fmaps.to(dev), cnets.to(dev)
+kw = presets.engine_kwargs("config2_fp16")
+
+
+def epe(single):
+    eng = HotPathEngine(P, device=dev, T=T, single_layers=single, **kw)
+    ups, _ = eng.forward(fd, cd, iters=iters)
+    return max(orc.epe(u.cpu(), o) for u, o in zip(ups, ups_o))
+
+
+base = epe(())
+print(json.dumps({"layers": [], "epe": base}), flush=True)
+names = sorted(HotPathEngine(P, device=dev, T=T, **kw).W.layers())
+res = {}
+for n in names:
+    res[n] = epe((n,))
+    print(json.dumps({"layers": [n], "epe": res[n]}), flush=True)
+order = sorted(names, key=lambda n: res[n])
+cum = []
+for n in order:
+    cum.append(n)
+    e = epe(tuple(cum))
+    print(json.dumps({"cumulative": len(cum), "added": n, "epe": e}), flush=True)
+print(json.dumps({"all": epe(("all",))}), flush=True)
