@@ -315,8 +315,8 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": {"fp32": "fp32", "f16x3": "f16x3-split (fp32 accumulate)",
                   "f16x2": ("f16x2 (weights hi+lo, activations fp16; fp32 accumulate)" if not cfg.get("single_layers") else
-                            f"f16x2 / f16 mixed (activations fp16, weights hi+lo in {39 - len(cfg['single_layers'])} layers and "
-                            f"fp16 in {len(cfg['single_layers'])}; fp32 accumulate)"),
+                            f"f16x2 / f16 mixed (activations fp16; weights fp16 in {len(cfg['single_layers'])} of the 45 "
+                            f"contraction / depthwise layers, hi+lo in the rest; fp32 accumulate)"),
                   "f16": "f16 (weights and activations fp16; fp32 accumulate)"}[args.precision] +
                  ("; fp16 correlation volumes" if args.corr_dtype == "f16" else ""), "data": "synthetic",
         "config": {"workload": f"{args.workload}_{H}x{W}_T{T}_iters{iters}", "clips_per_gpu_per_step": B,
@@ -331,7 +331,7 @@ def main():
                    "precision": {"fp32": "exact fp32 (v_mfma_f32_32x32x2_f32)",
                                  "f16x3": "split fp16x3 (x=hi+lo, 3x v_mfma_f32_32x32x16_f16, fp32 accumulate)",
                                  "f16x2": "weights hi+lo fp16, activations fp16 (2x v_mfma_f32_32x32x16_f16)" +
-                                          (f"; single fp16 weights (1x) in {len(cfg['single_layers'])} of 39 layers"
+                                          (f"; single fp16 weights (1x) in {len(cfg['single_layers'])} of 45 layers"
                                            if cfg.get("single_layers") else ""),
                                  "f16": "weights fp16, activations fp16 (1x v_mfma_f32_32x32x16_f16)"}[args.precision]},
     }

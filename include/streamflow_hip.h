@@ -248,8 +248,9 @@ int sf_softmax_rows(float* x, int64_t rows, int cols, void* out_f16, void* strea
  * (same for y with y_img_stride); wgt [C][K][K], bias [C].  x and y must not overlap.
  * precision SF_PRECISION_FP32: fp32 FMA stencil on the VALU.  Split precisions: every kernel row is a banded
  * Toeplitz GEMM on the matrix cores with fp32 accumulation.  SF_PRECISION_F16X3: (hi, lo) fp16 halves of both
- * operands, three products.  SF_PRECISION_F16X2 / _F16: sf_gemm's f16x2 arithmetic -- weights hi + lo, the activation
- * enters the products rounded to fp16 (two products); the residual x stays exact in every mode.
+ * operands, three products.  SF_PRECISION_F16X2: sf_gemm's f16x2 arithmetic -- weights hi + lo, the activation
+ * enters the products rounded to fp16 (two products).  SF_PRECISION_F16: the weights are rounded once to fp16 as well (one
+ * product; a single-product layer of the mixed preset).  The residual x stays exact in every mode.
  * y_f16 = 1: y receives IEEE fp16 planes of the same [img][c][h][w] order, y_img_stride counted in halves -- the
  * hand-over to a GEMM that reads them as SF_LAYOUT_F16_K_MAJOR (the engine's pw layer in the f16x2 mode, whose
  * residual is folded into its weights so that x3 has no other reader). */

@@ -178,7 +178,9 @@ struct DwmArgs {
 #endif
 // kProd = 3: x = hi + lo on both sides (f16x3).  kProd = 2 (the GEMMs' f16x2 arithmetic): the ACTIVATION enters the
 // products as its hi half only (weights stay hi + lo) -- two MFMAs and one fragment read per kernel row and tile instead
-// of three and two; both planes are still staged, the residual stays exact.
+// of three and two; both planes are still staged, the residual stays exact.  kProd = 1 (SF_PRECISION_F16, a single-product
+// layer of the mixed preset): the WEIGHTS are one round-to-nearest fp16 too -- one MFMA per kernel row and tile, half the
+// Toeplitz registers (60), three workgroups per CU.
 #ifndef SF_GEMM_FAST_GELU
 #define SF_GEMM_FAST_GELU 1
 #endif
@@ -186,7 +188,7 @@ struct DwmArgs {
 #define SF_DW_MINWG 2
 #endif
 template <int KS, bool kOutF16, int kProd>
-__global__ __launch_bounds__(256, (KS == 15 && kProd == 2) ? SF_DW_MINWG : 2) void dwconv_mfma_kernel(const DwmArgs g) {
+__global__ __launch_bounds__(256, kProd == 1 ? 3 : ((KS == 15 && kProd == 2) ? SF_DW_MINWG : 2)) void dwconv_mfma_kernel(const DwmArgs g) {
     using namespace sf_split;
     constexpr int R = KS / 2;
     constexpr int WZ = 64;                                      // zero-padded weight row: w[ky][j - 24]
@@ -214,9 +216,9 @@ __global__ __launch_bounds__(256, (KS == 15 && kProd == 2) ? SF_DW_MINWG : 2) vo
         float v[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = wz[ky * WZ + (kg * 8 + i) - n - 8 + R + 24];
-        const Split8 s8 = split8(v);
+        const Split8 s8 = (kProd == 1) ? split8_rn(v) : split8(v);
         bh[ky] = s8.hi;
-        bl[ky] = s8.lo;
+        bl[ky] = s8.lo;                                          // (dead for kProd = 1)
     }
     const float bv = g.bias[c];
 #ifdef SF_DW_TIMERS
@@ -268,7 +270,7 @@ __global__ __launch_bounds__(256, (KS == 15 && kProd == 2) ? SF_DW_MINWG : 2) vo
 #pragma unroll
             for (int u = 0; u < FU; ++u) {
                 if (off[u] < 0) continue;
-                const Split8 s8 = (kProd == 2) ? split8_rn(v[u]) : split8(v[u]);
+                const Split8 s8 = (kProd <= 2) ? split8_rn(v[u]) : split8(v[u]);
                 *reinterpret_cast<f16x8*>(hi + off[u]) = s8.hi;
                 *reinterpret_cast<f16x8*>(lo + off[u]) = s8.lo;
             }
@@ -318,8 +320,10 @@ __global__ __launch_bounds__(256, (KS == 15 && kProd == 2) ? SF_DW_MINWG : 2) vo
 #pragma unroll
                     for (int j = 0; j < TG; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[cur][j], bh[ky], acc[j], 0, 0, 0);
                 }
+                if constexpr (kProd >= 2) {
 #pragma unroll
-                for (int j = 0; j < TG; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[cur][j], bl[ky], acc[j], 0, 0, 0);
+                    for (int j = 0; j < TG; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[cur][j], bl[ky], acc[j], 0, 0, 0);
+                }
 #pragma unroll
                 for (int j = 0; j < TG; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[cur][j], bh[ky], acc[j], 0, 0, 0);
             }
@@ -339,7 +343,7 @@ __global__ __launch_bounds__(256, (KS == 15 && kProd == 2) ? SF_DW_MINWG : 2) vo
                                          (float)*reinterpret_cast<const _Float16*>(lo + xo);
                         t[u] = xv + (acc[j][r + u] + bv);
                     }
-                    const sf::f32x2 a = sf::gelu2<(kProd == 2) && kOutF16 && SF_GEMM_FAST_GELU>(t);   // polynomial GELU where the result leaves as fp16
+                    const sf::f32x2 a = sf::gelu2<(kProd <= 2) && kOutF16 && SF_GEMM_FAST_GELU>(t);   // polynomial GELU where the result leaves as fp16
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
                         const bool ok = (gx0 + j * 16 < g.w) && (gy0 + r + u < g.h);
@@ -382,6 +386,7 @@ extern "C" int sf_dwconv_res_gelu(const float* x, int64_t x_img_stride, const fl
     // 128 channels x 24 images); K = 15 runs 1.45x faster on the matrix cores
     static const bool force3 = getenv("SF_DW_PRODUCTS") && atoi(getenv("SF_DW_PRODUCTS")) == 3;   // A/B knob
     const bool two = precision != SF_PRECISION_FP32 && precision != SF_PRECISION_F16X3 && !force3;
+    const bool one = two && precision == SF_PRECISION_F16;       // weights rounded once to fp16 as well
     static const bool dw7_stencil = getenv("SF_DW7_MFMA") && atoi(getenv("SF_DW7_MFMA")) == 0;      // A/B knob
     // K = 7 in the two-product modes also runs on the matrix cores (7 x 2 MFMAs per tile against 49 FMAs per output)
     if (precision != SF_PRECISION_FP32 && (ksize == 15 || (two && !dw7_stencil))) {
@@ -411,11 +416,17 @@ extern "C" int sf_dwconv_res_gelu(const float* x, int64_t x_img_stride, const fl
         dim3 grid(C, strips, sf::ceil_div(n_img, m.imgs_per_wg));
         SF_REQUIRE(strips <= 65535 && grid.z <= 65535, "sf_dwconv_res_gelu: grid too large");
         if (ksize == 7) {
-            if (y_f16) hipLaunchKernelGGL((dwconv_mfma_kernel<7, true, 2>), grid, dim3(256), lds, (hipStream_t)stream, m);
+            if (one && y_f16) hipLaunchKernelGGL((dwconv_mfma_kernel<7, true, 1>), grid, dim3(256), lds, (hipStream_t)stream, m);
+            else if (one) hipLaunchKernelGGL((dwconv_mfma_kernel<7, false, 1>), grid, dim3(256), lds, (hipStream_t)stream, m);
+            else if (y_f16) hipLaunchKernelGGL((dwconv_mfma_kernel<7, true, 2>), grid, dim3(256), lds, (hipStream_t)stream, m);
             else hipLaunchKernelGGL((dwconv_mfma_kernel<7, false, 2>), grid, dim3(256), lds, (hipStream_t)stream, m);
             return sf::check_launch("sf_dwconv_res_gelu(mfma7)");
         }
-        if (y_f16 && two)
+        if (one && y_f16)
+            hipLaunchKernelGGL((dwconv_mfma_kernel<15, true, 1>), grid, dim3(256), lds, (hipStream_t)stream, m);
+        else if (one)
+            hipLaunchKernelGGL((dwconv_mfma_kernel<15, false, 1>), grid, dim3(256), lds, (hipStream_t)stream, m);
+        else if (y_f16 && two)
             hipLaunchKernelGGL((dwconv_mfma_kernel<15, true, 2>), grid, dim3(256), lds, (hipStream_t)stream, m);
         else if (y_f16)
             hipLaunchKernelGGL((dwconv_mfma_kernel<15, true, 3>), grid, dim3(256), lds, (hipStream_t)stream, m);

@@ -53,6 +53,7 @@ class SKBlockWeights:
         self.k = int(wk.shape[-1])
         self.dwk_w = f32(wk.reshape(wk.shape[0], -1))
         self.dwk_b = f32(g("conv_list.1.bias"))
+        self.dw_single = False                # the K x K depthwise weights as one fp16 value (layer name '<block>.dw')
 
 
 def _scratch(buf: Planes, n_img: int, rows: int, f16: bool = False, koct: bool = False) -> Planes:
@@ -110,11 +111,11 @@ def run_skblock(W: SKBlockWeights, X: Planes, Y: Planes, hid: Planes, xa: Planes
         # x3 in fp16 rows straight out of the depthwise kernel, residual folded into the pw weights: the pw GEMM reads half
         # the bytes, has a residual-free epilogue and may therefore write k-octets
         b16 = _scratch(xb, X.n_img, C, f16=True)
-        ops.dwconv_res_gelu(a, W.dwk_w, W.dwk_b, b16, h, w, W.k)               # x3 = gelu(x2 + dwKxK(x2))
+        ops.dwconv_res_gelu(a, W.dwk_w, W.dwk_b, b16, h, w, W.k, single=W.dw_single)   # x3 = gelu(x2 + dwKxK(x2))
         a4 = _handover(xa, X.n_img, C, X.P, consumer_rows=W.c_mid)
         ops.gemm(W.pw_res, b16, a4, EPI_GELU)                                   # x4 = gelu((pw + I) x3)
     else:
-        ops.dwconv_res_gelu(a, W.dwk_w, W.dwk_b, b, h, w, W.k)                 # x3 = gelu(x2 + dwKxK(x2))
+        ops.dwconv_res_gelu(a, W.dwk_w, W.dwk_b, b, h, w, W.k, single=W.dw_single)   # x3 = gelu(x2 + dwKxK(x2))
         # (fp16 ROWS, not k-octets: the k-octet epilogue fetches its residual with 8 dword loads per octet and made the
         # pw GEMMs 15-20 % slower -- more than their consumers gained)
         a4 = _handover(xa, X.n_img, C, X.P, consumer_rows=W.c_mid, allow_koct=False)
@@ -174,10 +175,13 @@ class HotPathWeights:
     def set_single(self, names) -> None:
         """Mark the named layers (or 'all') as single-product in the f16x2 mode (ops.PackedLinear.single)."""
         lay = self.layers()
-        names = list(lay) if names == "all" else list(names or [])
-        unknown = [n for n in names if n not in lay]
+        dws = [b + ".dw" for b in self.SK_BLOCKS]
+        names = (list(lay) + dws) if names == "all" else list(names or [])
+        unknown = [n for n in names if n not in lay and n not in dws]
         if unknown:
-            raise RuntimeError(f"unknown layer name(s) {unknown}; have {sorted(lay)}")
+            raise RuntimeError(f"unknown layer name(s) {unknown}; have {sorted(lay) + dws}")
+        for b in self.SK_BLOCKS:
+            getattr(self, b).dw_single = (b + ".dw") in names
         for n, pl in lay.items():
             pl.single = n in names
             if n.endswith(".pw"):

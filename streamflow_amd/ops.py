@@ -376,17 +376,20 @@ def splitk_combine(partial: torch.Tensor, split_stride: int, k_splits: int, part
 
 
 @on_tensor_device
-def dwconv_res_gelu(X: Planes, wgt: torch.Tensor, bias: torch.Tensor, Y: Planes, h: int, w: int, k: int) -> None:
-    """Y = gelu(X + dwconv_KxK(X) + bias).  Y may be fp16 row planes (Planes.f16, not koct): the hand-over to a GEMM."""
+def dwconv_res_gelu(X: Planes, wgt: torch.Tensor, bias: torch.Tensor, Y: Planes, h: int, w: int, k: int,
+                    single: bool = False) -> None:
+    """Y = gelu(X + dwconv_KxK(X) + bias).  Y may be fp16 row planes (Planes.f16, not koct): the hand-over to a GEMM.
+    single (f16x2 mode only): the weights enter the products as ONE fp16 value (a single-product layer)."""
     assert X.rows == Y.rows == wgt.shape[0] and X.P == h * w and not X.f16 and not Y.koct
+    prec = PRECISION_F16 if (single and PRECISION == PRECISION_F16X2) else PRECISION
     _launch("dwconv%d" % k, 2.0 * k * k * X.n_img * X.rows * h * w, (6.0 if Y.f16 else 8.0) * X.n_img * X.rows * h * w,
             lambda: _lib.check(_lib.load().sf_dwconv_res_gelu(X.ptr, X.img_stride, wgt.data_ptr(), bias.data_ptr(),
                                                               Y.ptr, Y.img_stride, int(Y.f16), X.n_img, X.rows, h, w, k,
-                                                              PRECISION, _lib.stream()),
+                                                              prec, _lib.stream()),
                                "sf_dwconv_res_gelu"),
             # matrix-core work: banded Toeplitz GEMMs (32 / 15 of the algorithmic flops) for K = 15 in the split modes, 2 or 3
             # products; the fp32 and 7 x 7 stencils run on the VALU
-            products=((32.0 / 15.0) * (3.0 if PRECISION == PRECISION_F16X3 else 2.0)) if (k == 15 and PRECISION != PRECISION_FP32) else 0.0)
+            products=((32.0 / 15.0) * _products(prec)) if (k == 15 and PRECISION != PRECISION_FP32) else 0.0)
 
 
 @on_tensor_device

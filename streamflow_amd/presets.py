@@ -37,6 +37,9 @@ PRESETS: Dict[str, Dict[str, object]] = {
 # layers that keep split (hi + lo) weights in `config2_mixed`
 MIXED_KEEP_SPLIT = ("gru.pw", "gru.ffn2_0", "gru.ffn2_2", "qkv", "proj", "fc1",
                     "flow_head.pw", "flow_head.ffn2_0", "flow_head.ffn2_2")
+# K x K depthwise layers with single-product weights in `config2_mixed` (tools/dw_ablation.py: the four 15 x 15 layers of the
+# motion encoder move the EPE by < 5e-6 px; the GRU's 7 x 7 and the flow head's 15 x 15 add 5e-5 .. 1.8e-4 and stay split)
+MIXED_SINGLE_DEPTHWISE = ("convc1.dw", "convc2.dw", "convf2.dw", "conv.dw")
 BENCH_PRESET = "config2_mixed"
 
 
@@ -47,5 +50,5 @@ def engine_kwargs(name: str) -> Dict[str, object]:
     if kw.get("single_layers") == "all_but_keep":
         from .engine import HotPathWeights
         names = list(HotPathWeights.PLAIN_LAYERS) + [f"{b}.{l}" for b in HotPathWeights.SK_BLOCKS for l in HotPathWeights.SK_LAYERS]
-        kw["single_layers"] = tuple(n for n in names if n not in MIXED_KEEP_SPLIT)
+        kw["single_layers"] = tuple(n for n in names if n not in MIXED_KEEP_SPLIT) + MIXED_SINGLE_DEPTHWISE
     return kw

@@ -300,7 +300,8 @@ def test_preset_selected_through_reference_args(dev):
         cfg = presets.engine_kwargs(want)
         assert eng.precision == ops._PRECISION_NAMES[cfg["precision"]] and eng.corr_f16 == (cfg["corr_dtype"] == "f16")
         assert eng.single_layers == tuple(cfg.get("single_layers", ()))
-        assert sum(pl.single for pl in eng.W.layers().values()) == len(cfg.get("single_layers", ()))
+        n_dw = sum(getattr(eng.W, b).dw_single for b in eng.W.SK_BLOCKS)
+        assert sum(pl.single for pl in eng.W.layers().values()) + n_dw == len(cfg.get("single_layers", ()))
     assert sfa.StreamFlowT4(None, Encoder="InjectEncoder").preset_name() == presets.BENCH_PRESET
     with pytest.raises(RuntimeError, match="unknown preset"):
         sfa.SKFlow_MF8(sfa.default_args(T=4, Encoder="InjectEncoder", preset="nope")).engine(dev)
