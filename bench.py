@@ -128,9 +128,16 @@ def mfma_busy_from_profiles(kernel_family):
         return None
 
 
-def newest_traffic_file():
-    """profiles/rNN*_traffic.json of the latest round (names sort by round); None if there is none."""
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]*traffic.json")))
+def newest_traffic_file(workload=None):
+    """profiles/rNN*traffic*.json of the latest round (names sort by round), preferring the file taken on `workload`;
+    None if there is none."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]*traffic*.json")))
+    if workload:
+        mine = [f for f in files if workload in os.path.basename(f)]
+        newest = files[-1][len(os.path.join(ROOT, "profiles", "")):][:3] if files else ""
+        mine = [f for f in mine if os.path.basename(f).startswith(newest)]
+        if mine:
+            return mine[-1]
     return files[-1] if files else None
 
 
@@ -367,7 +374,7 @@ def main():
         dom = max((k for k in kern if not k.startswith("gemm M")), key=lambda k: kern[k]["ms_per_step"])
         # HBM traffic of every family from the committed rocprofv3 PMC passes (bench.py cannot run the profiler on
         # itself): newest profiles/rNN*traffic.json
-        traffic, tfile = {}, newest_traffic_file()
+        traffic, tfile = {}, newest_traffic_file(args.workload)
         if tfile:
             try:
                 with open(tfile) as f:
@@ -378,7 +385,8 @@ def main():
         n_launch = max(d["launches_per_step"], 1)
         ms = d["ms_per_step"]
         same = (traffic.get("_workload", "sintel") == args.workload and int(traffic.get("_clips", 8)) == B and
-                traffic.get("_corr_dtype", "f32") == args.corr_dtype and traffic.get("_precision", "f16x3") == args.precision)
+                traffic.get("_corr_dtype", "f32") == args.corr_dtype and traffic.get("_precision", "f16x3") == args.precision and
+                traffic.get("_preset", args.preset or presets.BENCH_PRESET) == (args.preset or presets.BENCH_PRESET))
         fam = traffic.get(dom) if same else None           # PMC bytes only describe the configuration they were taken on
         pmc_bytes = int((fam["fetch_kib_per_launch"] + fam["write_kib_per_launch"]) * 1024) if fam else None
         alg_bytes = summ[dom]["bytes"] / reps if dom in summ else 0.0
@@ -420,7 +428,16 @@ def main():
                                        "build_gbps": cb["gbps_algorithmic"], "lookup_gbps": cl["gbps_algorithmic"],
                                        "build_tflops": cb["tflops"], "build_plus_lookup_ms_per_step": round(tot_ms, 4),
                                        "achieved": round(tot_b / (tot_ms * 1e-3) / 1e9, 1),
-                                       "frac": round(tot_b / (tot_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4)}
+                                       "frac": round(tot_b / (tot_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4),
+                                       "bytes": "SURVEY.md section 8(d), element size of the stored volume: per pair build = 2 N 256 4 + N cells e, "
+                                                "lookup = N (4 100 e + 8 + 324 4) -- the k-octet hand-over and the blocked layout's padding "
+                                                "are NOT counted"}
+            if same and traffic.get("corr_build") and traffic.get("corr_lookup"):
+                real = 1024.0 * ((traffic["corr_build"]["fetch_kib_per_launch"] + traffic["corr_build"]["write_kib_per_launch"]) * cb["launches_per_step"] +
+                                 (traffic["corr_lookup"]["fetch_kib_per_launch"] + traffic["corr_lookup"]["write_kib_per_launch"]) * cl["launches_per_step"])
+                result["roofline_corr"]["traffic"] = int(real)
+                result["roofline_corr"]["traffic_gbps"] = round(real / (tot_ms * 1e-3) / 1e9, 1)
+                result["roofline_corr"]["traffic_over_algorithmic"] = round(real / tot_b, 3)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import streamflow_oracle as orc

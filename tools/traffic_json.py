@@ -9,7 +9,7 @@ import collections, csv, json, re, sys
 
 FAMILY = [(r"corr_build|split_pack|pack_f16", "corr_build"), (r"corr_lookup", "corr_lookup"),
           (r"gma_flash|flash_pack_v", "gma_flash"), (r"flash_pack_qk", "flash_pack_qk"),
-          (r"gemm_f16x3_mfma<[^>]*, 1, [13], (true|false)>", "gemm_attn"), (r"gemm_f", "gemm"),
+          (r"gemm_f16x3_mfma<[^>]*, 1, [13], (true|false)>", "gemm_attn"), (r"gemm_f|gemm_bdirect", "gemm"),
           (r"splitk_epilogue", "gemm"), (r"splitk_combine", "splitk_combine"), (r"dwconv_mfma_kernel<7", "dwconv7"), (r"dwconv_mfma", "dwconv15"),
           (r"dwconv_res_gelu_kernel<15>", "dwconv15"), (r"dwconv_res_gelu_kernel<7>", "dwconv7"),
           (r"softmax_rows", "softmax_rows"), (r"layernorm", "layernorm"), (r"temporal_attn", "temporal_attn"),
@@ -33,18 +33,23 @@ def collect(path, counter):
             cnt[f] += 1
     return tot, cnt
 
-ft, fc = collect(sys.argv[1], "FETCH_SIZE")
-wt, wc = collect(sys.argv[2], "WRITE_SIZE")
-# split_pack + corr_build_dma are two launches of one sf_corr_build_pyramid call: count calls, not launches
-out = {"_note": "KiB per launch (mean). fetch = 2 x FETCH_SIZE (gfx950 correction, MI355X_MICROARCH.md HBM section), "
-                "write = WRITE_SIZE; calibrated on softmax_rows (known bytes)."}
-for f in sorted(set(ft) | set(wt)):
-    nf, nw = max(fc[f], 1), max(wc[f], 1)
-    if f in ("corr_build", "gma_flash"):          # pack + main kernel = two launches of one C-ABI call
-        nf, nw = max(nf // 2, 1), max(nw // 2, 1)
-    out[f] = {"fetch_kib_per_launch": round(2.0 * ft[f] / nf, 1), "write_kib_per_launch": round(wt[f] / nw, 1),
-              "fetch_size_raw_kib": round(ft[f] / nf, 1), "launches_profiled": nf}
-for kv in sys.argv[3:]:
-    k, v = kv.split("=", 1)
-    out[k] = int(v) if v.isdigit() else v
-print(json.dumps(out, indent=1))
+def main():
+    ft, fc = collect(sys.argv[1], "FETCH_SIZE")
+    wt, wc = collect(sys.argv[2], "WRITE_SIZE")
+    # split_pack + corr_build_dma are two launches of one sf_corr_build_pyramid call: count calls, not launches
+    out = {"_note": "KiB per launch (mean). fetch = 2 x FETCH_SIZE (gfx950 correction, MI355X_MICROARCH.md HBM section), "
+                    "write = WRITE_SIZE; calibrated on softmax_rows (known bytes)."}
+    for f in sorted(set(ft) | set(wt)):
+        nf, nw = max(fc[f], 1), max(wc[f], 1)
+        if f in ("corr_build", "gma_flash"):          # pack + main kernel = two launches of one C-ABI call
+            nf, nw = max(nf // 2, 1), max(nw // 2, 1)
+        out[f] = {"fetch_kib_per_launch": round(2.0 * ft[f] / nf, 1), "write_kib_per_launch": round(wt[f] / nw, 1),
+                  "fetch_size_raw_kib": round(ft[f] / nf, 1), "launches_profiled": nf}
+    for kv in sys.argv[3:]:
+        k, v = kv.split("=", 1)
+        out[k] = int(v) if v.isdigit() else v
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
