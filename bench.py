@@ -510,6 +510,48 @@ def main():
         except RuntimeError as e:
             result["single_clip"] = {"error": str(e)[:200]}
 
+    if rank == 0 and world == 1 and not args.no_kernel_breakdown and args.workload != "spring":
+        # frames -> flows: the reference's forward runs the encoder inside the call (streamflow.py:105-108); random frames,
+        # random-init Twins_CSC weights of the reference's architecture (fnet on T frames, cnet on T - 1), then the same
+        # engine.  Secondary numbers: `value` above starts at the features (BASELINE.json's hot path).
+        try:
+            from streamflow_amd.encoders import Twins_CSC
+            fnet, cnet = Twins_CSC().to(dev), Twins_CSC().to(dev)
+            fnet.svt.load_state_dict({k[4:]: v for k, v in syn.make_twins_params(1).items()}, strict=True)
+            cnet.svt.load_state_dict({k[4:]: v for k, v in syn.make_twins_params(2).items()}, strict=True)
+            frames = (torch.rand(B, T, 3, H, W, generator=torch.Generator().manual_seed(3)) * 2 - 1).to(dev)
+            prev = ops.set_precision(cfg["precision"])
+            try:
+                def encode():
+                    return fnet(frames).float().contiguous(), cnet(frames[:, :-1]).float().contiguous()
+                for _ in range(2):
+                    fm, cn = encode()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    fm, cn = encode()
+                torch.cuda.synchronize()
+                t_enc = (time.perf_counter() - t0) / 3
+                eng.forward(fm, cn, iters=iters, all_masks=args.all_masks)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    fm, cn = encode()
+                    eng.forward(fm, cn, iters=iters, all_masks=args.all_masks)
+                torch.cuda.synchronize()
+                t_all = (time.perf_counter() - t0) / 3
+            finally:
+                ops.set_precision(prev)
+            result["encoder_ms_per_clip"] = round(1e3 * t_enc / B, 3)
+            result["frames_to_flows_per_sec"] = {"value": B * pairs / t_all, "unit": "flow-fields/s", "ms_per_step": 1e3 * t_all,
+                                                 "encoder_share": round(t_enc / t_all, 3),
+                                                 "note": "Twins_CSC fnet + cnet (random-init weights of the reference architecture) on "
+                                                         "random frames, then the timed hot path; same clips per step"}
+            del fnet, cnet, frames
+            torch.cuda.empty_cache()
+        except RuntimeError as e:
+            result["frames_to_flows_per_sec"] = {"error": str(e)[:200]}
+
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:

@@ -42,8 +42,10 @@ __device__ __forceinline__ float erf_fast(float x) {
 }
 
 // exact (erf-based) GELU, as F.gelu / nn.GELU default: 0.5 x (1 + erf(x / sqrt(2)))
+// (x / 2 is clamped below where the erf argument saturates: 1 + erf_fast(-4) is 0 only to the fit's 4.5e-7, which times an
+// unbounded |x| / 2 would be an error growing with |x|; clamped it stays <= 1.3e-6 for every x)
 __device__ __forceinline__ float gelu_erf(float x) {
-    return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752440f));
+    return 0.5f * fmaxf(x, -5.6568542f) * (1.0f + erf_fast(x * 0.70710678118654752440f));
 }
 
 // Two GELUs at a time on packed fp32 (v_pk_fma_f32 / v_pk_mul_f32): the same operations in the same order as
@@ -72,15 +74,16 @@ __device__ __forceinline__ f32x2 erf_fast2(f32x2 x) {
     return (x * p) * r;
 }
 __device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
-    return splat2(0.5f) * x * (splat2(1.0f) + erf_fast2(x * splat2(0.70710678118654752440f)));
+    return splat2(0.5f) * __builtin_elementwise_max(x, splat2(-5.6568542f)) * (splat2(1.0f) + erf_fast2(x * splat2(0.70710678118654752440f)));
 }
 
 // GELU for results that leave as fp16 in the f16x2 / f16 arithmetic (kFast below: the k-octet GEMM epilogue, the fp16-row
 // output of the depthwise kernel): a pure polynomial -- erf(z) ~ z Q(z^2) on |z| <= 3 (degree-8 minimax
 // Q, |err| <= 2.2e-5, erf(3) = 1 - 2.2e-5 beyond), constants folded so that gelu(x) = h + h * (xc * D(xc^2)), h = x / 2,
 // xc = x clamped to +-3 sqrt 2: 14 issue slots per PAIR (2 v_med3, 10 v_pk_fma / v_pk_mul, no v_rcp) against 28 for the
-// rational form above.  |gelu error| <= 5.2e-5 absolute and <= 1.1e-5 relative for x > 0 -- a tenth of the fp16 rounding
-// (2^-11 relative) that every activation of these modes receives on its way into the next contraction.
+// rational form above.  |gelu error| <= 5.2e-5 absolute for EVERY x (h is clamped below at -3/sqrt 2, so that the residue of
+// erf(3) != 1 stays 4.7e-5 instead of growing like 1.1e-5 |x|: ADVICE r2) and <= 1.1e-5 relative for x > 0 -- a tenth of the
+// fp16 rounding (2^-11 relative) that every activation of these modes receives on its way into the next contraction.
 __device__ __forceinline__ f32x2 gelu_poly2(f32x2 x) {
     f32x2 xc;
     xc[0] = __builtin_amdgcn_fmed3f(x[0], -4.2426405f, 4.2426405f);
@@ -95,7 +98,7 @@ __device__ __forceinline__ f32x2 gelu_poly2(f32x2 x) {
     p = __builtin_elementwise_fma(p, t, splat2(0.019636236f));
     p = __builtin_elementwise_fma(p, t, splat2(-0.13269384f));
     p = __builtin_elementwise_fma(p, t, splat2(0.79780626f));
-    const f32x2 h = splat2(0.5f) * x;
+    const f32x2 h = splat2(0.5f) * __builtin_elementwise_max(x, splat2(-4.2426405f));
     return __builtin_elementwise_fma(h, xc * p, h);
 }
 template <bool kFast>

@@ -557,7 +557,7 @@ class HotPathEngine:
             ops.gemm(W.mask0, pl.nets, pl.m256, EPI_RELU, hw=(h, w))
             ops.gemm(W.mask2, pl.m256, pl.mask, EPI_NONE, alpha=0.25)
         # streamflow.py:138 + :133 for the next iteration
-        ops.flow_update(pl.coords1, pl.delta, pl.flow, pl.mf.slice(HDIM - 2, HDIM), n, h, w,
+        ops.flow_update(pl.coords1, pl.delta, pl.flow, pl.mf.slice(HDIM - 2, HDIM, unshadowed=True), n, h, w,
                         koct=pl.mf.shadow, koct_row=HDIM - 2)       # (+ the flow rows of mf's k-octet copy)
 
     @contextlib.contextmanager
@@ -620,7 +620,7 @@ class HotPathEngine:
                 raise RuntimeError(f"flow_init needs {T - 1} tensors, got {len(flow_init)}")
             for i, f in enumerate(flow_init):
                 coords1.view(Bc, T - 1, 2, h, w)[:, i] += f.to(coords1)
-        ops.flow_update(pl.coords1, None, pl.flow, pl.mf.slice(HDIM - 2, HDIM), n, h, w,
+        ops.flow_update(pl.coords1, None, pl.flow, pl.mf.slice(HDIM - 2, HDIM, unshadowed=True), n, h, w,
                         koct=pl.mf.shadow, koct_row=HDIM - 2)
         return pl
 
@@ -650,7 +650,7 @@ class HotPathEngine:
             pl.cnets_in = torch.empty_like(cnets)
         pl.fmaps_in.copy_(fmaps)
         pl.cnets_in.copy_(cnets)
-        key = key + (self.precision,)
+        key = key + (self.precision, self.split_solo, self.parallel_branches, self.single_layers)
         if pl.graph is None or pl.graph_key != key:
             # warm-up outside capture, then capture the whole clip as one graph.  The loop state (coords1, flow)
             # is re-initialised by the caller before every replay, so the graph itself is stateless.

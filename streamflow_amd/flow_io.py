@@ -53,8 +53,9 @@ def read_flo(path: str) -> np.ndarray:
 
 
 def kitti_encode(flow: np.ndarray) -> np.ndarray:
-    """[H, W, 2] flow -> uint16 [H, W, 3] = (64*u + 2^15, 64*v + 2^15, 1)  (frame_utils.py:137-141)"""
-    uv = 64.0 * np.asarray(flow, np.float64) + 2 ** 15
+    """[H, W, 2] flow -> uint16 [H, W, 3] = (64*u + 2^15, 64*v + 2^15, 1)  (frame_utils.py:137-141).  Computed in the DTYPE OF
+    `flow` like the reference (a float32 flow gives float32 codes before the truncation to uint16: pinned by the golden)."""
+    uv = 64.0 * np.asarray(flow) + 2 ** 15
     valid = np.ones(uv.shape[:2] + (1,))
     return np.concatenate([uv, valid], axis=-1).astype(np.uint16)
 
@@ -126,6 +127,10 @@ def read_png(path: str) -> np.ndarray:
     while pos + 8 <= len(data):
         n, tag = struct.unpack(">I", data[pos:pos + 4])[0], data[pos + 4:pos + 8]
         body = data[pos + 8:pos + 8 + n]
+        if len(body) != n or pos + 12 + n > len(data):
+            raise IOError(f"{path}: truncated PNG chunk {tag!r}")
+        if struct.unpack(">I", data[pos + 8 + n:pos + 12 + n])[0] != (zlib.crc32(tag + body) & 0xFFFFFFFF):
+            raise IOError(f"{path}: CRC mismatch in PNG chunk {tag!r}")
         if tag == b"IHDR":
             hdr = struct.unpack(">IIBBBBB", body)
         elif tag == b"IDAT":
@@ -146,32 +151,38 @@ def read_png(path: str) -> np.ndarray:
         raise IOError(f"{path}: truncated image data")
     raw = raw.reshape(h, stride + 1)
     out = np.zeros((h, stride), np.uint8)
-    prev = np.zeros(stride, np.int32)
+    prev = np.zeros(stride, np.uint8)
     for y in range(h):
-        ft, line = int(raw[y, 0]), raw[y, 1:].astype(np.int32)
+        ft, line = int(raw[y, 0]), raw[y, 1:]
         if ft == 0:
             cur = line
-        elif ft == 2:                                      # Up
-            cur = (line + prev) & 255
-        else:                                              # Sub / Average / Paeth depend on the pixel to the left
-            cur = np.zeros(stride, np.int32)
-            for x in range(stride):
-                a = cur[x - bpp] if x >= bpp else 0
-                b = prev[x]
-                cc = prev[x - bpp] if x >= bpp else 0
-                if ft == 1:
-                    pred = a
-                elif ft == 3:
-                    pred = (a + b) >> 1
-                elif ft == 4:
-                    p = a + b - cc
-                    pa, pb, pc = abs(p - a), abs(p - b), abs(p - cc)
-                    pred = a if (pa <= pb and pa <= pc) else (b if pb <= pc else cc)
-                else:
-                    raise IOError(f"{path}: bad filter type {ft}")
-                cur[x] = (line[x] + pred) & 255
+        elif ft == 2:                                      # Up: byte-wise sum with the row above (uint8 wraps mod 256)
+            cur = line + prev
+        elif ft == 1:                                      # Sub: a running sum per byte lane of the pixel
+            cur = np.cumsum(line.reshape(w, bpp), axis=0, dtype=np.uint8).reshape(stride)
+        elif ft in (3, 4):                                 # Average / Paeth: sequential in x; plain ints on bytes objects
+            lb, pb = line.tobytes(), prev.tobytes()        # (a numpy scalar per byte was ~20x slower: libpng writes
+            cb = bytearray(stride)                         # adaptive filters, so this IS the common KITTI path)
+            if ft == 3:
+                for x in range(stride):
+                    a = cb[x - bpp] if x >= bpp else 0
+                    cb[x] = (lb[x] + ((a + pb[x]) >> 1)) & 255
+            else:
+                for x in range(stride):
+                    if x >= bpp:
+                        a, c_ = cb[x - bpp], pb[x - bpp]
+                    else:
+                        a = c_ = 0
+                    b_ = pb[x]
+                    p = a + b_ - c_
+                    pa, pb_, pc = abs(p - a), abs(p - b_), abs(p - c_)
+                    pred = a if (pa <= pb_ and pa <= pc) else (b_ if pb_ <= pc else c_)
+                    cb[x] = (lb[x] + pred) & 255
+            cur = np.frombuffer(bytes(cb), np.uint8)
+        else:
+            raise IOError(f"{path}: bad filter type {ft}")
         out[y] = cur
-        prev = cur
+        prev = out[y]
     img = out.view(">u2").astype(np.uint16) if depth == 16 else out
     img = img.reshape(h, w, c)
     return img[:, :, 0] if c == 1 else img

@@ -78,6 +78,21 @@ class Profiler:
         return out
 
 
+# SF_DEBUG_RANGE=1: before every contraction that rounds / splits an fp32 operand to fp16, check max |x| < 65504 (the fp16
+# range: above it `hi` saturates silently) -- a host-side, synchronising debug aid; raises RuntimeError
+DEBUG_RANGE = os.environ.get("SF_DEBUG_RANGE", "0") == "1"
+F16_MAX = 65504.0
+
+
+def _check_range(X: "Planes", what: str) -> None:
+    if X.f16 or X.group:
+        return
+    m = float(X.tensor().abs().max())
+    if not (m < F16_MAX):
+        raise RuntimeError(f"SF_DEBUG_RANGE: {what}: max |activation| = {m:.4g} does not fit fp16 (65504): the split-precision "
+                           "modes would saturate it silently; run this layer with precision='fp32'")
+
+
 SPLIT_WS: Optional[torch.Tensor] = None     # scratch that lets sf_gemm split K for small grids (set by the engine)
 
 PROFILER: Optional[Profiler] = None
@@ -164,11 +179,17 @@ class Planes:
     def ptr(self) -> int:
         return self.base.data_ptr() + 4 * self.off
 
-    def slice(self, r0: int, r1: int) -> "Planes":
+    def slice(self, r0: int, r1: int, unshadowed: bool = False) -> "Planes":
+        """Rows r0 .. r1-1.  A slice of shadowed planes that does not start on an octet cannot carry the k-octet copy along:
+        the caller must say so (`unshadowed=True`) and keep that copy current itself -- a producer writing through such a
+        slice would otherwise leave the parent's copy stale without any error."""
         assert 0 <= r0 < r1 <= self.rows and self.group == 0
         if self.f16:                                # k-octet planes: whole octets only
             assert self.koct and r0 % 8 == 0 and self.shadow is None
             return replace(self, off=self.off + (r0 // 8) * self.P * 4, rows=r1 - r0)
+        if self.shadow is not None and r0 % 8 != 0 and not unshadowed:
+            raise RuntimeError(f"Planes.slice({r0}, {r1}): shadowed planes can only be sliced at octet boundaries "
+                               "(pass unshadowed=True and maintain the k-octet copy explicitly)")
         sh = self.shadow.slice(r0, r1) if (self.shadow is not None and r0 % 8 == 0) else None
         return replace(self, off=self.off + r0 * self.P, rows=r1 - r0, shadow=sh)
 
@@ -296,6 +317,8 @@ def gemm(A: PackedLinear, X: Planes, Y: Planes, epilogue: int = EPI_NONE, R: Opt
     if (X.shadow is not None and SHADOWS and PRECISION in (PRECISION_F16X2, PRECISION_F16) and not A.conv3x3 and
             uses_dma_tile(A.M)):
         X = X.shadow                                  # the fp16 k-octet copy: both operands by LDS-DMA
+    if DEBUG_RANGE and PRECISION != PRECISION_FP32:
+        _check_range(X, f"sf_gemm M{A.M} K{A.K}")
     g = SfGemm()
     g.A, g.B, g.C = A.wt.data_ptr(), X.ptr, Y.ptr
     g.bias = None if A.bias is None else A.bias.data_ptr()
@@ -381,6 +404,8 @@ def dwconv_res_gelu(X: Planes, wgt: torch.Tensor, bias: torch.Tensor, Y: Planes,
     """Y = gelu(X + dwconv_KxK(X) + bias).  Y may be fp16 row planes (Planes.f16, not koct): the hand-over to a GEMM.
     single (f16x2 mode only): the weights enter the products as ONE fp16 value (a single-product layer)."""
     assert X.rows == Y.rows == wgt.shape[0] and X.P == h * w and not X.f16 and not Y.koct
+    if DEBUG_RANGE and PRECISION != PRECISION_FP32:
+        _check_range(X, f"sf_dwconv_res_gelu C{X.rows} k{k}")
     prec = PRECISION_F16 if (single and PRECISION == PRECISION_F16X2) else PRECISION
     _launch("dwconv%d" % k, 2.0 * k * k * X.n_img * X.rows * h * w, (6.0 if Y.f16 else 8.0) * X.n_img * X.rows * h * w,
             lambda: _lib.check(_lib.load().sf_dwconv_res_gelu(X.ptr, X.img_stride, wgt.data_ptr(), bias.data_ptr(),

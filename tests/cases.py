@@ -101,3 +101,19 @@ def twins_inputs(tag):
     B, T, H, W, seed = TWINS_CASES[tag]
     x = torch.tanh(syn.randn(seed, "twins.x", (B, T, 3, H, W)))
     return syn.make_twins_params(seed), x
+
+
+def flow_io_inputs():
+    """Seeded inputs of the frame_utils fixture (f3): a flow with fractional parts that sit on the uint16 truncation edge of
+    the KITTI code in float32 vs float64 arithmetic, a 16-bit KITTI image, PFM payloads."""
+    import numpy as np
+    rng = np.random.default_rng(91)
+    flow = (rng.standard_normal((5, 7, 2)) * 20.0).astype(np.float32)
+    flow[0, 0] = [0.0, -512.0]
+    flow[0, 1] = [1.0 - 2.0 ** -7, 511.984375]          # 64 u + 2^15 lands 0.5 below an integer: float32 keeps it, truncation differs if mis-rounded
+    flow[0, 2] = [np.float32(3.99999976), np.float32(-0.0078125)]
+    kitti = rng.integers(0, 65536, size=(4, 6, 3)).astype(np.uint16)          # as cv2.imread returns it: B, G, R = valid, v, u
+    kitti[:, :, 0] = rng.integers(0, 2, size=(4, 6))
+    pfm3 = rng.standard_normal((3, 4, 3)).astype(np.float32)
+    pfm1 = rng.standard_normal((3, 4)).astype(np.float32)
+    return flow, kitti, pfm3, pfm1

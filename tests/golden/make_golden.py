@@ -322,6 +322,40 @@ def main():
             enc.eval()
             save(tag, out=enc(x))
 
+        # ---- f3 flow file formats: the reference's own core/utils/frame_utils.py, imported over in-memory cv2 / h5py stubs
+        # (readFlow / writeFlow / readPFM touch neither; the KITTI functions hand their uint16 arithmetic to cv2.imread /
+        # cv2.imwrite, which the stub captures: the PNG codec itself is cv2's, not the reference's) ----
+        if not ONLY or "frame_utils" in ONLY:
+            import tempfile
+            cap = {}
+            cv2 = _module("cv2")
+            cv2.setNumThreads = lambda n: None
+            cv2.ocl = types.SimpleNamespace(setUseOpenCL=lambda b: None)
+            cv2.IMREAD_ANYDEPTH, cv2.IMREAD_COLOR = 2, 1
+            cv2.imwrite = lambda fn, arr: cap.__setitem__("written", np.array(arr))
+            cv2.imread = lambda fn, flags: cap["to_read"].copy()
+            _module("h5py")
+            from utils import frame_utils as ref_fu
+            flow, kitti, pfm3, pfm1 = cases.flow_io_inputs()
+            with tempfile.TemporaryDirectory() as td:
+                fn = os.path.join(td, "a.flo")
+                ref_fu.writeFlow(fn, flow)
+                flo_bytes = np.fromfile(fn, np.uint8)
+                flo_back = ref_fu.readFlow(fn)
+                ref_fu.writeFlowKITTI(os.path.join(td, "k.png"), flow)
+                cap["to_read"] = kitti
+                kflow, kvalid = ref_fu.readFlowKITTI(os.path.join(td, "k.png"))
+                pf = {}
+                for tag, arr, hdr, end in (("pfm3_le", pfm3, b"PF", "<"), ("pfm1_be", pfm1, b"Pf", ">")):
+                    fnp = os.path.join(td, tag + ".pfm")
+                    with open(fnp, "wb") as f:
+                        f.write(hdr + b"\n" + f"{arr.shape[1]} {arr.shape[0]}\n".encode() + (b"-1.0\n" if end == "<" else b"1.0\n"))
+                        np.flipud(arr).astype(end + "f4").tofile(f)
+                    pf[tag + "_file"] = np.fromfile(fnp, np.uint8)
+                    pf[tag] = np.ascontiguousarray(ref_fu.readPFM(fnp)).astype(np.float32)
+            save("frame_utils", flo_bytes=flo_bytes, flo_back=flo_back, kitti_written_bgr=cap["written"], kitti_flow=kflow,
+                 kitti_valid=kvalid, **pf)
+
         # ---- a12 full forward through SKFlow_MF8.forward (config-1 style plumbing) -----------
         for tag, (B, T, H, W, iters, seed, use_init) in cases.FORWARD_CASES.items():
             P, fmaps, cnets, finit, iters = cases.forward_inputs(tag)

@@ -249,3 +249,70 @@ def test_flo5_reader_handles_other_layouts(tmp_path):
     open(p2, "wb").write(build(msgs, tree))
     got = flo5.read_flo5(p2)
     assert got.dtype == np.float32 and np.array_equal(got, d32)
+
+
+def test_flow_formats_pinned_against_reference_frame_utils(golden, tmp_path):
+    """f3 pinned: .flo, PFM and the KITTI uint16 arithmetic against outputs of the reference's own core/utils/frame_utils.py
+    (readFlow / writeFlow / readPFM / readFlowKITTI / writeFlowKITTI, executed over cv2 / h5py stubs by
+    tests/golden/make_golden.py).  The PNG container is cv2's in the reference and our own zlib codec here: what is
+    pinned for KITTI is the array handed to / received from the codec."""
+    import numpy as np
+    from streamflow_amd import flow_io
+    from tests import cases
+    g = golden("frame_utils")
+    flow, kitti, pfm3, pfm1 = cases.flow_io_inputs()
+    # .flo: byte-identical file, identical read-back
+    p = tmp_path / "a.flo"
+    flow_io.write_flo(str(p), flow)
+    assert np.array_equal(np.fromfile(p, np.uint8), g["flo_bytes"])
+    g["flo_bytes"].tofile(tmp_path / "ref.flo")
+    assert np.array_equal(flow_io.read_flo(str(tmp_path / "ref.flo")), g["flo_back"])
+    # KITTI encode: the reference passes uv[..., ::-1] (B, G, R = valid, v, u) to cv2.imwrite; ours holds (u, v, valid)
+    assert np.array_equal(flow_io.kitti_encode(flow)[..., ::-1], g["kitti_written_bgr"])
+    # ... through our PNG codec and back: the same codes
+    flow_io.write_flow_kitti(str(tmp_path / "k.png"), flow)
+    assert np.array_equal(flow_io.read_png(str(tmp_path / "k.png"))[..., ::-1], g["kitti_written_bgr"])
+    # KITTI decode: cv2.imread returns B, G, R; the file holds R, G, B = (u, v, valid)
+    flow_io.write_png(str(tmp_path / "in.png"), np.ascontiguousarray(kitti[..., ::-1]))
+    f, v = flow_io.read_flow_kitti(str(tmp_path / "in.png"))
+    assert f.dtype == np.float32 and np.array_equal(f, g["kitti_flow"]) and np.array_equal(v, g["kitti_valid"])
+    # PFM: the reference's reader on little-endian colour and big-endian grey files
+    for tag in ("pfm3_le", "pfm1_be"):
+        g[tag + "_file"].tofile(tmp_path / (tag + ".pfm"))
+        assert np.array_equal(flow_io.read_pfm(str(tmp_path / (tag + ".pfm"))), g[tag])
+    flow_io.write_pfm(str(tmp_path / "w.pfm"), pfm3)
+    assert np.array_equal(np.fromfile(tmp_path / "w.pfm", np.uint8), g["pfm3_le_file"])
+
+
+def test_png_reader_all_filter_types(tmp_path):
+    """libpng writes adaptive filters (Sub / Up / Average / Paeth): a 16-bit RGB image filtered by hand, every type in turn,
+    must decode exactly; a corrupted chunk CRC is rejected."""
+    import struct, zlib
+    import numpy as np
+    from streamflow_amd import flow_io
+    rng = np.random.default_rng(0)
+    h, w, bpp = 23, 31, 6
+    img = rng.integers(0, 65536, size=(h, w, 3)).astype(np.uint16)
+    rows = img.astype(">u2").reshape(h, -1).view(np.uint8).reshape(h, -1).astype(np.int32)
+    raw, prev = bytearray(), np.zeros(w * bpp, np.int32)
+    for y in range(h):
+        ft, cur, line = y % 5, rows[y], np.zeros(w * bpp, np.int32)
+        for x in range(w * bpp):
+            a, b, c = (cur[x - bpp] if x >= bpp else 0), prev[x], (prev[x - bpp] if x >= bpp else 0)
+            p = a + b - c
+            pa, pb, pc = abs(p - a), abs(p - b), abs(p - c)
+            pred = [0, a, b, (a + b) >> 1, a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)][ft]
+            line[x] = (cur[x] - pred) & 255
+        raw.append(ft)
+        raw += bytes(line.astype(np.uint8))
+        prev = cur
+    chunk = lambda tag, data: struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+    png = (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 16, 2, 0, 0, 0)) +
+           chunk(b"IDAT", zlib.compress(bytes(raw))) + chunk(b"IEND", b""))
+    (tmp_path / "f.png").write_bytes(png)
+    assert np.array_equal(flow_io.read_png(str(tmp_path / "f.png")), img)
+    bad = bytearray(png)
+    bad[60] ^= 0x40
+    (tmp_path / "bad.png").write_bytes(bytes(bad))
+    with pytest.raises(IOError):
+        flow_io.read_png(str(tmp_path / "bad.png"))

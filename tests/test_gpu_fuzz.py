@@ -348,7 +348,7 @@ def test_flow_update_koct_rows(dev):
     sh.base.view(torch.float16).fill_(3.0)
     flow = torch.empty(n, 2, P, device=dev)
     cp = Planes.of(coords.clone())
-    ops.flow_update(cp, Planes.of(delta), Planes.of(flow), Planes.of(mf).slice(126, 128), n, h, w, koct=sh, koct_row=126)
+    ops.flow_update(cp, Planes.of(delta), Planes.of(flow), Planes.of(mf).slice(126, 128), n, h, w, koct=sh, koct_row=126)   # (unshadowed planes: plain slice)
     torch.cuda.synchronize()
     got = sh.tensor().float()
     assert torch.equal(got[:, 126:128], flow.half().float())
@@ -435,11 +435,14 @@ def test_two_product_mode_gelu_accuracy(dev):
     """The f16x2 / f16 modes evaluate GELU as a polynomial (sf_common.h gelu_poly2) where the result is stored as fp16
     (k-octet epilogue).  Through an identity GEMM (K = M, W = I, inputs exactly representable in fp16, so the contraction
     is exact) the epilogue output IS gelu(x): the stored fp16 value must be within the polynomial's 6e-5 absolute plus one
-    fp16 rounding of float64 over [-12, 12]; fp32 results keep the erf-rational form (<= 2e-6) in every mode."""
+    fp16 rounding of float64 over [-12, 12] AND far outside (|x| up to 2000: the polynomial saturates, its error must not
+    grow with |x| -- ADVICE r2); fp32 results keep the erf-rational form (<= 2e-6) in every mode."""
     from streamflow_amd import ops
     from streamflow_amd.ops import PackedLinear, Planes
     M, P = 128, 4096
     x = (torch.linspace(-12, 12, M * P).view(1, P, M).permute(0, 2, 1)).contiguous().half().float()   # [1, M, P]
+    x[0, :, :64] = torch.linspace(-2000, -12, M * 64).view(64, M).t().half().float()                   # far negative tail
+    x[0, :, 64:128] = torch.linspace(12, 2000, M * 64).view(64, M).t().half().float()
     W = PackedLinear(torch.eye(M).view(M, M, 1, 1), None, dev)
     ref = torch.nn.functional.gelu(x.double())
     big = x >= 0.5
@@ -456,7 +459,7 @@ def test_two_product_mode_gelu_accuracy(dev):
         finally:
             ops.set_precision(prev)
         err = (y.double().cpu() - ref).abs()
-        assert err.max().item() < 2e-6 and (err[big] / ref[big]).max().item() < 2e-6, (prec, err.max().item())
+        assert bool((err <= 2e-6 + 2e-7 * ref.abs()).all()) and (err[big] / ref[big]).max().item() < 2e-6, (prec, err.max().item())
         if yk is not None:
             got = yk.tensor().double().cpu()
             err = (got - ref).abs()

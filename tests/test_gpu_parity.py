@@ -501,8 +501,15 @@ def test_spring_shape_smoke(dev):
     B, T, h, w = 1, 4, 136, 240
     P = syn.make_params(17, T)
     fmaps, cnets = syn.make_features(17, B, T, h, w)
+    from streamflow_amd import presets
+    eng2 = HotPathEngine(P, device=dev, T=T, **presets.engine_kwargs(presets.BENCH_PRESET))      # the bench preset at T = 4
+    ups2, _ = eng2.forward(fmaps.to(dev), cnets.to(dev), iters=1)
+    assert eng2.plan(B, h, w, 256).corr_blocked and all(torch.isfinite(u).all() for u in ups2)
+    del eng2
+    torch.cuda.empty_cache()
     eng = HotPathEngine(P, device=dev, T=T)
     ups, low = eng.forward(fmaps.to(dev), cnets.to(dev), iters=1)
+    assert max((a - b).abs().max().item() for a, b in zip(ups, ups2)) < 0.05      # two arithmetic classes, one iteration
     pl = eng.plan(B, h, w, 256)
     assert pl.attn_rows < h * w
     assert ups[0].shape == (1, 2, 1088, 1920)
@@ -515,6 +522,63 @@ def test_spring_shape_smoke(dev):
     assert (l0.view(h // 2, 2, w // 2, 2).mean(dim=(1, 3)) - l1).abs().max().item() < 1e-5
     ref = (fmaps[0, 0].reshape(256, N)[:, i].to(dev) @ fmaps[0, 1].reshape(256, N).to(dev)) / 16.0
     assert (l0.reshape(-1) - ref).abs().max().item() < 1e-3
+
+
+def test_stress_shape_1440x2560(dev):
+    """The reference's own memory-smoke shape (test_memory.py:478-483: 1 x 4 x 3 x 1440 x 2560 -> 180 x 320 grid, N = 57,600):
+    9.1 GB of blocked fp16 pyramids per pair (64-bit image / record addressing: a row-major fp16 level 0 alone is 6.6 GB,
+    past any 32-bit offset), fused GMA, one iteration in the bench preset; outputs finite, and the volume of one source
+    pixel agrees with a direct contraction and its own 2 x 2 pooling."""
+    from streamflow_amd import presets, synthetic as syn
+    from streamflow_amd.engine import HotPathEngine
+    B, T, h, w = 1, 4, 180, 320
+    P = syn.make_params(23, T)
+    fmaps, cnets = syn.make_features(23, B, T, h, w)
+    eng = HotPathEngine(P, device=dev, T=T, **presets.engine_kwargs(presets.BENCH_PRESET))
+    ups, low = eng.forward(fmaps.to(dev), cnets.to(dev), iters=1)
+    assert ups[0].shape == (1, 2, 1440, 2560)
+    for u in ups:
+        assert torch.isfinite(u).all()
+    pl = eng.plan(B, h, w, 256)
+    assert pl.corr_blocked and pl.flash
+    N, i, img = h * w, 43210, 2                                 # one source pixel of the LAST pair (highest addresses)
+    rec = torch.as_strided(pl.vol.buf, (pl.vol.rec,), (1,), img * pl.vol.img_stride + i * pl.vol.rec).clone()
+    lv = []
+    for l in range(2):
+        nby, nbx = pl.vol.nby[l], pl.vol.nbx[l]
+        blk = rec[pl.vol.off[l]: pl.vol.off[l] + nby * nbx * 128].view(torch.float16).view(nby, nbx, 8, 8)
+        lv.append(blk.permute(0, 3, 1, 2).reshape(nby * 8, nbx * 8)[: h >> l, : w >> l].float())
+    ref = (fmaps[0, 2].reshape(256, N)[:, i].half().float().to(dev) @ fmaps[0, 3].reshape(256, N).half().float().to(dev)) / 16.0
+    assert (lv[0].reshape(-1) - ref).abs().max().item() < 2e-3 * max(1.0, ref.abs().max().item())
+    assert (lv[0].view(h // 2, 2, w // 2, 2).mean(dim=(1, 3)) - lv[1]).abs().max().item() < 2e-3
+    del eng, pl
+    torch.cuda.empty_cache()
+
+
+def test_debug_range_check_catches_fp16_overflow(dev, monkeypatch):
+    """SF_DEBUG_RANGE: an activation beyond the fp16 range (the split modes would saturate its `hi` half silently) raises
+    before the contraction is launched; in-range data and the exact fp32 mode pass."""
+    from streamflow_amd import ops
+    from streamflow_amd.ops import PackedLinear, Planes
+    monkeypatch.setattr(ops, "DEBUG_RANGE", True)
+    W = PackedLinear(torch.randn(64, 32, 1, 1) * 0.1, None, dev)
+    x = torch.randn(1, 32, 256, device=dev)
+    y = torch.empty(1, 64, 256, device=dev)
+    prev = ops.set_precision("f16x2")
+    try:
+        ops.gemm(W, Planes.of(x), Planes.of(y))
+        x[0, 3, 7] = 1.0e5
+        with pytest.raises(RuntimeError, match="SF_DEBUG_RANGE"):
+            ops.gemm(W, Planes.of(x), Planes.of(y))
+        with pytest.raises(RuntimeError, match="SF_DEBUG_RANGE"):
+            ops.dwconv_res_gelu(Planes.of(x.view(1, 32, 256)), torch.zeros(32, 225, device=dev), torch.zeros(32, device=dev),
+                                Planes.of(torch.empty(1, 32, 256, device=dev)), 16, 16, 15)
+        ops.set_precision("fp32")
+        ops.gemm(W, Planes.of(x), Planes.of(y))
+        torch.cuda.synchronize()
+        assert torch.isfinite(y).all()
+    finally:
+        ops.set_precision(prev)
 
 
 def test_spring_shape_one_pair_vs_oracle(dev):
