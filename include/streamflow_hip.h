@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SF_VERSION 105
+#define SF_VERSION 106
 
 enum {
     SF_OK = 0,
@@ -301,11 +301,20 @@ int sf_flow_update(float* coords1, const float* delta, float* flow_a, int64_t fl
  *     out [n_img][C][H*W] = softmax(q k^T / sqrt(32)) v inside non-overlapping ws x ws windows.  Windows reaching past
  *     the grid are completed with zero tokens, whose k and v are qkv_bias (timm pads after the norm, before the Linear).
  * sf_subsample_attn: timm GlobalSubSampleAttn core.  q [n_img][C][N], kv [n_img][2C][M] (rows k | v) -> out [n_img][C][N].
+ * sf_subsample_attn_mfma: the same contraction on the matrix cores (flash-style, transposed logits, no N x M tensor):
+ *     precision SF_PRECISION_F16X3 = hi + lo fp16 split of q, k, the softmax weights and v (3 products per contraction,
+ *     fp32-class), SF_PRECISION_F16X2 / SF_PRECISION_F16 = every operand rounded once to fp16 (1 product); fp32
+ *     accumulation, softmax statistics in fp32.  ws: sf_subsample_attn_ws_bytes(n_img, heads, M) bytes, 16-byte aligned
+ *     (the packed k / v operand images; scratch, dead when the call's kernels have run).
  * sf_dwconv3x3_res: timm PosConv: y = x + depthwise3x3(x) + b on [n_img][C][H][W]; w [C][9]. */
 int sf_window_attn(const float* qkv, int64_t qkv_img_stride, const float* qkv_bias, float* out, int64_t out_img_stride,
                    int n_img, int C, int heads, int H, int W, int ws, void* stream);
 int sf_subsample_attn(const float* q, int64_t q_img_stride, const float* kv, int64_t kv_img_stride, float* out,
                       int64_t out_img_stride, int n_img, int C, int heads, int N, int M, void* stream);
+int64_t sf_subsample_attn_ws_bytes(int n_img, int heads, int M);
+int sf_subsample_attn_mfma(const float* q, int64_t q_img_stride, const float* kv, int64_t kv_img_stride, float* out,
+                           int64_t out_img_stride, int n_img, int C, int heads, int N, int M, void* ws, int64_t ws_bytes,
+                           int precision, void* stream);
 int sf_dwconv3x3_res(const float* x, int64_t x_img_stride, const float* w, const float* b, float* y,
                      int64_t y_img_stride, int n_img, int C, int H, int W, void* stream);
 

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void flash_pack_qk_kernel(const float* qk, int
     f16x8 hi, lo;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const float x = (p < P) ? src[(int64_t)i * P] * mul : 0.f;
+        const float x = (p < P) ? sf::mul_rn(src[(int64_t)i * P], mul) : 0.f;
         const _Float16 h = (_Float16)x;                    // round to nearest: x = hi + lo to ~22 bits
         hi[i] = h;
         lo[i] = (_Float16)(x - (float)h);

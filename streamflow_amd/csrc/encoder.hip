@@ -123,6 +123,181 @@ __global__ __launch_bounds__(256) void subsample_attn_kernel(const float* q, int
     for (int d = 0; d < HD; ++d) op[(int64_t)d * N] = o[d] * inv;
 }
 
+// ---- GlobalSubSampleAttn core on the matrix cores --------------------------------------------------------------------------
+// Same mathematics as subsample_attn_kernel, flash-style with the logits TRANSPOSED (csrc/attn.hip has the derivation):
+//   S^T[key][query] = K Q^T          v_mfma_f32_32x32x16_f16, A = K fragment, B = Q fragment (registers, whole kernel)
+//   O^T[d][query]  += V^T P^T        A = V fragment, B = P^T = the logits' accumulator registers converted in place
+// The C/D layout puts ONE query in a lane (col = lane & 31) with 16 keys of a 32-key tile in its registers
+// (key = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)), so max / sum of the online softmax are in-lane plus one exchange with
+// lane ^ 32, and registers 8m .. 8m+7 are directly the B operand of k-step m once V is packed in the same key order.
+// Head dim 32 = two k-steps of 16; M keys (1760 at the Sintel shape: the 55 x 32 grid of the sr conv) = M/32 tiles.
+// K and V of one (image, head) are 4 KB per tile and stay in L2; the softmax (16 v_exp_f32 + bookkeeping per query tile
+// and key tile) dominates the MFMA work 3:1, so fragments are read straight from the packed image with one lane-linear
+// 16-byte load each -- no LDS, no barriers: a wave is a self-contained stream over the tiles for its 64 queries.
+// NP = products per contraction: 1 (every operand rounded once to fp16) or 3 (hi + lo split of Q, K, P, V: fp32-class).
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int SQT = 2;             // 32-query tiles per wave
+constexpr int SPARTS = 8;          // 1 KB fragments per key tile: K s0, K s1, V m0, V m1 (hi), then the same four (lo)
+
+__device__ __forceinline__ void split8(const float (&x)[8], f16x8& hi, f16x8& lo) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const _Float16 h = (_Float16)x[i];
+        hi[i] = h;
+        lo[i] = (_Float16)(x[i] - (float)h);
+    }
+}
+
+// kv [img][2C][M] fp32 (rows k | v) -> ws[img][head][tile][part][lane][8 halves]
+__global__ __launch_bounds__(256) void subsample_pack_kv_kernel(const float* kv, int64_t kv_img_stride, char* ws, int C, int M,
+                                                                int tiles) {
+    const int tile = blockIdx.x, head = blockIdx.y, img = blockIdx.z, heads = gridDim.y;
+    const int part = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, khalf = lane >> 5;
+    const float* kp = kv + (int64_t)img * kv_img_stride + (int64_t)head * HD * M;
+    const float* vp = kp + (int64_t)C * M;
+    float x[8];
+    if (part < 2) {                                                   // K, k-step `part`: row = key, k = dims
+        const int key = tile * 32 + l31;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[i] = key < M ? kp[(int64_t)(16 * part + 8 * khalf + i) * M + key] : 0.f;
+    } else {                                                          // V, k-step m: row = d, k = keys in accumulator order
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int key = tile * 32 + 16 * (part - 2) + (i & 3) + 8 * (i >> 2) + 4 * khalf;
+            x[i] = key < M ? vp[(int64_t)l31 * M + key] : 0.f;
+        }
+    }
+    f16x8 hi, lo;
+    split8(x, hi, lo);
+    char* dst = ws + ((((int64_t)img * heads + head) * tiles + tile) * SPARTS + part) * 1024 + lane * 16;
+    *reinterpret_cast<f16x8*>(dst) = hi;
+    *reinterpret_cast<f16x8*>(dst + 4 * 1024) = lo;
+}
+
+template <int NP>
+__global__ __launch_bounds__(256) void subsample_attn_mfma_kernel(const float* q, int64_t q_img_stride, const char* ws, float* out,
+                                                                  int64_t out_img_stride, int N, int M, int tiles) {
+    constexpr bool kLo = NP == 3;
+    const int head = blockIdx.y, img = blockIdx.z, heads = gridDim.y;
+    const int lane = threadIdx.x & 63, l31 = lane & 31, khalf = lane >> 5;
+    const int n0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * (32 * SQT);
+    if (n0 >= N) return;                                              // wave-uniform; the kernel has no barrier
+    const float qmul = 0.17677669529663687f * 1.44269504088896340736f;   // 32^-0.5 * log2(e): softmax = exp2(s - max)
+    f16x8 qh[SQT][2], ql[SQT][2];
+    {
+        const float* qp = q + (int64_t)img * q_img_stride + (int64_t)head * HD * N;
+#pragma unroll
+        for (int t = 0; t < SQT; ++t) {
+            const int n = n0 + t * 32 + l31, nc = n < N ? n : N - 1;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                float x[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) x[i] = sf::mul_rn(qp[(int64_t)(16 * s + 8 * khalf + i) * N + nc], qmul);
+                split8(x, qh[t][s], ql[t][s]);
+            }
+        }
+    }
+    f32x16 o[SQT];
+    float m_run[SQT], l_run[SQT];
+#pragma unroll
+    for (int t = 0; t < SQT; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+        m_run[t] = -1.0e30f;
+        l_run[t] = 0.f;
+    }
+    const f16x8* wp = reinterpret_cast<const f16x8*>(ws + ((int64_t)img * heads + head) * tiles * (SPARTS * 1024)) + lane;
+    constexpr int NF = kLo ? 8 : 4;
+    f16x8 cur[NF], nxt[NF];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) cur[f] = wp[f * 64];
+    for (int kt = 0; kt < tiles; ++kt) {
+        const int kn = kt + 1 < tiles ? kt + 1 : kt;                  // the last trip re-reads its own tile (no branch)
+#pragma unroll
+        for (int f = 0; f < NF; ++f) nxt[f] = wp[(kn * SPARTS + f) * 64];
+        const bool ragged = (kt + 1) * 32 > M;
+#pragma unroll
+        for (int t = 0; t < SQT; ++t) {
+            f32x16 s;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                if (kLo) {
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[4 + ks], qh[t][ks], s, 0, 0, 0);
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[ks], ql[t][ks], s, 0, 0, 0);
+                }
+                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[ks], qh[t][ks], s, 0, 0, 0);
+            }
+            if (ragged) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[r] = (kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf < M) ? s[r] : -1.0e30f;
+            }
+            float mx = s[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run[t], mx);
+            const bool grew = __any(m_new > m_run[t]);                // rescale the accumulators only when some lane needs it
+            const float alpha = grew ? __builtin_amdgcn_exp2f(m_run[t] - m_new) : 1.0f;
+            m_run[t] = m_new;
+            float psum = 0.f;
+            f16x8 ph[2], pl[2];
+            if (kLo) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(s[r] - m_new);
+                    psum += p;
+                    const _Float16 h = (_Float16)p;
+                    ph[r >> 3][r & 7] = h;
+                    pl[r >> 3][r & 7] = (_Float16)(p - (float)h);
+                }
+            } else {
+                // one product: the row is normalised by the ROUNDED weights, the ones that are actually multiplied
+                const f16x2 ones = {(_Float16)1.0f, (_Float16)1.0f};
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    f16x2 pp;
+                    pp[0] = (_Float16)__builtin_amdgcn_exp2f(s[r] - m_new);
+                    pp[1] = (_Float16)__builtin_amdgcn_exp2f(s[r + 1] - m_new);
+                    psum = __builtin_amdgcn_fdot2(pp, ones, psum, false);
+                    ph[r >> 3][r & 7] = pp[0];
+                    ph[r >> 3][(r & 7) + 1] = pp[1];
+                }
+            }
+            l_run[t] = l_run[t] * alpha + psum;
+            if (grew) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+            }
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                if (kLo) {
+                    o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[6 + m], ph[m], o[t], 0, 0, 0);
+                    o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[2 + m], pl[m], o[t], 0, 0, 0);
+                }
+                o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[2 + m], ph[m], o[t], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int f = 0; f < NF; ++f) cur[f] = nxt[f];
+    }
+    float* op = out + (int64_t)img * out_img_stride + (int64_t)head * HD * N;
+#pragma unroll
+    for (int t = 0; t < SQT; ++t) {
+        const float inv = 1.0f / (l_run[t] + __shfl_xor(l_run[t], 32, 64));
+        const int n = n0 + t * 32 + l31;
+        if (n < N) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) op[(int64_t)((r & 3) + 8 * (r >> 2) + 4 * khalf) * N + n] = o[t][r] * inv;
+        }
+    }
+}
+
 // ---- PosConv: y = x + dwconv3x3(x) + b over the [H][W] token grid ----------------------------------------------------------
 __global__ __launch_bounds__(256) void dwconv3x3_res_kernel(const float* x, int64_t x_img_stride, const float* w, const float* b,
                                                             float* y, int64_t y_img_stride, int C, int H, int W) {
@@ -163,6 +338,34 @@ extern "C" int sf_subsample_attn(const float* q, int64_t q_img_stride, const flo
     hipLaunchKernelGGL(subsample_attn_kernel, dim3(sf::ceil_div(N, 256), heads, n_img), dim3(256), 0, (hipStream_t)stream, q,
                        q_img_stride, kv, kv_img_stride, out, out_img_stride, C, N, M);
     return sf::check_launch("sf_subsample_attn");
+}
+
+extern "C" int64_t sf_subsample_attn_ws_bytes(int n_img, int heads, int M) {
+    if (n_img <= 0 || heads <= 0 || M <= 0) return 0;
+    return (int64_t)n_img * heads * sf::ceil_div(M, 32) * (SPARTS * 1024);
+}
+
+extern "C" int sf_subsample_attn_mfma(const float* q, int64_t q_img_stride, const float* kv, int64_t kv_img_stride, float* out,
+                                      int64_t out_img_stride, int n_img, int C, int heads, int N, int M, void* ws,
+                                      int64_t ws_bytes, int precision, void* stream) {
+    SF_REQUIRE(q && kv && out && ws, "sf_subsample_attn_mfma: null pointer");
+    SF_REQUIRE(n_img > 0 && N > 0 && M > 0 && n_img <= 65535 && heads <= 65535, "sf_subsample_attn_mfma: bad dims");
+    SF_REQUIRE(heads >= 1 && C == heads * HD, "sf_subsample_attn_mfma: needs C = heads * 32 (got C=%d heads=%d)", C, heads);
+    SF_REQUIRE(precision == SF_PRECISION_F16X3 || precision == SF_PRECISION_F16X2 || precision == SF_PRECISION_F16,
+               "sf_subsample_attn_mfma: precision must be one of the split / fp16 classes (the exact fp32 core is sf_subsample_attn)");
+    SF_REQUIRE(ws_bytes >= sf_subsample_attn_ws_bytes(n_img, heads, M) && (reinterpret_cast<uintptr_t>(ws) & 15) == 0,
+               "sf_subsample_attn_mfma: workspace too small or misaligned");
+    const int tiles = sf::ceil_div(M, 32);
+    hipLaunchKernelGGL(subsample_pack_kv_kernel, dim3(tiles, heads, n_img), dim3(256), 0, (hipStream_t)stream, kv, kv_img_stride,
+                       (char*)ws, C, M, tiles);
+    const dim3 grid(sf::ceil_div(N, 4 * 32 * SQT), heads, n_img);
+    if (precision == SF_PRECISION_F16X3)
+        hipLaunchKernelGGL(subsample_attn_mfma_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, q, q_img_stride, (const char*)ws,
+                           out, out_img_stride, N, M, tiles);
+    else
+        hipLaunchKernelGGL(subsample_attn_mfma_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, q, q_img_stride, (const char*)ws,
+                           out, out_img_stride, N, M, tiles);
+    return sf::check_launch("sf_subsample_attn_mfma");
 }
 
 extern "C" int sf_dwconv3x3_res(const float* x, int64_t x_img_stride, const float* w, const float* b, float* y,

@@ -48,6 +48,17 @@ __device__ __forceinline__ float gelu_erf(float x) {
     return 0.5f * fmaxf(x, -5.6568542f) * (1.0f + erf_fast(x * 0.70710678118654752440f));
 }
 
+// a * b rounded ONCE to fp32, opaque to the optimiser.  hipcc folds "x = a * b; h = (half)x" into v_fma_mixlo_f16 (h =
+// RN16 of the EXACT product) while "x - (float)h" elsewhere uses RN16(RN32(a b)): two roundings of one value that differ
+// when RN32(a b) sits on an fp16 tie.  Once in ~2^13 values the hi that is multiplied is then not the hi that lo was
+// computed against and a hi + lo split is off by a whole fp16 ulp (measured: csrc/encoder.hip's three-product attention,
+// 4.7e-5 on two queries in 1560 instead of 4e-7; `#pragma clang fp contract(off)` does not stop the fold).
+__device__ __forceinline__ float mul_rn(float a, float b) {
+    float r = a * b;
+    asm volatile("" : "+v"(r));
+    return r;
+}
+
 // Two GELUs at a time on packed fp32 (v_pk_fma_f32 / v_pk_mul_f32): the same operations in the same order as
 // gelu_erf, i.e. bit-identical results at half the VALU issue slots.  The GEMM epilogues are VALU-bound on small-K
 // shapes (M384 K256: 186 us with the GELU epilogue vs 141 us without), and a lane holds its outputs in pairs anyway.

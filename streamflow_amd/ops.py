@@ -460,13 +460,32 @@ def window_attn(QKV: Planes, qkv_bias: torch.Tensor, OUT: Planes, heads: int, H:
 
 
 @on_tensor_device
-def subsample_attn(Q: Planes, KV: Planes, OUT: Planes, heads: int) -> None:
-    """timm GlobalSubSampleAttn core: OUT = softmax(q k^T / sqrt(32)) v, keys/values = the M sub-sampled tokens."""
+def subsample_attn(Q: Planes, KV: Planes, OUT: Planes, heads: int, ws: Optional[torch.Tensor] = None) -> None:
+    """timm GlobalSubSampleAttn core: OUT = softmax(q k^T / sqrt(32)) v, keys/values = the M sub-sampled tokens.
+    PRECISION_FP32: the exact VALU kernel; every other class: the matrix-core kernel (3 products per contraction for
+    F16X3, 1 for the fp16 classes) over `ws` (uint8, >= subsample_attn_ws_bytes; allocated here when not given)."""
     C = Q.rows
     assert KV.rows == 2 * C and OUT.rows == C and Q.P == OUT.P and Q.n_img == KV.n_img == OUT.n_img
-    _launch("subsample_attn", 4.0 * Q.n_img * Q.P * KV.P * C, 4.0 * Q.n_img * C * (2 * Q.P + 2 * KV.P),
-            lambda: _lib.check(_lib.load().sf_subsample_attn(Q.ptr, Q.img_stride, KV.ptr, KV.img_stride, OUT.ptr, OUT.img_stride,
-                                                             Q.n_img, C, heads, Q.P, KV.P, _lib.stream()), "sf_subsample_attn"))
+    nbytes = 4.0 * Q.n_img * C * (2 * Q.P + 2 * KV.P)
+    if PRECISION == PRECISION_FP32 or os.environ.get("SF_SUBSAMPLE_EXACT", "0") == "1":
+        _launch("subsample_attn", 4.0 * Q.n_img * Q.P * KV.P * C, nbytes,
+                lambda: _lib.check(_lib.load().sf_subsample_attn(Q.ptr, Q.img_stride, KV.ptr, KV.img_stride, OUT.ptr, OUT.img_stride,
+                                                                 Q.n_img, C, heads, Q.P, KV.P, _lib.stream()), "sf_subsample_attn"))
+        return
+    need = subsample_attn_ws_bytes(Q.n_img, heads, KV.P)
+    if ws is None:
+        ws = torch.empty(need, dtype=torch.uint8, device=Q.base.device)
+    assert ws.dtype == torch.uint8 and ws.numel() >= need and ws.device == Q.base.device
+    prec = PRECISION
+    _launch("subsample_attn_mfma", 4.0 * Q.n_img * Q.P * KV.P * C, nbytes,
+            lambda: _lib.check(_lib.load().sf_subsample_attn_mfma(Q.ptr, Q.img_stride, KV.ptr, KV.img_stride, OUT.ptr,
+                                                                  OUT.img_stride, Q.n_img, C, heads, Q.P, KV.P, ws.data_ptr(),
+                                                                  ws.numel(), prec, _lib.stream()), "sf_subsample_attn_mfma"),
+            products=3 if prec == PRECISION_F16X3 else 1)
+
+
+def subsample_attn_ws_bytes(n_img: int, heads: int, M: int) -> int:
+    return int(_lib.load().sf_subsample_attn_ws_bytes(n_img, heads, M))
 
 
 @on_tensor_device

@@ -494,3 +494,39 @@ def test_two_chain_schedule_is_bitwise_the_one_chain_schedule(dev, preset, monke
         for chains in ("2", "4"):
             for a, b2 in zip(outs["0"], outs[chains]):
                 assert torch.equal(a, b2), (preset, B, graph, chains)
+
+
+@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("prec", ["fp32", "f16x3", "f16x2"])
+def test_subsample_attn_random_shapes(dev, seed, prec):
+    """Encoder f1: GlobalSubSampleAttn core (exact VALU kernel for fp32, the matrix-core kernel for the split / fp16 classes)
+    against a float64 softmax(q k^T / sqrt(32)) v: ragged key counts (M % 32 != 0), query counts that end inside a wave's
+    64-query strip, several heads and images, logits large enough that the running maximum matters."""
+    from streamflow_amd import ops
+    from streamflow_amd.ops import Planes
+    rng = np.random.default_rng(7000 + seed)
+    heads = int(rng.choice([1, 4, 8]))
+    N = int(rng.choice([1, 31, 64, 65, 200, 257, 1000]))
+    M = int(rng.choice([1, 5, 32, 33, 64, 100, 330]))
+    n = int(rng.integers(1, 4))
+    C = heads * 32
+    g = torch.Generator().manual_seed(seed)
+    gain = float(rng.choice([1.0, 4.0]))
+    q = torch.randn(n, C, N, generator=g) * gain
+    kv = torch.randn(n, 2 * C, M, generator=g)
+    kv[:, :C] *= gain
+    out = torch.full((n, C, N), float("nan"), device=dev)
+    prev = ops.set_precision(prec)
+    try:
+        ops.subsample_attn(Planes.of(q.to(dev)), Planes.of(kv.to(dev)), Planes.of(out), heads)
+    finally:
+        ops.set_precision(prev)
+    qd = q.double().view(n, heads, 32, N)
+    kd, vd = kv[:, :C].double().view(n, heads, 32, M), kv[:, C:].double().view(n, heads, 32, M)
+    att = torch.softmax(torch.einsum("bhdn,bhdm->bhnm", qd, kd) * 32 ** -0.5, dim=-1)
+    ref = torch.einsum("bhnm,bhdm->bhdn", att, vd).reshape(n, C, N)
+    err = (out.cpu().double() - ref).abs().max().item()
+    # fp16 classes: logits carry the fp16 rounding of q and k (2^-11 relative each, |q||k| up to ~ 16 * 32 * gain^2 / sqrt(32))
+    tol = {"fp32": 2e-5, "f16x3": 2e-5, "f16x2": 4e-3 * gain * gain}[prec]
+    print(f"subsample_attn {prec} heads={heads} N={N} M={M} n={n} gain={gain}: max abs err {err:.3e}")
+    assert err <= tol, (err, tol)
