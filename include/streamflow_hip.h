@@ -300,6 +300,7 @@ int sf_flow_update(float* coords1, const float* delta, float* flow_a, int64_t fl
  * sf_window_attn: timm LocallyGroupedAttn core.  qkv [n_img][3C][H*W] (rows q | k | v, the qkv Linear output) ->
  *     out [n_img][C][H*W] = softmax(q k^T / sqrt(32)) v inside non-overlapping ws x ws windows.  Windows reaching past
  *     the grid are completed with zero tokens, whose k and v are qkv_bias (timm pads after the norm, before the Linear).
+ * sf_window_attn_mfma: the same on the matrix cores, one wave per (window, head); precision as sf_subsample_attn_mfma.
  * sf_subsample_attn: timm GlobalSubSampleAttn core.  q [n_img][C][N], kv [n_img][2C][M] (rows k | v) -> out [n_img][C][N].
  * sf_subsample_attn_mfma: the same contraction on the matrix cores (flash-style, transposed logits, no N x M tensor):
  *     precision SF_PRECISION_F16X3 = hi + lo fp16 split of q, k, the softmax weights and v (3 products per contraction,
@@ -309,6 +310,8 @@ int sf_flow_update(float* coords1, const float* delta, float* flow_a, int64_t fl
  * sf_dwconv3x3_res: timm PosConv: y = x + depthwise3x3(x) + b on [n_img][C][H][W]; w [C][9]. */
 int sf_window_attn(const float* qkv, int64_t qkv_img_stride, const float* qkv_bias, float* out, int64_t out_img_stride,
                    int n_img, int C, int heads, int H, int W, int ws, void* stream);
+int sf_window_attn_mfma(const float* qkv, int64_t qkv_img_stride, const float* qkv_bias, float* out, int64_t out_img_stride,
+                        int n_img, int C, int heads, int H, int W, int ws, int precision, void* stream);
 int sf_subsample_attn(const float* q, int64_t q_img_stride, const float* kv, int64_t kv_img_stride, float* out,
                       int64_t out_img_stride, int n_img, int C, int heads, int N, int M, void* stream);
 int64_t sf_subsample_attn_ws_bytes(int n_img, int heads, int M);

@@ -316,6 +316,190 @@ __global__ __launch_bounds__(256) void dwconv3x3_res_kernel(const float* x, int6
     y[(int64_t)img * y_img_stride + (int64_t)c * H * W + p] = xp[p] + acc;
 }
 
+// ---- LocallyGroupedAttn core on the matrix cores ---------------------------------------------------------------------------
+// One wave = one (window, head): ws x ws <= 49 tokens padded to 64 = two 32-token tiles on both sides.  Same transposed
+// scheme as the sub-sample kernel, without the online part (all keys of a query are in registers at once):
+//   S^T[key][query] = K Q^T : A = K fragment (row = key token, k = dims), B = Q fragment (col = query token), both loaded
+//        straight from the planes -- a lane is a token, so a wave instruction reads the window's rows of ws pixels;
+//   O^T[d][query] = V^T P^T : the V fragment wants row = d, k = tokens in accumulator order: V is loaded like K (lane =
+//        token) and turned through a per-wave LDS image [d][token] (fp16 hi [, lo]).
+// Tokens of the window that lie outside the grid are the reference's zero padding: k = v = the qkv bias, they take part in
+// the softmax; tokens >= ws*ws (padding to 64) are masked out.  NP as in the sub-sample kernel.
+constexpr int WLS = 72;            // halves per d-row of the LDS V image (64 tokens + 8: 144-byte rows)
+
+template <int NP>
+__global__ __launch_bounds__(256) void window_attn_mfma_kernel(const float* qkv, int64_t img_stride, const float* bias, float* out,
+                                                               int64_t out_img_stride, int C, int H, int W, int ws, int nww) {
+    constexpr bool kLo = NP == 3;
+    __shared__ _Float16 lds[4 * 2 * HD * WLS];
+    const int wave = threadIdx.x >> 6, head = blockIdx.z * 4 + wave, lane = threadIdx.x & 63, l31 = lane & 31, khalf = lane >> 5;
+    const int wy = blockIdx.x / nww, wx = blockIdx.x % nww, img = blockIdx.y;
+    const int nt = ws * ws, N = H * W;
+    const float* base = qkv + (int64_t)img * img_stride;
+    _Float16* vh = lds + wave * 2 * HD * WLS;
+    _Float16* vl = vh + HD * WLS;
+    const float qmul = 0.17677669529663687f * 1.44269504088896340736f;
+
+    // this lane's token in each of the two tiles: pixel offset, or -1 (outside the grid / beyond ws*ws)
+    int pix[2];
+    bool tok[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int k = t * 32 + l31, y = wy * ws + k / ws, x = wx * ws + k % ws;
+        tok[t] = k < nt;
+        pix[t] = (tok[t] && y < H && x < W) ? y * W + x : -1;
+    }
+    f16x8 qh[2][2], ql[2][2], kh[2][2], kl[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            float xq[8], xk[8], xv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int ch = head * HD + 16 * ks + 8 * khalf + i;
+                const bool in = pix[t] >= 0;
+                const int64_t o = (int64_t)ch * N + (in ? pix[t] : 0);
+                xq[i] = in ? sf::mul_rn(base[o], qmul) : 0.f;
+                xk[i] = in ? base[o + (int64_t)C * N] : (tok[t] ? bias[C + ch] : 0.f);
+                xv[i] = in ? base[o + (int64_t)2 * C * N] : (tok[t] ? bias[2 * C + ch] : 0.f);
+            }
+            split8(xq, qh[t][ks], ql[t][ks]);
+            split8(xk, kh[t][ks], kl[t][ks]);
+            f16x8 h8, l8;
+            split8(xv, h8, l8);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int d = 16 * ks + 8 * khalf + i;
+                vh[d * WLS + t * 32 + l31] = h8[i];
+                if (kLo) vl[d * WLS + t * 32 + l31] = l8[i];
+            }
+        }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");        // the image is this wave's own: no workgroup barrier
+    __builtin_amdgcn_wave_barrier();
+    // V^T fragments: k-step j (keys 16j .. 16j+15): lane (d = l31, khalf) holds keys 16j + (i & 3) + 8 (i >> 2) + 4 khalf
+    f16x8 vfh[4], vfl[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+        const h4 a = *reinterpret_cast<const h4*>(vh + l31 * WLS + 16 * j + 4 * khalf);
+        const h4 b = *reinterpret_cast<const h4*>(vh + l31 * WLS + 16 * j + 4 * khalf + 8);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { vfh[j][i] = a[i]; vfh[j][4 + i] = b[i]; }
+        if (kLo) {
+            const h4 c = *reinterpret_cast<const h4*>(vl + l31 * WLS + 16 * j + 4 * khalf);
+            const h4 e = *reinterpret_cast<const h4*>(vl + l31 * WLS + 16 * j + 4 * khalf + 8);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { vfl[j][i] = c[i]; vfl[j][4 + i] = e[i]; }
+        }
+    }
+    float* op = out + (int64_t)img * out_img_stride + (int64_t)head * HD * N;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {                                     // query tile
+        if (t * 32 >= nt) break;
+        f32x16 sc[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sc[kt][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                if (kLo) {
+                    sc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl[kt][ks], qh[t][ks], sc[kt], 0, 0, 0);
+                    sc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[kt][ks], ql[t][ks], sc[kt], 0, 0, 0);
+                }
+                sc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[kt][ks], qh[t][ks], sc[kt], 0, 0, 0);
+            }
+        }
+        float mx = -1.0e30f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const bool valid = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf < nt;
+                sc[kt][r] = valid ? sc[kt][r] : -1.0e30f;
+                mx = fmaxf(mx, sc[kt][r]);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float psum = 0.f;
+        f16x8 ph[4], pl[4];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            if (kLo) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(sc[kt][r] - mx);
+                    psum += p;
+                    const _Float16 h = (_Float16)p;
+                    ph[kt * 2 + (r >> 3)][r & 7] = h;
+                    pl[kt * 2 + (r >> 3)][r & 7] = (_Float16)(p - (float)h);
+                }
+            } else {
+                const f16x2 ones = {(_Float16)1.0f, (_Float16)1.0f};
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    f16x2 pp;
+                    pp[0] = (_Float16)__builtin_amdgcn_exp2f(sc[kt][r] - mx);
+                    pp[1] = (_Float16)__builtin_amdgcn_exp2f(sc[kt][r + 1] - mx);
+                    psum = __builtin_amdgcn_fdot2(pp, ones, psum, false);
+                    ph[kt * 2 + (r >> 3)][r & 7] = pp[0];
+                    ph[kt * 2 + (r >> 3)][(r & 7) + 1] = pp[1];
+                }
+            }
+        }
+        f32x16 o;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (kLo) {
+                o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfl[j], ph[j], o, 0, 0, 0);
+                o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfh[j], pl[j], o, 0, 0, 0);
+            }
+            o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfh[j], ph[j], o, 0, 0, 0);
+        }
+        const float inv = 1.0f / (psum + __shfl_xor(psum, 32, 64));
+        if (pix[t] >= 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) op[(int64_t)((r & 3) + 8 * (r >> 2) + 4 * khalf) * N + pix[t]] = o[r] * inv;
+        }
+    }
+}
+
+// Four consecutive pixels per thread (W % 4 == 0): one 16-byte load per row plus the two neighbours; same taps in the same
+// order as the scalar kernel (a tap outside the grid contributes fmaf(w, 0, acc) = acc).
+__global__ __launch_bounds__(256) void dwconv3x3_res_vec4_kernel(const float* x, int64_t x_img_stride, const float* w, const float* b,
+                                                                 float* y, int64_t y_img_stride, int C, int H, int W) {
+    const int p = (blockIdx.x * 256 + threadIdx.x) * 4, c = blockIdx.y, img = blockIdx.z;
+    if (p >= H * W) return;
+    const int py = p / W, px = p % W;
+    const float* xp = x + (int64_t)img * x_img_stride + (int64_t)c * H * W;
+    float wt[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) wt[i] = w[c * 9 + i];
+    const float bias = b[c];
+    float acc[4] = {bias, bias, bias, bias}, mid[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy) {
+        const int yy = py + dy;
+        float v[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (yy >= 0 && yy < H) {
+            const float4 m = *reinterpret_cast<const float4*>(xp + yy * W + px);
+            v[1] = m.x; v[2] = m.y; v[3] = m.z; v[4] = m.w;
+            if (px > 0) v[0] = xp[yy * W + px - 1];
+            if (px + 4 < W) v[5] = xp[yy * W + px + 4];
+        }
+        if (dy == 0) { mid[0] = v[1]; mid[1] = v[2]; mid[2] = v[3]; mid[3] = v[4]; }
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = fmaf(wt[(dy + 1) * 3 + dx], v[j + dx], acc[j]);
+    }
+    float4 o;
+    o.x = mid[0] + acc[0]; o.y = mid[1] + acc[1]; o.z = mid[2] + acc[2]; o.w = mid[3] + acc[3];
+    *reinterpret_cast<float4*>(y + (int64_t)img * y_img_stride + (int64_t)c * H * W + p) = o;
+}
+
 }  // namespace
 
 extern "C" int sf_window_attn(const float* qkv, int64_t qkv_img_stride, const float* qkv_bias, float* out,
@@ -328,6 +512,26 @@ extern "C" int sf_window_attn(const float* qkv, int64_t qkv_img_stride, const fl
     hipLaunchKernelGGL(window_attn_kernel, dim3(nwh * nww, n_img, heads / 4), dim3(256), 0, (hipStream_t)stream, qkv, qkv_img_stride,
                        qkv_bias, out, out_img_stride, C, H, W, ws, nww);
     return sf::check_launch("sf_window_attn");
+}
+
+extern "C" int sf_window_attn_mfma(const float* qkv, int64_t qkv_img_stride, const float* qkv_bias, float* out,
+                                   int64_t out_img_stride, int n_img, int C, int heads, int H, int W, int ws, int precision,
+                                   void* stream) {
+    SF_REQUIRE(qkv && qkv_bias && out, "sf_window_attn_mfma: null pointer");
+    SF_REQUIRE(n_img > 0 && H > 0 && W > 0 && n_img <= 65535, "sf_window_attn_mfma: bad dims");
+    SF_REQUIRE(heads >= 4 && heads % 4 == 0 && C == heads * HD, "sf_window_attn_mfma: needs C = heads * 32, heads a multiple of 4 (got C=%d heads=%d)", C, heads);
+    SF_REQUIRE(ws >= 2 && ws <= 7, "sf_window_attn_mfma: window size must be 2..7 (got %d)", ws);
+    SF_REQUIRE(precision == SF_PRECISION_F16X3 || precision == SF_PRECISION_F16X2 || precision == SF_PRECISION_F16,
+               "sf_window_attn_mfma: precision must be one of the split / fp16 classes (the exact fp32 core is sf_window_attn)");
+    const int nwh = sf::ceil_div(H, ws), nww = sf::ceil_div(W, ws);
+    const dim3 grid(nwh * nww, n_img, heads / 4);
+    if (precision == SF_PRECISION_F16X3)
+        hipLaunchKernelGGL(window_attn_mfma_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, qkv, qkv_img_stride, qkv_bias, out,
+                           out_img_stride, C, H, W, ws, nww);
+    else
+        hipLaunchKernelGGL(window_attn_mfma_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, qkv, qkv_img_stride, qkv_bias, out,
+                           out_img_stride, C, H, W, ws, nww);
+    return sf::check_launch("sf_window_attn_mfma");
 }
 
 extern "C" int sf_subsample_attn(const float* q, int64_t q_img_stride, const float* kv, int64_t kv_img_stride, float* out,
@@ -372,7 +576,13 @@ extern "C" int sf_dwconv3x3_res(const float* x, int64_t x_img_stride, const floa
                                 int64_t y_img_stride, int n_img, int C, int H, int W, void* stream) {
     SF_REQUIRE(x && w && b && y, "sf_dwconv3x3_res: null pointer");
     SF_REQUIRE(n_img > 0 && C > 0 && H > 0 && W > 0 && n_img <= 65535 && C <= 65535, "sf_dwconv3x3_res: bad dims");
-    hipLaunchKernelGGL(dwconv3x3_res_kernel, dim3(sf::ceil_div(H * W, 256), C, n_img), dim3(256), 0, (hipStream_t)stream, x,
-                       x_img_stride, w, b, y, y_img_stride, C, H, W);
+    const bool vec4 = W % 4 == 0 && (x_img_stride & 3) == 0 && (y_img_stride & 3) == 0 &&
+                      ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
+    if (vec4)
+        hipLaunchKernelGGL(dwconv3x3_res_vec4_kernel, dim3(sf::ceil_div(H * W / 4, 256), C, n_img), dim3(256), 0, (hipStream_t)stream,
+                           x, x_img_stride, w, b, y, y_img_stride, C, H, W);
+    else
+        hipLaunchKernelGGL(dwconv3x3_res_kernel, dim3(sf::ceil_div(H * W, 256), C, n_img), dim3(256), 0, (hipStream_t)stream, x,
+                           x_img_stride, w, b, y, y_img_stride, C, H, W);
     return sf::check_launch("sf_dwconv3x3_res");
 }

@@ -599,7 +599,8 @@ int auto_splits(int M, int N, int K, int batch) {
     if (wgs >= 96 || nk < 8) return 1;       // measured: for 165-workgroup grids the slab round trip eats the gain
     int ks = (int)((512 + wgs - 1) / wgs);
     if (ks > nk / 3) ks = nk / 3;
-    if (ks > 8) ks = 8;
+    const int cap = (wgs <= 16 && nk >= 64) ? 16 : 8;   // skinny outputs over a deep K (the encoder's sr convs: 14 workgroups, K = 8192)
+    if (ks > cap) ks = cap;
     return ks < 2 ? 1 : ks;
 }
 

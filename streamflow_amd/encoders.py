@@ -167,7 +167,14 @@ class Twins_CSC(nn.Module):
 
             def lin(name, X, epi=EPI_NONE, R=None):
                 Y = new(pk[name].M, X.P)
-                ops.gemm(pk[name], X, Y, epi, R=R)
+                A = pk[name]
+                need = ops.gemm_split_ws_floats(A.M, X.P, A.K, B)      # skinny outputs over a deep K (the sr convs): split-K
+                prev = ops.SPLIT_WS
+                ops.SPLIT_WS = torch.empty(need, dtype=torch.float32, device=dev) if need else None
+                try:
+                    ops.gemm(A, X, Y, epi, R=R)
+                finally:
+                    ops.SPLIT_WS = prev
                 return Y
 
             grid = x.permute(0, 2, 1, 3, 4).reshape(B, C, T * H, W)     # frames stacked along the height (twins_csc.py:30-32)

@@ -373,6 +373,13 @@ def gemm(A: PackedLinear, X: Planes, Y: Planes, epilogue: int = EPI_NONE, R: Opt
         refresh_shadow(Y)
 
 
+def gemm_split_ws_floats(M: int, N: int, K: int, batch: int) -> int:
+    """floats of scratch with which sf_gemm would split K on its own for this shape (0: it would not); see SPLIT_WS."""
+    if PRECISION == PRECISION_FP32:
+        return 0
+    return int(_lib.load().sf_gemm_split_ws_floats(M, N, K, batch))
+
+
 def gemm_raw(**kw) -> None:
     """Fully explicit sf_gemm call (used for the attention logits and attn @ v contractions)."""
     g = SfGemm()
@@ -451,12 +458,22 @@ def softmax_rows(x: torch.Tensor, rows: int, cols: int, out16: Optional[torch.Te
 
 @on_tensor_device
 def window_attn(QKV: Planes, qkv_bias: torch.Tensor, OUT: Planes, heads: int, H: int, W: int, ws: int = 7) -> None:
-    """timm LocallyGroupedAttn core on token planes (encoder; see include/streamflow_hip.h)."""
+    """timm LocallyGroupedAttn core on token planes (encoder; see include/streamflow_hip.h).  PRECISION_FP32: the exact
+    VALU kernel; every other class: the matrix-core kernel (3 products per contraction for F16X3, 1 for the fp16 classes)."""
     C = OUT.rows
     assert QKV.rows == 3 * C and QKV.P == H * W == OUT.P and qkv_bias.numel() == 3 * C
-    _launch("window_attn", 4.0 * QKV.n_img * H * W * ws * ws * C, 4.0 * QKV.n_img * 4 * C * H * W,
-            lambda: _lib.check(_lib.load().sf_window_attn(QKV.ptr, QKV.img_stride, qkv_bias.data_ptr(), OUT.ptr, OUT.img_stride,
-                                                          QKV.n_img, C, heads, H, W, ws, _lib.stream()), "sf_window_attn"))
+    flops, nbytes = 4.0 * QKV.n_img * H * W * ws * ws * C, 4.0 * QKV.n_img * 4 * C * H * W
+    if PRECISION == PRECISION_FP32 or os.environ.get("SF_WINDOW_EXACT", "0") == "1":
+        _launch("window_attn", flops, nbytes,
+                lambda: _lib.check(_lib.load().sf_window_attn(QKV.ptr, QKV.img_stride, qkv_bias.data_ptr(), OUT.ptr, OUT.img_stride,
+                                                              QKV.n_img, C, heads, H, W, ws, _lib.stream()), "sf_window_attn"))
+        return
+    prec = PRECISION
+    _launch("window_attn_mfma", flops, nbytes,
+            lambda: _lib.check(_lib.load().sf_window_attn_mfma(QKV.ptr, QKV.img_stride, qkv_bias.data_ptr(), OUT.ptr,
+                                                               OUT.img_stride, QKV.n_img, C, heads, H, W, ws, prec,
+                                                               _lib.stream()), "sf_window_attn_mfma"),
+            products=3 if prec == PRECISION_F16X3 else 1)
 
 
 @on_tensor_device

@@ -530,3 +530,40 @@ def test_subsample_attn_random_shapes(dev, seed, prec):
     tol = {"fp32": 2e-5, "f16x3": 2e-5, "f16x2": 4e-3 * gain * gain}[prec]
     print(f"subsample_attn {prec} heads={heads} N={N} M={M} n={n} gain={gain}: max abs err {err:.3e}")
     assert err <= tol, (err, tol)
+
+
+@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("prec", ["fp32", "f16x3", "f16x2"])
+def test_window_attn_random_shapes(dev, seed, prec):
+    """Encoder f1: LocallyGroupedAttn core against float64 on grids that are not multiples of the window (padded tokens
+    carry k = v = the qkv bias and take part in the softmax, as in timm's pad-after-norm), window sizes 2..7."""
+    from streamflow_amd import ops
+    from streamflow_amd.ops import Planes
+    rng = np.random.default_rng(8000 + seed)
+    heads = int(rng.choice([4, 8]))
+    ws = int(rng.choice([2, 3, 5, 7, 7, 7]))
+    H, W = int(rng.integers(3, 30)), int(rng.integers(3, 40))
+    n = int(rng.integers(1, 3))
+    C = heads * 32
+    g = torch.Generator().manual_seed(seed)
+    gain = float(rng.choice([1.0, 3.0]))
+    qkv = torch.randn(n, 3 * C, H * W, generator=g)
+    qkv[:, : 2 * C] *= gain
+    bias = torch.randn(3 * C, generator=g)
+    out = torch.full((n, C, H * W), float("nan"), device=dev)
+    prev = ops.set_precision(prec)
+    try:
+        ops.window_attn(Planes.of(qkv.to(dev)), bias.to(dev), Planes.of(out), heads, H, W, ws)
+    finally:
+        ops.set_precision(prev)
+    # float64 reference: pad the grid with "bias tokens" to a multiple of ws, attend inside windows, crop
+    Hp, Wp = -(-H // ws) * ws, -(-W // ws) * ws
+    full = bias.double().view(1, 3 * C, 1, 1).expand(n, 3 * C, Hp, Wp).clone()
+    full[:, :, :H, :W] = qkv.double().view(n, 3 * C, H, W)
+    t = full.view(n, 3, heads, 32, Hp // ws, ws, Wp // ws, ws).permute(1, 0, 2, 4, 6, 5, 7, 3).reshape(3, n, heads, -1, ws * ws, 32)
+    att = torch.softmax(t[0] @ t[1].transpose(-1, -2) * 32 ** -0.5, dim=-1) @ t[2]          # [n, heads, windows, ws*ws, 32]
+    ref = att.view(n, heads, Hp // ws, Wp // ws, ws, ws, 32).permute(0, 1, 6, 2, 4, 3, 5).reshape(n, C, Hp, Wp)[:, :, :H, :W]
+    err = (out.cpu().double().view(n, C, H, W) - ref).abs().max().item()
+    tol = {"fp32": 2e-5, "f16x3": 2e-5, "f16x2": 4e-3 * gain * gain}[prec]
+    print(f"window_attn {prec} heads={heads} ws={ws} H={H} W={W} n={n} gain={gain}: max abs err {err:.3e}")
+    assert err <= tol, (err, tol)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Twins_CSC encoder (fnet on T frames + cnet on T-1 frames) at the Sintel shape: ms per clip and the per-kernel table.
-usage: encoder_bench.py [clips]"""
+usage: encoder_bench.py [clips] [shapes]"""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -24,8 +24,11 @@ for prec in ("f16x3", "f16x2"):
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / 3 * 1e3
     ops.PROFILER = ops.Profiler()
+    ops.PROFILE_SHAPES = len(sys.argv) > 2 and sys.argv[2] == "shapes"
     fnet(x); cnet(x[:, :-1])
     summ = ops.PROFILER.summary()
     ops.PROFILER = None
-    rows = sorted(((k, round(v["ms"], 3), v["launches"]) for k, v in summ.items()), key=lambda r: -r[1])
+    ops.PROFILE_SHAPES = False
+    rows = sorted(((k, round(v["ms"], 3), v["launches"], round(v["bytes"] / v["ms"] / 1e6), round(v["flops"] / v["ms"] / 1e9, 1))
+                   for k, v in summ.items()), key=lambda r: -r[1])       # name, ms, launches, algorithmic GB/s, TFLOP/s
     print(json.dumps({"precision": prec, "clips": B, "encoder_ms_per_clip": round(ms / B, 3), "kernels": rows}))
