@@ -190,3 +190,23 @@ def test_full_checkpoint_contract_with_twins_encoder(tmp_path):
     torch.save(bad, path)
     with pytest.raises(RuntimeError, match="fnet.svt.blocks.0.0.attn.qkv.bias"):
         sfa.StreamFlowT4(str(path))
+
+
+def test_mixed_preset_layer_sets():
+    """config2_mixed: exactly the nine layers of the ablation keep split weights, the other 30 contraction
+    layers and the motion encoder's four 15x15 depthwise layers are single-product; every name exists in the engine's
+    layer inventory; the other presets name no single-product layer."""
+    from streamflow_amd import presets
+    from streamflow_amd.engine import HotPathWeights
+    inventory = set(HotPathWeights.PLAIN_LAYERS) | {f"{b}.{l}" for b in HotPathWeights.SK_BLOCKS for l in HotPathWeights.SK_LAYERS}
+    assert len(inventory) == 39
+    kw = presets.engine_kwargs("config2_mixed")
+    single = set(kw["single_layers"])
+    gemm_single = single & inventory
+    assert set(presets.MIXED_KEEP_SPLIT) <= inventory and len(presets.MIXED_KEEP_SPLIT) == 9
+    assert gemm_single == inventory - set(presets.MIXED_KEEP_SPLIT) and len(gemm_single) == 30
+    assert single - inventory == {"convc1.dw", "convc2.dw", "convf2.dw", "conv.dw"}
+    assert {"flow_head.ffn2_2", "gru.pw", "qkv"} <= set(presets.MIXED_KEEP_SPLIT)
+    for name in ("fp32_class", "config2_fp16"):
+        assert not presets.engine_kwargs(name).get("single_layers")
+    assert presets.BENCH_PRESET == "config2_mixed"

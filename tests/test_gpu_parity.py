@@ -275,7 +275,8 @@ def test_headline_config_batched_vs_oracle(dev, preset):
             mag = ups_o[i].norm(dim=1).mean().item()
             print(f"headline config [{preset}], clip {clip} of {B}, pair {i}: EPE vs oracle after {iters} iterations = {e:.3e} px "
                   f"(mean |flow| {mag:.2f} px)")
-            assert e <= 1e-3, (clip, i, e)
+            # north star: 1e-3 px; the mixed preset was chosen by ablation to stay below half of that
+            assert e <= (5e-4 if preset == "config2_mixed" else 1e-3), (clip, i, e)
     # clips are independent: the same clip at another batch position must give the same flows
     fd2 = fd.clone()
     fd2[3], cd2 = fd[B - 1], cd.clone()
