@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SF_VERSION 106
+#define SF_VERSION 108
 
 enum {
     SF_OK = 0,
@@ -307,17 +307,22 @@ int sf_flow_update(float* coords1, const float* delta, float* flow_a, int64_t fl
  *     fp32-class), SF_PRECISION_F16X2 / SF_PRECISION_F16 = every operand rounded once to fp16 (1 product); fp32
  *     accumulation, softmax statistics in fp32.  ws: sf_subsample_attn_ws_bytes(n_img, heads, M) bytes, 16-byte aligned
  *     (the packed k / v operand images; scratch, dead when the call's kernels have run).
+ *     sf_window_attn_mfma, qkv_koct = 1 (one-product classes only): qkv points to fp16 k-octet planes [3C/8][H*W][8] (the
+ *     qkv sf_gemm's c_f16 = 2 output; image stride in halves) instead of fp32 planes.
+ *     Both *_mfma cores: out_koct (optional) = the result as fp16 k-octet planes [C/8][N][8] (SF_LAYOUT_F16_KOCT, image
+ *     stride in halves): the B operand image of the proj sf_gemm that consumes it; out may then be NULL.
  * sf_dwconv3x3_res: timm PosConv: y = x + depthwise3x3(x) + b on [n_img][C][H][W]; w [C][9]. */
 int sf_window_attn(const float* qkv, int64_t qkv_img_stride, const float* qkv_bias, float* out, int64_t out_img_stride,
                    int n_img, int C, int heads, int H, int W, int ws, void* stream);
-int sf_window_attn_mfma(const float* qkv, int64_t qkv_img_stride, const float* qkv_bias, float* out, int64_t out_img_stride,
-                        int n_img, int C, int heads, int H, int W, int ws, int precision, void* stream);
+int sf_window_attn_mfma(const void* qkv, int64_t qkv_img_stride, int qkv_koct, const float* qkv_bias, float* out,
+                        int64_t out_img_stride, void* out_koct, int64_t out_koct_img_stride, int n_img, int C, int heads,
+                        int H, int W, int ws, int precision, void* stream);
 int sf_subsample_attn(const float* q, int64_t q_img_stride, const float* kv, int64_t kv_img_stride, float* out,
                       int64_t out_img_stride, int n_img, int C, int heads, int N, int M, void* stream);
 int64_t sf_subsample_attn_ws_bytes(int n_img, int heads, int M);
 int sf_subsample_attn_mfma(const float* q, int64_t q_img_stride, const float* kv, int64_t kv_img_stride, float* out,
-                           int64_t out_img_stride, int n_img, int C, int heads, int N, int M, void* ws, int64_t ws_bytes,
-                           int precision, void* stream);
+                           int64_t out_img_stride, void* out_koct, int64_t out_koct_img_stride, int n_img, int C, int heads,
+                           int N, int M, void* ws, int64_t ws_bytes, int precision, void* stream);
 int sf_dwconv3x3_res(const float* x, int64_t x_img_stride, const float* w, const float* b, float* y,
                      int64_t y_img_stride, int n_img, int C, int H, int W, void* stream);
 

@@ -73,10 +73,10 @@ SIGNATURES = {
     "sf_context_split": (_i, [_vp, _vp, _i64, _vp, _i64, _i, _i, _i, _vp]),
     "sf_flow_update": (_i, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _vp]),
     "sf_window_attn": (_i, [_vp, _i64, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _vp]),
-    "sf_window_attn_mfma": (_i, [_vp, _i64, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "sf_window_attn_mfma": (_i, [_vp, _i64, _i, _vp, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "sf_subsample_attn": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _vp]),
     "sf_subsample_attn_ws_bytes": (_i64, [_i, _i, _i]),
-    "sf_subsample_attn_mfma": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _vp, _i64, _i, _vp]),
+    "sf_subsample_attn_mfma": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _vp, _i64, _i, _vp]),
     "sf_dwconv3x3_res": (_i, [_vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp]),
     "sf_upsample_flow": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "sf_forward_interpolate": (_i, [_vp, _vp, _i, _i, _i, _vp]),
@@ -105,7 +105,7 @@ def load() -> C.CDLL:
             raise RuntimeError(f"{LIB_PATH} does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
-    if lib.sf_version() < 106:
+    if lib.sf_version() < 108:
         raise RuntimeError("libstreamflow_hip.so is too old; rebuild")
     _lib = lib
     return lib

@@ -139,7 +139,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
-constexpr int SQT = 2;             // 32-query tiles per wave
+constexpr int SQT = 1;             // 32-query tiles per wave
 constexpr int SPARTS = 8;          // 1 KB fragments per key tile: K s0, K s1, V m0, V m1 (hi), then the same four (lo)
 
 __device__ __forceinline__ void split8(const float (&x)[8], f16x8& hi, f16x8& lo) {
@@ -148,6 +148,29 @@ __device__ __forceinline__ void split8(const float (&x)[8], f16x8& hi, f16x8& lo
         const _Float16 h = (_Float16)x[i];
         hi[i] = h;
         lo[i] = (_Float16)(x[i] - (float)h);
+    }
+}
+
+// One lane's 16 outputs of a 32-query tile (channels head*32 + (r & 3) + 8 (r >> 2) + 4 khalf of token n): fp32 planes
+// [C][N] and / or fp16 k-octet planes [C/8][N][8] (SF_LAYOUT_F16_KOCT, the operand image of the proj GEMM): registers
+// 4g .. 4g+3 are four consecutive channels of octet head*4 + g -- one 8-byte store, lanes l and l ^ 32 complete the octet.
+__device__ __forceinline__ void store_attn_out(float* out, int64_t out_img_stride, _Float16* out16, int64_t out16_img_stride, int img,
+                                               int head, int N, int n, int khalf, const f32x16& o, float inv) {
+    if (out) {
+        float* op = out + (int64_t)img * out_img_stride + (int64_t)head * HD * N + n;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) op[(int64_t)((r & 3) + 8 * (r >> 2) + 4 * khalf) * N] = o[r] * inv;
+    }
+    if (out16) {
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+        _Float16* op = out16 + (int64_t)img * out16_img_stride + ((int64_t)head * 4 * N + n) * 8 + khalf * 4;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            h4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (_Float16)(o[4 * g + e] * inv);
+            *reinterpret_cast<h4*>(op + (int64_t)g * N * 8) = v;
+        }
     }
 }
 
@@ -179,7 +202,8 @@ __global__ __launch_bounds__(256) void subsample_pack_kv_kernel(const float* kv,
 
 template <int NP>
 __global__ __launch_bounds__(256) void subsample_attn_mfma_kernel(const float* q, int64_t q_img_stride, const char* ws, float* out,
-                                                                  int64_t out_img_stride, int N, int M, int tiles) {
+                                                                  int64_t out_img_stride, _Float16* out16, int64_t out16_img_stride,
+                                                                  int N, int M, int tiles) {
     constexpr bool kLo = NP == 3;
     const int head = blockIdx.y, img = blockIdx.z, heads = gridDim.y;
     const int lane = threadIdx.x & 63, l31 = lane & 31, khalf = lane >> 5;
@@ -286,15 +310,11 @@ __global__ __launch_bounds__(256) void subsample_attn_mfma_kernel(const float* q
 #pragma unroll
         for (int f = 0; f < NF; ++f) cur[f] = nxt[f];
     }
-    float* op = out + (int64_t)img * out_img_stride + (int64_t)head * HD * N;
 #pragma unroll
     for (int t = 0; t < SQT; ++t) {
         const float inv = 1.0f / (l_run[t] + __shfl_xor(l_run[t], 32, 64));
         const int n = n0 + t * 32 + l31;
-        if (n < N) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) op[(int64_t)((r & 3) + 8 * (r >> 2) + 4 * khalf) * N + n] = o[t][r] * inv;
-        }
+        if (n < N) store_attn_out(out, out_img_stride, out16, out16_img_stride, img, head, N, n, khalf, o[t], inv);
     }
 }
 
@@ -329,11 +349,15 @@ constexpr int WLS = 72;            // halves per d-row of the LDS V image (64 to
 
 template <int NP>
 __global__ __launch_bounds__(256) void window_attn_mfma_kernel(const float* qkv, int64_t img_stride, const float* bias, float* out,
-                                                               int64_t out_img_stride, int C, int H, int W, int ws, int nww) {
+                                                               int64_t out_img_stride, _Float16* out16, int64_t out16_img_stride,
+                                                               int C, int H, int W, int ws, int nww) {
     constexpr bool kLo = NP == 3;
     __shared__ _Float16 lds[4 * 2 * HD * WLS];
     const int wave = threadIdx.x >> 6, head = blockIdx.z * 4 + wave, lane = threadIdx.x & 63, l31 = lane & 31, khalf = lane >> 5;
-    const int wy = blockIdx.x / nww, wx = blockIdx.x % nww, img = blockIdx.y;
+    // a 128-byte line of a token row is shared by 4.6 windows of a window row: consecutive windows must meet in ONE L2
+    // (workgroup b runs on XCD b % 8: with the plain order every line was fetched by ~4.5 XCDs)
+    const int win = sf::xcd_linear_id(blockIdx.x, gridDim.x);
+    const int wy = win / nww, wx = win % nww, img = blockIdx.y;
     const int nt = ws * ws, N = H * W;
     const float* base = qkv + (int64_t)img * img_stride;
     _Float16* vh = lds + wave * 2 * HD * WLS;
@@ -393,7 +417,6 @@ __global__ __launch_bounds__(256) void window_attn_mfma_kernel(const float* qkv,
             for (int i = 0; i < 4; ++i) { vfl[j][i] = c[i]; vfl[j][4 + i] = e[i]; }
         }
     }
-    float* op = out + (int64_t)img * out_img_stride + (int64_t)head * HD * N;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {                                     // query tile
         if (t * 32 >= nt) break;
@@ -459,10 +482,111 @@ __global__ __launch_bounds__(256) void window_attn_mfma_kernel(const float* qkv,
             o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfh[j], ph[j], o, 0, 0, 0);
         }
         const float inv = 1.0f / (psum + __shfl_xor(psum, 32, 64));
-        if (pix[t] >= 0) {
+        if (pix[t] >= 0) store_attn_out(out, out_img_stride, out16, out16_img_stride, img, head, N, pix[t], khalf, o, inv);
+    }
+}
+
+// The same with q, k, v read from fp16 k-octet planes [3C/8][N][8] (the qkv GEMM's c_f16 = 2 output): a lane's 8 dims of a
+// token are ONE 16-byte load (12 loads per wave instead of 96 dwords, half the bytes, 112-byte runs per window row instead
+// of 28).  One-product arithmetic (the operands ARE fp16); the 32^-0.5 log2(e) factor moves from q into the exponent.
+__global__ __launch_bounds__(256) void window_attn_mfma16_kernel(const _Float16* qkv, int64_t img_stride, const float* bias, float* out,
+                                                                 int64_t out_img_stride, _Float16* out16, int64_t out16_img_stride,
+                                                                 int C, int H, int W, int ws, int nww) {
+    __shared__ _Float16 lds[4 * HD * WLS];
+    const int wave = threadIdx.x >> 6, head = blockIdx.z * 4 + wave, lane = threadIdx.x & 63, l31 = lane & 31, khalf = lane >> 5;
+    const int win = sf::xcd_linear_id(blockIdx.x, gridDim.x);
+    const int wy = win / nww, wx = win % nww, img = blockIdx.y;
+    const int nt = ws * ws, N = H * W;
+    const _Float16* base = qkv + (int64_t)img * img_stride;
+    _Float16* vh = lds + wave * HD * WLS;
+    const float qmul = 0.17677669529663687f * 1.44269504088896340736f;
+    int pix[2];
+    bool tok[2];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) op[(int64_t)((r & 3) + 8 * (r >> 2) + 4 * khalf) * N + pix[t]] = o[r] * inv;
+    for (int t = 0; t < 2; ++t) {
+        const int k = t * 32 + l31, y = wy * ws + k / ws, x = wx * ws + k % ws;
+        tok[t] = k < nt;
+        pix[t] = (tok[t] && y < H && x < W) ? y * W + x : -1;
+    }
+    f16x8 qh[2][2], kh[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int oct = head * 4 + 2 * ks + khalf;                   // channels head*32 + 16 ks + 8 khalf .. + 7
+            f16x8 q8, k8, v8;
+            if (pix[t] >= 0) {
+                const _Float16* p = base + ((int64_t)oct * N + pix[t]) * 8;
+                q8 = *reinterpret_cast<const f16x8*>(p);
+                k8 = *reinterpret_cast<const f16x8*>(p + (int64_t)(C / 8) * N * 8);
+                v8 = *reinterpret_cast<const f16x8*>(p + (int64_t)(C / 4) * N * 8);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    q8[i] = (_Float16)0.f;
+                    k8[i] = tok[t] ? (_Float16)bias[C + oct * 8 + i] : (_Float16)0.f;
+                    v8[i] = tok[t] ? (_Float16)bias[2 * C + oct * 8 + i] : (_Float16)0.f;
+                }
+            }
+            qh[t][ks] = q8;
+            kh[t][ks] = k8;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) vh[(16 * ks + 8 * khalf + i) * WLS + t * 32 + l31] = v8[i];
         }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    f16x8 vfh[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+        const h4 a = *reinterpret_cast<const h4*>(vh + l31 * WLS + 16 * j + 4 * khalf);
+        const h4 b = *reinterpret_cast<const h4*>(vh + l31 * WLS + 16 * j + 4 * khalf + 8);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { vfh[j][i] = a[i]; vfh[j][4 + i] = b[i]; }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        if (t * 32 >= nt) break;
+        f32x16 sc[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sc[kt][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) sc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[kt][ks], qh[t][ks], sc[kt], 0, 0, 0);
+        }
+        float mx = -1.0e30f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const bool valid = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf < nt;
+                sc[kt][r] = valid ? sc[kt][r] : -1.0e30f;
+                mx = fmaxf(mx, sc[kt][r]);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float off = -mx * qmul;
+        float psum = 0.f;
+        f16x8 ph[4];
+        const f16x2 ones = {(_Float16)1.0f, (_Float16)1.0f};
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                f16x2 pp;
+                pp[0] = (_Float16)__builtin_amdgcn_exp2f(fmaf(sc[kt][r], qmul, off));
+                pp[1] = (_Float16)__builtin_amdgcn_exp2f(fmaf(sc[kt][r + 1], qmul, off));
+                psum = __builtin_amdgcn_fdot2(pp, ones, psum, false);
+                ph[kt * 2 + (r >> 3)][r & 7] = pp[0];
+                ph[kt * 2 + (r >> 3)][(r & 7) + 1] = pp[1];
+            }
+        f32x16 o;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfh[j], ph[j], o, 0, 0, 0);
+        const float inv = 1.0f / (psum + __shfl_xor(psum, 32, 64));
+        if (pix[t] >= 0) store_attn_out(out, out_img_stride, out16, out16_img_stride, img, head, N, pix[t], khalf, o, inv);
     }
 }
 
@@ -514,10 +638,12 @@ extern "C" int sf_window_attn(const float* qkv, int64_t qkv_img_stride, const fl
     return sf::check_launch("sf_window_attn");
 }
 
-extern "C" int sf_window_attn_mfma(const float* qkv, int64_t qkv_img_stride, const float* qkv_bias, float* out,
-                                   int64_t out_img_stride, int n_img, int C, int heads, int H, int W, int ws, int precision,
-                                   void* stream) {
-    SF_REQUIRE(qkv && qkv_bias && out, "sf_window_attn_mfma: null pointer");
+extern "C" int sf_window_attn_mfma(const void* qkv, int64_t qkv_img_stride, int qkv_koct, const float* qkv_bias, float* out,
+                                   int64_t out_img_stride, void* out_koct, int64_t out_koct_img_stride, int n_img, int C,
+                                   int heads, int H, int W, int ws, int precision, void* stream) {
+    SF_REQUIRE(qkv && qkv_bias && (out || out_koct), "sf_window_attn_mfma: null pointer");
+    SF_REQUIRE(!out_koct || ((reinterpret_cast<uintptr_t>(out_koct) & 15) == 0 && (out_koct_img_stride & 7) == 0),
+               "sf_window_attn_mfma: out_koct must be 16-byte aligned with an image stride that is a multiple of 8 halves");
     SF_REQUIRE(n_img > 0 && H > 0 && W > 0 && n_img <= 65535, "sf_window_attn_mfma: bad dims");
     SF_REQUIRE(heads >= 4 && heads % 4 == 0 && C == heads * HD, "sf_window_attn_mfma: needs C = heads * 32, heads a multiple of 4 (got C=%d heads=%d)", C, heads);
     SF_REQUIRE(ws >= 2 && ws <= 7, "sf_window_attn_mfma: window size must be 2..7 (got %d)", ws);
@@ -525,12 +651,19 @@ extern "C" int sf_window_attn_mfma(const float* qkv, int64_t qkv_img_stride, con
                "sf_window_attn_mfma: precision must be one of the split / fp16 classes (the exact fp32 core is sf_window_attn)");
     const int nwh = sf::ceil_div(H, ws), nww = sf::ceil_div(W, ws);
     const dim3 grid(nwh * nww, n_img, heads / 4);
-    if (precision == SF_PRECISION_F16X3)
-        hipLaunchKernelGGL(window_attn_mfma_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, qkv, qkv_img_stride, qkv_bias, out,
-                           out_img_stride, C, H, W, ws, nww);
-    else
-        hipLaunchKernelGGL(window_attn_mfma_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, qkv, qkv_img_stride, qkv_bias, out,
-                           out_img_stride, C, H, W, ws, nww);
+    if (qkv_koct) {
+        SF_REQUIRE(precision != SF_PRECISION_F16X3, "sf_window_attn_mfma: fp16 k-octet q / k / v are an input of the one-product classes only");
+        SF_REQUIRE((reinterpret_cast<uintptr_t>(qkv) & 15) == 0 && (qkv_img_stride & 7) == 0,
+                   "sf_window_attn_mfma: k-octet qkv must be 16-byte aligned with an image stride that is a multiple of 8 halves");
+        hipLaunchKernelGGL(window_attn_mfma16_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const _Float16*)qkv, qkv_img_stride,
+                           qkv_bias, out, out_img_stride, (_Float16*)out_koct, out_koct_img_stride, C, H, W, ws, nww);
+    } else if (precision == SF_PRECISION_F16X3) {
+        hipLaunchKernelGGL(window_attn_mfma_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)qkv, qkv_img_stride,
+                           qkv_bias, out, out_img_stride, (_Float16*)out_koct, out_koct_img_stride, C, H, W, ws, nww);
+    } else {
+        hipLaunchKernelGGL(window_attn_mfma_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)qkv, qkv_img_stride,
+                           qkv_bias, out, out_img_stride, (_Float16*)out_koct, out_koct_img_stride, C, H, W, ws, nww);
+    }
     return sf::check_launch("sf_window_attn_mfma");
 }
 
@@ -550,9 +683,11 @@ extern "C" int64_t sf_subsample_attn_ws_bytes(int n_img, int heads, int M) {
 }
 
 extern "C" int sf_subsample_attn_mfma(const float* q, int64_t q_img_stride, const float* kv, int64_t kv_img_stride, float* out,
-                                      int64_t out_img_stride, int n_img, int C, int heads, int N, int M, void* ws,
-                                      int64_t ws_bytes, int precision, void* stream) {
-    SF_REQUIRE(q && kv && out && ws, "sf_subsample_attn_mfma: null pointer");
+                                      int64_t out_img_stride, void* out_koct, int64_t out_koct_img_stride, int n_img, int C,
+                                      int heads, int N, int M, void* ws, int64_t ws_bytes, int precision, void* stream) {
+    SF_REQUIRE(q && kv && (out || out_koct) && ws, "sf_subsample_attn_mfma: null pointer");
+    SF_REQUIRE(!out_koct || ((reinterpret_cast<uintptr_t>(out_koct) & 15) == 0 && (out_koct_img_stride & 7) == 0),
+               "sf_subsample_attn_mfma: out_koct must be 16-byte aligned with an image stride that is a multiple of 8 halves");
     SF_REQUIRE(n_img > 0 && N > 0 && M > 0 && n_img <= 65535 && heads <= 65535, "sf_subsample_attn_mfma: bad dims");
     SF_REQUIRE(heads >= 1 && C == heads * HD, "sf_subsample_attn_mfma: needs C = heads * 32 (got C=%d heads=%d)", C, heads);
     SF_REQUIRE(precision == SF_PRECISION_F16X3 || precision == SF_PRECISION_F16X2 || precision == SF_PRECISION_F16,
@@ -565,10 +700,10 @@ extern "C" int sf_subsample_attn_mfma(const float* q, int64_t q_img_stride, cons
     const dim3 grid(sf::ceil_div(N, 4 * 32 * SQT), heads, n_img);
     if (precision == SF_PRECISION_F16X3)
         hipLaunchKernelGGL(subsample_attn_mfma_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, q, q_img_stride, (const char*)ws,
-                           out, out_img_stride, N, M, tiles);
+                           out, out_img_stride, (_Float16*)out_koct, out_koct_img_stride, N, M, tiles);
     else
         hipLaunchKernelGGL(subsample_attn_mfma_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, q, q_img_stride, (const char*)ws,
-                           out, out_img_stride, N, M, tiles);
+                           out, out_img_stride, (_Float16*)out_koct, out_koct_img_stride, N, M, tiles);
     return sf::check_launch("sf_subsample_attn_mfma");
 }
 

@@ -11,6 +11,8 @@ positional conv through the kernels of ``csrc/encoder.hip``; torch is used for m
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -158,16 +160,28 @@ class Twins_CSC(nn.Module):
         with torch.cuda.device(dev):
             pk = self._packed(dev)
             new = lambda rows, n: Planes.of(torch.empty(B, rows, n, dtype=torch.float32, device=dev))
+            # fp16 k-octet planes [rows/8][n][8] (ops.Planes.koct): in the two-product / fp16 classes every tensor that only
+            # feeds a GEMM (LayerNorm outputs, attention outputs, the MLP hidden) is handed over as the consumer's operand
+            # image, exactly as in the refinement loop; the fp32-class modes keep fp32 planes throughout
+            handover = (ops.PRECISION in (ops.PRECISION_F16X2, ops.PRECISION_F16) and (T * H * W) % 256 == 0
+                        and os.environ.get("SF_ENCODER_KOCT", "1") != "0")
 
-            def ln(X, name):
+            def newk(rows, n):
+                if not handover:
+                    return new(rows, n)
+                assert rows % 8 == 0
+                return Planes(torch.empty(B * rows * n // 2, dtype=torch.float32, device=dev), 0, rows * n, B, rows, n,
+                              f16=True, koct=True)
+
+            def ln(X, name, koct=False):
                 w, b, eps = pk[name]
-                Y = new(X.rows, X.P)
+                Y = newk(X.rows, X.P) if koct else new(X.rows, X.P)
                 ops.layernorm_cm(X, w, b, Y, eps)
                 return Y
 
-            def lin(name, X, epi=EPI_NONE, R=None):
-                Y = new(pk[name].M, X.P)
+            def lin(name, X, epi=EPI_NONE, R=None, koct=False):
                 A = pk[name]
+                Y = newk(A.M, X.P) if koct else new(A.M, X.P)
                 need = ops.gemm_split_ws_floats(A.M, X.P, A.K, B)      # skinny outputs over a deep K (the sr convs): split-K
                 prev = ops.SPLIT_WS
                 ops.SPLIT_WS = torch.empty(need, dtype=torch.float32, device=dev) if need else None
@@ -186,11 +200,11 @@ class Twins_CSC(nn.Module):
                 tok = ln(lin(f"patch_embeds.{i}.proj", Planes.of(_im2col(grid, k))), f"patch_embeds.{i}.norm")
                 # block 0: locally grouped (7x7 window) attention + MLP, both residual
                 b0 = f"blocks.{i}.0"
-                qkv = lin(b0 + ".attn.qkv", ln(tok, b0 + ".norm1"))
-                att = new(E, N)
+                qkv = lin(b0 + ".attn.qkv", ln(tok, b0 + ".norm1", koct=True), koct=True)
+                att = newk(E, N)
                 ops.window_attn(qkv, pk["qkv_bias"][i], att, heads, gh, gw, self.WS)
                 tok = lin(b0 + ".attn.proj", att, EPI_RES, R=tok)
-                tok = lin(b0 + ".mlp.fc2", lin(b0 + ".mlp.fc1", ln(tok, b0 + ".norm2"), EPI_GELU), EPI_RES, R=tok)
+                tok = lin(b0 + ".mlp.fc2", lin(b0 + ".mlp.fc1", ln(tok, b0 + ".norm2", koct=True), EPI_GELU, koct=True), EPI_RES, R=tok)
                 # positional conv after the first block (twins_csc.py:73-74)
                 pw, pb = pk[f"pos_block.{i}.proj.0"]
                 peg = new(E, N)
@@ -202,10 +216,10 @@ class Twins_CSC(nn.Module):
                 q = lin(b1 + ".attn.q", y)
                 s = lin(b1 + ".attn.sr", Planes.of(_im2col(y.tensor().view(B, E, gh, gw), sr)))
                 kv = lin(b1 + ".attn.kv", ln(s, b1 + ".attn.norm"))
-                att = new(E, N)
+                att = newk(E, N)
                 ops.subsample_attn(q, kv, att, heads)
                 tok = lin(b1 + ".attn.proj", att, EPI_RES, R=tok)
-                tok = lin(b1 + ".mlp.fc2", lin(b1 + ".mlp.fc1", ln(tok, b1 + ".norm2"), EPI_GELU), EPI_RES, R=tok)
+                tok = lin(b1 + ".mlp.fc2", lin(b1 + ".mlp.fc1", ln(tok, b1 + ".norm2", koct=True), EPI_GELU, koct=True), EPI_RES, R=tok)
                 grid = tok.tensor().view(B, E, gh, gw)
             h, w = H // 8, W // 8
             return grid.view(B, self.DIMS[1], T, h, w).permute(0, 2, 1, 3, 4).contiguous()

@@ -461,18 +461,23 @@ def window_attn(QKV: Planes, qkv_bias: torch.Tensor, OUT: Planes, heads: int, H:
     """timm LocallyGroupedAttn core on token planes (encoder; see include/streamflow_hip.h).  PRECISION_FP32: the exact
     VALU kernel; every other class: the matrix-core kernel (3 products per contraction for F16X3, 1 for the fp16 classes)."""
     C = OUT.rows
-    assert QKV.rows == 3 * C and QKV.P == H * W == OUT.P and qkv_bias.numel() == 3 * C
-    flops, nbytes = 4.0 * QKV.n_img * H * W * ws * ws * C, 4.0 * QKV.n_img * 4 * C * H * W
+    assert QKV.rows == 3 * C and QKV.P == H * W == OUT.P and qkv_bias.numel() == 3 * C and (not OUT.f16 or OUT.koct)
+    assert not QKV.f16 or (QKV.koct and PRECISION in (PRECISION_F16X2, PRECISION_F16))
+    flops, nbytes = 4.0 * QKV.n_img * H * W * ws * ws * C, (2.0 if QKV.f16 else 4.0) * QKV.n_img * 3 * C * H * W + 4.0 * QKV.n_img * C * H * W
     if PRECISION == PRECISION_FP32 or os.environ.get("SF_WINDOW_EXACT", "0") == "1":
+        assert not OUT.f16 and not QKV.f16
         _launch("window_attn", flops, nbytes,
                 lambda: _lib.check(_lib.load().sf_window_attn(QKV.ptr, QKV.img_stride, qkv_bias.data_ptr(), OUT.ptr, OUT.img_stride,
                                                               QKV.n_img, C, heads, H, W, ws, _lib.stream()), "sf_window_attn"))
         return
     prec = PRECISION
-    _launch("window_attn_mfma", flops, nbytes,
-            lambda: _lib.check(_lib.load().sf_window_attn_mfma(QKV.ptr, QKV.img_stride, qkv_bias.data_ptr(), OUT.ptr,
-                                                               OUT.img_stride, QKV.n_img, C, heads, H, W, ws, prec,
-                                                               _lib.stream()), "sf_window_attn_mfma"),
+    ko = OUT.f16                                          # fp16 k-octet planes: the hand-over to the proj GEMM
+    _launch("window_attn_mfma", flops, nbytes - (2.0 * QKV.n_img * C * H * W if ko else 0.0),
+            lambda: _lib.check(_lib.load().sf_window_attn_mfma(QKV.ptr, QKV.img_stride, int(QKV.f16), qkv_bias.data_ptr(),
+                                                               None if ko else OUT.ptr, 0 if ko else OUT.img_stride,
+                                                               OUT.ptr if ko else None, OUT.img_stride if ko else 0,
+                                                               QKV.n_img, C, heads, H, W, ws, prec, _lib.stream()),
+                               "sf_window_attn_mfma"),
             products=3 if prec == PRECISION_F16X3 else 1)
 
 
@@ -482,9 +487,10 @@ def subsample_attn(Q: Planes, KV: Planes, OUT: Planes, heads: int, ws: Optional[
     PRECISION_FP32: the exact VALU kernel; every other class: the matrix-core kernel (3 products per contraction for
     F16X3, 1 for the fp16 classes) over `ws` (uint8, >= subsample_attn_ws_bytes; allocated here when not given)."""
     C = Q.rows
-    assert KV.rows == 2 * C and OUT.rows == C and Q.P == OUT.P and Q.n_img == KV.n_img == OUT.n_img
+    assert KV.rows == 2 * C and OUT.rows == C and Q.P == OUT.P and Q.n_img == KV.n_img == OUT.n_img and (not OUT.f16 or OUT.koct)
     nbytes = 4.0 * Q.n_img * C * (2 * Q.P + 2 * KV.P)
     if PRECISION == PRECISION_FP32 or os.environ.get("SF_SUBSAMPLE_EXACT", "0") == "1":
+        assert not OUT.f16
         _launch("subsample_attn", 4.0 * Q.n_img * Q.P * KV.P * C, nbytes,
                 lambda: _lib.check(_lib.load().sf_subsample_attn(Q.ptr, Q.img_stride, KV.ptr, KV.img_stride, OUT.ptr, OUT.img_stride,
                                                                  Q.n_img, C, heads, Q.P, KV.P, _lib.stream()), "sf_subsample_attn"))
@@ -494,10 +500,13 @@ def subsample_attn(Q: Planes, KV: Planes, OUT: Planes, heads: int, ws: Optional[
         ws = torch.empty(need, dtype=torch.uint8, device=Q.base.device)
     assert ws.dtype == torch.uint8 and ws.numel() >= need and ws.device == Q.base.device
     prec = PRECISION
-    _launch("subsample_attn_mfma", 4.0 * Q.n_img * Q.P * KV.P * C, nbytes,
-            lambda: _lib.check(_lib.load().sf_subsample_attn_mfma(Q.ptr, Q.img_stride, KV.ptr, KV.img_stride, OUT.ptr,
-                                                                  OUT.img_stride, Q.n_img, C, heads, Q.P, KV.P, ws.data_ptr(),
-                                                                  ws.numel(), prec, _lib.stream()), "sf_subsample_attn_mfma"),
+    ko = OUT.f16
+    _launch("subsample_attn_mfma", 4.0 * Q.n_img * Q.P * KV.P * C, nbytes - (2.0 * Q.n_img * C * Q.P if ko else 0.0),
+            lambda: _lib.check(_lib.load().sf_subsample_attn_mfma(Q.ptr, Q.img_stride, KV.ptr, KV.img_stride,
+                                                                  None if ko else OUT.ptr, 0 if ko else OUT.img_stride,
+                                                                  OUT.ptr if ko else None, OUT.img_stride if ko else 0,
+                                                                  Q.n_img, C, heads, Q.P, KV.P, ws.data_ptr(), ws.numel(), prec,
+                                                                  _lib.stream()), "sf_subsample_attn_mfma"),
             products=3 if prec == PRECISION_F16X3 else 1)
 
 

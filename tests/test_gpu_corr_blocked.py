@@ -138,3 +138,39 @@ def test_gemm_koct_residual(dev, M, K, P, n):
     assert (Y.double().cpu() - ref).abs().max().item() < 2e-4
     # and within fp32 rounding of the fp32-residual epilogue fed the same (fp16-representable) residual values
     assert (Y - Y2).abs().max().item() < 2e-5
+
+
+def test_integration_md_binding_examples_run(dev):
+    """The ctypes stubs INTEGRATION.md section 2 shows a reference maintainer are executed as written (only the library
+    path is made absolute) and their results checked against the oracle: row-major pyramid, blocked build, blocked lookup."""
+    import os
+    import re
+    from oracle import streamflow_oracle as orc
+    from streamflow_amd import ops, synthetic as syn, _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    md = open(os.path.join(root, "INTEGRATION.md")).read()
+    sec = md[md.index("## 2. Binding the C ABI"):md.index("## 3. Build")]
+    blocks = re.findall(r"```python\n(.*?)```", sec, flags=re.S)
+    assert len(blocks) == 2
+    ns = {}
+    for code in blocks:
+        exec(code.replace('"streamflow_amd/libstreamflow_hip.so"', repr(_lib.LIB_PATH)), ns)
+    B, T, D, h, w = 1, 3, 256, 16, 24
+    fmaps = syn.randn(77, "fmaps", (B, T, D, h, w)).to(dev).contiguous()
+    # row-major fp32 pyramid of pair 0 (split precision f16x3)
+    lv = ns["corr_pyramid"](fmaps[:, 0].contiguous(), fmaps[:, 1].contiguous())
+    ref = orc.corr_pyramid(fmaps[:, 0].cpu(), fmaps[:, 1].cpu())
+    for a, b in zip(lv, ref):
+        assert (a.cpu() - b).abs().max().item() < 2e-4
+    # blocked fp16 volume + lookup into k-octets, both pairs
+    vol, img_bytes = ns["corr_blocked"](fmaps, B, T, D, h, w)
+    n_img, pairs = B * (T - 1), T - 1
+    coords = orc.coords_grid(n_img, h, w) + syn.randn(78, "dc", (n_img, 2, h, w)) * 3.0
+    koct = ns["lookup_blocked"](vol, img_bytes, coords.to(dev).contiguous(), n_img, pairs, h, w)
+    torch.cuda.synchronize()
+    got = koct.float().permute(0, 1, 3, 2).reshape(n_img, 328, h * w)[:, :324].cpu()
+    for t in range(pairs):
+        pyr = orc.corr_pyramid(fmaps[:, t].cpu(), fmaps[:, t + 1].cpu())
+        want = orc.corr_lookup(pyr, coords[t:t + 1]).reshape(324, h * w)
+        err = (got[t] - want).abs().max().item()
+        assert err < 2e-2 * max(1.0, want.abs().max().item() / 8), (t, err)       # fp16 cells and fp16 hand-over

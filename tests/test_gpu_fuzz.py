@@ -567,3 +567,49 @@ def test_window_attn_random_shapes(dev, seed, prec):
     tol = {"fp32": 2e-5, "f16x3": 2e-5, "f16x2": 4e-3 * gain * gain}[prec]
     print(f"window_attn {prec} heads={heads} ws={ws} H={H} W={W} n={n} gain={gain}: max abs err {err:.3e}")
     assert err <= tol, (err, tol)
+
+
+def _koct_planes(ops, n, rows, P, dev):
+    from streamflow_amd.ops import Planes
+    return Planes(torch.zeros(n * rows * P // 2, dtype=torch.float32, device=dev), 0, rows * P, n, rows, P, f16=True, koct=True)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_attention_cores_koct_handover(dev, seed):
+    """The encoder's fp16 hand-over (f16x2 / f16 classes): the window core fed with k-octet q / k / v (the qkv GEMM's
+    c_f16 = 2 output) and both cores writing k-octet outputs must agree with the same cores on fp32 planes of the SAME
+    fp16-rounded inputs to within the output rounding."""
+    from streamflow_amd import ops
+    from streamflow_amd.ops import Planes
+    rng = np.random.default_rng(9000 + seed)
+    heads = int(rng.choice([4, 8]))
+    C = heads * 32
+    H, W = int(rng.integers(5, 20)), 4 * int(rng.integers(2, 9))
+    N, n = H * W, int(rng.integers(1, 3))
+    g = torch.Generator().manual_seed(seed)
+    qkv = (torch.randn(n, 3 * C, N, generator=g) * 1.5).half().float().to(dev)      # exactly representable: both paths see the same operands
+    bias = torch.randn(3 * C, generator=g).half().float().to(dev)
+    prev = ops.set_precision("f16x2")
+    try:
+        ref = torch.empty(n, C, N, device=dev)
+        ops.window_attn(Planes.of(qkv), bias, Planes.of(ref), heads, H, W, 7)
+        qk = _koct_planes(ops, n, 3 * C, N, dev)
+        ops.pack_koct(Planes.of(qkv), qk)
+        outk = _koct_planes(ops, n, C, N, dev)
+        ops.window_attn(qk, bias, outk, heads, H, W, 7)
+        got = outk.tensor().float()
+        err = (got - ref).abs().max().item()
+        print(f"window core, k-octet in/out vs fp32 planes: {err:.3e}")
+        assert err <= 2e-3 + 1e-3 * ref.abs().max().item()        # q is rounded before / after its scale factor; fp16 output
+        # sub-sample core: k-octet output only
+        M = int(rng.choice([33, 64, 100]))
+        q = torch.randn(n, C, N, generator=g).to(dev)
+        kv = torch.randn(n, 2 * C, M, generator=g).to(dev)
+        ref2 = torch.empty(n, C, N, device=dev)
+        ops.subsample_attn(Planes.of(q), Planes.of(kv), Planes.of(ref2), heads)
+        out2 = _koct_planes(ops, n, C, N, dev)
+        ops.subsample_attn(Planes.of(q), Planes.of(kv), out2, heads)
+        err2 = (out2.tensor().float() - ref2).abs().max().item()
+        assert err2 <= 1e-3 * max(1.0, ref2.abs().max().item()), err2              # only the fp16 rounding of the result
+    finally:
+        ops.set_precision(prev)
