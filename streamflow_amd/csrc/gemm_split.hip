@@ -481,7 +481,12 @@ int launch_cfg(const SplitArgs& a, hipStream_t st) {
             // measured per shape (tools/gemm_koct_bench.py, 24 x 7040 pixels): 2 x 4 waves win for M >= 512 (+7..9 %), 1 x 8 for
             // 192 <= M < 512 (+0..15 %); M <= 128 stays on the 128 x 128 kernel (-10 % otherwise)
             static const int bd_min_m = getenv("SF_GEMM_BD_MIN_M") ? atoi(getenv("SF_GEMM_BD_MIN_M")) : 192;
-            if (bdirect && g.M >= bd_min_m && g.k_splits <= 1 && (int64_t)g.ldb * 16 * 2 < ((int64_t)1 << 31)) {
+            // A/B knob: fall back to the 128 x 128 kernel when the 128 x 256 tiles would not fill the chip (a single clip gives
+            // M = 384 just 249 of them for 256 CUs).  Measured at one clip: 183 / 190 / 182 / 184 ff/s for thresholds 0 / 384 /
+            // 512 / 768 -- inside the run-to-run noise, so the default stays 0 (always B-direct)
+            static const int bd_min_wg = getenv("SF_GEMM_BD_MIN_WG") ? atoi(getenv("SF_GEMM_BD_MIN_WG")) : 0;
+            const int64_t n_wg2 = (int64_t)sf::ceil_div(g.N, 256) * sf::ceil_div(g.M, 128) * g.batch;
+            if (bdirect && g.M >= bd_min_m && n_wg2 >= bd_min_wg && g.k_splits <= 1 && (int64_t)g.ldb * 16 * 2 < ((int64_t)1 << 31)) {
                 dim3 grid2(sf::ceil_div(g.N, 256) * sf::ceil_div(g.M, 128) * g.batch);
                 if (g.M >= 512) hipLaunchKernelGGL((gemm_bdirect_kernel<PM, 2>), grid2, dim3(kBdThreads), 0, st, a);
                 else hipLaunchKernelGGL((gemm_bdirect_kernel<PM, 1>), grid2, dim3(kBdThreads), 0, st, a);
