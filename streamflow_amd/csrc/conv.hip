@@ -256,7 +256,11 @@ __global__ __launch_bounds__(256, kProd == 1 ? 3 : ((KS == 15 && kProd == 2) ? S
                 const bool live = idx < rows_in * noct;
                 const bool rowok = live && gy >= 0 && gy < g.h;
                 off[u] = live ? (ry_ * g.stride16 + co) * 16 : -1;
+#if defined(SF_DW_ABLATE) && SF_DW_ABLATE == 2
+                if (false) {
+#else
                 if (rowok && g.vec_ok && gx >= 0 && gx + 8 <= g.w) {
+#endif
                     const float4 q0 = *reinterpret_cast<const float4*>(xp + gy * g.w + gx);
                     const float4 q1 = *reinterpret_cast<const float4*>(xp + gy * g.w + gx + 4);
                     v[u][0] = q0.x; v[u][1] = q0.y; v[u][2] = q0.z; v[u][3] = q0.w;
@@ -264,7 +268,11 @@ __global__ __launch_bounds__(256, kProd == 1 ? 3 : ((KS == 15 && kProd == 2) ? S
                 } else {
 #pragma unroll
                     for (int i = 0; i < 8; ++i)
+#if defined(SF_DW_ABLATE) && SF_DW_ABLATE == 2
+                        v[u][i] = (float)(idx + i) * 1e-4f;
+#else
                         v[u][i] = (rowok && gx + i >= 0 && gx + i < g.w) ? xp[gy * g.w + gx + i] : 0.f;
+#endif
                 }
             }
 #pragma unroll
@@ -306,8 +314,13 @@ __global__ __launch_bounds__(256, kProd == 1 ? 3 : ((KS == 15 && kProd == 2) ? S
                 ah[0][j] = *reinterpret_cast<const f16x8*>(hi + offj[j]);
                 if constexpr (kProd == 3) al[0][j] = *reinterpret_cast<const f16x8*>(lo + offj[j]);
             }
+#if defined(SF_DW_ABLATE) && SF_DW_ABLATE == 3
+#pragma unroll
+            for (int ky = 0; ky < 1; ++ky) {
+#else
 #pragma unroll
             for (int ky = 0; ky < KS; ++ky) {
+#endif
                 const int cur = ky & 1, nxt = cur ^ 1;
                 if (ky + 1 < KS) {
 #pragma unroll
@@ -346,7 +359,11 @@ __global__ __launch_bounds__(256, kProd == 1 ? 3 : ((KS == 15 && kProd == 2) ? S
                     const sf::f32x2 a = sf::gelu2<(kProd <= 2) && kOutF16 && SF_GEMM_FAST_GELU>(t);   // polynomial GELU where the result leaves as fp16
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
+#if defined(SF_DW_ABLATE) && SF_DW_ABLATE == 1
+                        const bool ok = a[u] == 123.456f;              // (never true: the value still has to be computed)
+#else
                         const bool ok = (gx0 + j * 16 < g.w) && (gy0 + r + u < g.h);
+#endif
                         const int so = ok ? off0 + ((r + u) * g.w + j * 16) * EB : (int)0x80000000u;
                         if constexpr (kOutF16) {
                             const _Float16 o = (_Float16)a[u];
