@@ -331,10 +331,15 @@ __global__ __launch_bounds__(kThreads, (TM * TN >= 8) ? 2 : SF_GEMM_WAVES) void 
 constexpr int kBdThreads = 512;
 // wave grid WM x (8 / WM): 2 x 4 (64 x 64 per wave: every activation fragment is loaded by two waves) or 1 x 8 (each wave all
 // 128 rows x 32 pixels: no duplicate activation loads, but every wave re-reads all weight fragments from LDS)
-template <int PM, int WM>
-__global__ __launch_bounds__(kBdThreads, 4) void gemm_bdirect_kernel(const SplitArgs args) {
+// BM = 256 (single-product weights only: three 16-KB stages): 2 x 4 waves of 128 x 64 -- every activation fragment feeds FOUR
+// MFMAs of a wave instead of two and is pulled from L2 once per 256 output rows instead of once per 128: the activations
+// (N = images x pixels columns) are the large operand of every GEMM of the update block, the weights are not.
+template <int PM, int WM, int BM>
+__device__ __forceinline__ void gemm_bdirect_body(const SplitArgs& args) {
     const SfGemm& g = args.g;
-    constexpr int BM = 128, BN = 256, WN = 8 / WM, TM = 4 / WM, TN = WM, NST = 3;
+    static_assert(BM == 128 || (BM == 256 && PM == 1 && WM == 2), "the 256-row tile is built for one product, 2 x 4 waves");
+    constexpr int BN = 256, WN = 8 / WM, TM = BM / 32 / WM, TN = WM, NST = 3;
+    constexpr int NPC = BM / 128;                                    // DMA pieces per wave, plane and stage
     constexpr int kPlane = (BK / 8) * BM * 16;                       // bytes of one plane (hi or lo) of a stage: 8 KB
     constexpr int kStage = PM * kPlane;
     constexpr int kEpiBytes = 8 * sf::kEpiScratchFloats * 4;
@@ -353,12 +358,20 @@ __global__ __launch_bounds__(kBdThreads, 4) void gemm_bdirect_kernel(const Split
     const int a_plane = (int)(args.a_bytes);
     const __amdgpu_buffer_rsrc_t rah = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.A_hi), 0, a_plane, 0x00020000);
     const __amdgpu_buffer_rsrc_t ral = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.A_lo), 0, a_plane, 0x00020000);
-    const int voa = ((tid >> 7) * (int)g.lda_h + m0 + (tid & 127)) * 16;
+    int voa[NPC];
+#pragma unroll
+    for (int p_ = 0; p_ < NPC; ++p_) {
+        const int sl = tid + p_ * kBdThreads;                        // slot = k-octet * BM + row
+        voa[p_] = ((sl / BM) * (int)g.lda_h + m0 + (sl % BM)) * 16;
+    }
     auto issue_a = [&](int kt, int slot) {
-        char* dst = smem + slot * kStage + wave * 1024;
         const int so = kt * (BK / 8) * (int)g.lda_h * 16;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rah, (lds_ptr)(dst), 16, voa, so, 0, 0);
-        if (PM == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(ral, (lds_ptr)(dst + kPlane), 16, voa, so, 0, 0);
+#pragma unroll
+        for (int p_ = 0; p_ < NPC; ++p_) {
+            char* dst = smem + slot * kStage + (p_ * 8 + wave) * 1024;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rah, (lds_ptr)(dst), 16, voa[p_], so, 0, 0);
+            if (PM == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(ral, (lds_ptr)(dst + kPlane), 16, voa[p_], so, 0, 0);
+        }
     };
     // ---- activations straight into registers: fragment (j, k-step ks) of stage kt = k-octet 4 kt + 2 ks + khalf of pixel
     // n0 + (wn * 2 + j) * 32 + l31 (pixels past N clamped: never stored) ----
@@ -406,7 +419,7 @@ __global__ __launch_bounds__(kBdThreads, 4) void gemm_bdirect_kernel(const Split
         SF_BD_STAMP(tm)
         // stage kt of the weights has landed (this wave's pieces; the barrier makes it everyone's): behind it in the queue
         // are only B(kt) -- needed now anyway -- and the PM pieces of DMA(kt + 1)
-        __builtin_amdgcn_s_waitcnt(PM == 2 ? 0x0F72 : 0x0F71);                       // vmcnt(PM)
+        __builtin_amdgcn_s_waitcnt(0x0F70 | (PM * NPC));                             // vmcnt(PM * NPC)
         SF_BD_STAMP(tw)
         __builtin_amdgcn_s_barrier();                       // ... and slot2 (stage kt - 1) is no longer read by anyone
         SF_BD_STAMP(tb)
@@ -458,7 +471,17 @@ __global__ __launch_bounds__(kBdThreads, 4) void gemm_bdirect_kernel(const Split
     }
 #endif
 }
+// (two __global__ wrappers: a __launch_bounds__ that depends on a template parameter left hipcc without the host stub of
+// some instantiations -- "undefined symbol __device_stub__gemm_bdirect_kernel<1, 2, 256>" at load time)
+template <int PM, int WM>
+__global__ __launch_bounds__(kBdThreads, 4) void gemm_bdirect_kernel(const SplitArgs args) { gemm_bdirect_body<PM, WM, 128>(args); }
+__global__ __launch_bounds__(kBdThreads, 2) void gemm_bdirect256_kernel(const SplitArgs args) { gemm_bdirect_body<1, 2, 256>(args); }
 
+void launch_bd256(const SplitArgs& a, hipStream_t st) {
+    const SfGemm& g = a.g;
+    dim3 grid(sf::ceil_div(g.N, 256) * sf::ceil_div(g.M, 256) * g.batch);
+    hipLaunchKernelGGL(gemm_bdirect256_kernel, grid, dim3(kBdThreads), 0, st, a);
+}
 
 template <int WM, int WN, int TM, int TN, int PM>
 int launch_cfg(const SplitArgs& a, hipStream_t st) {
@@ -488,6 +511,14 @@ int launch_cfg(const SplitArgs& a, hipStream_t st) {
             const int64_t n_wg2 = (int64_t)sf::ceil_div(g.N, 256) * sf::ceil_div(g.M, 128) * g.batch;
             if (bdirect && g.M >= bd_min_m && n_wg2 >= bd_min_wg && g.k_splits <= 1 && (int64_t)g.ldb * 16 * 2 < ((int64_t)1 << 31)) {
                 dim3 grid2(sf::ceil_div(g.N, 256) * sf::ceil_div(g.M, 128) * g.batch);
+                // 256-row tiles: single-product layers whose M pads to the same size either way, from M = SF_GEMM_BD256 up (0 =
+                // never).  Measured (tools/gemm_koct_bench.py, SF_SINGLE=1, 24 x 7040 pixels): M960 K640 426 -> 404 us; but M486
+                // K324 126 -> 148, M256 K384 62 -> 72, M256 K256 54 -> 63: one or two row tiles leave too few workgroups
+                static const int bd256 = getenv("SF_GEMM_BD256") ? atoi(getenv("SF_GEMM_BD256")) : 768;
+                if (PM == 1 && bd256 && sf::ceil_div(g.M, 256) * 256 == sf::ceil_div(g.M, 128) * 128 && g.M >= bd256) {
+                    launch_bd256(a, st);
+                    return sf::check_launch("sf_gemm(B-direct 256)");
+                }
                 if (g.M >= 512) hipLaunchKernelGGL((gemm_bdirect_kernel<PM, 2>), grid2, dim3(kBdThreads), 0, st, a);
                 else hipLaunchKernelGGL((gemm_bdirect_kernel<PM, 1>), grid2, dim3(kBdThreads), 0, st, a);
                 return sf::check_launch("sf_gemm(B-direct)");

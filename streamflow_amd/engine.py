@@ -461,7 +461,11 @@ class HotPathEngine:
         def two_chains(fn):
             """fn(image0, count): chain 0 on the main stream, the others on their own streams."""
             keep = ops.SPLIT_WS
-            ops.SPLIT_WS = None                                    # (one scratch buffer: no automatic split-K while the chains run)
+            # One scratch buffer: no automatic split-K while the chains run.  auto_splits() only fires for grids of fewer than
+            # 96 workgroups with K >= 256 (gemm_split.hip) -- never at the Sintel / KITTI / Spring shapes, whose smallest GEMM
+            # has 165 workgroups per clip -- so the two-chain schedule changes results (summation order) only at toy shapes;
+            # the bitwise test of the two schedules therefore runs with SF_AUTO_SPLITK=0 (ADVICE r2).
+            ops.SPLIT_WS = None
             try:
                 for c in range(1, len(parts)):
                     sc = self._chain_streams[c - 1]

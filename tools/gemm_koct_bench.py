@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """f16x2 GEMMs with a k-octet fp16 B operand (the hand-over format of the conv stack) at the shapes that hold the GEMM time,
-24 images of 7040 pixels.  Prints us and algorithmic TF per shape; SF_GEMM_BDIRECT=0/1 selects the kernel.
+24 images of 7040 pixels.  Prints us and algorithmic TF per shape; SF_GEMM_BDIRECT=0/1 selects the kernel, SF_SINGLE=1 single-product weights, SF_GEMM_BD256=0/1 the 256-row tile.
 usage: gemm_koct_bench.py [epi: none|gelu|koct]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -15,6 +15,7 @@ shapes = [(960, 640), (640, 960), (640, 640), (128, 960), (486, 324), (324, 486)
 tot = 0.0
 for M, K in shapes:
     W = PackedLinear(torch.randn(M, K, 1, 1) / K ** 0.5, torch.randn(M) * 0.1, dev)
+    W.single = os.environ.get("SF_SINGLE", "0") == "1"          # single-product weights (a layer of the mixed preset)
     Ka = (K + 7) // 8 * 8
     xs = torch.randn(n, Ka, P, device=dev)
     X = Planes(torch.zeros(n * Ka * P // 2, device=dev), 0, Ka * P, n, K, P, f16=True, koct=True)
