@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SF_VERSION 108
+#define SF_VERSION 109
 
 enum {
     SF_OK = 0,
@@ -220,22 +220,28 @@ int sf_splitk_combine(const float* partial, int64_t split_stride, int k_splits, 
  * The reference's demo recomputes softmax(q k^T) v in every refinement iteration (flash_attn_func or a naive einsum)
  * instead of keeping the attention matrix; this is that path: online softmax, logits never leave the CU.
  *   sf_gma_flash_pack_qk: once per clip.  qk [n_img][256][P] fp32 (rows 0..127 = q, 128..255 = k: the to_qk output,
- *       gma.py:57) -> fp16 (hi, lo) operand images in `ws` (q pre-scaled by scale * log2 e).
+ *       gma.py:57) -> fp16 (hi, lo) operand images in `ws` (q pre-scaled by scale * log2 e).  stats_qk_products = 1 / 2 / 3
+ *       additionally runs the logits once (with that many products) and stores every query's softmax statistics (row
+ *       maximum, 1 / row sum) in `ws`: q and k do not change over the refinement loop, so the per-iteration kernel can
+ *       skip its running maximum, accumulator rescale and row sum (use_stats below; -21 % per iteration).  0 = none.
  *   sf_gma_flash_aggregate: every iteration.  v [n_img][128][P] (to_v output), mf and out [n_img][128][P] planes with
  *       image strides in floats; packs v into `ws`, then one fused kernel.  qk_products = MFMA products per logit:
  *       3 = split precision (q_hi k_hi + q_lo k_hi + q_hi k_lo, fp32-class logits), 2 = k rounded to fp16,
  *       1 = q and k rounded to fp16 (the arithmetic of the reference's fp16 flash-attn path).  Softmax weights and v
  *       enter the second contraction as fp16 (like the materialised matrix of sf_softmax_rows), accumulation is fp32.
+ *       use_stats = 1: use the statistics stored by pack_qk, which must have been called with stats_qk_products ==
+ *       qk_products (same logits); 0: self-contained online softmax.
  *       out_koct (optional): `out` a second time, rounded to fp16, as k-octet planes [16][P][8] per image
  *       (SF_LAYOUT_F16_KOCT, image stride in halves) -- the operand format of the GEMM that reads it next.
  * ws: caller-owned scratch of sf_gma_flash_ws_bytes(n_img, P) bytes, 16-byte aligned; must persist from pack_qk to the
  * last aggregate of the clip. */
 int64_t sf_gma_flash_ws_bytes(int n_img, int P);
 int sf_gma_flash_pack_qk(const float* qk, int64_t qk_img_stride, void* ws, int64_t ws_bytes, int n_img, int P,
-                         float scale, void* stream);
+                         float scale, int stats_qk_products, void* stream);
 int sf_gma_flash_aggregate(void* ws, int64_t ws_bytes, const float* v, int64_t v_img_stride, const float* mf,
                            int64_t mf_img_stride, const float* gamma, float* out, int64_t out_img_stride,
-                           void* out_koct, int64_t out_koct_img_stride, int n_img, int P, int qk_products, void* stream);
+                           void* out_koct, int64_t out_koct_img_stride, int n_img, int P, int qk_products, int use_stats,
+                           void* stream);
 
 /* ---- row softmax (gma.py:63): x [rows][cols] ----------------------------------------------------
  * out_f16 == NULL: in place.  Otherwise the weights are written as IEEE fp16 to out_f16 [rows][cols] (x is then

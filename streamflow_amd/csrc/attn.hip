@@ -45,6 +45,11 @@ struct FlashArgs {
 };
 
 __host__ __device__ inline int64_t plane_bytes(int Ppad) { return (int64_t)256 * Ppad; }
+// per image: [Qh | Ql | Kh | Kl | Vp] planes, then the softmax statistics of every query: (row maximum, 1 / row sum) in the
+// log2 domain of the scaled logits -- q and k are constant over the refinement loop, so they are computed ONCE per clip
+// (sf_gma_flash_pack_qk) and the per-iteration kernel starts its logit accumulators at -max: no running maximum, no
+// accumulator rescale, no row sum in the loop that runs 15 times.
+__host__ __device__ inline int64_t img_ws_bytes(int Ppad) { return 5 * plane_bytes(Ppad) + (int64_t)Ppad * 8; }
 
 // ---- pack q, k: qk planes [img][2*HD][P] fp32 (rows 0..127 = q, 128..255 = k) -------------------------------------------
 __global__ __launch_bounds__(256) void flash_pack_qk_kernel(const float* qk, int64_t qk_img_stride, char* ws, int P, int Ppad,
@@ -61,7 +66,7 @@ __global__ __launch_bounds__(256) void flash_pack_qk_kernel(const float* qk, int
         hi[i] = h;
         lo[i] = (_Float16)(x - (float)h);
     }
-    char* img_ws = ws + (int64_t)img * 5 * plane_bytes(Ppad);
+    char* img_ws = ws + (int64_t)img * img_ws_bytes(Ppad);
     char* dst = img_ws + (int64_t)(side * 2) * plane_bytes(Ppad) + ((int64_t)dq * Ppad + p) * 16;
     *reinterpret_cast<f16x8*>(dst) = hi;
     *reinterpret_cast<f16x8*>(dst + plane_bytes(Ppad)) = lo;
@@ -80,7 +85,7 @@ __global__ __launch_bounds__(256) void flash_pack_v_kernel(const float* v, int64
         const int key = base + (i & 3) + 8 * (i >> 2);
         h[i] = (_Float16)((key < P) ? row[key] : 0.f);
     }
-    char* dst = ws + (int64_t)img * 5 * plane_bytes(Ppad) + 4 * plane_bytes(Ppad) + ((int64_t)o * HD + d) * 16;
+    char* dst = ws + (int64_t)img * img_ws_bytes(Ppad) + 4 * plane_bytes(Ppad) + ((int64_t)o * HD + d) * 16;
     *reinterpret_cast<f16x8*>(dst) = h;
 }
 
@@ -91,9 +96,13 @@ __device__ __forceinline__ float xor32(float v) {          // value of lane ^ 32
 #ifndef SF_FLASH_V1
 #define SF_FLASH_V1 1     // one-product kernel: ONE V stage (48 KB of LDS, 3 workgroups per CU) instead of two (64 KB, 2 per CU)
 #endif
-template <int QKP>
+// MODE 0: self-contained online softmax (running maximum, rescale, row sum).  MODE 1: the statistics of the workspace are
+// used (accumulators start at -max, weights are exp2 of the accumulator, the result is scaled by the stored 1 / row sum).
+// MODE 2: the statistics pass -- logits and the online maximum / sum only (no V tile, no P V), writes (max, 1 / sum).
+template <int QKP, int MODE>
 __global__ __launch_bounds__(256, (QKP == 3) ? 1 : ((QKP == 1 && SF_FLASH_V1) ? 3 : 2)) void gma_flash_kernel(const FlashArgs g) {
     constexpr bool kKlo = (QKP == 3);
+    constexpr bool kUseStats = MODE == 1, kStatsPass = MODE == 2;
     constexpr int KSTAGE = KPLANE * (kKlo ? 2 : 1);
     // kV1: K tiles double-buffered, V single-buffered.  V(t) is requested at the top of tile t (every wave has finished
     // P V of tile t-1 by then) and has the logits + softmax of tile t to land; a second barrier precedes P V.
@@ -106,7 +115,7 @@ __global__ __launch_bounds__(256, (QKP == 3) ? 1 : ((QKP == 1 && SF_FLASH_V1) ? 
     const int img = blockIdx.y, q0 = blockIdx.x * BQ;
     const int P = g.P, Ppad = g.Ppad;
     const int plane = (int)plane_bytes(Ppad);                       // < 2 GiB (host-checked)
-    const char* ws = g.ws + (int64_t)img * 5 * plane;
+    const char* ws = g.ws + (int64_t)img * img_ws_bytes(Ppad);
     const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(ws), 0, 2 * plane, 0x00020000);
     const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(ws) + 2 * (int64_t)plane, 0, 2 * plane, 0x00020000);
     const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(ws) + 4 * (int64_t)plane, 0, plane, 0x00020000);
@@ -121,6 +130,9 @@ __global__ __launch_bounds__(256, (QKP == 3) ? 1 : ((QKP == 1 && SF_FLASH_V1) ? 
         if (QKP >= 2) ql[ks] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rq, off, plane, 0));
     }
 
+    float2* stats = reinterpret_cast<float2*>(const_cast<char*>(ws) + 5 * (int64_t)plane);
+    float st_m = 0.f, st_inv = 0.f;
+    if (kUseStats) { const float2 st = stats[q]; st_m = st.x; st_inv = st.y; }
     // ---- tile DMA: K tile = 16 d-octet rows of 64 keys x 16 B (1 KB pieces), V tile = 16 KB contiguous ----
     auto issue_v = [&](int t, int buf) {
         const int j0 = t * BJ;
@@ -153,14 +165,14 @@ __global__ __launch_bounds__(256, (QKP == 3) ? 1 : ((QKP == 1 && SF_FLASH_V1) ? 
 
     const int nt = Ppad / BJ;
     issue_k(0, 0);
-    if (!kV1) issue_v(0, 0);
+    if (!kV1 && !kStatsPass) issue_v(0, 0);
     for (int t = 0; t < nt; ++t) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's pieces of tile t have landed ...
         __builtin_amdgcn_s_barrier();                             // ... everyone's; the other stage is no longer read
-        if (kV1) issue_v(t, 0);                                   // (V first: its wait below leaves the K pieces in flight)
+        if (kV1 && !kStatsPass) issue_v(t, 0);                    // (V first: its wait below leaves the K pieces in flight)
         if (t + 1 < nt) {
             issue_k(t + 1, (t + 1) & 1);
-            if (!kV1) issue_v(t + 1, (t + 1) & 1);
+            if (!kV1 && !kStatsPass) issue_v(t + 1, (t + 1) & 1);
         }
         const char* kb = smem + (t & 1) * KSTAGE;
         const char* vb = smem + 2 * KSTAGE + (kV1 ? 0 : (t & 1)) * VTILE;
@@ -170,7 +182,7 @@ __global__ __launch_bounds__(256, (QKP == 3) ? 1 : ((QKP == 1 && SF_FLASH_V1) ? 
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[sub][r] = 0.f;
+            for (int r = 0; r < 16; ++r) s[sub][r] = kUseStats ? -st_m : 0.f;     // (a lane holds ONE query: its -max is the start value)
         }
 #pragma unroll
         for (int ks = 0; ks < HD / 16; ++ks) {
@@ -196,18 +208,22 @@ __global__ __launch_bounds__(256, (QKP == 3) ? 1 : ((QKP == 1 && SF_FLASH_V1) ? 
                     s[sub][r] = (key < P) ? s[sub][r] : -1.0e30f;
                 }
         }
-        float mx = s[0][0];
+        float m_new = 0.f, alpha = 1.0f;
+        bool grew = false;
+        if constexpr (!kUseStats) {
+            float mx = s[0][0];
 #pragma unroll
-        for (int sub = 0; sub < 2; ++sub)
+            for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[sub][r]);
-        mx = fmaxf(mx, xor32(mx));
-        const float m_new = fmaxf(m_run, mx);
-        // the running maximum of a query stops growing after a few tiles: rescale the 64 accumulator registers only when
-        // some lane of the wave needs it (wave-uniform branch)
-        const bool grew = __any(m_new > m_run);
-        const float alpha = grew ? __builtin_amdgcn_exp2f(m_run - m_new) : 1.0f;
-        m_run = m_new;
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[sub][r]);
+            mx = fmaxf(mx, xor32(mx));
+            m_new = fmaxf(m_run, mx);
+            // the running maximum of a query stops growing after a few tiles: rescale the 64 accumulator registers only when
+            // some lane of the wave needs it (wave-uniform branch)
+            grew = __any(m_new > m_run);
+            alpha = grew ? __builtin_amdgcn_exp2f(m_run - m_new) : 1.0f;
+            m_run = m_new;
+        }
         float psum = 0.f;
         f16x8 pf[4];                                              // P^T as B operands: k-step kk = sub*2 + m
         // two weights at a time: one v_cvt_pk_f16_f32 (round to nearest) and one v_dot2 that adds the two ROUNDED values
@@ -218,22 +234,27 @@ __global__ __launch_bounds__(256, (QKP == 3) ? 1 : ((QKP == 1 && SF_FLASH_V1) ? 
         for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
-                const float p0 = __builtin_amdgcn_exp2f(s[sub][r] - m_new), p1 = __builtin_amdgcn_exp2f(s[sub][r + 1] - m_new);
+                // (kUseStats: the accumulator started at -max, the logit IS the exponent)
+                const float p0 = __builtin_amdgcn_exp2f(kUseStats ? s[sub][r] : s[sub][r] - m_new);
+                const float p1 = __builtin_amdgcn_exp2f(kUseStats ? s[sub][r + 1] : s[sub][r + 1] - m_new);
                 hp2 ph;
                 ph[0] = (_Float16)p0;
                 ph[1] = (_Float16)p1;
-                psum = __builtin_amdgcn_fdot2(ph, ones, psum, false);
+                if constexpr (!kUseStats) psum = __builtin_amdgcn_fdot2(ph, ones, psum, false);
                 const unsigned bits = __builtin_bit_cast(unsigned, ph);
                 pf[sub * 2 + (r >> 3)][r & 7] = __builtin_bit_cast(_Float16, (unsigned short)(bits & 0xffffu));
                 pf[sub * 2 + (r >> 3)][(r & 7) + 1] = __builtin_bit_cast(_Float16, (unsigned short)(bits >> 16));
             }
-        l_run = l_run * alpha + psum;
-        if (grew) {
+        if constexpr (!kUseStats) {
+            l_run = l_run * alpha + psum;
+            if (grew && !kStatsPass) {
 #pragma unroll
-            for (int td = 0; td < HD / 32; ++td)
+                for (int td = 0; td < HD / 32; ++td)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) o[td][r] *= alpha;
+                    for (int r = 0; r < 16; ++r) o[td][r] *= alpha;
+            }
         }
+        if constexpr (kStatsPass) continue;                       // (no V tile was requested: nothing to wait for, no P V)
         if (kV1) {                                                // V(t): 4 pieces per wave, requested before the K(t+1) pieces
             if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -252,7 +273,11 @@ __global__ __launch_bounds__(256, (QKP == 3) ? 1 : ((QKP == 1 && SF_FLASH_V1) ? 
 
     // ---- epilogue: out[d][q] = mf[d][q] + gamma * O^T[d][q] / rowsum ----
     const float l_tot = l_run + xor32(l_run);
-    const float w = g.gamma[0] / l_tot;
+    if constexpr (kStatsPass) {
+        if (khalf == 0) stats[q] = make_float2(m_run, 1.0f / l_tot);
+        return;
+    }
+    const float w = kUseStats ? g.gamma[0] * st_inv : g.gamma[0] / l_tot;
     if (q < P) {
         const float* mf = g.mf + (int64_t)img * g.mf_img_stride + q;
         float* out = g.out + (int64_t)img * g.out_img_stride + q;
@@ -283,11 +308,12 @@ __global__ __launch_bounds__(256, (QKP == 3) ? 1 : ((QKP == 1 && SF_FLASH_V1) ? 
 extern "C" int64_t sf_gma_flash_ws_bytes(int n_img, int P) {
     if (n_img <= 0 || P <= 0) return 0;
     const int Ppad = sf::ceil_div(P, BQ) * BQ;
-    return (int64_t)n_img * 5 * plane_bytes(Ppad);
+    return (int64_t)n_img * img_ws_bytes(Ppad);
 }
 
 extern "C" int sf_gma_flash_pack_qk(const float* qk, int64_t qk_img_stride, void* ws, int64_t ws_bytes, int n_img, int P,
-                                    float scale, void* stream) {
+                                    float scale, int stats_qk_products, void* stream) {
+    SF_REQUIRE(stats_qk_products >= 0 && stats_qk_products <= 3, "sf_gma_flash_pack_qk: stats_qk_products must be 0 (none), 1, 2 or 3");
     SF_REQUIRE(qk && ws, "sf_gma_flash_pack_qk: null pointer");
     SF_REQUIRE(n_img > 0 && P > 0 && n_img <= 65535, "sf_gma_flash_pack_qk: bad dims");
     SF_REQUIRE(ws_bytes >= sf_gma_flash_ws_bytes(n_img, P) && (reinterpret_cast<uintptr_t>(ws) & 15) == 0,
@@ -296,13 +322,23 @@ extern "C" int sf_gma_flash_pack_qk(const float* qk, int64_t qk_img_stride, void
     SF_REQUIRE(2 * plane_bytes(Ppad) < ((int64_t)1 << 31), "sf_gma_flash_pack_qk: image too large");
     hipLaunchKernelGGL(flash_pack_qk_kernel, dim3(sf::ceil_div(Ppad, 256), 32, n_img), dim3(256), 0, (hipStream_t)stream, qk,
                        qk_img_stride, (char*)ws, P, Ppad, scale * 1.44269504088896340736f);
+    if (stats_qk_products) {                                 // the softmax statistics of every query, once per clip
+        FlashArgs g = {};
+        g.ws = (const char*)ws; g.P = P; g.Ppad = Ppad;
+        dim3 grid(Ppad / BQ, n_img);
+        switch (stats_qk_products) {
+            case 1: hipLaunchKernelGGL((gma_flash_kernel<1, 2>), grid, dim3(256), 0, (hipStream_t)stream, g); break;
+            case 2: hipLaunchKernelGGL((gma_flash_kernel<2, 2>), grid, dim3(256), 0, (hipStream_t)stream, g); break;
+            default: hipLaunchKernelGGL((gma_flash_kernel<3, 2>), grid, dim3(256), 0, (hipStream_t)stream, g); break;
+        }
+    }
     return sf::check_launch("sf_gma_flash_pack_qk");
 }
 
 extern "C" int sf_gma_flash_aggregate(void* ws, int64_t ws_bytes, const float* v, int64_t v_img_stride, const float* mf,
                                       int64_t mf_img_stride, const float* gamma, float* out, int64_t out_img_stride,
                                       void* out_koct, int64_t out_koct_img_stride, int n_img, int P, int qk_products,
-                                      void* stream) {
+                                      int use_stats, void* stream) {
     SF_REQUIRE(!out_koct || ((reinterpret_cast<uintptr_t>(out_koct) & 15) == 0 && (out_koct_img_stride & 7) == 0),
                "sf_gma_flash_aggregate: out_koct must be 16-byte aligned, its image stride a multiple of 8 halves");
     SF_REQUIRE(ws && v && mf && gamma && out, "sf_gma_flash_aggregate: null pointer");
@@ -319,10 +355,13 @@ extern "C" int sf_gma_flash_aggregate(void* ws, int64_t ws_bytes, const float* v
     g.out16 = static_cast<_Float16*>(out_koct); g.out16_img_stride = out_koct_img_stride;
     g.mf_img_stride = mf_img_stride; g.out_img_stride = out_img_stride; g.P = P; g.Ppad = Ppad;
     dim3 grid(Ppad / BQ, n_img);
-    switch (qk_products) {
-        case 1: hipLaunchKernelGGL(gma_flash_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, g); break;
-        case 2: hipLaunchKernelGGL(gma_flash_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, g); break;
-        default: hipLaunchKernelGGL(gma_flash_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, g); break;
+    switch (qk_products * 2 + (use_stats ? 1 : 0)) {
+        case 2: hipLaunchKernelGGL((gma_flash_kernel<1, 0>), grid, dim3(256), 0, (hipStream_t)stream, g); break;
+        case 3: hipLaunchKernelGGL((gma_flash_kernel<1, 1>), grid, dim3(256), 0, (hipStream_t)stream, g); break;
+        case 4: hipLaunchKernelGGL((gma_flash_kernel<2, 0>), grid, dim3(256), 0, (hipStream_t)stream, g); break;
+        case 5: hipLaunchKernelGGL((gma_flash_kernel<2, 1>), grid, dim3(256), 0, (hipStream_t)stream, g); break;
+        case 6: hipLaunchKernelGGL((gma_flash_kernel<3, 0>), grid, dim3(256), 0, (hipStream_t)stream, g); break;
+        default: hipLaunchKernelGGL((gma_flash_kernel<3, 1>), grid, dim3(256), 0, (hipStream_t)stream, g); break;
     }
     return sf::check_launch("sf_gma_flash_aggregate");
 }

@@ -405,7 +405,8 @@ class HotPathEngine:
         # a6: attn = softmax(scale * q k^T) over the context features (gma.py:53-65), computed once
         ops.gemm(W.to_qk, pl.inps, pl.qk, EPI_NONE)
         if pl.flash:
-            ops.gma_flash_pack_qk(pl.qk, pl.flash_ws, float(HDIM) ** -0.5)       # q, k are constant over the loop
+            # q, k are constant over the loop: packed once, and the softmax statistics of every query with them
+            ops.gma_flash_pack_qk(pl.qk, pl.flash_ws, float(HDIM) ** -0.5, stats_qk_products=self.flash_qk_products)
         elif pl.attn_rows == P:
             self._attention_rows(pl, 0, P)
 
@@ -515,7 +516,7 @@ class HotPathEngine:
                               else (pl.attn.data_ptr(), LAYOUT_K_MINOR))
         if pl.flash:
             # fused recompute (K6' of SURVEY.md): one kernel, online softmax, logits never written
-            ops.gma_flash_aggregate(pl.flash_ws, pl.v128, pl.mf, W.gamma, pl.mfg, self.flash_qk_products)
+            ops.gma_flash_aggregate(pl.flash_ws, pl.v128, pl.mf, W.gamma, pl.mfg, self.flash_qk_products, use_stats=True)
         elif pl.attn_rows < P:
             # high-resolution path: recompute the attention rows chunk by chunk (K6' of SURVEY.md)
             for i0 in range(0, P, pl.attn_rows):

@@ -527,18 +527,28 @@ def gma_flash_ws_bytes(n_img: int, P: int) -> int:
     return int(_lib.load().sf_gma_flash_ws_bytes(n_img, P))
 
 
+# SF_FLASH_STATS=0: A/B knob -- the fused GMA kernel keeps its own running maximum / row sum in every iteration
+FLASH_STATS = os.environ.get("SF_FLASH_STATS", "1") != "0"
+
+
 @on_tensor_device
-def gma_flash_pack_qk(QK: Planes, ws: torch.Tensor, scale: float) -> None:
-    """QK [n_img][256][P] (to_qk output) -> packed fp16 operand images in ws (once per clip)."""
+def gma_flash_pack_qk(QK: Planes, ws: torch.Tensor, scale: float, stats_qk_products: int = 0) -> None:
+    """QK [n_img][256][P] (to_qk output) -> packed fp16 operand images in ws (once per clip); stats_qk_products = 1 / 2 / 3
+    also stores every query's softmax statistics for gma_flash_aggregate(..., use_stats=True) with the same product count."""
     assert QK.rows == 256 and ws.dtype == torch.uint8
-    _launch("flash_pack_qk", 0, 4.0 * QK.n_img * 256 * QK.P * 2,
+    sq = int(stats_qk_products) if FLASH_STATS else 0
+    _launch("flash_pack_qk", 2.0 * QK.n_img * QK.P * QK.P * 128 * (1 if sq else 0), 4.0 * QK.n_img * 256 * QK.P * 2,
             lambda: _lib.check(_lib.load().sf_gma_flash_pack_qk(QK.ptr, QK.img_stride, ws.data_ptr(), ws.numel(), QK.n_img,
-                                                                QK.P, float(scale), _lib.stream()), "sf_gma_flash_pack_qk"))
+                                                                QK.P, float(scale), sq, _lib.stream()), "sf_gma_flash_pack_qk"),
+            products=(sq + 1) / 2.0 if sq else 1.0)
 
 
 @on_tensor_device
-def gma_flash_aggregate(ws: torch.Tensor, V: Planes, MF: Planes, gamma: torch.Tensor, OUT: Planes, qk_products: int = 3) -> None:
-    """OUT = MF + gamma * softmax(scale q k^T) V, fused (no N x N tensor); q, k come packed in ws."""
+def gma_flash_aggregate(ws: torch.Tensor, V: Planes, MF: Planes, gamma: torch.Tensor, OUT: Planes, qk_products: int = 3,
+                        use_stats: bool = False) -> None:
+    """OUT = MF + gamma * softmax(scale q k^T) V, fused (no N x N tensor); q, k come packed in ws.  use_stats: the softmax
+    statistics stored by gma_flash_pack_qk(..., stats_qk_products=qk_products) are used instead of an online softmax."""
+    use_stats = bool(use_stats) and FLASH_STATS
     assert V.rows == MF.rows == OUT.rows == 128 and V.n_img == MF.n_img == OUT.n_img
     n, P = V.n_img, V.P
     # algorithmic: the two contractions; bytes: v, mf in, out (q/k/v tiles are re-read from L2 by every query tile)
@@ -547,7 +557,7 @@ def gma_flash_aggregate(ws: torch.Tensor, V: Planes, MF: Planes, gamma: torch.Te
             lambda: _lib.check(_lib.load().sf_gma_flash_aggregate(
                 ws.data_ptr(), ws.numel(), V.ptr, V.img_stride, MF.ptr, MF.img_stride, gamma.data_ptr(), OUT.ptr,
                 OUT.img_stride, None if sh is None else sh.ptr, 0 if sh is None else sh.img_stride, n, P,
-                int(qk_products), _lib.stream()), "sf_gma_flash_aggregate"), products=(qk_products + 1) / 2.0)
+                int(qk_products), int(use_stats), _lib.stream()), "sf_gma_flash_aggregate"), products=(qk_products + 1) / 2.0)
     if sh is None:
         refresh_shadow(OUT)
 
