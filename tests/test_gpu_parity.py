@@ -901,9 +901,11 @@ def test_twins_csc_encoder_vs_reference(golden, dev, tag, precision):
 
 
 @pytest.mark.gpu
-def test_real_frames_end_to_end_with_twins_encoder(dev):
+@pytest.mark.parametrize("mixed", [False, True])
+def test_real_frames_end_to_end_with_twins_encoder(dev, mixed):
     """No stand-in anywhere: frames in 0..255 -> Twins_CSC fnet / cnet -> refinement loop -> flows, through the
-    reference's SKFlow_MF8 signature; against the CPU oracles chained the same way (encoder oracle -> hot-path oracle)."""
+    reference's SKFlow_MF8 signature; against the CPU oracles chained the same way (encoder oracle -> hot-path oracle).
+    mixed: args.mixed_precision = True -- encoders AND loop in the bench preset's arithmetic (fp16 hand-over everywhere)."""
     from oracle import streamflow_oracle as orc, twins_oracle as two
     from streamflow_amd import synthetic as syn
     from streamflow_amd.model import SKFlow_MF8, default_args
@@ -912,7 +914,7 @@ def test_real_frames_end_to_end_with_twins_encoder(dev):
     sd = dict(hot)
     sd.update({"fnet." + k: v for k, v in ef.items()})
     sd.update({"cnet." + k: v for k, v in ec.items()})
-    model = SKFlow_MF8(default_args(T=T)).to(dev)
+    model = SKFlow_MF8(default_args(T=T, mixed_precision=mixed)).to(dev)
     model.load_state_dict(sd, strict=True)
     frames = [(syn.randn(24, f"frame{t}", (B, 3, H, W)).sigmoid() * 255.0) for t in range(T)]
     ups = model([f.to(dev) for f in frames], iters=iters, test_mode=True)
@@ -923,5 +925,5 @@ def test_real_frames_end_to_end_with_twins_encoder(dev):
     assert len(ups) == T - 1 and ups[0].shape == (B, 2, H, W)
     for i in range(T - 1):
         e = orc.epe(ups[i].cpu(), ups_o[i])
-        print(f"real frames -> Twins_CSC -> loop, pair {i}: EPE vs chained oracles = {e:.3e}")
+        print(f"real frames -> Twins_CSC -> loop [mixed_precision={mixed}], pair {i}: EPE vs chained oracles = {e:.3e}")
         assert e <= 1e-3, (i, e)
