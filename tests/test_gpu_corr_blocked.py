@@ -1,7 +1,6 @@
 """Blocked fp16 correlation volumes (csrc/corr_blocked.hip; reference core/corr.py:7-54) through the C ABI:
 build vs the oracle pyramid of the fp16-rounded features, lookup vs the oracle lookup on the stored cells, the k-octet
 hand-over, robustness against garbage in the padding cells, and the k-octet residual of sf_gemm (SfGemm.r_f16)."""
-import numpy as np
 import pytest
 import torch
 
@@ -146,7 +145,7 @@ def test_integration_md_binding_examples_run(dev):
     import os
     import re
     from oracle import streamflow_oracle as orc
-    from streamflow_amd import ops, synthetic as syn, _lib
+    from streamflow_amd import synthetic as syn, _lib
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     md = open(os.path.join(root, "INTEGRATION.md")).read()
     sec = md[md.index("## 2. Binding the C ABI"):md.index("## 3. Build")]

@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from oracle import streamflow_oracle as orc
 from streamflow_amd import presets, synthetic as syn
-from streamflow_amd.engine import HotPathEngine, HotPathWeights
+from streamflow_amd.engine import HotPathEngine
 seed = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1] != "hard" else 0
 dev = torch.device("cuda:0")
 if "hard" in sys.argv:
