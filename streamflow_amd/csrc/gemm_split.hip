@@ -514,12 +514,21 @@ int launch_cfg(const SplitArgs& a, hipStream_t st) {
                 // 256-row tiles: single-product layers whose M pads to the same size either way, from M = SF_GEMM_BD256 up (0 =
                 // never).  Measured (tools/gemm_koct_bench.py, SF_SINGLE=1, 24 x 7040 pixels): M960 K640 426 -> 404 us; but M486
                 // K324 126 -> 148, M256 K384 62 -> 72, M256 K256 54 -> 63: one or two row tiles leave too few workgroups
-                static const int bd256 = getenv("SF_GEMM_BD256") ? atoi(getenv("SF_GEMM_BD256")) : 768;
+                // ... and against 1 x 8 waves of 128 x 32 (three interleaved runs): M960 K640 410 / 414 / 416 vs 402 / 386 / 417 us:
+                // no better than the simpler form, so the 256-row tile stays an opt-in knob (default 0 = never)
+                static const int bd256 = getenv("SF_GEMM_BD256") ? atoi(getenv("SF_GEMM_BD256")) : 0;
                 if (PM == 1 && bd256 && sf::ceil_div(g.M, 256) * 256 == sf::ceil_div(g.M, 128) * 128 && g.M >= bd256) {
                     launch_bd256(a, st);
                     return sf::check_launch("sf_gemm(B-direct 256)");
                 }
-                if (g.M >= 512) hipLaunchKernelGGL((gemm_bdirect_kernel<PM, 2>), grid2, dim3(kBdThreads), 0, st, a);
+                // wave grid: 2 x 4 waves of 64 x 64 from M = wm2_min up, else 1 x 8 waves of 128 x 32 (every activation fragment
+                // loaded once and used for four MFMAs).  Two-product layers: 2 x 4 from M = 512 (round-3 tuning above).  SINGLE-
+                // product layers have half the MFMA work behind every activation byte and want 1 x 8 everywhere (three
+                // interleaved runs, tools/gemm_koct_bench.py SF_SINGLE=1): M960 K640 402 / 386 / 417 vs 447 / 426 / 444 us,
+                // M640 K960 329 / 308 / 321 vs 349 / 347 / 351, M640 K640 229 / 237 / 235 vs 265 / 252 / 264
+                static const int wm2_env = getenv("SF_GEMM_BD_WM2_MIN_M") ? atoi(getenv("SF_GEMM_BD_WM2_MIN_M")) : -1;
+                const int wm2_min = wm2_env >= 0 ? wm2_env : (PM == 1 ? (1 << 30) : 512);
+                if (g.M >= wm2_min) hipLaunchKernelGGL((gemm_bdirect_kernel<PM, 2>), grid2, dim3(kBdThreads), 0, st, a);
                 else hipLaunchKernelGGL((gemm_bdirect_kernel<PM, 1>), grid2, dim3(kBdThreads), 0, st, a);
                 return sf::check_launch("sf_gemm(B-direct)");
             }

@@ -1,4 +1,4 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT"
-for bd in 0 1; do echo "SF_GEMM_BD256=$bd single koct"; SF_SINGLE=1 SF_GEMM_BD256=$bd python tools/gemm_koct_bench.py koct 2>&1 | grep -E "^M|sum"; done
-timeout 900 python -m pytest tests/test_gpu_fuzz.py tests/test_gpu_corr_blocked.py -q -k "gemm or koct" 2>&1 | tail -3
+for rep in 1 2 3; do
+for cfg in "512 0" "4096 0" "4096 768" "512 768"; do set -- $cfg; echo "rep $rep WM2_MIN_M=$1 BD256=$2"; SF_SINGLE=1 SF_GEMM_BD_WM2_MIN_M=$1 SF_GEMM_BD256=$2 python tools/gemm_koct_bench.py koct 2>&1 | grep -E "^M (960|640) " | awk '{printf "%s %s %s us | ", $2, $4, $7} END {print ""}'; done; done
