@@ -509,7 +509,10 @@ int launch_cfg(const SplitArgs& a, hipStream_t st) {
             // 512 / 768 -- inside the run-to-run noise, so the default stays 0 (always B-direct)
             static const int bd_min_wg = getenv("SF_GEMM_BD_MIN_WG") ? atoi(getenv("SF_GEMM_BD_MIN_WG")) : 0;
             const int64_t n_wg2 = (int64_t)sf::ceil_div(g.N, 256) * sf::ceil_div(g.M, 128) * g.batch;
-            if (bdirect && g.M >= bd_min_m && n_wg2 >= bd_min_wg && g.k_splits <= 1 && (int64_t)g.ldb * 16 * 2 < ((int64_t)1 << 31)) {
+            // one row tile (96 < M <= 128) with a short K also wins there (three interleaved runs: M128 K192 33.1 -> 29.7 us, M128
+            // K128 29.1 -> 26.1 single-product, 34.2 -> 31.6 / 39.3 -> 37.9 two-product), a long K does not (M128 K960 95 -> 100)
+            const bool bd_m = g.M >= bd_min_m || (g.M > 96 && g.K <= 192);
+            if (bdirect && bd_m && n_wg2 >= bd_min_wg && g.k_splits <= 1 && (int64_t)g.ldb * 16 * 2 < ((int64_t)1 << 31)) {
                 dim3 grid2(sf::ceil_div(g.N, 256) * sf::ceil_div(g.M, 128) * g.batch);
                 // 256-row tiles: single-product layers whose M pads to the same size either way, from M = SF_GEMM_BD256 up (0 =
                 // never).  Measured (tools/gemm_koct_bench.py, SF_SINGLE=1, 24 x 7040 pixels): M960 K640 426 -> 404 us; but M486
