@@ -1,6 +1,9 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT"
-timeout 900 python -m pytest tests -q -m gpu -k "dwconv or depthwise or skblock" 2>&1 | tail -3
-for args in "640 24 7 f16x2 f16out" "324 24 15 f16x2 f16out single" "256 24 15 f16x2 f16out single" "384 8 15 f16x2 f16out" "640 3 7 f16x2 f16out" "324 3 15 f16x2 f16out single"; do
-  python tools/dwconv_one.py $args 2>&1 | tail -1
-done
+for rep in 1 2; do
+for t in 2048 4096 8192 16384; do
+  echo "rep $rep SF_DW_TARGET_WGS=$t"
+  for args in "640 24 7 f16x2 f16out" "324 24 15 f16x2 f16out single" "256 24 15 f16x2 f16out single" "128 24 15 f16x2 f16out single" "384 8 15 f16x2 f16out"; do
+    SF_DW_TARGET_WGS=$t python tools/dwconv_one.py $args 2>&1 | tail -1 | awk '{printf "%s %s %s us | ", $1, $2, $5}'
+  done; echo
+done; done
