@@ -613,3 +613,67 @@ def test_attention_cores_koct_handover(dev, seed):
         assert err2 <= 1e-3 * max(1.0, ref2.abs().max().item()), err2              # only the fp16 rounding of the result
     finally:
         ops.set_precision(prev)
+
+
+@pytest.mark.parametrize("M,K", [(128, 128), (128, 192), (128, 960), (126, 384), (200, 136), (256, 136), (384, 256), (486, 324), (640, 960), (960, 640)])
+@pytest.mark.parametrize("single", [False, True])
+@pytest.mark.parametrize("epi", ["none", "gelu_koct", "res_gelu_dw1"])
+def test_koct_gemm_dispatch_branches_vs_float64(dev, M, K, single, epi):
+    """Every dispatch branch of the k-octet-fed GEMM (csrc/gemm_split.hip, lay == 13): the 128 x 128 DMA kernel (M <= 128 with
+    a long K), the B-direct kernel as 1 x 8 waves (single-product layers, and 192 <= M < 512) and 2 x 4 waves (two-product,
+    M >= 512), the short-K one-row-tile rule -- with split and single-product weights and the three epilogue families of the
+    update block, ragged pixel counts and two images, against a float64 product of the SAME fp16-rounded operands."""
+    from streamflow_amd import ops
+    from streamflow_amd.ops import Planes, PackedLinear
+    g = torch.Generator().manual_seed(M * 7 + K + int(single))
+    n, P = 2, 1012                                           # not a multiple of the 256-pixel tile; a multiple of 4
+    Wt = torch.randn(M, K, generator=g) / K ** 0.5
+    bias = torch.randn(M, generator=g) * 0.1
+    x = torch.randn(n, K, P, generator=g).half().float()     # exactly representable activations
+    R = torch.randn(n, M, P, generator=g)
+    dw_w, dw_b = torch.randn(M, generator=g) * 0.5, torch.randn(M, generator=g) * 0.1
+    prev = ops.set_precision("f16x2")
+    try:
+        A = PackedLinear(Wt.reshape(M, K, 1, 1), bias, dev)
+        A.single = single
+        Ka = (K + 7) // 8 * 8
+        X = _koct_planes(ops, n, Ka, P, dev)
+        X = Planes(X.base, 0, Ka * P, n, K, P, f16=True, koct=True)
+        if not ops.uses_dma_tile(M):                         # M = 200 pads to 256 (28 % waste): the 64-row tile has no k-octet path
+            with pytest.raises(RuntimeError, match="SF_LAYOUT_F16_KOCT"):
+                ops.gemm(A, X, Planes.of(torch.empty(n, M, P, device=dev)), ops.EPI_NONE)
+            return
+        xs = torch.zeros(n, Ka, P)
+        xs[:, :K] = x
+        ops.pack_koct(Planes.of(xs.to(dev)), Planes(X.base, 0, Ka * P, n, Ka, P, f16=True, koct=True))
+        if epi == "gelu_koct":
+            Ma = (M + 7) // 8 * 8
+            Yk = _koct_planes(ops, n, Ma, P, dev)
+            Y = Planes(Yk.base, 0, Ma * P, n, M, P, f16=True, koct=True)
+            ops.gemm(A, X, Y, ops.EPI_GELU)
+            got = Y.tensor().float().cpu()
+        elif epi == "res_gelu_dw1":
+            Yt = torch.full((n, M, P), float("nan"), device=dev)
+            ops.gemm(A, X, Planes.of(Yt), ops.EPI_RES_GELU_DW1, R=Planes.of(R.to(dev)), dw_w=dw_w.to(dev), dw_b=dw_b.to(dev))
+            got = Yt.cpu()
+        else:
+            Yt = torch.full((n, M, P), float("nan"), device=dev)
+            ops.gemm(A, X, Planes.of(Yt), ops.EPI_NONE)
+            got = Yt.cpu()
+        torch.cuda.synchronize()
+        # the weights the kernel multiplies by: hi (+ lo) of the scaled split image
+        hi = A.hi.float().permute(1, 0, 2).reshape(A.lda_h, -1)[:M, :K].cpu()
+        lo = A.lo.float().permute(1, 0, 2).reshape(A.lda_h, -1)[:M, :K].cpu()
+        Wk = (hi if single else hi + lo).double() / A.split_scale
+    finally:
+        ops.set_precision(prev)
+    v = torch.einsum("mk,zkp->zmp", Wk, x.double()) + bias.double()[None, :, None]
+    if epi == "gelu_koct":
+        ref, tol = F.gelu(v), 2e-3 + 1e-3 * F.gelu(v).abs().max().item()       # fp16 output, polynomial GELU
+    elif epi == "res_gelu_dw1":
+        t = F.gelu(R.double() + v)
+        ref, tol = F.gelu(t + (dw_w.double()[None, :, None] * t + dw_b.double()[None, :, None])), 5e-5
+    else:
+        ref, tol = v, 5e-5
+    err = (got.double() - ref).abs().max().item()
+    assert err <= tol, (M, K, single, epi, err)
