@@ -504,10 +504,10 @@ int launch_cfg(const SplitArgs& a, hipStream_t st) {
             // measured per shape (tools/gemm_koct_bench.py, 24 x 7040 pixels): 2 x 4 waves win for M >= 512 (+7..9 %), 1 x 8 for
             // 192 <= M < 512 (+0..15 %); M <= 128 stays on the 128 x 128 kernel (-10 % otherwise)
             static const int bd_min_m = getenv("SF_GEMM_BD_MIN_M") ? atoi(getenv("SF_GEMM_BD_MIN_M")) : 192;
-            // A/B knob: fall back to the 128 x 128 kernel when the 128 x 256 tiles would not fill the chip (a single clip gives
-            // M = 384 just 249 of them for 256 CUs).  Measured at one clip: 183 / 190 / 182 / 184 ff/s for thresholds 0 / 384 /
-            // 512 / 768 -- inside the run-to-run noise, so the default stays 0 (always B-direct)
-            static const int bd_min_wg = getenv("SF_GEMM_BD_MIN_WG") ? atoi(getenv("SF_GEMM_BD_MIN_WG")) : 0;
+            // Fall back to the 128 x 128 kernel when the 128 x 256 tiles would not fill the chip (a single clip gives M = 384
+            // just 249 of them for 256 CUs).  Measured at one clip, two interleaved runs: threshold 0: 186.7 / 189.2 ff/s,
+            // 384: 192.7 / 192.6, 512: 190.2 / 192.8.  Batched steps never get there (>= 660 workgroups per row tile)
+            static const int bd_min_wg = getenv("SF_GEMM_BD_MIN_WG") ? atoi(getenv("SF_GEMM_BD_MIN_WG")) : 384;
             const int64_t n_wg2 = (int64_t)sf::ceil_div(g.N, 256) * sf::ceil_div(g.M, 128) * g.batch;
             // one row tile (96 < M <= 128) with a short K also wins there (three interleaved runs: M128 K192 33.1 -> 29.7 us, M128
             // K128 29.1 -> 26.1 single-product, 34.2 -> 31.6 / 39.3 -> 37.9 two-product), a long K does not (M128 K960 95 -> 100)
