@@ -42,6 +42,8 @@ struct FlashArgs {
     _Float16* out16; int64_t out16_img_stride;      // optional fp16 k-octet copy of out (SF_LAYOUT_F16_KOCT), halves
     int64_t mf_img_stride, out_img_stride;
     int P, Ppad;
+    float* part;                    // nsplit > 1 (statistics mode only): partial results [split][img][128][Ppad], summed by
+    int nsplit;                     // flash_combine_kernel -- key ranges in parallel when the query tiles cannot fill the chip
 };
 
 __host__ __device__ inline int64_t plane_bytes(int Ppad) { return (int64_t)256 * Ppad; }
@@ -50,6 +52,8 @@ __host__ __device__ inline int64_t plane_bytes(int Ppad) { return (int64_t)256 *
 // (sf_gma_flash_pack_qk) and the per-iteration kernel starts its logit accumulators at -max: no running maximum, no
 // accumulator rescale, no row sum in the loop that runs 15 times.
 __host__ __device__ inline int64_t img_ws_bytes(int Ppad) { return 5 * plane_bytes(Ppad) + (int64_t)Ppad * 8; }
+constexpr int kMaxSplit = 2;        // key-range splits of the statistics-mode kernel (partial buffers follow the images in ws)
+__host__ __device__ inline int64_t part_bytes(int n_img, int Ppad) { return (int64_t)kMaxSplit * n_img * HD * Ppad * 4; }
 
 // ---- pack q, k: qk planes [img][2*HD][P] fp32 (rows 0..127 = q, 128..255 = k) -------------------------------------------
 __global__ __launch_bounds__(256) void flash_pack_qk_kernel(const float* qk, int64_t qk_img_stride, char* ws, int P, int Ppad,
@@ -163,10 +167,12 @@ __global__ __launch_bounds__(256, (QKP == 3) ? 1 : ((QKP == 1 && SF_FLASH_V1) ? 
         for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
     float m_run = -1.0e30f, l_run = 0.f;
 
-    const int nt = Ppad / BJ;
-    issue_k(0, 0);
-    if (!kV1 && !kStatsPass) issue_v(0, 0);
-    for (int t = 0; t < nt; ++t) {
+    const int nt_all = Ppad / BJ;
+    const int nsp = (kUseStats && g.nsplit > 1) ? g.nsplit : 1, sp = (nsp > 1) ? (int)blockIdx.z : 0;
+    const int tb = nt_all * sp / nsp, nt = nt_all * (sp + 1) / nsp;            // this workgroup's key tiles [tb, nt)
+    issue_k(tb, tb & 1);
+    if (!kV1 && !kStatsPass) issue_v(tb, tb & 1);
+    for (int t = tb; t < nt; ++t) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's pieces of tile t have landed ...
         __builtin_amdgcn_s_barrier();                             // ... everyone's; the other stage is no longer read
         if (kV1 && !kStatsPass) issue_v(t, 0);                    // (V first: its wait below leaves the K pieces in flight)
@@ -278,6 +284,14 @@ __global__ __launch_bounds__(256, (QKP == 3) ? 1 : ((QKP == 1 && SF_FLASH_V1) ? 
         return;
     }
     const float w = kUseStats ? g.gamma[0] * st_inv : g.gamma[0] / l_tot;
+    if (kUseStats && nsp > 1) {                              // partial sums over this key range: [split][img][d][Ppad]
+        float* pp = g.part + (((int64_t)sp * gridDim.y + img) * HD) * Ppad + q;
+#pragma unroll
+        for (int td = 0; td < HD / 32; ++td)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pp[(int64_t)(td * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf) * Ppad] = w * o[td][r];
+        return;
+    }
     if (q < P) {
         const float* mf = g.mf + (int64_t)img * g.mf_img_stride + q;
         float* out = g.out + (int64_t)img * g.out_img_stride + q;
@@ -303,12 +317,30 @@ __global__ __launch_bounds__(256, (QKP == 3) ? 1 : ((QKP == 1 && SF_FLASH_V1) ? 
     }
 }
 
+// out = mf + sum of the key-range partials (+ the fp16 k-octet copy): thread = (pixel, channel octet)
+__global__ __launch_bounds__(256) void flash_combine_kernel(const float* part, int nsplit, const float* mf, int64_t mf_img_stride,
+                                                            float* out, int64_t out_img_stride, _Float16* out16,
+                                                            int64_t out16_img_stride, int P, int Ppad) {
+    const int q = blockIdx.x * 256 + threadIdx.x, oct = blockIdx.y, img = blockIdx.z, n_img = gridDim.z;
+    if (q >= P) return;
+    f16x8 hv;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int d = oct * 8 + e;
+        float v = mf[(int64_t)img * mf_img_stride + (int64_t)d * P + q];
+        for (int s = 0; s < nsplit; ++s) v += part[(((int64_t)s * n_img + img) * HD + d) * Ppad + q];
+        out[(int64_t)img * out_img_stride + (int64_t)d * P + q] = v;
+        hv[e] = (_Float16)v;
+    }
+    if (out16) *reinterpret_cast<f16x8*>(out16 + (int64_t)img * out16_img_stride + ((int64_t)oct * P + q) * 8) = hv;
+}
+
 }  // namespace
 
 extern "C" int64_t sf_gma_flash_ws_bytes(int n_img, int P) {
     if (n_img <= 0 || P <= 0) return 0;
     const int Ppad = sf::ceil_div(P, BQ) * BQ;
-    return (int64_t)n_img * img_ws_bytes(Ppad);
+    return (int64_t)n_img * img_ws_bytes(Ppad) + part_bytes(n_img, Ppad);
 }
 
 extern "C" int sf_gma_flash_pack_qk(const float* qk, int64_t qk_img_stride, void* ws, int64_t ws_bytes, int n_img, int P,
@@ -354,7 +386,13 @@ extern "C" int sf_gma_flash_aggregate(void* ws, int64_t ws_bytes, const float* v
     g.ws = (const char*)ws; g.mf = mf; g.gamma = gamma; g.out = out;
     g.out16 = static_cast<_Float16*>(out_koct); g.out16_img_stride = out_koct_img_stride;
     g.mf_img_stride = mf_img_stride; g.out_img_stride = out_img_stride; g.P = P; g.Ppad = Ppad;
-    dim3 grid(Ppad / BQ, n_img);
+    // Too few query tiles to fill the chip (a single Sintel clip: 165 workgroups for 256 CUs, each a serial chain over 110
+    // key tiles): with stored statistics the key range splits without any rescaling -- partial sums, then one add pass
+    static const int split_env = getenv("SF_FLASH_SPLIT") ? atoi(getenv("SF_FLASH_SPLIT")) : -1;      // A/B knob: 1 = never, 2 = always
+    const int wgs = (Ppad / BQ) * n_img;
+    g.nsplit = (use_stats && Ppad / BJ >= 8 && (split_env == 2 || (split_env != 1 && wgs < 384))) ? kMaxSplit : 1;
+    g.part = reinterpret_cast<float*>(static_cast<char*>(ws) + (int64_t)n_img * img_ws_bytes(Ppad));
+    dim3 grid(Ppad / BQ, n_img, g.nsplit);
     switch (qk_products * 2 + (use_stats ? 1 : 0)) {
         case 2: hipLaunchKernelGGL((gma_flash_kernel<1, 0>), grid, dim3(256), 0, (hipStream_t)stream, g); break;
         case 3: hipLaunchKernelGGL((gma_flash_kernel<1, 1>), grid, dim3(256), 0, (hipStream_t)stream, g); break;
@@ -363,5 +401,8 @@ extern "C" int sf_gma_flash_aggregate(void* ws, int64_t ws_bytes, const float* v
         case 6: hipLaunchKernelGGL((gma_flash_kernel<3, 0>), grid, dim3(256), 0, (hipStream_t)stream, g); break;
         default: hipLaunchKernelGGL((gma_flash_kernel<3, 1>), grid, dim3(256), 0, (hipStream_t)stream, g); break;
     }
+    if (g.nsplit > 1)
+        hipLaunchKernelGGL(flash_combine_kernel, dim3(sf::ceil_div(P, 256), HD / 8, n_img), dim3(256), 0, (hipStream_t)stream, g.part,
+                           g.nsplit, mf, mf_img_stride, out, out_img_stride, g.out16, g.out16_img_stride, P, Ppad);
     return sf::check_launch("sf_gma_flash_aggregate");
 }
