@@ -202,7 +202,19 @@ typedef struct SfGemm {
        plane, strideR in halves, 16-byte aligned, no grouping) -- e.g. the tensor that was this block's GEMM operand, read
        a second time as the residual without an fp32 copy of it ever having been written (correlation features). */
     int32_t r_f16;
+    /* SPLIT_F16 weights: the k extent the A_hi / A_lo planes are zero-padded to is K rounded up to a multiple of a_k_pad
+       (0 or 32: the minimum the tiled kernels need; 128: what the activation-stationary kernel needs -- streamflow_amd
+       packs 128). */
+    int32_t a_k_pad;
+    /* kernel family: SF_ALGO_AUTO picks per problem; the other two force one (tests, A/B timing) and fail when it cannot run */
+    int32_t algo;
 } SfGemm;
+enum { SF_ALGO_AUTO = 0,
+       SF_ALGO_TILED = 1,     /* 128 x 128 / 128 x 256 output tiles, operands staged per k-tile (csrc/gemm_split.hip) */
+       SF_ALGO_BSTAT = 2 };   /* activation-stationary: a wave keeps the K values of its 32 pixels in registers and the weights
+                                 stream past them through LDS (csrc/gemm_bstat.hip): F16X2 / F16, SPLIT_F16 weights with
+                                 a_k_pad = 128, 64 < K <= 640, B as fp32 planes / fp16 rows / k-octets, C as fp32 planes and / or
+                                 k-octets (c_f16 0, 2, 3) */
 
 /* floats of scratch that let sf_gemm auto-split a problem of this size (0 if it never would) */
 int64_t sf_gemm_split_ws_floats(int M, int N, int K, int batch);

@@ -19,6 +19,7 @@ LIB_PATH = os.environ.get("SF_HIP_LIB") or os.path.join(_HERE, "libstreamflow_hi
 LAYOUT_K_MAJOR, LAYOUT_K_MINOR, LAYOUT_SPLIT_F16, LAYOUT_F16_K_MINOR, LAYOUT_F16_K_MAJOR, LAYOUT_F16_KOCT = 0, 1, 2, 3, 4, 5
 PRECISION_FP32, PRECISION_F16X3, PRECISION_F16X2, PRECISION_F16 = 0, 1, 2, 3
 EPI_NONE, EPI_GELU, EPI_RELU, EPI_RES, EPI_RES_GELU, EPI_RES_GELU_DW1, EPI_AXPY = range(7)
+ALGO_AUTO, ALGO_TILED, ALGO_BSTAT = 0, 1, 2
 
 _vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -40,6 +41,7 @@ class SfGemm(C.Structure):
         ("c_f16", C.c_int32),
         ("C16", _vp), ("strideC16", _i64),
         ("r_f16", C.c_int32),
+        ("a_k_pad", C.c_int32), ("algo", C.c_int32),
     ]
 
 

@@ -17,11 +17,19 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libstreamflow_hip.so")
-SOURCES = ["misc.hip", "corr.hip", "corr_blocked.hip", "conv.hip", "gemm.hip", "gemm_split.hip", "attn.hip", "encoder.hip"]
+SOURCES = ["misc.hip", "corr.hip", "corr_blocked.hip", "conv.hip", "gemm.hip", "gemm_split.hip", "gemm_bstat.hip", "attn.hip", "encoder.hip"]
 HEADERS = [os.path.join(CSRC, "sf_common.h"), os.path.join(CSRC, "gemm_epilogue.h"), os.path.join(CSRC, "split_operand.h"),
            os.path.join(HERE, "..", "include", "streamflow_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-Wall",
-         "-Wno-unused-function"]
+         "-Wno-unused-function",
+         # per-kernel registers / scratch / occupancy as compiler remarks: kept next to every object (<name>.res) and checked
+         # by check_resources() -- a hot kernel that spills must fail the build, not ship
+         "-Rpass-analysis=kernel-resource-usage"]
+# kernels that may not use scratch memory (substring of the demangled name): everything that shows up in the top rows of the
+# step's kernel table (profiles/r*_kernel_stats_sintel_serial.md)
+HOT_KERNELS = ("gemm_bstat_kernel", "gemm_bdirect_kernel", "gma_flash_kernel", "dwconv_mfma_kernel", "corr_lookup_blocked_kernel",
+               "corr_build_blocked_kernel", "temporal_block_kernel", "temporal_attn_kernel", "layernorm_cm_split_kernel",
+               "flash_pack_v_kernel", "ffn_pair_kernel")
 
 
 def hipcc() -> str:
@@ -38,6 +46,76 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _strip_remarks(stderr: str) -> str:
+    """Compiler output without the resource-usage remarks (each is a remark line + two source-context lines)."""
+    out, skip = [], 0
+    for ln in stderr.splitlines():
+        if "kernel-resource-usage" in ln:
+            skip = 2
+            continue
+        if skip and (ln.lstrip().startswith("|") or (ln.lstrip()[:1].isdigit() and "|" in ln)):
+            skip -= 1
+            continue
+        skip = 0
+        if "remarks generated" in ln or "remark generated" in ln:
+            continue
+        out.append(ln)
+    return "\n".join(out)
+
+
+def resources() -> dict:
+    """{demangled kernel name: {"sgpr", "vgpr", "agpr", "scratch", "occupancy", "lds", "file"}} from the .res files the
+    last build() left next to the objects."""
+    import re
+    res, cur = {}, None
+    keys = {"TotalSGPRs": "sgpr", "VGPRs": "vgpr", "AGPRs": "agpr", "ScratchSize [bytes/lane]": "scratch",
+            "Occupancy [waves/SIMD]": "occupancy", "LDS Size [bytes/block]": "lds", "VGPRs Spill": "vgpr_spill",
+            "SGPRs Spill": "sgpr_spill"}
+    mangled = []
+    for src in SOURCES:
+        path = os.path.join(OBJ, src.replace(".hip", ".res"))
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} missing: run streamflow_amd.build.build(force=True)")
+        for ln in open(path):
+            m = re.search(r"remark:\s+(.*?):\s+(\S+) \[-Rpass", ln)
+            if not m:
+                continue
+            k, v = m.group(1).strip(), m.group(2)
+            if k == "Function Name":
+                cur = {"file": src}
+                res[v] = cur
+                mangled.append(v)
+            elif cur is not None and k in keys:
+                cur[keys[k]] = int(v)
+    filt = shutil.which("llvm-cxxfilt") or shutil.which("c++filt") or "/usr/bin/c++filt"
+    if os.path.exists(filt) and mangled:
+        names = subprocess.run([filt], input="\n".join(mangled), capture_output=True, text=True).stdout.splitlines()
+        if len(names) == len(mangled):
+            res = {n.replace("(anonymous namespace)::", ""): res[m_] for n, m_ in zip(names, mangled)}
+    return res
+
+
+def check_resources(hot=HOT_KERNELS) -> dict:
+    """Fail when a hot kernel uses scratch memory (register spills or a dynamically indexed register array)."""
+    res = resources()
+    bad = {n: r for n, r in res.items() if r.get("scratch", 0) > 0 and any(h in n for h in hot)}
+    if bad:
+        raise RuntimeError("hot kernels with scratch memory (spills): " +
+                           "; ".join(f"{n}: {r['scratch']} B/lane, {r.get('vgpr_spill', 0)} VGPRs spilled" for n, r in bad.items()))
+    return res
+
+
+def resources_markdown() -> str:
+    res = resources()
+    rows = ["| kernel | file | VGPRs | AGPRs | SGPRs | scratch B/lane | waves/SIMD | LDS B/WG |", "|---|---|---:|---:|---:|---:|---:|---:|"]
+    for n in sorted(res, key=lambda n: (res[n]["file"], n)):
+        r = res[n]
+        short = n.split("(")[0] if "<" not in n else n[: n.rfind(">") + 1]
+        rows.append(f"| `{short}` | {r['file']} | {r.get('vgpr')} | {r.get('agpr')} | {r.get('sgpr')} | {r.get('scratch')} | "
+                    f"{r.get('occupancy')} | {r.get('lds')} |")
+    return "\n".join(rows) + "\n"
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(OBJ, exist_ok=True)
     cc = hipcc()
@@ -45,7 +123,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJ, src.replace(".hip", ".o"))
-        if force or _stale(o, [s] + HEADERS):
+        if force or _stale(o, [s] + HEADERS) or not os.path.exists(o[:-2] + ".res"):
             jobs.append((s, o))
 
     def compile_one(job):
@@ -56,8 +134,12 @@ def build(force: bool = False, verbose: bool = True) -> str:
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {s}:\n{r.stdout}\n{r.stderr}")
-        if verbose and r.stderr.strip():
-            print(r.stderr, file=sys.stderr)
+        remarks = [ln for ln in r.stderr.splitlines() if "kernel-resource-usage" in ln]
+        with open(o[:-2] + ".res", "w") as f:
+            f.write("\n".join(remarks) + "\n")
+        other = _strip_remarks(r.stderr)
+        if verbose and other.strip():
+            print(other, file=sys.stderr)
         return o
 
     with ThreadPoolExecutor(max_workers=4) as ex:
@@ -75,3 +157,6 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv))
+    if "--resources" in sys.argv:
+        print(resources_markdown())
+    check_resources()

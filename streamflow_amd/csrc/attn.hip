@@ -51,14 +51,25 @@ __host__ __device__ inline int64_t plane_bytes(int Ppad) { return (int64_t)256 *
 // log2 domain of the scaled logits -- q and k are constant over the refinement loop, so they are computed ONCE per clip
 // (sf_gma_flash_pack_qk) and the per-iteration kernel starts its logit accumulators at -max: no running maximum, no
 // accumulator rescale, no row sum in the loop that runs 15 times.
-__host__ __device__ inline int64_t img_ws_bytes(int Ppad) { return 5 * plane_bytes(Ppad) + (int64_t)Ppad * 8; }
+// ... then a 16-byte header {magic, products per logit the statistics were computed with (0 = none stored)}: the per-iteration
+// kernel checks it, so statistics of a different (or no) pack call are never used silently.
+constexpr int kHdrMagic = 0x53464b51;
+__host__ __device__ inline int64_t img_ws_bytes(int Ppad) { return 5 * plane_bytes(Ppad) + (int64_t)Ppad * 8 + 16; }
+__host__ __device__ inline int64_t hdr_offset(int Ppad) { return 5 * plane_bytes(Ppad) + (int64_t)Ppad * 8; }
 constexpr int kMaxSplit = 2;        // key-range splits of the statistics-mode kernel (partial buffers follow the images in ws)
+// key ranges are split exactly when the query tiles alone cannot fill the chip (a single Sintel clip: 165 workgroups for 256
+// CUs, each a serial chain over 110 key tiles); the workspace carries the partial buffers only then
+__host__ inline bool use_key_split(int n_img, int Ppad);
 __host__ __device__ inline int64_t part_bytes(int n_img, int Ppad) { return (int64_t)kMaxSplit * n_img * HD * Ppad * 4; }
 
 // ---- pack q, k: qk planes [img][2*HD][P] fp32 (rows 0..127 = q, 128..255 = k) -------------------------------------------
 __global__ __launch_bounds__(256) void flash_pack_qk_kernel(const float* qk, int64_t qk_img_stride, char* ws, int P, int Ppad,
-                                                            float qscale) {
+                                                            float qscale, int stats_products) {
     const int p = blockIdx.x * 256 + threadIdx.x, dq = blockIdx.y & 15, side = blockIdx.y >> 4, img = blockIdx.z;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        int* hdr = reinterpret_cast<int*>(ws + (int64_t)img * img_ws_bytes(Ppad) + hdr_offset(Ppad));
+        hdr[0] = kHdrMagic; hdr[1] = stats_products; hdr[2] = P; hdr[3] = 0;
+    }
     if (p >= Ppad) return;
     const float* src = qk + (int64_t)img * qk_img_stride + (int64_t)(side * HD + dq * 8) * P + p;
     const float mul = side == 0 ? qscale : 1.0f;
@@ -136,7 +147,12 @@ __global__ __launch_bounds__(256, (QKP == 3) ? 1 : ((QKP == 1 && SF_FLASH_V1) ? 
 
     float2* stats = reinterpret_cast<float2*>(const_cast<char*>(ws) + 5 * (int64_t)plane);
     float st_m = 0.f, st_inv = 0.f;
-    if (kUseStats) { const float2 st = stats[q]; st_m = st.x; st_inv = st.y; }
+    if (kUseStats) {
+        const float2 st = stats[q]; st_m = st.x; st_inv = st.y;
+        // statistics stored by another product count (or none at all): poison the result instead of using them
+        const int* hdr = reinterpret_cast<const int*>(ws + hdr_offset(Ppad));
+        if (hdr[0] != kHdrMagic || hdr[1] != QKP || hdr[2] != P) st_inv = __builtin_nanf("");
+    }
     // ---- tile DMA: K tile = 16 d-octet rows of 64 keys x 16 B (1 KB pieces), V tile = 16 KB contiguous ----
     auto issue_v = [&](int t, int buf) {
         const int j0 = t * BJ;
@@ -337,10 +353,14 @@ __global__ __launch_bounds__(256) void flash_combine_kernel(const float* part, i
 
 }  // namespace
 
+namespace {
+__host__ inline bool use_key_split(int n_img, int Ppad) { return Ppad / BJ >= 8 && (int64_t)(Ppad / BQ) * n_img < 384; }
+}
+
 extern "C" int64_t sf_gma_flash_ws_bytes(int n_img, int P) {
     if (n_img <= 0 || P <= 0) return 0;
     const int Ppad = sf::ceil_div(P, BQ) * BQ;
-    return (int64_t)n_img * img_ws_bytes(Ppad) + part_bytes(n_img, Ppad);
+    return (int64_t)n_img * img_ws_bytes(Ppad) + (use_key_split(n_img, Ppad) ? part_bytes(n_img, Ppad) : 0);
 }
 
 extern "C" int sf_gma_flash_pack_qk(const float* qk, int64_t qk_img_stride, void* ws, int64_t ws_bytes, int n_img, int P,
@@ -353,7 +373,7 @@ extern "C" int sf_gma_flash_pack_qk(const float* qk, int64_t qk_img_stride, void
     const int Ppad = sf::ceil_div(P, BQ) * BQ;
     SF_REQUIRE(2 * plane_bytes(Ppad) < ((int64_t)1 << 31), "sf_gma_flash_pack_qk: image too large");
     hipLaunchKernelGGL(flash_pack_qk_kernel, dim3(sf::ceil_div(Ppad, 256), 32, n_img), dim3(256), 0, (hipStream_t)stream, qk,
-                       qk_img_stride, (char*)ws, P, Ppad, scale * 1.44269504088896340736f);
+                       qk_img_stride, (char*)ws, P, Ppad, scale * 1.44269504088896340736f, stats_qk_products);
     if (stats_qk_products) {                                 // the softmax statistics of every query, once per clip
         FlashArgs g = {};
         g.ws = (const char*)ws; g.P = P; g.Ppad = Ppad;
@@ -386,11 +406,9 @@ extern "C" int sf_gma_flash_aggregate(void* ws, int64_t ws_bytes, const float* v
     g.ws = (const char*)ws; g.mf = mf; g.gamma = gamma; g.out = out;
     g.out16 = static_cast<_Float16*>(out_koct); g.out16_img_stride = out_koct_img_stride;
     g.mf_img_stride = mf_img_stride; g.out_img_stride = out_img_stride; g.P = P; g.Ppad = Ppad;
-    // Too few query tiles to fill the chip (a single Sintel clip: 165 workgroups for 256 CUs, each a serial chain over 110
-    // key tiles): with stored statistics the key range splits without any rescaling -- partial sums, then one add pass
-    static const int split_env = getenv("SF_FLASH_SPLIT") ? atoi(getenv("SF_FLASH_SPLIT")) : -1;      // A/B knob: 1 = never, 2 = always
-    const int wgs = (Ppad / BQ) * n_img;
-    g.nsplit = (use_stats && Ppad / BJ >= 8 && (split_env == 2 || (split_env != 1 && wgs < 384))) ? kMaxSplit : 1;
+    // Too few query tiles to fill the chip: with stored statistics the key range splits without any rescaling -- partial sums,
+    // then one add pass (use_key_split: the same predicate sizes the workspace)
+    g.nsplit = (use_stats && use_key_split(n_img, Ppad)) ? kMaxSplit : 1;
     g.part = reinterpret_cast<float*>(static_cast<char*>(ws) + (int64_t)n_img * img_ws_bytes(Ppad));
     dim3 grid(Ppad / BQ, n_img, g.nsplit);
     switch (qk_products * 2 + (use_stats ? 1 : 0)) {

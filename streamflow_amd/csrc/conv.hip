@@ -401,12 +401,10 @@ extern "C" int sf_dwconv_res_gelu(const float* x, int64_t x_img_stride, const fl
     SF_REQUIRE((int64_t)h * w < (1 << 30), "sf_dwconv_res_gelu: plane too large");
     // K = 7, three products: only 7/32 of the Toeplitz entries are non-zero and the stencil is the faster kernel (65 vs 87 us at
     // 128 channels x 24 images); K = 15 runs 1.45x faster on the matrix cores
-    static const bool force3 = getenv("SF_DW_PRODUCTS") && atoi(getenv("SF_DW_PRODUCTS")) == 3;   // A/B knob
-    const bool two = precision != SF_PRECISION_FP32 && precision != SF_PRECISION_F16X3 && !force3;
+    const bool two = precision != SF_PRECISION_FP32 && precision != SF_PRECISION_F16X3;
     const bool one = two && precision == SF_PRECISION_F16;       // weights rounded once to fp16 as well
-    static const bool dw7_stencil = getenv("SF_DW7_MFMA") && atoi(getenv("SF_DW7_MFMA")) == 0;      // A/B knob
     // K = 7 in the two-product modes also runs on the matrix cores (7 x 2 MFMAs per tile against 49 FMAs per output)
-    if (precision != SF_PRECISION_FP32 && (ksize == 15 || (two && !dw7_stencil))) {
+    if (precision != SF_PRECISION_FP32 && (ksize == 15 || two)) {
         DwmArgs m;
         m.x = x; m.wgt = wgt; m.bias = bias; m.y = y; m.x_img_stride = x_img_stride; m.y_img_stride = y_img_stride;
         m.n_img = n_img; m.C = C; m.h = h; m.w = w;
@@ -423,8 +421,8 @@ extern "C" int sf_dwconv_res_gelu(const float* x, int64_t x_img_stride, const fl
         m.vec_ok = ((w & 3) == 0) && ((x_img_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
         // several images of a channel per workgroup (the Toeplitz fragments are built once), but keep >= ~2048 workgroups
         const int strips = sf::ceil_div(h, strip);
-        // (A/B knob; 4096 / 8192 / 16384 workgroups measured within +-3 % of 2048 on every layer shape of the update block)
-        static const int target_wgs = getenv("SF_DW_TARGET_WGS") ? atoi(getenv("SF_DW_TARGET_WGS")) : 2048;
+        // (4096 / 8192 / 16384 workgroups measured within +-3 % of 2048 on every layer shape of the update block)
+        constexpr int target_wgs = 2048;
         int groups = sf::ceil_div(target_wgs, C * strips);
         if (groups > n_img) groups = n_img;
         if (groups < 1) groups = 1;

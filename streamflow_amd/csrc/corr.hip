@@ -972,9 +972,11 @@ extern "C" int sf_corr_build_pyramid(const float* f1, const float* f2, int64_t f
         }
         // measured on MI355X (r02): the transposed 16-byte epilogue is SLOWER than the dword one (fp16 build 2.20 vs
         // 1.68 ms, f16x3 build 3.03 vs 2.34 ms per 24 images) -- the build is not bound by store-instruction count.
-        // Kept as an experiment knob (SF_CORR_VEC=1); see DESIGN.md.
-        const char* e = getenv("SF_CORR_VEC");
-        g.vec_store = (al && e && atoi(e) == 1) ? 1 : 0;
+        // Kept as a compile-time experiment (-DSF_CORR_VEC=1 through tools/build_variant.sh); see DESIGN.md.
+#ifndef SF_CORR_VEC
+#define SF_CORR_VEC 0
+#endif
+        g.vec_store = (al && SF_CORR_VEC == 1) ? 1 : 0;
     }
     // patches per L2-resident block: ~1.75 MB of packed target features (of the 4 MiB L2 of an XCD)
     const int patch_bytes = BN * Dp * (precision == SF_PRECISION_F16 ? 2 : 4);

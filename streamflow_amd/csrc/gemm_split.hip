@@ -455,7 +455,10 @@ __device__ __forceinline__ void gemm_bdirect_body(const SplitArgs& args) {
         stage(kt + 1, bq1, bq0);
     }
     constexpr bool kFastGelu = SF_GEMM_FAST_GELU;
-    __syncthreads();                                         // the stage ring becomes the epilogues' transpose scratch
+    // the stages issue DMA pieces past the end of K unconditionally (zero fills): drain them explicitly before the stage ring
+    // becomes the epilogues' transpose scratch -- a late piece would otherwise land in another wave's scratch
+    __builtin_amdgcn_s_waitcnt(0x0070);                      // vmcnt(0) lgkmcnt(0)
+    __syncthreads();
 #ifdef SF_GEMM_TIMERS
     const long long ts2 = __builtin_readcyclecounter();
 #endif
@@ -473,15 +476,21 @@ __device__ __forceinline__ void gemm_bdirect_body(const SplitArgs& args) {
 }
 // (two __global__ wrappers: a __launch_bounds__ that depends on a template parameter left hipcc without the host stub of
 // some instantiations -- "undefined symbol __device_stub__gemm_bdirect_kernel<1, 2, 256>" at load time)
-template <int PM, int WM>
-__global__ __launch_bounds__(kBdThreads, 4) void gemm_bdirect_kernel(const SplitArgs args) { gemm_bdirect_body<PM, WM, 128>(args); }
+// Wave grid: 1 x 8 waves of 128 x 32 (every activation fragment loaded once, used for four MFMAs) is what ships.  The 2 x 4
+// grid of 64 x 64 measured equal within the noise for two-product layers and slower for single-product ones (DESIGN.md
+// section 11), and at its 128-register cap its epilogue spilled 140 VGPRs; the 256-row tile was no better
+// than 1 x 8 either.  Both stay reachable for experiments: tools/build_variant.sh ... -DSF_GEMM_BD_WM=2 / -DSF_GEMM_BD256_MIN_M=..
+#ifndef SF_GEMM_BD_WM
+#define SF_GEMM_BD_WM 1
+#endif
+#ifndef SF_GEMM_BD256_MIN_M
+#define SF_GEMM_BD256_MIN_M 0            // 0 = never
+#endif
+template <int PM>
+__global__ __launch_bounds__(kBdThreads, 4) void gemm_bdirect_kernel(const SplitArgs args) { gemm_bdirect_body<PM, SF_GEMM_BD_WM, 128>(args); }
+#if SF_GEMM_BD256_MIN_M
 __global__ __launch_bounds__(kBdThreads, 2) void gemm_bdirect256_kernel(const SplitArgs args) { gemm_bdirect_body<1, 2, 256>(args); }
-
-void launch_bd256(const SplitArgs& a, hipStream_t st) {
-    const SfGemm& g = a.g;
-    dim3 grid(sf::ceil_div(g.N, 256) * sf::ceil_div(g.M, 256) * g.batch);
-    hipLaunchKernelGGL(gemm_bdirect256_kernel, grid, dim3(kBdThreads), 0, st, a);
-}
+#endif
 
 template <int WM, int WN, int TM, int TN, int PM>
 int launch_cfg(const SplitArgs& a, hipStream_t st) {
@@ -499,40 +508,33 @@ int launch_cfg(const SplitArgs& a, hipStream_t st) {
     }
     if (lay == 13) {                                     // split weights x fp16 k-octet activations: both operands by LDS-DMA
         if constexpr (!SB && WM * TM * 32 == 128) {
-            // B-direct kernel (128 x 256 tile, activations straight into registers): SF_GEMM_BDIRECT=0 keeps the 128 x 128 one
-            static const bool bdirect = !(getenv("SF_GEMM_BDIRECT") && atoi(getenv("SF_GEMM_BDIRECT")) == 0);
-            // measured per shape (tools/gemm_koct_bench.py, 24 x 7040 pixels): 2 x 4 waves win for M >= 512 (+7..9 %), 1 x 8 for
-            // 192 <= M < 512 (+0..15 %); M <= 128 stays on the 128 x 128 kernel (-10 % otherwise)
-            static const int bd_min_m = getenv("SF_GEMM_BD_MIN_M") ? atoi(getenv("SF_GEMM_BD_MIN_M")) : 192;
-            // Fall back to the 128 x 128 kernel when the 128 x 256 tiles would not fill the chip (a single clip gives M = 384
-            // just 249 of them for 256 CUs).  Measured at one clip, two interleaved runs: threshold 0: 186.7 / 189.2 ff/s,
-            // 384: 192.7 / 192.6, 512: 190.2 / 192.8.  Batched steps never get there (>= 660 workgroups per row tile)
-            static const int bd_min_wg = getenv("SF_GEMM_BD_MIN_WG") ? atoi(getenv("SF_GEMM_BD_MIN_WG")) : 384;
+            // B-direct kernel (128 x 256 tile, activations straight into registers).  Dispatch rule, measured per shape
+            // (tools/gemm_koct_bench.py, 24 x 7040 pixels) and fixed at compile time (experiments:
+            // tools/build_variant.sh with -DSF_GEMM_BD_MIN_M / -DSF_GEMM_BD_MIN_WG / -DSF_GEMM_BDIRECT=0):
+            //  * M >= 192 (+0..15 %), or one row tile (96 < M <= 128) with a short K <= 192 (M128 K192 33.1 -> 29.7 us; K = 960: no);
+            //  * only when the 128 x 256 tiles fill the chip: a single clip gives M = 384 just 249 of them for 256 CUs and runs
+            //    better on the 128 x 128 kernel (threshold 0: 186.7 / 189.2 ff/s, 384: 192.7 / 192.6); batched steps always pass.
+#ifndef SF_GEMM_BDIRECT
+#define SF_GEMM_BDIRECT 1
+#endif
+#ifndef SF_GEMM_BD_MIN_M
+#define SF_GEMM_BD_MIN_M 192
+#endif
+#ifndef SF_GEMM_BD_MIN_WG
+#define SF_GEMM_BD_MIN_WG 384
+#endif
             const int64_t n_wg2 = (int64_t)sf::ceil_div(g.N, 256) * sf::ceil_div(g.M, 128) * g.batch;
-            // one row tile (96 < M <= 128) with a short K also wins there (three interleaved runs: M128 K192 33.1 -> 29.7 us, M128
-            // K128 29.1 -> 26.1 single-product, 34.2 -> 31.6 / 39.3 -> 37.9 two-product), a long K does not (M128 K960 95 -> 100)
-            const bool bd_m = g.M >= bd_min_m || (g.M > 96 && g.K <= 192);
-            if (bdirect && bd_m && n_wg2 >= bd_min_wg && g.k_splits <= 1 && (int64_t)g.ldb * 16 * 2 < ((int64_t)1 << 31)) {
+            const bool bd_m = g.M >= SF_GEMM_BD_MIN_M || (g.M > 96 && g.K <= 192);
+            if (SF_GEMM_BDIRECT && bd_m && n_wg2 >= SF_GEMM_BD_MIN_WG && g.k_splits <= 1 && (int64_t)g.ldb * 16 * 2 < ((int64_t)1 << 31)) {
                 dim3 grid2(sf::ceil_div(g.N, 256) * sf::ceil_div(g.M, 128) * g.batch);
-                // 256-row tiles: single-product layers whose M pads to the same size either way, from M = SF_GEMM_BD256 up (0 =
-                // never).  Measured (tools/gemm_koct_bench.py, SF_SINGLE=1, 24 x 7040 pixels): M960 K640 426 -> 404 us; but M486
-                // K324 126 -> 148, M256 K384 62 -> 72, M256 K256 54 -> 63: one or two row tiles leave too few workgroups
-                // ... and against 1 x 8 waves of 128 x 32 (three interleaved runs): M960 K640 410 / 414 / 416 vs 402 / 386 / 417 us:
-                // no better than the simpler form, so the 256-row tile stays an opt-in knob (default 0 = never)
-                static const int bd256 = getenv("SF_GEMM_BD256") ? atoi(getenv("SF_GEMM_BD256")) : 0;
-                if (PM == 1 && bd256 && sf::ceil_div(g.M, 256) * 256 == sf::ceil_div(g.M, 128) * 128 && g.M >= bd256) {
-                    launch_bd256(a, st);
+#if SF_GEMM_BD256_MIN_M
+                if (PM == 1 && sf::ceil_div(g.M, 256) * 256 == sf::ceil_div(g.M, 128) * 128 && g.M >= SF_GEMM_BD256_MIN_M) {
+                    dim3 grid3(sf::ceil_div(g.N, 256) * sf::ceil_div(g.M, 256) * g.batch);
+                    hipLaunchKernelGGL(gemm_bdirect256_kernel, grid3, dim3(kBdThreads), 0, st, a);
                     return sf::check_launch("sf_gemm(B-direct 256)");
                 }
-                // wave grid: 2 x 4 waves of 64 x 64 from M = wm2_min up, else 1 x 8 waves of 128 x 32 (every activation fragment
-                // loaded once and used for four MFMAs).  Two-product layers: 2 x 4 from M = 512 (round-3 tuning above).  SINGLE-
-                // product layers have half the MFMA work behind every activation byte and want 1 x 8 everywhere (three
-                // interleaved runs, tools/gemm_koct_bench.py SF_SINGLE=1): M960 K640 402 / 386 / 417 vs 447 / 426 / 444 us,
-                // M640 K960 329 / 308 / 321 vs 349 / 347 / 351, M640 K640 229 / 237 / 235 vs 265 / 252 / 264
-                static const int wm2_env = getenv("SF_GEMM_BD_WM2_MIN_M") ? atoi(getenv("SF_GEMM_BD_WM2_MIN_M")) : -1;
-                const int wm2_min = wm2_env >= 0 ? wm2_env : (PM == 1 ? (1 << 30) : 512);
-                if (g.M >= wm2_min) hipLaunchKernelGGL((gemm_bdirect_kernel<PM, 2>), grid2, dim3(kBdThreads), 0, st, a);
-                else hipLaunchKernelGGL((gemm_bdirect_kernel<PM, 1>), grid2, dim3(kBdThreads), 0, st, a);
+#endif
+                hipLaunchKernelGGL((gemm_bdirect_kernel<PM>), grid2, dim3(kBdThreads), 0, st, a);
                 return sf::check_launch("sf_gemm(B-direct)");
             }
             hipLaunchKernelGGL((gemm_f16x3_mfma<WM, WN, TM, TN, 2, 5, PM>), grid, dim3(kThreads), 0, st, a);
@@ -565,12 +567,11 @@ int pick_tile(const SplitArgs& a, hipStream_t st) {
     // waste more than a quarter of the MFMAs
     const int M = g.M;
     auto padded = [&](int bm) { return (M + bm - 1) / bm * bm; };
-    if (const char* e = getenv("SF_GEMM_BM")) {          // experiment knob
-        const int bm = atoi(e);
-        if (bm == 128) return launch_cfg<2, 2, 2, 2, PM>(a, st);
-        if (bm == 64) return launch_cfg<1, 4, 2, 1, PM>(a, st);
-        if (bm == 32) return launch_cfg<1, 4, 1, 1, PM>(a, st);
-    }
+#ifdef SF_GEMM_BM                                        // experiment builds only (tools/build_variant.sh ... -DSF_GEMM_BM=64)
+    if (SF_GEMM_BM == 128) return launch_cfg<2, 2, 2, 2, PM>(a, st);
+    if (SF_GEMM_BM == 64) return launch_cfg<1, 4, 2, 1, PM>(a, st);
+    if (SF_GEMM_BM == 32) return launch_cfg<1, 4, 1, 1, PM>(a, st);
+#endif
     // (a wave-specialised producer/consumer variant of the 128x128 kernel was faster for K >= 768 early in the round;
     // after the cheaper split and epilogue it measured 2-25 % slower at every batch size and was removed)
     if (padded(128) * 4 <= M * 5) return launch_cfg<2, 2, 2, 2, PM>(a, st);
@@ -698,6 +699,8 @@ int64_t gemm_split_ws_floats(int M, int N, int K, int batch) {
 }
 
 int gemm_split_dispatch_inner(const SfGemm& g, hipStream_t st);
+bool gemm_bstat_ok(const SfGemm& g);                       // gemm_bstat.hip
+int gemm_bstat_launch(const SfGemm& g, hipStream_t st);
 
 int gemm_split_dispatch(const SfGemm& g, hipStream_t st) {
     // automatic split-K through caller-provided scratch
@@ -742,6 +745,9 @@ int gemm_split_dispatch_inner(const SfGemm& g, hipStream_t st) {
     // tile choice: the 128-row tile moves the fewest bytes per MAC; drop to 64/32 rows when padding M would
     // waste more than a quarter of the MFMAs
     // output / residual format rules: checked for EVERY operand layout (the fp16-in -> fp16-out hand-over is the common case)
+    // activation-stationary kernel (gemm_bstat.hip) wherever it applies: K <= 640 held in registers, weights streamed
+    if (g.algo != SF_ALGO_TILED && gemm_bstat_ok(g)) return gemm_bstat_launch(g, st);
+    if (g.algo == SF_ALGO_BSTAT) return fail(SF_ERR_UNSUPPORTED, "sf_gemm: SF_ALGO_BSTAT cannot run this problem (see include/streamflow_hip.h)");
     if (const int rc = check_output_formats(g); rc != SF_OK) return rc;
     if (g.b_layout == SF_LAYOUT_F16_KOCT) {
         if (g.a_layout != SF_LAYOUT_SPLIT_F16 || (g.precision != SF_PRECISION_F16X2 && g.precision != SF_PRECISION_F16) ||

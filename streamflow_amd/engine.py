@@ -65,11 +65,12 @@ def _scratch(buf: Planes, n_img: int, rows: int, f16: bool = False, koct: bool =
 
 
 def _handover(buf: Planes, n_img: int, rows: int, P: int, consumer_rows: int, allow_koct: bool = True) -> Planes:
+    # (rows = K of the consuming layer, consumer_rows = its M)
     """Scratch view for a tensor that is written by one GEMM and read only as the B operand of the next: fp32 planes in
     the exact / f16x3 modes; in f16x2 fp16 values -- as k-octet planes when the consumer runs on the DMA-fed 128-row tile
     (both of its operands then go HBM/L2 -> LDS without touching registers), as fp16 rows otherwise."""
     f16 = hidden_f16_ok(P)
-    koct = f16 and allow_koct and ops.uses_dma_tile(consumer_rows) and os.environ.get("SF_HIDDEN_KOCT", "1") != "0"
+    koct = f16 and allow_koct and ops.takes_koct(consumer_rows, rows) and os.environ.get("SF_HIDDEN_KOCT", "1") != "0"
     return _scratch(buf, n_img, rows, f16=f16, koct=koct)
 
 

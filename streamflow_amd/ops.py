@@ -259,7 +259,9 @@ class PackedLinear:
         # |x| >= 6.1e-5, so the lo part of an unscaled small weight (|w| < 0.12) would fall into fp16 subnormals
         # (absolute spacing 6e-8) and a layer whose weights are all ~1e-3 would keep ~15 bits instead of ~21.  The
         # scale is exact (power of two) and is undone in the epilogue: alpha' = alpha / s, bias' = bias * s.
-        mp, kp = (self.M + 127) // 128 * 128, (self.K + 31) // 32 * 32
+        # (K padded to 128: the tiled kernels read K rounded up to 32, the activation-stationary one whole weight stages)
+        mp, kp = (self.M + 127) // 128 * 128, (self.K + 127) // 128 * 128
+        self.k_pad = 128
         wmax = float(w2.abs().max()) if w2.numel() else 0.0
         if not torch.isfinite(torch.tensor(wmax)):
             raise RuntimeError("PackedLinear: non-finite weight")
@@ -303,19 +305,26 @@ def refresh_shadow(X: Planes) -> None:
 
 
 def uses_dma_tile(M: int) -> bool:
-    """Does sf_gemm run an M-row problem on the 128-row, DMA-fed tile (gemm_split.hip pick_tile)?  Only that kernel takes
-    a k-octet fp16 B operand."""
+    """Does sf_gemm run an M-row problem on the 128-row, DMA-fed tile (gemm_split.hip pick_tile)?  Of the tiled kernels only
+    that one takes a k-octet fp16 B operand."""
     return (M + 127) // 128 * 128 * 4 <= M * 5
+
+
+def takes_koct(M: int, K: int) -> bool:
+    """Can sf_gemm read the B operand of an M x K layer as fp16 k-octet planes?  The activation-stationary kernel does for
+    64 < K <= 640 at every M (gemm_bstat.hip), the tiled family on its 128-row tile."""
+    return 64 < K <= 640 or uses_dma_tile(M)
 
 
 def gemm(A: PackedLinear, X: Planes, Y: Planes, epilogue: int = EPI_NONE, R: Optional[Planes] = None,
          dw_w: Optional[torch.Tensor] = None, dw_b: Optional[torch.Tensor] = None, alpha: float = 1.0,
-         hw: Optional[Sequence[int]] = None) -> None:
-    """Y[img] = epilogue(alpha * (W @ X[img] + bias)) for every image (batched over grid.z)."""
+         hw: Optional[Sequence[int]] = None, algo: int = 0) -> None:
+    """Y[img] = epilogue(alpha * (W @ X[img] + bias)) for every image (batched over grid.z).
+    algo: _lib.ALGO_AUTO / ALGO_TILED / ALGO_BSTAT (SfGemm.algo: force one kernel family; tests and A/B timing)."""
     assert X.rows * (9 if A.conv3x3 else 1) == A.K, (X.rows, A.K)
     assert Y.rows == A.M and X.n_img == Y.n_img and X.P == Y.P, (Y.rows, A.M)
     if (X.shadow is not None and SHADOWS and PRECISION in (PRECISION_F16X2, PRECISION_F16) and not A.conv3x3 and
-            uses_dma_tile(A.M)):
+            takes_koct(A.M, A.K)):
         X = X.shadow                                  # the fp16 k-octet copy: both operands by LDS-DMA
     if DEBUG_RANGE and PRECISION != PRECISION_FP32:
         _check_range(X, f"sf_gemm M{A.M} K{A.K}")
@@ -344,7 +353,7 @@ def gemm(A: PackedLinear, X: Planes, Y: Planes, epilogue: int = EPI_NONE, R: Opt
         fused_shadow = True
     if prec != PRECISION_FP32:
         g.a_layout = LAYOUT_SPLIT_F16
-        g.A_hi, g.A_lo, g.lda_h = A.hi.data_ptr(), A.lo.data_ptr(), A.lda_h
+        g.A_hi, g.A_lo, g.lda_h, g.a_k_pad = A.hi.data_ptr(), A.lo.data_ptr(), A.lda_h, A.k_pad
         # the split image holds split_scale * W: C = alpha/s * (s W X + s b)
         alpha = alpha / A.split_scale
         g.bias = None if A.bias_split is None else A.bias_split.data_ptr()
@@ -360,7 +369,7 @@ def gemm(A: PackedLinear, X: Planes, Y: Planes, epilogue: int = EPI_NONE, R: Opt
         g.dw_w, g.dw_b = dw_w.data_ptr(), dw_b.data_ptr()
     if A.conv3x3:
         g.conv3x3, g.h, g.w = 1, int(hw[0]), int(hw[1])
-    g.alpha, g.epilogue, g.precision = float(alpha), int(epilogue), prec
+    g.alpha, g.epilogue, g.precision, g.algo = float(alpha), int(epilogue), prec, int(algo)
     if SPLIT_WS is not None and prec != PRECISION_FP32:
         g.split_ws, g.split_ws_floats = SPLIT_WS.data_ptr(), SPLIT_WS.numel()
     name = "gemm" if not PROFILE_SHAPES else f"gemm M{g.M} K{g.K} b{g.batch} e{g.epilogue}"

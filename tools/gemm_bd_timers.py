@@ -11,6 +11,7 @@ n, P = 24, 7040
 dev = torch.device("cuda:0")
 ops.set_precision("f16x2")
 W = PackedLinear(torch.randn(M, K, 1, 1) / K ** 0.5, torch.randn(M) * 0.1, dev)
+W.single = os.environ.get("SF_SINGLE", "0") == "1"
 X = Planes(torch.zeros(n * K * P // 2, device=dev), 0, K * P, n, K, P, f16=True, koct=True)
 ops.pack_koct(Planes.of(torch.randn(n, K, P, device=dev)), X)
 Y = Planes.of(torch.empty(n, M, P, device=dev))

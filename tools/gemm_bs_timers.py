@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Per-wave phase timers of the activation-stationary GEMM (needs tools/build_variant.sh bst gemm_bstat.hip -DSF_BSTAT_TIMERS and
+SF_HIP_LIB=.../variant_bst.so).  usage: gemm_bs_timers.py M K   (SF_SINGLE=1: one product)"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from streamflow_amd import _lib, ops
+from streamflow_amd.ops import Planes, PackedLinear
+M, K = int(sys.argv[1]), int(sys.argv[2])
+n, P = 24, 7040
+dev = torch.device("cuda:0")
+ops.set_precision("f16x2")
+W = PackedLinear(torch.randn(M, K, 1, 1) / K ** 0.5, torch.randn(M) * 0.1, dev)
+W.single = os.environ.get("SF_SINGLE", "0") == "1"
+X = Planes(torch.zeros(n * K * P // 2, device=dev), 0, K * P, n, K, P, f16=True, koct=True)
+ops.pack_koct(Planes.of(torch.randn(n, K, P, device=dev)), X)
+Mo = (M + 7) // 8 * 8
+Y = Planes(torch.zeros(n * Mo * P // 2, device=dev), 0, Mo * P, n, M, P, f16=True, koct=True)
+for _ in range(3):
+    ops.gemm(W, X, Y, ops.EPI_GELU, algo=_lib.ALGO_BSTAT)
+torch.cuda.synchronize()
+ts = torch.zeros(4096 * 4 * 8, dtype=torch.int64, device=dev)
+os.environ["SF_GEMM_TS_BUF"] = str(ts.data_ptr())
+ops.gemm(W, X, Y, ops.EPI_GELU, algo=_lib.ALGO_BSTAT); torch.cuda.synchronize()
+t = ts.view(-1, 8).cpu().double()
+t = t[t[:, 6] > 0]
+sk = 128 if W.single else 64
+nstage = ((K + sk - 1) // sk) * ((M + 63) // 64)
+print(f"M{M} K{K} single={W.single}: {t.shape[0]} waves, {nstage} stages each ({(M + 63) // 64} m-steps)")
+for name, col in (("vmcnt wait", 1), ("barrier", 2), ("issue DMA", 3), ("mfma block", 4)):
+    v = t[:, col] / nstage
+    print(f"  {name:12s} per stage: mean {v.mean().item():7.0f} median {v.median().item():7.0f} min {v.min().item():7.0f} max {v.max().item():7.0f} cycles")
+v = t[:, 5] / ((M + 63) // 64)
+print(f"  epilogue per m-step    : mean {v.mean().item():7.0f} median {v.median().item():7.0f} min {v.min().item():7.0f} max {v.max().item():7.0f} cycles")
+for name, col in (("prologue (B loads)", 0), ("whole wave", 6)):
+    v = t[:, col]
+    print(f"  {name:18s}: mean {v.mean().item():8.0f} median {v.median().item():8.0f} min {v.min().item():8.0f} max {v.max().item():8.0f} cycles")
+print(f"  clock {(t[:, 6].sum() / t[:, 7].sum()).item() * 100:.0f} MHz")

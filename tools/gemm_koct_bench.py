@@ -8,14 +8,20 @@ import torch
 from streamflow_amd import ops
 from streamflow_amd.ops import Planes, PackedLinear
 mode = sys.argv[1] if len(sys.argv) > 1 else "none"
+ALGO = int(os.environ.get("SF_ALGO", "0"))          # 0 auto, 1 tiled kernels, 2 activation-stationary kernel
 n, P = int(os.environ.get("SF_N_IMG", "24")), 7040
 dev = torch.device("cuda:0")
 ops.set_precision("f16x2")
 shapes = [(960, 640), (640, 960), (640, 640), (128, 960), (486, 324), (324, 486), (384, 256), (256, 384), (256, 256), (192, 128), (128, 192), (128, 128)]
+if os.environ.get("SF_SHAPES"):                                 # e.g. SF_SHAPES=960x640,384x256
+    shapes = [tuple(int(v) for v in t.split("x")) for t in os.environ["SF_SHAPES"].split(",")]
 tot = 0.0
 for M, K in shapes:
     W = PackedLinear(torch.randn(M, K, 1, 1) / K ** 0.5, torch.randn(M) * 0.1, dev)
     W.single = os.environ.get("SF_SINGLE", "0") == "1"          # single-product weights (a layer of the mixed preset)
+    R = int(os.environ.get("SF_REPL", "1"))                     # experiment builds with -DSF_BSTAT_REPL=R: R copies of the planes
+    if R > 1:
+        W.hi, W.lo = torch.cat([W.hi] * R).contiguous(), torch.cat([W.lo] * R).contiguous()
     Ka = (K + 7) // 8 * 8
     xs = torch.randn(n, Ka, P, device=dev)
     X = Planes(torch.zeros(n * Ka * P // 2, device=dev), 0, Ka * P, n, K, P, f16=True, koct=True)
@@ -27,14 +33,16 @@ for M, K in shapes:
     else:
         Y = Planes.of(torch.empty(n, M, P, device=dev))
         epi = ops.EPI_GELU if mode == "gelu" else ops.EPI_NONE
-    if mode == "koct" and not ops.uses_dma_tile(M):
+    if mode == "koct" and not (ops.uses_dma_tile(M) if ALGO == 1 else ops.takes_koct(M, K)):
+        continue
+    if ALGO == 2 and K > 640:
         continue
     for _ in range(3):
-        ops.gemm(W, X, Y, epi)
+        ops.gemm(W, X, Y, epi, algo=ALGO)
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
     for _ in range(10):
-        ops.gemm(W, X, Y, epi)
+        ops.gemm(W, X, Y, epi, algo=ALGO)
     e.record(); torch.cuda.synchronize()
     us = s.elapsed_time(e) * 100
     tot += us

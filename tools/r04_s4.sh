@@ -1,0 +1,8 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/r04; mkdir -p $O
+V=streamflow_amd/csrc/build/variant_bst.so
+for single in 1 0; do for s in "960 640" "384 256"; do
+  SF_SINGLE=$single SF_HIP_LIB=$V timeout 300 python tools/gemm_bs_timers.py $s 2>&1 | grep -v amdgpu.ids
+done; done > $O/s4_timers.log 2>&1
+cat $O/s4_timers.log
