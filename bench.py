@@ -74,8 +74,17 @@ def shard(n_items: int, world: int, rank: int):
     return list(range(rank, n_items, world))
 
 
-def timed_steps(step_fn, steps: int, warmup: int, world: int, sync_fn, barrier_fn, allreduce_max_fn) -> float:
-    """W untimed warm-up steps, then exactly K steps bracketed by barrier + device sync; MAX over ranks."""
+def batches(n_clips: int, per_launch: int):
+    """Launch sizes of one rank's step in the strong-scaling mode: its clips in batches of at most `per_launch` (the last one
+    may be smaller; a rank without clips runs nothing and only takes part in the barriers)."""
+    full, rest = divmod(n_clips, per_launch)
+    return [per_launch] * full + ([rest] if rest else [])
+
+
+def timed_steps(step_fn, steps: int, warmup: int, world: int, sync_fn, barrier_fn, allreduce_max_fn, own=None) -> float:
+    """W untimed warm-up steps, then exactly K steps bracketed by barrier + device sync; MAX over ranks.
+    own (optional list): receives this rank's own time up to its device sync, BEFORE the closing barrier (diagnosis of a
+    scaling run: which rank was the slow one)."""
     for _ in range(warmup):
         step_fn()
     sync_fn()
@@ -84,6 +93,8 @@ def timed_steps(step_fn, steps: int, warmup: int, world: int, sync_fn, barrier_f
     for _ in range(steps):
         step_fn()
     sync_fn()
+    if own is not None:
+        own.append(time.perf_counter() - t0)
     barrier_fn()
     dt = time.perf_counter() - t0
     return allreduce_max_fn(dt)
@@ -141,6 +152,14 @@ def newest_traffic_file(workload=None):
     return files[-1] if files else None
 
 
+def pinned_device_env(local_rank: int, visible=None) -> dict:
+    """Environment that restricts a rank to ONE GPU before it initialises the runtime: the local_rank-th of the devices this
+    process may see (HIP_VISIBLE_DEVICES of the parent, if set).  The rank then addresses it as device 0 (SF_BENCH_DEVICE)."""
+    devs = [d for d in visible.split(",") if d != ""] if visible else None
+    dev = devs[local_rank % len(devs)] if devs else str(local_rank)
+    return {"HIP_VISIBLE_DEVICES": dev, "SF_BENCH_DEVICE": "0"}
+
+
 def _free_port() -> int:
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -153,9 +172,14 @@ def spawn_ranks(n: int, argv, script: str = None) -> int:
     GPU, wait for them, return the worst exit code.  Rank 0 inherits stdout and prints the one JSON line."""
     port = _free_port()
     procs = []
+    # SF_BENCH_PIN=visible: every child sees exactly ONE device (HIP_VISIBLE_DEVICES = its local rank, set before the child
+    # initialises the GPU: SURVEY.md 8e) and uses device index 0; default: all devices visible, device index = LOCAL_RANK
+    pin = os.environ.get("SF_BENCH_PIN", "index")
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        if pin == "visible":
+            env.update(pinned_device_env(r, os.environ.get("HIP_VISIBLE_DEVICES")))
         procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + list(argv), env=env))
     rc = 0
     try:
@@ -184,6 +208,13 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="sintel", choices=list(WORKLOADS))
+    ap.add_argument("--total-clips", type=int, default=0,
+                    help="STRONG scaling: this many clips in total per step at every --gpus N (BASELINE.json config 4: 64), "
+                         "round-robined over the ranks and run in launches of --clips; 0 (default) = weak scaling, "
+                         "--clips per GPU per step")
+    ap.add_argument("--pin", default=os.environ.get("SF_BENCH_PIN", "index"), choices=["index", "visible"],
+                    help="how a rank takes its GPU: index = cuda:LOCAL_RANK with every device visible; visible = "
+                         "HIP_VISIBLE_DEVICES restricted to its one device before the runtime starts (SURVEY.md 8e)")
     ap.add_argument("--clips", type=int, default=8,
                     help="clips per GPU per step, batched through every launch (default 8 = the per-GPU share of "
                          "BASELINE.json's 8-GPU 'Sintel-shape batch=64' configuration; 1 = single-clip latency)")
@@ -232,6 +263,11 @@ def main():
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
     if args.gpus > 1 and world == 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE=1")
+    if args.pin == "visible" and world > 1 and "SF_BENCH_DEVICE" not in os.environ and not args.share_device:
+        # under an external launcher: restrict this rank to its device now -- nothing has initialised the GPU yet
+        os.environ.update(pinned_device_env(local_rank, os.environ.get("HIP_VISIBLE_DEVICES")))
+    if "SF_BENCH_DEVICE" in os.environ and not args.share_device:
+        local_rank = int(os.environ["SF_BENCH_DEVICE"])
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
     if args.share_device:
         local_rank %= torch.cuda.device_count()
@@ -272,11 +308,16 @@ def main():
     h, w, B = H // 8, W // 8, args.clips
     pairs = T - 1
     params = syn.make_params(0, T)
+    strong = args.total_clips > 0
+    my_batches = batches(len(shard(args.total_clips, world, rank)), B) if strong else [B]
     fmaps_c, cnets_c = syn.make_features(1000 + rank, B, T, h, w)
     fmaps, cnets = fmaps_c.to(dev), cnets_c.to(dev)
     eng = HotPathEngine(params, device=dev, T=T, use_graph=not args.no_graph, **cfg)
     if args.serial_branches:
         eng.parallel_branches = False
+    if strong:
+        args.no_kernel_breakdown = args.no_cpu_baseline = True          # (the N = 1 weak-scaling line carries those)
+        assert args.streams == 1, "--total-clips and --streams exclude each other"
 
     if args.streams > 1:
         assert B % args.streams == 0, "--clips must be a multiple of --streams"
@@ -294,6 +335,13 @@ def main():
                     e.forward(f, c, iters=iters, all_masks=args.all_masks)
             for st in strs:
                 cur.wait_stream(st)
+    elif strong:
+        # one input set per distinct launch size (the same synthetic clips every launch: timing does not depend on the values)
+        feats = {b: (fmaps[:b].contiguous(), cnets[:b].contiguous()) for b in set(my_batches)}
+
+        def step():
+            for b in my_batches:
+                eng.forward(*feats[b], iters=iters, all_masks=args.all_masks)
     else:
         def step():
             eng.forward(fmaps, cnets, iters=iters, all_masks=args.all_masks)
@@ -313,21 +361,33 @@ def main():
     step()
     torch.cuda.synchronize()
     log("first step done (includes graph capture)")
-    dt = timed_steps(step, args.steps, args.warmup, world, torch.cuda.synchronize, barrier, allreduce_max)
-    log(f"timed region: {args.steps} steps in {dt:.3f}s")
-    fields = world * B * pairs * args.steps
+    own = []
+    dt = timed_steps(step, args.steps, args.warmup, world, torch.cuda.synchronize, barrier, allreduce_max, own=own)
+    log(f"timed region: {args.steps} steps in {dt:.3f}s (this rank: {own[0]:.3f}s)")
+    per_rank = [own[0]]
+    if world > 1:
+        t_own = torch.tensor([own[0]], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
+        t_all = [torch.zeros_like(t_own) for _ in range(world)]
+        dist.all_gather(t_all, t_own)
+        per_rank = [float(t.item()) for t in t_all]
+    clips_all = args.total_clips if strong else world * B
+    fields = clips_all * pairs * args.steps
     result = {
         "metric": "flow_fields_per_sec", "value": fields / dt, "unit": "flow-fields/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
+        "per_rank_ms_per_step": [round(1e3 * t / args.steps, 3) for t in per_rank],
         "dtype": {"fp32": "fp32", "f16x3": "f16x3-split (fp32 accumulate)",
                   "f16x2": ("f16x2 (weights hi+lo, activations fp16; fp32 accumulate)" if not cfg.get("single_layers") else
                             f"f16x2 / f16 mixed (activations fp16; weights fp16 in {len(cfg['single_layers'])} of the 45 "
                             f"contraction / depthwise layers, hi+lo in the rest; fp32 accumulate)"),
                   "f16": "f16 (weights and activations fp16; fp32 accumulate)"}[args.precision] +
                  ("; fp16 correlation volumes" if args.corr_dtype == "f16" else ""), "data": "synthetic",
-        "config": {"workload": f"{args.workload}_{H}x{W}_T{T}_iters{iters}", "clips_per_gpu_per_step": B,
-                   "clips_per_step_all_gpus": world * B,
+        "config": {"workload": f"{args.workload}_{H}x{W}_T{T}_iters{iters}",
+                   "clips_per_gpu_per_step": (B if not strong else None), "clips_per_launch": B,
+                   "clips_per_step_all_gpus": clips_all,
+                   "clips_per_rank": ([len(shard(args.total_clips, world, r)) for r in range(world)] if strong else [B] * world),
+                   "device_pinning": args.pin,
                    "flow_fields_per_clip": pairs, "feature_grid": [h, w], "parallelism": f"replicas{world}",
                    "hip_graph": not args.no_graph, "mask_head_every_iteration": bool(args.all_masks),
                    "preset": args.preset or presets.BENCH_PRESET,
@@ -520,10 +580,10 @@ def main():
             fnet.svt.load_state_dict({k[4:]: v for k, v in syn.make_twins_params(1).items()}, strict=True)
             cnet.svt.load_state_dict({k[4:]: v for k, v in syn.make_twins_params(2).items()}, strict=True)
             frames = (torch.rand(B, T, 3, H, W, generator=torch.Generator().manual_seed(3)) * 2 - 1).to(dev)
-            prev = ops.set_precision(cfg["precision"])
-            try:
+            if True:
                 def encode():
-                    return fnet(frames).float().contiguous(), cnet(frames[:, :-1]).float().contiguous()
+                    return (fnet(frames, precision=cfg["precision"]).float().contiguous(),
+                            cnet(frames[:, :-1], precision=cfg["precision"]).float().contiguous())
                 for _ in range(2):
                     fm, cn = encode()
                 torch.cuda.synchronize()
@@ -540,8 +600,6 @@ def main():
                     eng.forward(fm, cn, iters=iters, all_masks=args.all_masks)
                 torch.cuda.synchronize()
                 t_all = (time.perf_counter() - t0) / 3
-            finally:
-                ops.set_precision(prev)
             result["encoder_ms_per_clip"] = round(1e3 * t_enc / B, 3)
             result["frames_to_flows_per_sec"] = {"value": B * pairs / t_all, "unit": "flow-fields/s", "ms_per_step": 1e3 * t_all,
                                                  "encoder_share": round(t_enc / t_all, 3),

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SF_VERSION 109
+#define SF_VERSION 110
 
 enum {
     SF_OK = 0,

@@ -259,7 +259,7 @@ __global__ __launch_bounds__(kThreads, (PM == 1 && NKS <= 16 && RES == 0) ? 4 : 
                 for (int r = 0; r < 16; ++r) {
                     const int dr = (r & 3) + 8 * (r >> 2);                                // (+ 4 khalf per lane)
                     rf[t][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                        rr, (row0 + dr + 4 * khalf < g.M) ? vo : kOob, base + dr * (int)g.ldr * 4, 0));
+                        rr, (4 * khalf < __builtin_amdgcn_readfirstlane(g.M - row0 - dr)) ? vo : kOob, base + dr * (int)g.ldr * 4, 0));
                 }
             }
         } else if (RES == 2) {
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(kThreads, (PM == 1 && NKS <= 16 && RES == 0) ? 4 : 
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int mr = m * 64 + t * 32 + 8 * j;
-                    rk[t][j] = __builtin_amdgcn_raw_buffer_load_b64(rr, (mr + 4 * khalf < g.M) ? (nc * 16 + khalf * 8) : kOob,
+                    rk[t][j] = __builtin_amdgcn_raw_buffer_load_b64(rr, (4 * khalf < __builtin_amdgcn_readfirstlane(g.M - mr)) ? (nc * 16 + khalf * 8) : kOob,
                                                                     (mr >> 3) * (int)g.ldr * 16, 0);
                 }
         }
@@ -284,26 +284,36 @@ __global__ __launch_bounds__(kThreads, (PM == 1 && NKS <= 16 && RES == 0) ? 4 : 
         c16, 0, (g.c_f16 >= 2) ? (int)((int64_t)((g.M + 7) / 8) * g.ldc * 16) : 0, 0x00020000);
 
     f32x16 acc[TM];
-    auto epilogue = [&](int m, auto epi_tag, auto fast_tag) {
+    // per-lane parts of the store offsets (pixel, k-half); the row part is wave-uniform and travels in the scalar offset
+    const int lane_c32 = (n < g.N) ? (4 * khalf * (int)g.ldc + n) * 4 : kOob;             // fp32 planes: + row * ldc * 4
+    const int lane_k16 = (n < g.N) ? n * 16 + khalf * 8 : kOob;                           // k-octets: + (row / 8) * ldc * 16
+    const int ldc4 = (int)g.ldc * 4;
+    const int k4 = 4 * khalf;
+    // "row rb + e + 4 khalf < M" as  k4 < (M - rb - e)  with the right side forced into a scalar register: written the other
+    // way round, hipcc hoists one per-lane constant PER (tile, group, element) out of the m-loop -- 40 VGPRs of them
+    auto rows_left = [&](int r) { return __builtin_amdgcn_readfirstlane(g.M - r); };
+    // CF = SfGemm.c_f16 (0: fp32 planes, 2: k-octets, 3: both); results that leave as fp16 ONLY take the polynomial GELU of the
+    // two-product modes, like the tiled kernels.  The bias is already in the accumulators (m-step start).
+    auto epilogue = [&](int m, auto epi_tag, auto cf_tag) {
         constexpr int EPI = decltype(epi_tag)::value;
-        constexpr bool kFast = decltype(fast_tag)::value;
+        constexpr int CF = decltype(cf_tag)::value;
+        constexpr bool kFast = (CF == 2);
 #pragma unroll
         for (int t = 0; t < TM; ++t)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int mr = m * 64 + t * 32 + 8 * j + 4 * khalf;                       // first of this lane's 4 consecutive rows
-                const f32x4 bias4 = *reinterpret_cast<const f32x4*>(sbias + mr);
+                const int rb = m * 64 + t * 32 + 8 * j;                                   // (wave-uniform) this lane's rows: rb + 4 khalf + 0..3
                 f32x4 dw4 = {0.f, 0.f, 0.f, 0.f}, db4 = {0.f, 0.f, 0.f, 0.f};
                 if (EPI == SF_EPI_RES_GELU_DW1) {
-                    dw4 = *reinterpret_cast<const f32x4*>(sdww + mr);
-                    db4 = *reinterpret_cast<const f32x4*>(sdwb + mr);
+                    dw4 = *reinterpret_cast<const f32x4*>(sdww + rb + 4 * khalf);
+                    db4 = *reinterpret_cast<const f32x4*>(sdwb + rb + 4 * khalf);
                 }
                 float o[4];
 #pragma unroll
                 for (int e = 0; e < 4; e += 2) {
                     f32x2 v, r = {0.f, 0.f}, dww, dwb;
-                    v[0] = g.alpha * (acc[t][4 * j + e] + bias4[e]);
-                    v[1] = g.alpha * (acc[t][4 * j + e + 1] + bias4[e + 1]);
+                    v[0] = g.alpha * acc[t][4 * j + e];
+                    v[1] = g.alpha * acc[t][4 * j + e + 1];
                     if (RES == 1) { r[0] = rf[t][4 * j + e]; r[1] = rf[t][4 * j + e + 1]; }
                     if (RES == 2) {
                         const unsigned u = rk[t][j][e >> 1];
@@ -314,50 +324,53 @@ __global__ __launch_bounds__(kThreads, (PM == 1 && NKS <= 16 && RES == 0) ? 4 : 
                     const f32x2 res = epi2<EPI, kFast>(v, r, dww, dwb, gam);
                     o[e] = res[0]; o[e + 1] = res[1];
                 }
-                if (g.c_f16 != 2) {                                                       // fp32 planes: 128-byte row segments
+                if (CF != 2) {                                                            // fp32 planes: 128-byte row segments
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o[e]), rc32,
-                                                              (n < g.N && mr + e < g.M) ? ((mr + e) * (int)g.ldc + n) * 4 : kOob, 0, 0);
+                                                              (k4 < rows_left(rb + e)) ? lane_c32 : kOob, (rb + e) * ldc4, 0);
                 }
-                if (g.c_f16 >= 2) {                                                       // k-octets: 8 bytes = rows mr .. mr + 3 of pixel n
+                if (CF >= 2) {                                                            // k-octets: 8 bytes = 4 rows of pixel n
                     f16x4 h;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) h[e] = (_Float16)o[e];
-                    const int off = ((mr >> 3) * (int)g.ldc + n) * 16 + (mr & 7) * 2;
-                    const bool full = (g.c_f16 == 2) ? (mr < g.M) : (mr + 4 <= g.M);      // c_f16 = 3: rows >= M belong to someone else
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, h), rc16, (n < g.N && full) ? off : kOob, 0, 0);
-                    if (g.c_f16 == 3 && mr < g.M && mr + 4 > g.M) {                       // partial last group (e.g. M = 126): row by row
+                    const int so = (rb >> 3) * ldc4 * 4;
+                    // CF = 3: rows >= M of a last octet belong to someone else (flow rows of the motion features)
+                    const bool full = (CF == 2) ? (k4 < rows_left(rb)) : (k4 < rows_left(rb + 3));
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, h), rc16, full ? lane_k16 : kOob, so, 0);
+                    if (CF == 3 && (g.M & 3) && rb + 8 > g.M && rb < g.M) {               // (wave-uniform) partial last group: row by row
 #pragma unroll
                         for (int e = 0; e < 3; ++e) {
                             const _Float16 he = h[e];                    // (bit_cast of a vector element lvalue reads element 0)
+                            const bool part = k4 < rows_left(rb) && !(k4 < rows_left(rb + 3)) && k4 < rows_left(rb + e);
                             __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, he), rc16,
-                                                                  (n < g.N && mr + e < g.M) ? off + e * 2 : kOob, 0, 0);
+                                                                  part ? lane_k16 + e * 2 : kOob, so, 0);
                         }
                     }
                 }
+                // one group at a time: scheduled together, the eight groups of an m-step keep ~50 more registers alive than
+                // the activation fragments leave room for (K = 640: spills)
+                __builtin_amdgcn_sched_barrier(0);
             }
     };
-    auto run_epilogue = [&](int m) {
-        // (results that leave as fp16 ONLY take the polynomial GELU of the two-product modes, like the tiled kernels)
+    auto run_cf = [&](int m, auto epi_tag) {
         using std::integral_constant;
-        const bool fast = g.c_f16 == 2;
+        constexpr int EPI = decltype(epi_tag)::value;
+        constexpr bool kKoctOnly = (EPI == SF_EPI_NONE || EPI == SF_EPI_GELU || EPI == SF_EPI_RES_GELU);   // (host-checked)
+        if (kKoctOnly && g.c_f16 == 2) epilogue(m, epi_tag, integral_constant<int, 2>{});
+        else if (g.c_f16 == 3) epilogue(m, epi_tag, integral_constant<int, 3>{});
+        else epilogue(m, epi_tag, integral_constant<int, 0>{});
+    };
+    auto run_epilogue = [&](int m) {
+        using std::integral_constant;
         switch (g.epilogue) {                                                             // wave-uniform
-            case SF_EPI_GELU:
-                if (fast) epilogue(m, integral_constant<int, SF_EPI_GELU>{}, integral_constant<bool, true>{});
-                else epilogue(m, integral_constant<int, SF_EPI_GELU>{}, integral_constant<bool, false>{});
-                break;
-            case SF_EPI_RELU: epilogue(m, integral_constant<int, SF_EPI_RELU>{}, integral_constant<bool, false>{}); break;
-            case SF_EPI_RES: if (RES) epilogue(m, integral_constant<int, SF_EPI_RES>{}, integral_constant<bool, false>{}); break;
-            case SF_EPI_RES_GELU:
-                if (RES) {
-                    if (fast) epilogue(m, integral_constant<int, SF_EPI_RES_GELU>{}, integral_constant<bool, true>{});
-                    else epilogue(m, integral_constant<int, SF_EPI_RES_GELU>{}, integral_constant<bool, false>{});
-                }
-                break;
-            case SF_EPI_RES_GELU_DW1: if (RES) epilogue(m, integral_constant<int, SF_EPI_RES_GELU_DW1>{}, integral_constant<bool, false>{}); break;
-            case SF_EPI_AXPY: if (RES) epilogue(m, integral_constant<int, SF_EPI_AXPY>{}, integral_constant<bool, false>{}); break;
-            default: epilogue(m, integral_constant<int, SF_EPI_NONE>{}, integral_constant<bool, false>{}); break;
+            case SF_EPI_GELU: run_cf(m, integral_constant<int, SF_EPI_GELU>{}); break;
+            case SF_EPI_RELU: run_cf(m, integral_constant<int, SF_EPI_RELU>{}); break;
+            case SF_EPI_RES: if (RES) run_cf(m, integral_constant<int, SF_EPI_RES>{}); break;
+            case SF_EPI_RES_GELU: if (RES) run_cf(m, integral_constant<int, SF_EPI_RES_GELU>{}); break;
+            case SF_EPI_RES_GELU_DW1: if (RES) run_cf(m, integral_constant<int, SF_EPI_RES_GELU_DW1>{}); break;
+            case SF_EPI_AXPY: if (RES) run_cf(m, integral_constant<int, SF_EPI_AXPY>{}); break;
+            default: run_cf(m, integral_constant<int, SF_EPI_NONE>{}); break;
         }
     };
 
@@ -372,10 +385,15 @@ __global__ __launch_bounds__(kThreads, (PM == 1 && NKS <= 16 && RES == 0) ? 4 : 
     int slot = 0;
     const char* sa_base = smem + (khalf * 64 + l31) * 16;
     for (int m = ms_beg; m < ms_end; ++m) {
+        // accumulators start at the bias (LDS copy; rows >= M: zero): v = alpha * (acc + bias) needs no parameter in the epilogue
 #pragma unroll
         for (int t = 0; t < TM; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(sbias + m * 64 + t * 32 + 8 * j + 4 * khalf);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[t][4 * j + e] = b4[e];
+            }
         load_res(m);
         __builtin_amdgcn_sched_barrier(0);                         // (the counted waits below assume this issue order)
 #pragma unroll
@@ -473,6 +491,7 @@ bool gemm_bstat_ok(const SfGemm& g) {
     if (g.a_layout != SF_LAYOUT_SPLIT_F16 || g.conv3x3 || g.k_splits > 1) return false;
     if (g.b_layout != SF_LAYOUT_F16_KOCT && g.b_layout != SF_LAYOUT_K_MAJOR && g.b_layout != SF_LAYOUT_F16_K_MAJOR) return false;
     if (g.K <= 64 || g.K > 640 || g.M > kParamRows || g.c_f16 == 1) return false;
+    if (g.c_f16 == 2 && g.epilogue != SF_EPI_NONE && g.epilogue != SF_EPI_GELU && g.epilogue != SF_EPI_RES_GELU) return false;
     if (g.b_layout == SF_LAYOUT_F16_K_MAJOR && g.b_group) return false;
     if (g.b_group % 32 || g.r_group % 32) return false;
     if (g.a_k_pad < 128 || g.a_k_pad % 128) return false;               // weight planes must reach K rounded up to 128

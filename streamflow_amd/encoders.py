@@ -129,6 +129,8 @@ class Twins_CSC(nn.Module):
         self.svt = _Svt()
         self._pack = None
         self._pack_key = None
+        self.koct_handover = True        # fp16 k-octet hand-over between the kernels in the two-product / fp16 classes
+        self.exact_attention = False     # the exact-fp32 VALU attention cores in every class (tests)
 
     def _packed(self, device):
         from . import ops
@@ -148,9 +150,13 @@ class Twins_CSC(nn.Module):
         return self._pack
 
     @torch.no_grad()
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, precision=None) -> torch.Tensor:
+        """precision: 'fp32' | 'f16x3' | 'f16x2' | 'f16' (or the integer constant): the arithmetic class of this call; None = the
+        package default (ops.PRECISION).  Passed explicitly to every launch: the module keeps no launch state."""
         from . import ops
         from .ops import EPI_GELU, EPI_NONE, EPI_RES, Planes
+        prec = ops.PRECISION if precision is None else (ops._PRECISION_NAMES[precision] if isinstance(precision, str) else int(precision))
+        cx0 = ops.Ctx(prec)
         x = x.float().contiguous()
         ops._dev_check(x)
         B, T, C, H, W = x.shape
@@ -163,8 +169,7 @@ class Twins_CSC(nn.Module):
             # fp16 k-octet planes [rows/8][n][8] (ops.Planes.koct): in the two-product / fp16 classes every tensor that only
             # feeds a GEMM (LayerNorm outputs, attention outputs, the MLP hidden) is handed over as the consumer's operand
             # image, exactly as in the refinement loop; the fp32-class modes keep fp32 planes throughout
-            handover = (ops.PRECISION in (ops.PRECISION_F16X2, ops.PRECISION_F16) and (T * H * W) % 256 == 0
-                        and os.environ.get("SF_ENCODER_KOCT", "1") != "0")
+            handover = prec in (ops.PRECISION_F16X2, ops.PRECISION_F16) and (T * H * W) % 256 == 0 and self.koct_handover
 
             def newk(rows, n):
                 if not handover:
@@ -182,13 +187,9 @@ class Twins_CSC(nn.Module):
             def lin(name, X, epi=EPI_NONE, R=None, koct=False):
                 A = pk[name]
                 Y = newk(A.M, X.P) if koct else new(A.M, X.P)
-                need = ops.gemm_split_ws_floats(A.M, X.P, A.K, B)      # skinny outputs over a deep K (the sr convs): split-K
-                prev = ops.SPLIT_WS
-                ops.SPLIT_WS = torch.empty(need, dtype=torch.float32, device=dev) if need else None
-                try:
-                    ops.gemm(A, X, Y, epi, R=R)
-                finally:
-                    ops.SPLIT_WS = prev
+                need = ops.gemm_split_ws_floats(A.M, X.P, A.K, B, cx=cx0)   # skinny outputs over a deep K (the sr convs): split-K
+                ws = torch.empty(need, dtype=torch.float32, device=dev) if need else None
+                ops.gemm(A, X, Y, epi, R=R, cx=ops.Ctx(prec, split_ws=ws))
                 return Y
 
             grid = x.permute(0, 2, 1, 3, 4).reshape(B, C, T * H, W)     # frames stacked along the height (twins_csc.py:30-32)
@@ -202,7 +203,7 @@ class Twins_CSC(nn.Module):
                 b0 = f"blocks.{i}.0"
                 qkv = lin(b0 + ".attn.qkv", ln(tok, b0 + ".norm1", koct=True), koct=True)
                 att = newk(E, N)
-                ops.window_attn(qkv, pk["qkv_bias"][i], att, heads, gh, gw, self.WS)
+                ops.window_attn(qkv, pk["qkv_bias"][i], att, heads, gh, gw, self.WS, cx=cx0, exact=self.exact_attention)
                 tok = lin(b0 + ".attn.proj", att, EPI_RES, R=tok)
                 tok = lin(b0 + ".mlp.fc2", lin(b0 + ".mlp.fc1", ln(tok, b0 + ".norm2", koct=True), EPI_GELU, koct=True), EPI_RES, R=tok)
                 # positional conv after the first block (twins_csc.py:73-74)
@@ -217,7 +218,7 @@ class Twins_CSC(nn.Module):
                 s = lin(b1 + ".attn.sr", Planes.of(_im2col(y.tensor().view(B, E, gh, gw), sr)))
                 kv = lin(b1 + ".attn.kv", ln(s, b1 + ".attn.norm"))
                 att = newk(E, N)
-                ops.subsample_attn(q, kv, att, heads)
+                ops.subsample_attn(q, kv, att, heads, cx=cx0, exact=self.exact_attention)
                 tok = lin(b1 + ".attn.proj", att, EPI_RES, R=tok)
                 tok = lin(b1 + ".mlp.fc2", lin(b1 + ".mlp.fc1", ln(tok, b1 + ".norm2", koct=True), EPI_GELU, koct=True), EPI_RES, R=tok)
                 grid = tok.tensor().view(B, E, gh, gw)

@@ -14,7 +14,7 @@ from __future__ import annotations
 
 import contextlib
 import os
-from dataclasses import replace
+from dataclasses import dataclass, fields, replace
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -25,6 +25,42 @@ from .ops import (EPI_AXPY, EPI_GELU, EPI_NONE, EPI_RELU, EPI_RES, EPI_RES_GELU,
 
 HDIM = 128
 COR_PLANES = 324
+
+
+@dataclass(frozen=True)
+class EngineOptions:
+    """Scheduling and hand-over switches of HotPathEngine (the A/B knobs that used to be environment variables).  Results are
+    the same arithmetic under every setting unless noted; every field is part of the engine's graph key.
+    `HotPathEngine(options=EngineOptions(split_solo=0))`, or from the shell for an experiment: SF_ENGINE_OPTS="split_solo=0,pw_fold=0"."""
+    parallel_branches: bool = True   # independent chains of an iteration on a second stream
+    split_solo: int = 2              # 0 / 2 / 4: sections without a concurrent branch run as half-batch chains on own streams
+    auto_split_k: bool = True        # let sf_gemm split K for small grids (changes summation order at toy shapes only)
+    attn_chunk_rows: int = 0         # > 0 forces the chunked recompute of the attention matrix
+    attn_k_splits: int = 3           # split-K of attn @ v (materialised matrix), <= 4
+    corr_blocked: bool = True        # fp16 volumes in the blocked layout (k-octet-only hand-over of the correlation features)
+    shadows: bool = True             # fp16 k-octet copies of the SK blocks' inputs
+    shadow_fused: bool = True        # ... written by their producers' epilogues instead of a pack pass
+    hidden_f16: bool = True          # GEMM-to-GEMM tensors as fp16 in the f16x2 / f16 modes
+    hidden_koct: bool = True         # ... as k-octet planes where the consumer takes them
+    pw_fold: bool = True             # pw residual folded into the weights (x3 handed over in fp16)
+    flash_stats: bool = True         # fused GMA: softmax statistics computed once per clip
+    max_plans: int = 4               # buffer sets (and graphs) kept, least recently used evicted
+
+    @staticmethod
+    def from_env(base: Optional["EngineOptions"] = None) -> "EngineOptions":
+        opt = base or EngineOptions()
+        spec = os.environ.get("SF_ENGINE_OPTS", "")
+        if not spec:
+            return opt
+        types = {f.name: f.type for f in fields(EngineOptions)}
+        kw = {}
+        for item in spec.split(","):
+            k, _, v = item.partition("=")
+            k = k.strip()
+            if k not in types:
+                raise RuntimeError(f"SF_ENGINE_OPTS: unknown option {k!r} (have {sorted(types)})")
+            kw[k] = (v.strip() not in ("0", "false", "False", "")) if types[k] in (bool, "bool") else int(v)
+        return replace(opt, **kw)
 
 
 class SKBlockWeights:
@@ -64,13 +100,13 @@ def _scratch(buf: Planes, n_img: int, rows: int, f16: bool = False, koct: bool =
     return Planes(buf.base, buf.off, rows_alloc * buf.P, n_img, rows, buf.P, f16=f16, koct=f16 and koct)
 
 
-def _handover(buf: Planes, n_img: int, rows: int, P: int, consumer_rows: int, allow_koct: bool = True) -> Planes:
+def _handover(cx: ops.Ctx, buf: Planes, n_img: int, rows: int, P: int, consumer_rows: int, allow_koct: bool = True) -> Planes:
     # (rows = K of the consuming layer, consumer_rows = its M)
     """Scratch view for a tensor that is written by one GEMM and read only as the B operand of the next: fp32 planes in
     the exact / f16x3 modes; in f16x2 fp16 values -- as k-octet planes when the consumer runs on the DMA-fed 128-row tile
     (both of its operands then go HBM/L2 -> LDS without touching registers), as fp16 rows otherwise."""
-    f16 = hidden_f16_ok(P)
-    koct = f16 and allow_koct and ops.takes_koct(consumer_rows, rows) and os.environ.get("SF_HIDDEN_KOCT", "1") != "0"
+    f16 = hidden_f16_ok(cx, P)
+    koct = f16 and allow_koct and ops.takes_koct(consumer_rows, rows) and cx.hidden_koct
     return _scratch(buf, n_img, rows, f16=f16, koct=koct)
 
 
@@ -88,42 +124,42 @@ def _part(buf: Planes, i0: int, cnt: int) -> Planes:
     return replace(buf, off=buf.off + i0 * buf.img_stride, n_img=cnt)
 
 
-def hidden_f16_ok(P: int) -> bool:
+def hidden_f16_ok(cx: ops.Ctx, P: int) -> bool:
     """FFN hidden activations are handed from GEMM to GEMM as fp16 in the f16x2 mode (bit-identical: that mode rounds a
     B operand to fp16 on load anyway) when the plane geometry allows 8-byte stores / dword loads."""
-    return (ops.PRECISION in (ops.PRECISION_F16X2, ops.PRECISION_F16) and P % 4 == 0 and
-            os.environ.get("SF_HIDDEN_F16", "1") != "0")
+    return cx.precision in (ops.PRECISION_F16X2, ops.PRECISION_F16) and P % 4 == 0 and cx.hidden_f16
 
 
 def run_skblock(W: SKBlockWeights, X: Planes, Y: Planes, hid: Planes, xa: Planes, xb: Planes, h: int, w: int,
-                final_gelu: bool = False) -> None:
+                final_gelu: bool = False, cx: Optional[ops.Ctx] = None) -> None:
     """One PCBlock4_Deep_nopool_res forward, op order of reference update.py:30-36:
     x1 = gelu(x + ffn1(x)); x2 = gelu(x1 + dw1x1(x1)); x3 = gelu(x2 + dwKxK(x2)); x4 = gelu(x3 + pw(x3));
     y = ffn2(x4).  hid/xa/xb are scratch allocations (capacity >= n_img*c_mid / n_img*c_in rows)."""
+    cx = ops._cx(cx)
     C = W.c_in
     assert X.rows == C and Y.rows == W.c_out and X.n_img == Y.n_img
     a, b = _scratch(xa, X.n_img, C), _scratch(xb, X.n_img, C)
-    hidden = _handover(hid, X.n_img, W.c_mid, X.P, consumer_rows=C)                 # ffn1.0 -> ffn1.2
-    ops.gemm(W.ffn1_0, X, hidden, EPI_GELU)
+    hidden = _handover(cx, hid, X.n_img, W.c_mid, X.P, consumer_rows=C)             # ffn1.0 -> ffn1.2
+    ops.gemm(W.ffn1_0, X, hidden, EPI_GELU, cx=cx)
     # x1 = gelu(x + ffn1(x)); x2 = gelu(x1 + dw1x1(x1))  (both fused in the epilogue)
-    ops.gemm(W.ffn1_2, hidden, a, EPI_RES_GELU_DW1, R=X, dw_w=W.dw1_w, dw_b=W.dw1_b)
+    ops.gemm(W.ffn1_2, hidden, a, EPI_RES_GELU_DW1, R=X, dw_w=W.dw1_w, dw_b=W.dw1_b, cx=cx)
     # x4 is read by ffn2.0 only: the same GEMM-to-GEMM hand-over as the hidden activations (x2 in `xa` is dead by now)
-    if hidden_f16_ok(X.P) and os.environ.get("SF_PW_FOLD", "1") != "0":
+    if hidden_f16_ok(cx, X.P) and cx.pw_fold:
         # x3 in fp16 rows straight out of the depthwise kernel, residual folded into the pw weights: the pw GEMM reads half
         # the bytes, has a residual-free epilogue and may therefore write k-octets
         b16 = _scratch(xb, X.n_img, C, f16=True)
-        ops.dwconv_res_gelu(a, W.dwk_w, W.dwk_b, b16, h, w, W.k, single=W.dw_single)   # x3 = gelu(x2 + dwKxK(x2))
-        a4 = _handover(xa, X.n_img, C, X.P, consumer_rows=W.c_mid)
-        ops.gemm(W.pw_res, b16, a4, EPI_GELU)                                   # x4 = gelu((pw + I) x3)
+        ops.dwconv_res_gelu(a, W.dwk_w, W.dwk_b, b16, h, w, W.k, single=W.dw_single, cx=cx)   # x3 = gelu(x2 + dwKxK(x2))
+        a4 = _handover(cx, xa, X.n_img, C, X.P, consumer_rows=W.c_mid)
+        ops.gemm(W.pw_res, b16, a4, EPI_GELU, cx=cx)                            # x4 = gelu((pw + I) x3)
     else:
-        ops.dwconv_res_gelu(a, W.dwk_w, W.dwk_b, b, h, w, W.k, single=W.dw_single)   # x3 = gelu(x2 + dwKxK(x2))
+        ops.dwconv_res_gelu(a, W.dwk_w, W.dwk_b, b, h, w, W.k, single=W.dw_single, cx=cx)   # x3 = gelu(x2 + dwKxK(x2))
         # (fp16 ROWS, not k-octets: the k-octet epilogue fetches its residual with 8 dword loads per octet and made the
         # pw GEMMs 15-20 % slower -- more than their consumers gained)
-        a4 = _handover(xa, X.n_img, C, X.P, consumer_rows=W.c_mid, allow_koct=False)
-        ops.gemm(W.pw, b, a4, EPI_RES_GELU, R=b)                                # x4 = gelu(x3 + pw(x3))
-    hidden = _handover(hid, X.n_img, W.c_mid, X.P, consumer_rows=W.c_out)           # ffn2.0 -> ffn2.2
-    ops.gemm(W.ffn2_0, a4, hidden, EPI_GELU)
-    ops.gemm(W.ffn2_2, hidden, Y, EPI_GELU if final_gelu else EPI_NONE)
+        a4 = _handover(cx, xa, X.n_img, C, X.P, consumer_rows=W.c_mid, allow_koct=False)
+        ops.gemm(W.pw, b, a4, EPI_RES_GELU, R=b, cx=cx)                         # x4 = gelu(x3 + pw(x3))
+    hidden = _handover(cx, hid, X.n_img, W.c_mid, X.P, consumer_rows=W.c_out)       # ffn2.0 -> ffn2.2
+    ops.gemm(W.ffn2_0, a4, hidden, EPI_GELU, cx=cx)
+    ops.gemm(W.ffn2_2, hidden, Y, EPI_GELU if final_gelu else EPI_NONE, cx=cx)
 
 
 class HotPathWeights:
@@ -297,7 +333,7 @@ class HotPathEngine:
     def __init__(self, state_dict: Dict[str, torch.Tensor], device="cuda:0", T: Optional[int] = None,
                  use_graph: bool = False, precision: Optional[str] = None, corr_dtype: str = "f32",
                  gma_mode: Optional[str] = None, flash_qk_products: Optional[int] = None,
-                 single_layers: Optional[Sequence[str]] = None):
+                 single_layers: Optional[Sequence[str]] = None, options: Optional[EngineOptions] = None):
         """precision: 'f16x3' (split fp16, fp32-class accuracy, default), 'fp32' (exact fp32 MFMA), 'f16x2'
         (weights split, activations rounded to fp16: ~1e-4 px EPE, faster) or 'f16' (weights and activations fp16);
         None = the package-wide setting (streamflow_amd.ops.PRECISION).
@@ -306,33 +342,35 @@ class HotPathEngine:
         gma_mode: 'matrix' = attention matrix materialised once per clip (gma.py), 'flash' = fused recompute kernel every
         iteration (demo.py:235-258), 'auto' (default) = flash exactly when the matrix cannot be kept (high resolution).
         flash_qk_products: MFMA products per logit of the fused kernel (3 = split precision, 1 = fp16 q and k).
-        See streamflow_amd.presets for the two named configurations."""
+        options: scheduling / hand-over switches (EngineOptions; SF_ENGINE_OPTS overrides single fields for experiments).
+        See streamflow_amd.presets for the named configurations."""
         _lib.load()
+        self.options = EngineOptions.from_env(options)
         self.precision = ops.PRECISION if precision is None else ops._PRECISION_NAMES[precision]
         if corr_dtype not in ("f32", "f16"):
             raise RuntimeError(f"corr_dtype must be 'f32' or 'f16', got {corr_dtype!r}")
         self.corr_f16 = corr_dtype == "f16"
         # fp16 volumes in the blocked layout (+ k-octet-only hand-over of the correlation features) wherever the f16x2 / f16
-        # hand-over formats are active; SF_CORR_BLOCKED=0 keeps the row-major fp16 volumes (A/B knob)
-        self.corr_blocked = self.corr_f16 and os.environ.get("SF_CORR_BLOCKED", "1") != "0"
+        # hand-over formats are active; options.corr_blocked = False keeps the row-major fp16 volumes
+        self.corr_blocked = self.corr_f16 and self.options.corr_blocked
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("HotPathEngine needs an MI355X device (cuda:N); there is no CPU fallback")
         # independent chains of one iteration (flow branch || corr branch of the motion encoder; temporal block ||
         # global aggregation) are enqueued on a second stream, so the tails of one chain's small kernels are
         # filled by the other; inside a captured graph these become parallel branches.
-        self.parallel_branches = True
-        self.auto_split_k = os.environ.get("SF_AUTO_SPLITK", "1") != "0"
-        self.attn_chunk_rows = int(os.environ.get("SF_ATTN_CHUNK_ROWS", "0"))  # > 0 forces the recompute path
-        self.attn_k_splits = min(4, int(os.environ.get("SF_ATTN_KSPLITS", "3")))     # 1 = no split-K (<= 4)
+        self.parallel_branches = self.options.parallel_branches
+        self.auto_split_k = self.options.auto_split_k
+        self.attn_chunk_rows = int(self.options.attn_chunk_rows)            # > 0 forces the recompute path
+        self.attn_k_splits = min(4, int(self.options.attn_k_splits))        # 1 = no split-K (<= 4)
         # GMA aggregation: 'matrix' = attention matrix materialised once (gma.py), chunked recompute when it cannot be
         # kept; 'flash' = fused recompute kernel every iteration (demo.py:235-258); 'auto' = flash exactly when the
         # matrix would have to be chunked (high resolution)
-        self.gma_mode = gma_mode or os.environ.get("SF_GMA_MODE", "auto")
+        self.gma_mode = gma_mode or "auto"
         if self.gma_mode not in ("auto", "matrix", "flash"):
             raise RuntimeError(f"gma_mode must be auto, matrix or flash, got {self.gma_mode!r}")
         # MFMA products per logit of the fused kernel: 3 = split precision (fp32-class), 2 / 1 = k / q and k in fp16
-        self.flash_qk_products = (int(flash_qk_products or 0) or int(os.environ.get("SF_FLASH_QKP", "0"))
+        self.flash_qk_products = (int(flash_qk_products or 0)
                                   or {ops.PRECISION_F16X2: 2, ops.PRECISION_F16: 1}.get(self.precision, 3))
         if self.flash_qk_products not in (1, 2, 3):
             raise RuntimeError(f"flash_qk_products must be 1, 2 or 3, got {self.flash_qk_products}")
@@ -340,15 +378,15 @@ class HotPathEngine:
         self._chain_streams = [torch.cuda.Stream(device=self.device) for _ in range(3)]
         # Where the main stream has no concurrent branch (corr encoder, motion-encoder tail, GRU + flow head) a batch of an
         # even number of clips is cut in two halves that run as two chains on two streams: a dependent kernel boundary costs
-        # ~8 us on this part and each chain hides the other's.  SF_SPLIT_SOLO = 0 / 2 / 4 chains.
-        self.split_solo = int(os.environ.get("SF_SPLIT_SOLO", "2"))
+        # ~8 us on this part and each chain hides the other's.  options.split_solo = 0 / 2 / 4 chains.
+        self.split_solo = int(self.options.split_solo)
         self.W = HotPathWeights(state_dict, self.device, T)
         # layers whose weights are used as ONE fp16 value in the f16x2 mode (see presets.py: chosen by measured EPE)
         self.single_layers = tuple(single_layers or ())
         self.W.set_single("all" if self.single_layers == ("all",) else self.single_layers)
         self.use_graph = use_graph
         self._plans: Dict[Tuple[int, int, int, int], _Plan] = {}
-        self.max_plans = int(os.environ.get("SF_MAX_PLANS", "4"))
+        self.max_plans = int(self.options.max_plans)
 
     # ---------------------------------------------------------------------------------------------
     def plan(self, Bc: int, h: int, w: int, D: int) -> _Plan:
@@ -365,18 +403,26 @@ class HotPathEngine:
                                    "the materialised / chunked attention path")
             flash = {"auto": None, "matrix": False, "flash": True}[self.gma_mode]
             pl = _Plan(self.W, Bc, h, w, D, self.device, self.attn_chunk_rows, attn_f16=split, corr_f16=self.corr_f16,
-                       flash=flash, shadows=(ops.SHADOWS and (h * w) % 4 == 0 and
+                       flash=flash, shadows=(self.options.shadows and (h * w) % 4 == 0 and
                                              self.precision in (ops.PRECISION_F16X2, ops.PRECISION_F16) and
-                                             os.environ.get("SF_HIDDEN_F16", "1") != "0"),
+                                             self.options.hidden_f16),
                        corr_blocked=self.corr_blocked)
         self._plans[key] = pl                                        # (re)insert as most recent
         return pl
 
     # ---------------------------------------------------------------------------------------------
-    def _attention_rows(self, pl: _Plan, i0: int, rows: int) -> None:
+    def _ctx(self, pl: _Plan) -> ops.Ctx:
+        """The launch context of one forward over plan `pl`: passed to every op (no process-wide launch state)."""
+        o = self.options
+        return ops.Ctx(precision=self.precision,
+                       split_ws=pl.splitws.tensor().view(-1) if self.auto_split_k else None,
+                       shadows=o.shadows, shadow_fused=o.shadow_fused, flash_stats=o.flash_stats,
+                       hidden_f16=o.hidden_f16, hidden_koct=o.hidden_koct, pw_fold=o.pw_fold)
+
+    def _attention_rows(self, cx: ops.Ctx, pl: _Plan, i0: int, rows: int) -> None:
         """attn[:, :rows, :] = softmax(scale * q[:, i0:i0+rows]^T k)   (gma.py:53-65) for every image."""
         P, n = pl.P, pl.n
-        ops.gemm_raw(A=pl.qk.ptr + 4 * i0, B=pl.qk.ptr + 4 * HDIM * P, C=pl.attn.data_ptr(), M=rows, N=P, K=HDIM,
+        ops.gemm_raw(cx, A=pl.qk.ptr + 4 * i0, B=pl.qk.ptr + 4 * HDIM * P, C=pl.attn.data_ptr(), M=rows, N=P, K=HDIM,
                      batch=n, lda=P, ldb=P, ldc=P, strideA=pl.qk.img_stride, strideB=pl.qk.img_stride,
                      strideC=pl.attn_rows * P, a_layout=LAYOUT_K_MAJOR, b_layout=LAYOUT_K_MAJOR,
                      alpha=float(HDIM) ** -0.5, epilogue=EPI_NONE)
@@ -387,7 +433,7 @@ class HotPathEngine:
                 ops.softmax_rows(pl.attn[img], rows, P, out16=None if pl.attn16 is None else pl.attn16[img])
 
     # ---------------------------------------------------------------------------------------------
-    def _setup(self, pl: _Plan, fmaps: torch.Tensor, cnets: torch.Tensor) -> None:
+    def _setup(self, cx: ops.Ctx, pl: _Plan, fmaps: torch.Tensor, cnets: torch.Tensor) -> None:
         """Everything before the iteration loop: volumes, context split, GMA attention matrix."""
         W = self.W
         Bc, Pn, h, w, P, n, D = pl.Bc, pl.Pn, pl.h, pl.w, pl.P, pl.n, pl.D
@@ -398,25 +444,27 @@ class HotPathEngine:
                                    ws=pl.corr_ws)
         else:
             ops.corr_build(fmaps.data_ptr(), fmaps.data_ptr() + 4 * D * P, T * D * P, D * P, pl.lvls, pl.lvl_pair_stride,
-                           Bc, Pn, D, h, w, ws=pl.corr_ws)
+                           Bc, Pn, D, h, w, ws=pl.corr_ws, cx=cx)
         # streamflow.py:119-122: nets = tanh(.), inps = relu(.)
         ops.context_split(cnets, pl.nets, pl.inps, HDIM)
-        ops.refresh_shadow(pl.nets)
-        ops.refresh_shadow(pl.inps)
+        ops.refresh_shadow(pl.nets, cx)
+        ops.refresh_shadow(pl.inps, cx)
         # a6: attn = softmax(scale * q k^T) over the context features (gma.py:53-65), computed once
-        ops.gemm(W.to_qk, pl.inps, pl.qk, EPI_NONE)
+        ops.gemm(W.to_qk, pl.inps, pl.qk, EPI_NONE, cx=cx)
         if pl.flash:
             # q, k are constant over the loop: packed once, and the softmax statistics of every query with them
-            ops.gma_flash_pack_qk(pl.qk, pl.flash_ws, float(HDIM) ** -0.5, stats_qk_products=self.flash_qk_products)
+            ops.gma_flash_pack_qk(pl.qk, pl.flash_ws, float(HDIM) ** -0.5, stats_qk_products=self.flash_qk_products, cx=cx)
         elif pl.attn_rows == P:
-            self._attention_rows(pl, 0, P)
+            self._attention_rows(cx, pl, 0, P)
 
-    def _iteration(self, pl: _Plan, with_mask: bool) -> None:
+    def _iteration(self, cx: ops.Ctx, pl: _Plan, with_mask: bool) -> None:
         W = self.W
         Bc, Pn, h, w, P, n = pl.Bc, pl.Pn, pl.h, pl.w, pl.P, pl.n
-        sk = lambda Wt, X, Y, fg=False: run_skblock(Wt, X, Y, pl.hid, pl.xa, pl.xb, h, w, fg)
+        sk = lambda Wt, X, Y, fg=False: run_skblock(Wt, X, Y, pl.hid, pl.xa, pl.xb, h, w, fg, cx=cx)
         main = torch.cuda.current_stream()
         side = self._side if self.parallel_branches else main
+        # the automatic split-K scratch is ONE buffer: only the main stream may use it while two streams run concurrently
+        cs = cx.no_split() if side is not main else cx
 
         def fork():
             if side is not main:
@@ -424,16 +472,8 @@ class HotPathEngine:
 
         @contextlib.contextmanager
         def on_side():
-            # the automatic split-K scratch (ops.SPLIT_WS) is ONE buffer: only the main stream may use it while
-            # the two streams run concurrently
-            keep = ops.SPLIT_WS
-            if side is not main:
-                ops.SPLIT_WS = None
-            try:
-                with torch.cuda.stream(side):
-                    yield
-            finally:
-                ops.SPLIT_WS = keep
+            with torch.cuda.stream(side):
+                yield
 
         def join():
             if side is not main:
@@ -442,13 +482,13 @@ class HotPathEngine:
         # a9: motion encoder (update.py:329-339).  flow branch (convf1 -> convf2) on the side stream ...
         fork()
         with on_side():
-            ops.gemm(W.convf1, pl.flow, pl.f128, EPI_NONE)
-            run_skblock(W.convf2, pl.f128, pl.cat256.slice(192, 256), pl.hid2, pl.xa2, pl.xb2, h, w)
+            ops.gemm(W.convf1, pl.flow, pl.f128, EPI_NONE, cx=cs)
+            run_skblock(W.convf2, pl.f128, pl.cat256.slice(192, 256), pl.hid2, pl.xa2, pl.xb2, h, w, cx=cs)
         # ... while the main stream does a3 (correlation lookup for all pairs, streamflow.py:132) and the corr branch
         if pl.corr_blocked:
             ops.corr_lookup_blocked(pl.vol, pl.coords1, None, pl.corr, Bc, Pn)
         else:
-            ops.corr_lookup(pl.lvls, pl.lvl_pair_stride, pl.coords1, pl.corr, Bc, Pn, h, w)
+            ops.corr_lookup(pl.lvls, pl.lvl_pair_stride, pl.coords1, pl.corr, Bc, Pn, h, w, cx=cx)
         # image ranges of the chains: whole clips when the clip count divides, else (a single clip, an odd batch) two
         # ranges of images -- every block but the flow head works image by image
         nch = self.split_solo if (self.split_solo in (2, 4) and side is not main) else 1
@@ -460,31 +500,28 @@ class HotPathEngine:
             parts, by_clip = [(0, n)], True
         split = len(parts) > 1
 
+        # One scratch buffer: no automatic split-K while the chains run (context `cc`).  auto_splits() only fires for grids of
+        # fewer than 96 workgroups with K >= 256 (gemm_split.hip) -- never at the Sintel / KITTI / Spring shapes, whose
+        # smallest GEMM has 165 workgroups per clip -- so the two-chain schedule changes results (summation order) only at toy
+        # shapes; the bitwise test of the two schedules therefore runs with auto_split_k = False.
+        cc = cx.no_split()
+
         def two_chains(fn):
             """fn(image0, count): chain 0 on the main stream, the others on their own streams."""
-            keep = ops.SPLIT_WS
-            # One scratch buffer: no automatic split-K while the chains run.  auto_splits() only fires for grids of fewer than
-            # 96 workgroups with K >= 256 (gemm_split.hip) -- never at the Sintel / KITTI / Spring shapes, whose smallest GEMM
-            # has 165 workgroups per clip -- so the two-chain schedule changes results (summation order) only at toy shapes;
-            # the bitwise test of the two schedules therefore runs with SF_AUTO_SPLITK=0 (ADVICE r2).
-            ops.SPLIT_WS = None
-            try:
-                for c in range(1, len(parts)):
-                    sc = self._chain_streams[c - 1]
-                    sc.wait_stream(main)
-                    with torch.cuda.stream(sc):
-                        fn(*parts[c])
-                fn(*parts[0])
-            finally:
-                ops.SPLIT_WS = keep
+            for c in range(1, len(parts)):
+                sc = self._chain_streams[c - 1]
+                sc.wait_stream(main)
+                with torch.cuda.stream(sc):
+                    fn(*parts[c])
+            fn(*parts[0])
             for c in range(1, len(parts)):
                 main.wait_stream(self._chain_streams[c - 1])
 
         if split:
             def corr_chain(i0, cnt):
                 hid, xa, xb = _part(pl.hid, i0, cnt), _part(pl.xa, i0, cnt), _part(pl.xb, i0, cnt)
-                run_skblock(W.convc1, _sub(pl.corr, i0, cnt), _sub(pl.cor256, i0, cnt), hid, xa, xb, h, w, True)
-                run_skblock(W.convc2, _sub(pl.cor256, i0, cnt), _sub(pl.cat256.slice(0, 192), i0, cnt), hid, xa, xb, h, w)
+                run_skblock(W.convc1, _sub(pl.corr, i0, cnt), _sub(pl.cor256, i0, cnt), hid, xa, xb, h, w, True, cx=cc)
+                run_skblock(W.convc2, _sub(pl.cor256, i0, cnt), _sub(pl.cat256.slice(0, 192), i0, cnt), hid, xa, xb, h, w, cx=cc)
             two_chains(corr_chain)
         else:
             sk(W.convc1, pl.corr, pl.cor256, True)                 # cor = gelu(convc1(corr))
@@ -492,38 +529,39 @@ class HotPathEngine:
         join()
         if split:                                                   # mf = cat(out, flow); flow rows kept by flow_update
             two_chains(lambda i0, cnt: run_skblock(W.conv, _sub(pl.cat256, i0, cnt), _sub(pl.mf.slice(0, HDIM - 2), i0, cnt),
-                                                   _part(pl.hid, i0, cnt), _part(pl.xa, i0, cnt), _part(pl.xb, i0, cnt), h, w))
+                                                   _part(pl.hid, i0, cnt), _part(pl.xa, i0, cnt), _part(pl.xb, i0, cnt), h, w,
+                                                   cx=cc))
         else:
             sk(W.conv, pl.cat256, pl.mf.slice(0, HDIM - 2))
         # a10: temporal transformer block over the T-1 tokens of each pixel (update.py:481-484,770), side stream
         fork()
         with on_side():
             # LayerNorm / attention outputs have ONE reader, a GEMM: in the f16x2 mode they leave as its k-octet operand
-            ko = lambda buf, M: (lambda t: t if t.koct else buf)(_handover(buf, pl.n, HDIM, P, consumer_rows=M))
+            ko = lambda buf, M: (lambda t: t if t.koct else buf)(_handover(cs, buf, pl.n, HDIM, P, consumer_rows=M))
             ln, att = ko(pl.ln128, W.qkv.M), ko(pl.att128, W.proj.M)
             ops.layernorm_cm(pl.mf, W.ln1_w, W.ln1_b, ln)
-            ops.gemm(W.qkv, ln, pl.qkv, EPI_NONE)
+            ops.gemm(W.qkv, ln, pl.qkv, EPI_NONE, cx=cs)
             ops.temporal_attn(pl.qkv, att, Bc, Pn, HDIM)
-            ops.gemm(W.proj, att, pl.tx128, EPI_RES, R=pl.mf)
+            ops.gemm(W.proj, att, pl.tx128, EPI_RES, R=pl.mf, cx=cs)
             ln = ko(pl.ln128, W.fc1.M)
             ops.layernorm_cm(pl.tx128, W.ln2_w, W.ln2_b, ln)
-            h256 = _handover(pl.h256, pl.n, 256, P, consumer_rows=HDIM)            # fc1 -> fc2 only
-            ops.gemm(W.fc1, ln, h256, EPI_GELU)
-            ops.gemm(W.fc2, h256, pl.mft, EPI_RES, R=pl.tx128)
+            h256 = _handover(cs, pl.h256, pl.n, 256, P, consumer_rows=HDIM)        # fc1 -> fc2 only
+            ops.gemm(W.fc1, ln, h256, EPI_GELU, cx=cs)
+            ops.gemm(W.fc2, h256, pl.mft, EPI_RES, R=pl.tx128, cx=cs)
         # a7: global aggregation  mfg = mf + gamma * attn @ to_v(mf)   (gma.py:91-104), main stream
-        ops.gemm(W.to_v, pl.mf, pl.v128, EPI_NONE)
+        ops.gemm(W.to_v, pl.mf, pl.v128, EPI_NONE, cx=cx)
         ks = self.attn_k_splits if self.precision != ops.PRECISION_FP32 else 1
         attn_ptr, attn_lay = ((pl.attn16.data_ptr(), LAYOUT_F16_K_MINOR) if pl.attn16 is not None
                               else (pl.attn.data_ptr(), LAYOUT_K_MINOR))
         if pl.flash:
             # fused recompute (K6' of SURVEY.md): one kernel, online softmax, logits never written
-            ops.gma_flash_aggregate(pl.flash_ws, pl.v128, pl.mf, W.gamma, pl.mfg, self.flash_qk_products, use_stats=True)
+            ops.gma_flash_aggregate(pl.flash_ws, pl.v128, pl.mf, W.gamma, pl.mfg, self.flash_qk_products, use_stats=True, cx=cx)
         elif pl.attn_rows < P:
             # high-resolution path: recompute the attention rows chunk by chunk (K6' of SURVEY.md)
             for i0 in range(0, P, pl.attn_rows):
                 rows = min(pl.attn_rows, P - i0)
-                self._attention_rows(pl, i0, rows)
-                ops.gemm_raw(A=pl.v128.ptr, B=attn_ptr, C=pl.mfg.ptr + 4 * i0, R=pl.mf.ptr + 4 * i0,
+                self._attention_rows(cx, pl, i0, rows)
+                ops.gemm_raw(cx, A=pl.v128.ptr, B=attn_ptr, C=pl.mfg.ptr + 4 * i0, R=pl.mf.ptr + 4 * i0,
                              gamma=W.gamma.data_ptr(), M=HDIM, N=rows, K=P, batch=n, lda=P, ldb=P, ldc=P, ldr=P,
                              strideA=pl.v128.img_stride, strideB=pl.attn_rows * P, strideC=pl.mfg.img_stride,
                              strideR=pl.mf.img_stride, a_layout=LAYOUT_K_MINOR, b_layout=attn_lay, alpha=1.0,
@@ -531,27 +569,27 @@ class HotPathEngine:
         elif ks > 1 and P % 4 == 0:
             # attn @ v streams the N x N matrix (HBM-bound) but has only N/128 * images workgroups: split K so that
             # enough bytes are in flight; partial products go to slabs, combined with the AXPY of gma.py:102
-            ops.gemm_raw(A=pl.v128.ptr, B=attn_ptr, C=pl.part.ptr, M=HDIM, N=P, K=P, batch=n, lda=P, ldb=P,
+            ops.gemm_raw(cx, A=pl.v128.ptr, B=attn_ptr, C=pl.part.ptr, M=HDIM, N=P, K=P, batch=n, lda=P, ldb=P,
                          ldc=P, strideA=pl.v128.img_stride, strideB=P * P, strideC=HDIM * P,       # slabs: [split][img][128][P]
                          a_layout=LAYOUT_K_MINOR, b_layout=attn_lay, alpha=1.0, epilogue=EPI_NONE,
                          k_splits=ks, split_stride=n * HDIM * P)
             ops.splitk_combine(pl.part.base[pl.part.off:], n * HDIM * P, ks, HDIM * P, pl.mf, W.gamma, pl.mfg)
         else:
-            ops.gemm_raw(A=pl.v128.ptr, B=attn_ptr, C=pl.mfg.ptr, R=pl.mf.ptr, gamma=W.gamma.data_ptr(),
+            ops.gemm_raw(cx, A=pl.v128.ptr, B=attn_ptr, C=pl.mfg.ptr, R=pl.mf.ptr, gamma=W.gamma.data_ptr(),
                          M=HDIM, N=P, K=P, batch=n, lda=P, ldb=P, ldc=P, ldr=P, strideA=pl.v128.img_stride,
                          strideB=P * P, strideC=pl.mfg.img_stride, strideR=pl.mf.img_stride,
                          a_layout=LAYOUT_K_MINOR, b_layout=attn_lay, alpha=1.0, epilogue=EPI_AXPY)
         if not pl.flash:
-            ops.refresh_shadow(pl.mfg)                              # (the flash kernel writes the k-octet copy itself)
+            ops.refresh_shadow(pl.mfg, cx)                          # (the flash kernel writes the k-octet copy itself)
         join()
         # "gru": SKBlock(640 -> 128) over cat[nets, inps, mf, mfg, mft]; new nets overwrite the nets slice
         if split:
             def gru_chain(i0, cnt):
                 hid, xa, xb = _part(pl.hid, i0, cnt), _part(pl.xa, i0, cnt), _part(pl.xb, i0, cnt)
-                run_skblock(W.gru, _sub(pl.concat, i0, cnt), _sub(pl.nets, i0, cnt), hid, xa, xb, h, w)
+                run_skblock(W.gru, _sub(pl.concat, i0, cnt), _sub(pl.nets, i0, cnt), hid, xa, xb, h, w, cx=cc)
                 if by_clip:     # flow head sees all T-1 hidden states of a clip jointly (update.py:774): clips i0 / Pn ..
                     run_skblock(W.flow_head, _sub(pl.nets_grouped, i0 // Pn, cnt // Pn),
-                                _sub(pl.delta_fh, i0 // Pn, cnt // Pn), hid, xa, xb, h, w)
+                                _sub(pl.delta_fh, i0 // Pn, cnt // Pn), hid, xa, xb, h, w, cx=cc)
             two_chains(gru_chain)
             if not by_clip:
                 sk(W.flow_head, pl.nets_grouped, pl.delta_fh)
@@ -560,29 +598,17 @@ class HotPathEngine:
             # flow head sees all T-1 hidden states of a clip jointly (update.py:774)
             sk(W.flow_head, pl.nets_grouped, pl.delta_fh)
         if with_mask:                                               # update.py:756-759,777
-            ops.gemm(W.mask0, pl.nets, pl.m256, EPI_RELU, hw=(h, w))
-            ops.gemm(W.mask2, pl.m256, pl.mask, EPI_NONE, alpha=0.25)
+            ops.gemm(W.mask0, pl.nets, pl.m256, EPI_RELU, hw=(h, w), cx=cx)
+            ops.gemm(W.mask2, pl.m256, pl.mask, EPI_NONE, alpha=0.25, cx=cx)
         # streamflow.py:138 + :133 for the next iteration
         ops.flow_update(pl.coords1, pl.delta, pl.flow, pl.mf.slice(HDIM - 2, HDIM, unshadowed=True), n, h, w,
-                        koct=pl.mf.shadow, koct_row=HDIM - 2)       # (+ the flow rows of mf's k-octet copy)
-
-    @contextlib.contextmanager
-    def _kernel_context(self, pl: _Plan):
-        """Package-wide kernel settings for the duration of one forward: arithmetic mode and the split-K scratch."""
-        prev = ops.set_precision(self.precision)
-        prev_ws = ops.SPLIT_WS
-        ops.SPLIT_WS = pl.splitws.tensor().view(-1) if self.auto_split_k else None
-        try:
-            yield
-        finally:
-            ops.set_precision(prev)
-            ops.SPLIT_WS = prev_ws
+                        koct=pl.mf.shadow, koct_row=HDIM - 2, cx=cx)   # (+ the flow rows of mf's k-octet copy)
 
     def _run(self, pl: _Plan, fmaps: torch.Tensor, cnets: torch.Tensor, iters: int, all_masks: bool) -> None:
-        with self._kernel_context(pl):
-            self._setup(pl, fmaps, cnets)
-            for it in range(iters):
-                self._iteration(pl, with_mask=all_masks or it == iters - 1)
+        cx = self._ctx(pl)
+        self._setup(cx, pl, fmaps, cnets)
+        for it in range(iters):
+            self._iteration(cx, pl, with_mask=all_masks or it == iters - 1)
         flow_t = pl.flow.tensor().view(pl.n, 2, pl.h, pl.w)
         mask_t = pl.mask.tensor().view(pl.n, 576, pl.h, pl.w)
         _lib.check(_lib.load().sf_upsample_flow(flow_t.data_ptr(), mask_t.data_ptr(), pl.up.data_ptr(), pl.n, pl.h,
@@ -627,7 +653,7 @@ class HotPathEngine:
             for i, f in enumerate(flow_init):
                 coords1.view(Bc, T - 1, 2, h, w)[:, i] += f.to(coords1)
         ops.flow_update(pl.coords1, None, pl.flow, pl.mf.slice(HDIM - 2, HDIM, unshadowed=True), n, h, w,
-                        koct=pl.mf.shadow, koct_row=HDIM - 2)
+                        koct=pl.mf.shadow, koct_row=HDIM - 2, cx=self._ctx(pl))
         return pl
 
     @torch.no_grad()
@@ -639,14 +665,14 @@ class HotPathEngine:
             pl = self._begin(fmaps, cnets, flow_init)
             Bc, T, h, w, n = pl.Bc, pl.Pn + 1, pl.h, pl.w, pl.n
             preds: List[List[torch.Tensor]] = [[] for _ in range(T - 1)]
-            with self._kernel_context(pl):
-                self._setup(pl, fmaps, cnets)
-                for _ in range(iters):
-                    self._iteration(pl, with_mask=True)
-                    up = ops.upsample_flow(pl.flow.tensor().view(n, 2, h, w), pl.mask.tensor().view(n, 576, h, w))
-                    up = up.view(Bc, T - 1, 2, 8 * h, 8 * w)
-                    for i in range(T - 1):
-                        preds[i].append(up[:, i])
+            cx = self._ctx(pl)
+            self._setup(cx, pl, fmaps, cnets)
+            for _ in range(iters):
+                self._iteration(cx, pl, with_mask=True)
+                up = ops.upsample_flow(pl.flow.tensor().view(n, 2, h, w), pl.mask.tensor().view(n, 576, h, w))
+                up = up.view(Bc, T - 1, 2, 8 * h, 8 * w)
+                for i in range(T - 1):
+                    preds[i].append(up[:, i])
             return preds
 
     def _forward_graph(self, pl: _Plan, fmaps, cnets, iters, all_masks) -> None:
@@ -656,7 +682,7 @@ class HotPathEngine:
             pl.cnets_in = torch.empty_like(cnets)
         pl.fmaps_in.copy_(fmaps)
         pl.cnets_in.copy_(cnets)
-        key = key + (self.precision, self.split_solo, self.parallel_branches, self.single_layers)
+        key = key + (self.precision, self.options, self.gma_mode, self.flash_qk_products, self.corr_f16, self.single_layers)
         if pl.graph is None or pl.graph_key != key:
             # warm-up outside capture, then capture the whole clip as one graph.  The loop state (coords1, flow)
             # is re-initialised by the caller before every replay, so the graph itself is stateless.
@@ -673,5 +699,5 @@ class HotPathEngine:
             pl.coords1.tensor().copy_(state[0])
             pl.flow.tensor().copy_(state[1])
             pl.mf.tensor().copy_(state[2])
-            ops.refresh_shadow(pl.mf.slice(HDIM - 8, HDIM))       # ... and the flow rows of mf's k-octet copy
+            ops.refresh_shadow(pl.mf.slice(HDIM - 8, HDIM), self._ctx(pl))       # ... and the flow rows of mf's k-octet copy
         pl.graph.replay()

@@ -95,13 +95,12 @@ class SKFlow_MF8(nn.Module):
         """fnet over the T frames, cnet over the first T-1 (streamflow.py:112-117).  The encoders run in the arithmetic class
         of the selected preset (the reference's autocast region covers them too, streamflow.py:106-108): split precision
         for `fp32_class`, fp16 activations with the fp16 k-octet hand-over for the config-2 presets."""
-        from . import ops, presets
-        prev = ops.set_precision(presets.PRESETS[self.preset_name()]["precision"])
-        try:
-            fmaps = self.fnet(images).float().contiguous()
-            cnets = self.cnet(images[:, :-1]).float().contiguous()
-        finally:
-            ops.set_precision(prev)
+        from . import presets
+        from .encoders import Twins_CSC
+        prec = presets.PRESETS[self.preset_name()]["precision"]
+        run = lambda enc, x: enc(x, precision=prec) if isinstance(enc, Twins_CSC) else enc(x)     # (stand-in encoders: no arithmetic)
+        fmaps = run(self.fnet, images).float().contiguous()
+        cnets = run(self.cnet, images[:, :-1]).float().contiguous()
         return fmaps, cnets
 
     @torch.no_grad()

@@ -47,6 +47,33 @@ def precision_name() -> str:
     return {v: k for k, v in _PRECISION_NAMES.items()}[PRECISION]
 
 
+@dataclass(frozen=True)
+class Ctx:
+    """Everything a launch depends on besides its operands -- passed explicitly (`cx=`) by the engine and the encoder, so
+    that two engines with different presets can be driven from two threads (there is no process-wide launch
+    state; the module-level PRECISION below is only the DEFAULT of calls that do not pass a context, like a default dtype).
+    precision: PRECISION_*.  split_ws: scratch that lets sf_gemm split K for small grids (None: never).
+    shadows / shadow_fused: use and maintain Planes.shadow; producers write the k-octet copy in their own epilogue.
+    flash_stats: the fused GMA kernel uses the softmax statistics stored once per clip.
+    hidden_f16 / hidden_koct / pw_fold: hand-over formats inside an SK block (engine.run_skblock)."""
+    precision: int
+    split_ws: Optional[torch.Tensor] = None
+    shadows: bool = True
+    shadow_fused: bool = True
+    flash_stats: bool = True
+    hidden_f16: bool = True
+    hidden_koct: bool = True
+    pw_fold: bool = True
+
+    def no_split(self) -> "Ctx":
+        """The same context without the split-K scratch (ONE buffer: only one stream may use it at a time)."""
+        return self if self.split_ws is None else replace(self, split_ws=None)
+
+
+def _cx(cx: Optional["Ctx"]) -> "Ctx":
+    return cx if cx is not None else Ctx(PRECISION)
+
+
 class Profiler:
     """Per-launch HIP-event timing on the stream the kernels are launched on (torch's current stream).
     Used by bench.py's instrumented pass: every wrapped op records (name, algorithmic flops, algorithmic
@@ -92,8 +119,6 @@ def _check_range(X: "Planes", what: str) -> None:
         raise RuntimeError(f"SF_DEBUG_RANGE: {what}: max |activation| = {m:.4g} does not fit fp16 (65504): the split-precision "
                            "modes would saturate it silently; run this layer with precision='fp32'")
 
-
-SPLIT_WS: Optional[torch.Tensor] = None     # scratch that lets sf_gemm split K for small grids (set by the engine)
 
 PROFILER: Optional[Profiler] = None
 PROFILE_SHAPES = False      # tag GEMM launches with their shape in the profiler (bench.py --gemm-shapes)
@@ -278,9 +303,6 @@ class PackedLinear:
         self.split_error = float(((hi.float() + lo.float()) - wm).abs().max() / max(wmax * self.split_scale, 1e-30))
 
 
-SHADOWS = os.environ.get("SF_SHADOW", "1") != "0"     # use / maintain Planes.shadow (A/B knob)
-
-
 def new_shadow(X: Planes, device) -> Planes:
     """Allocate the k-octet copy of fp32 planes X (zeroed: rows past X.rows in the last octet must stay finite)."""
     assert not X.f16 and X.group == 0
@@ -298,9 +320,9 @@ def pack_koct(X: Planes, Y: Planes) -> None:
                                                         _lib.stream()), "sf_pack_koct"))
 
 
-def refresh_shadow(X: Planes) -> None:
+def refresh_shadow(X: Planes, cx: Optional[Ctx] = None) -> None:
     """After a producer without a fused k-octet output wrote X: bring X.shadow up to date."""
-    if X.shadow is not None and SHADOWS:
+    if X.shadow is not None and _cx(cx).shadows:
         pack_koct(replace(X, shadow=None), X.shadow)
 
 
@@ -318,9 +340,12 @@ def takes_koct(M: int, K: int) -> bool:
 
 def gemm(A: PackedLinear, X: Planes, Y: Planes, epilogue: int = EPI_NONE, R: Optional[Planes] = None,
          dw_w: Optional[torch.Tensor] = None, dw_b: Optional[torch.Tensor] = None, alpha: float = 1.0,
-         hw: Optional[Sequence[int]] = None, algo: int = 0) -> None:
+         hw: Optional[Sequence[int]] = None, algo: int = 0, cx: Optional[Ctx] = None) -> None:
     """Y[img] = epilogue(alpha * (W @ X[img] + bias)) for every image (batched over grid.z).
-    algo: _lib.ALGO_AUTO / ALGO_TILED / ALGO_BSTAT (SfGemm.algo: force one kernel family; tests and A/B timing)."""
+    algo: _lib.ALGO_AUTO / ALGO_TILED / ALGO_BSTAT (SfGemm.algo: force one kernel family; tests and A/B timing).
+    cx: launch context (arithmetic mode, split-K scratch, hand-over switches); None = Ctx(ops.PRECISION)."""
+    cx = _cx(cx)
+    PRECISION, SHADOWS, SPLIT_WS = cx.precision, cx.shadows, cx.split_ws
     assert X.rows * (9 if A.conv3x3 else 1) == A.K, (X.rows, A.K)
     assert Y.rows == A.M and X.n_img == Y.n_img and X.P == Y.P, (Y.rows, A.M)
     if (X.shadow is not None and SHADOWS and PRECISION in (PRECISION_F16X2, PRECISION_F16) and not A.conv3x3 and
@@ -348,7 +373,7 @@ def gemm(A: PackedLinear, X: Planes, Y: Planes, epilogue: int = EPI_NONE, R: Opt
             g.c_f16 = 2 if Y.koct else 1
     fused_shadow = False
     if (Y.shadow is not None and SHADOWS and not Y.f16 and prec in (PRECISION_F16X2, PRECISION_F16) and Y.P % 4 == 0
-            and os.environ.get("SF_SHADOW_FUSED", "1") != "0"):
+            and cx.shadow_fused):
         g.c_f16, g.C16, g.strideC16 = 3, Y.shadow.ptr, Y.shadow.img_stride       # fp32 planes + their k-octet copy
         fused_shadow = True
     if prec != PRECISION_FP32:
@@ -379,18 +404,19 @@ def gemm(A: PackedLinear, X: Planes, Y: Planes, epilogue: int = EPI_NONE, R: Opt
     _launch(name, 2.0 * g.M * g.N * g.K * g.batch, nbytes,
             lambda: _lib.check(_lib.load().sf_gemm(C.byref(g), _lib.stream()), "sf_gemm"), products=_products(prec))
     if not fused_shadow:
-        refresh_shadow(Y)
+        refresh_shadow(Y, cx)
 
 
-def gemm_split_ws_floats(M: int, N: int, K: int, batch: int) -> int:
-    """floats of scratch with which sf_gemm would split K on its own for this shape (0: it would not); see SPLIT_WS."""
-    if PRECISION == PRECISION_FP32:
+def gemm_split_ws_floats(M: int, N: int, K: int, batch: int, cx: Optional[Ctx] = None) -> int:
+    """floats of scratch with which sf_gemm would split K on its own for this shape (0: it would not); see Ctx.split_ws."""
+    if _cx(cx).precision == PRECISION_FP32:
         return 0
     return int(_lib.load().sf_gemm_split_ws_floats(M, N, K, batch))
 
 
-def gemm_raw(**kw) -> None:
+def gemm_raw(cx: Optional[Ctx] = None, **kw) -> None:
     """Fully explicit sf_gemm call (used for the attention logits and attn @ v contractions)."""
+    PRECISION = _cx(cx).precision
     g = SfGemm()
     g.alpha = 1.0
     for k, v in kw.items():
@@ -416,9 +442,10 @@ def splitk_combine(partial: torch.Tensor, split_stride: int, k_splits: int, part
 
 @on_tensor_device
 def dwconv_res_gelu(X: Planes, wgt: torch.Tensor, bias: torch.Tensor, Y: Planes, h: int, w: int, k: int,
-                    single: bool = False) -> None:
+                    single: bool = False, cx: Optional[Ctx] = None) -> None:
     """Y = gelu(X + dwconv_KxK(X) + bias).  Y may be fp16 row planes (Planes.f16, not koct): the hand-over to a GEMM.
     single (f16x2 mode only): the weights enter the products as ONE fp16 value (a single-product layer)."""
+    PRECISION = _cx(cx).precision
     assert X.rows == Y.rows == wgt.shape[0] and X.P == h * w and not X.f16 and not Y.koct
     if DEBUG_RANGE and PRECISION != PRECISION_FP32:
         _check_range(X, f"sf_dwconv_res_gelu C{X.rows} k{k}")
@@ -466,14 +493,16 @@ def softmax_rows(x: torch.Tensor, rows: int, cols: int, out16: Optional[torch.Te
 
 
 @on_tensor_device
-def window_attn(QKV: Planes, qkv_bias: torch.Tensor, OUT: Planes, heads: int, H: int, W: int, ws: int = 7) -> None:
+def window_attn(QKV: Planes, qkv_bias: torch.Tensor, OUT: Planes, heads: int, H: int, W: int, ws: int = 7,
+                cx: Optional[Ctx] = None, exact: bool = False) -> None:
     """timm LocallyGroupedAttn core on token planes (encoder; see include/streamflow_hip.h).  PRECISION_FP32: the exact
     VALU kernel; every other class: the matrix-core kernel (3 products per contraction for F16X3, 1 for the fp16 classes)."""
+    PRECISION = _cx(cx).precision
     C = OUT.rows
     assert QKV.rows == 3 * C and QKV.P == H * W == OUT.P and qkv_bias.numel() == 3 * C and (not OUT.f16 or OUT.koct)
     assert not QKV.f16 or (QKV.koct and PRECISION in (PRECISION_F16X2, PRECISION_F16))
     flops, nbytes = 4.0 * QKV.n_img * H * W * ws * ws * C, (2.0 if QKV.f16 else 4.0) * QKV.n_img * 3 * C * H * W + 4.0 * QKV.n_img * C * H * W
-    if PRECISION == PRECISION_FP32 or os.environ.get("SF_WINDOW_EXACT", "0") == "1":
+    if PRECISION == PRECISION_FP32 or exact:
         assert not OUT.f16 and not QKV.f16
         _launch("window_attn", flops, nbytes,
                 lambda: _lib.check(_lib.load().sf_window_attn(QKV.ptr, QKV.img_stride, qkv_bias.data_ptr(), OUT.ptr, OUT.img_stride,
@@ -491,14 +520,16 @@ def window_attn(QKV: Planes, qkv_bias: torch.Tensor, OUT: Planes, heads: int, H:
 
 
 @on_tensor_device
-def subsample_attn(Q: Planes, KV: Planes, OUT: Planes, heads: int, ws: Optional[torch.Tensor] = None) -> None:
+def subsample_attn(Q: Planes, KV: Planes, OUT: Planes, heads: int, ws: Optional[torch.Tensor] = None,
+                   cx: Optional[Ctx] = None, exact: bool = False) -> None:
     """timm GlobalSubSampleAttn core: OUT = softmax(q k^T / sqrt(32)) v, keys/values = the M sub-sampled tokens.
     PRECISION_FP32: the exact VALU kernel; every other class: the matrix-core kernel (3 products per contraction for
     F16X3, 1 for the fp16 classes) over `ws` (uint8, >= subsample_attn_ws_bytes; allocated here when not given)."""
+    PRECISION = _cx(cx).precision
     C = Q.rows
     assert KV.rows == 2 * C and OUT.rows == C and Q.P == OUT.P and Q.n_img == KV.n_img == OUT.n_img and (not OUT.f16 or OUT.koct)
     nbytes = 4.0 * Q.n_img * C * (2 * Q.P + 2 * KV.P)
-    if PRECISION == PRECISION_FP32 or os.environ.get("SF_SUBSAMPLE_EXACT", "0") == "1":
+    if PRECISION == PRECISION_FP32 or exact:
         assert not OUT.f16
         _launch("subsample_attn", 4.0 * Q.n_img * Q.P * KV.P * C, nbytes,
                 lambda: _lib.check(_lib.load().sf_subsample_attn(Q.ptr, Q.img_stride, KV.ptr, KV.img_stride, OUT.ptr, OUT.img_stride,
@@ -536,16 +567,12 @@ def gma_flash_ws_bytes(n_img: int, P: int) -> int:
     return int(_lib.load().sf_gma_flash_ws_bytes(n_img, P))
 
 
-# SF_FLASH_STATS=0: A/B knob -- the fused GMA kernel keeps its own running maximum / row sum in every iteration
-FLASH_STATS = os.environ.get("SF_FLASH_STATS", "1") != "0"
-
-
 @on_tensor_device
-def gma_flash_pack_qk(QK: Planes, ws: torch.Tensor, scale: float, stats_qk_products: int = 0) -> None:
+def gma_flash_pack_qk(QK: Planes, ws: torch.Tensor, scale: float, stats_qk_products: int = 0, cx: Optional[Ctx] = None) -> None:
     """QK [n_img][256][P] (to_qk output) -> packed fp16 operand images in ws (once per clip); stats_qk_products = 1 / 2 / 3
     also stores every query's softmax statistics for gma_flash_aggregate(..., use_stats=True) with the same product count."""
     assert QK.rows == 256 and ws.dtype == torch.uint8
-    sq = int(stats_qk_products) if FLASH_STATS else 0
+    sq = int(stats_qk_products) if _cx(cx).flash_stats else 0
     _launch("flash_pack_qk", 2.0 * QK.n_img * QK.P * QK.P * 128 * (1 if sq else 0), 4.0 * QK.n_img * 256 * QK.P * 2,
             lambda: _lib.check(_lib.load().sf_gma_flash_pack_qk(QK.ptr, QK.img_stride, ws.data_ptr(), ws.numel(), QK.n_img,
                                                                 QK.P, float(scale), sq, _lib.stream()), "sf_gma_flash_pack_qk"),
@@ -554,21 +581,22 @@ def gma_flash_pack_qk(QK: Planes, ws: torch.Tensor, scale: float, stats_qk_produ
 
 @on_tensor_device
 def gma_flash_aggregate(ws: torch.Tensor, V: Planes, MF: Planes, gamma: torch.Tensor, OUT: Planes, qk_products: int = 3,
-                        use_stats: bool = False) -> None:
+                        use_stats: bool = False, cx: Optional[Ctx] = None) -> None:
     """OUT = MF + gamma * softmax(scale q k^T) V, fused (no N x N tensor); q, k come packed in ws.  use_stats: the softmax
     statistics stored by gma_flash_pack_qk(..., stats_qk_products=qk_products) are used instead of an online softmax."""
-    use_stats = bool(use_stats) and FLASH_STATS
+    cx = _cx(cx)
+    use_stats = bool(use_stats) and cx.flash_stats
     assert V.rows == MF.rows == OUT.rows == 128 and V.n_img == MF.n_img == OUT.n_img
     n, P = V.n_img, V.P
     # algorithmic: the two contractions; bytes: v, mf in, out (q/k/v tiles are re-read from L2 by every query tile)
-    sh = OUT.shadow if (OUT.shadow is not None and SHADOWS and os.environ.get("SF_SHADOW_FUSED", "1") != "0") else None
+    sh = OUT.shadow if (OUT.shadow is not None and cx.shadows and cx.shadow_fused) else None
     _launch("gma_flash", 4.0 * n * P * P * 128, 4.0 * n * 128 * P * 3 + 2.0 * n * 128 * P * (2 if sh is None else 3),
             lambda: _lib.check(_lib.load().sf_gma_flash_aggregate(
                 ws.data_ptr(), ws.numel(), V.ptr, V.img_stride, MF.ptr, MF.img_stride, gamma.data_ptr(), OUT.ptr,
                 OUT.img_stride, None if sh is None else sh.ptr, 0 if sh is None else sh.img_stride, n, P,
                 int(qk_products), int(use_stats), _lib.stream()), "sf_gma_flash_aggregate"), products=(qk_products + 1) / 2.0)
     if sh is None:
-        refresh_shadow(OUT)
+        refresh_shadow(OUT, cx)
 
 
 @on_tensor_device
@@ -589,11 +617,11 @@ def context_split(cnets: torch.Tensor, nets: Planes, inps: Planes, hdim: int) ->
 
 @on_tensor_device
 def flow_update(coords1: Planes, delta: Optional[Planes], flow_a: Optional[Planes], flow_b: Optional[Planes],
-                n_img: int, h: int, w: int, koct: Optional[Planes] = None, koct_row: int = 0) -> None:
+                n_img: int, h: int, w: int, koct: Optional[Planes] = None, koct_row: int = 0, cx: Optional[Ctx] = None) -> None:
     """koct / koct_row: k-octet planes (Planes.shadow of the tensor flow_b is a slice of) and the row the x component
     goes to: keeps that copy's flow rows current."""
     assert coords1.img_stride == 2 * h * w and (delta is None or delta.img_stride == 2 * h * w)
-    if not SHADOWS:
+    if not _cx(cx).shadows:
         koct = None
     assert koct is None or (koct.f16 and koct.koct and koct_row + 2 <= (koct.rows + 7) // 8 * 8)
     _launch("flow_update", 0, 0, lambda: _lib.check(_lib.load().sf_flow_update(
@@ -640,14 +668,14 @@ def corr_build_ws_bytes(B: int, pairs: int, D: int, h: int, w: int) -> int:
 @on_tensor_device
 def corr_build(f1_ptr: int, f2_ptr: int, clip_stride: int, pair_stride: int, lvls: Sequence[torch.Tensor],
                lvl_pair_stride: Optional[Sequence[int]], B: int, pairs: int, D: int, h: int, w: int,
-               ws: Optional[torch.Tensor] = None) -> None:
+               ws: Optional[torch.Tensor] = None, cx: Optional[Ctx] = None) -> None:
     """ws: scratch of corr_build_ws_bytes() bytes for the split-precision / fp16 builds (allocated here when omitted).
     The dtype of `lvls` selects the volume format: float32 (arithmetic = the package precision, fp32 or f16x3) or
     float16 (SF_PRECISION_F16: single f16 products, fp16 cells)."""
     N = h * w
     vol16 = lvls[0].dtype == torch.float16
     assert all(t.dtype == lvls[0].dtype for t in lvls) and lvls[0].dtype in (torch.float16, torch.float32)
-    prec = PRECISION_F16 if vol16 else min(PRECISION, PRECISION_F16X3)
+    prec = PRECISION_F16 if vol16 else min(_cx(cx).precision, PRECISION_F16X3)
     need = corr_build_ws_bytes(B, pairs, D, h, w) if prec != PRECISION_FP32 else 0
     if need and (ws is None or ws.numel() * ws.element_size() < need):
         ws = torch.empty(need, dtype=torch.uint8, device=lvls[0].device)
@@ -664,14 +692,14 @@ def corr_build(f1_ptr: int, f2_ptr: int, clip_stride: int, pair_stride: int, lvl
 
 @on_tensor_device
 def corr_lookup(lvls: Sequence[torch.Tensor], lvl_pair_stride: Optional[Sequence[int]], coords: Planes,
-                out: Planes, B: int, pairs: int, h: int, w: int) -> None:
+                out: Planes, B: int, pairs: int, h: int, w: int, cx: Optional[Ctx] = None) -> None:
     assert out.rows == 324 and out.n_img == B * pairs and coords.img_stride == 2 * h * w
     N = h * w
     vol16 = lvls[0].dtype == torch.float16
     # algorithmic bytes per image: 10x10 footprint x 4 levels read + coords + 324 output channels
     # the k-octet copy of the output (Planes.shadow) comes out of the same kernel when the volumes are fp16
-    sh = out.shadow if (out.shadow is not None and SHADOWS and vol16 and
-                        os.environ.get("SF_SHADOW_FUSED", "1") != "0") else None
+    cx = _cx(cx)
+    sh = out.shadow if (out.shadow is not None and cx.shadows and vol16 and cx.shadow_fused) else None
     # (footprints + coords + the 324 fp32 output channels; the k-octet copy is extra traffic)
     nbytes = B * pairs * (N * 4 * 100 * (2.0 if vol16 else 4.0) + N * 2 * 4.0 + N * 324 * 4.0)
     _launch("corr_lookup", 0, nbytes, lambda: _lib.check(_lib.load().sf_corr_lookup(
@@ -680,7 +708,7 @@ def corr_lookup(lvls: Sequence[torch.Tensor], lvl_pair_stride: Optional[Sequence
         None if sh is None else sh.ptr, 0 if sh is None else sh.img_stride, B, pairs, h, w, 4, 4,
         PRECISION_F16 if vol16 else PRECISION_FP32, _lib.stream()), "sf_corr_lookup"))
     if sh is None:
-        refresh_shadow(out)
+        refresh_shadow(out, cx)
 
 
 @dataclass(frozen=True)

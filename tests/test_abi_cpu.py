@@ -33,10 +33,10 @@ def test_every_declared_symbol_is_exported(lib):
 def test_struct_layout_matches_header():
     from streamflow_amd._lib import SfGemm
     # 8 pointers + 4 i32 + 8 i64 + 2 i32 + (i32,pad,i64)*2 + 3 i32 + f32 + 2 i32  (natural alignment)
-    assert ctypes.sizeof(SfGemm) == 296                         # ... + split-K fields + c_f16 (offset 264) + C16, strideC16, r_f16
+    assert ctypes.sizeof(SfGemm) == 304                         # ... + split-K fields + c_f16 (offset 264) + C16, strideC16, r_f16, a_k_pad, algo
     assert SfGemm.lda.offset == 80 and SfGemm.b_group_stride.offset == 160 and SfGemm.alpha.offset == 196
     assert SfGemm.c_f16.offset == 264 and SfGemm.C16.offset == 272 and SfGemm.strideC16.offset == 280
-    assert SfGemm.r_f16.offset == 288
+    assert SfGemm.r_f16.offset == 288 and SfGemm.a_k_pad.offset == 292 and SfGemm.algo.offset == 296
 
 
 def test_blocked_volume_geometry(lib):
@@ -140,11 +140,11 @@ def test_packed_linear_layout():
     p = PackedLinear(w, None, "cpu")
     assert (p.K, p.M, p.lda) == (5, 6, 128) and tuple(p.wt.shape) == (32, 128)
     assert torch.equal(p.wt[:5, :6], w.view(6, 5).t()) and p.wt[:, 6:].abs().sum() == 0 and p.wt[5:].abs().sum() == 0
-    # split image: k-octet planes [K up to 32 / 8][M up to 128][8]; element (m, k) at [k // 8, m, k % 8]
-    assert tuple(p.hi.shape) == (4, 128, 8) and p.lda_h == 128
+    # split image: k-octet planes [K up to 128 / 8][M up to 128][8]; element (m, k) at [k // 8, m, k % 8]
+    assert tuple(p.hi.shape) == (16, 128, 8) and p.lda_h == 128 and p.k_pad == 128     # (K padded to 128: whole weight stages)
     # the image holds split_scale * W (power of two, max|w| scaled into [1, 2)); undone by alpha / bias in ops.gemm
     assert p.split_scale == 2.0 ** -4 and p.split_error == 0.0
-    full = (p.hi.float() + p.lo.float()).permute(1, 0, 2).reshape(128, 32) / p.split_scale
+    full = (p.hi.float() + p.lo.float()).permute(1, 0, 2).reshape(128, 128) / p.split_scale
     assert torch.equal(full[:6, :5], w.view(6, 5)) and full[6:].abs().sum() == 0 and full[:, 5:].abs().sum() == 0
     # a layer of tiny weights keeps ~21 bits after scaling (unscaled, its lo parts would be fp16 subnormals: ~15 bits)
     tiny = PackedLinear(torch.randn(64, 96, 1, 1, generator=torch.Generator().manual_seed(0)) * 1e-3,

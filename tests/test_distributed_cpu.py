@@ -102,3 +102,37 @@ def test_bench_gpus_gt1_does_not_touch_gpu_in_launcher(monkeypatch):
     except SystemExit as e:
         assert e.code == 0
     assert seen == {"n": 4, "argv": ["--gpus", "4", "--steps", "2"]}
+
+
+def test_strong_scaling_shards_and_batches():
+    """--total-clips (BASELINE.json config 4: 64 Sintel clips at every N): round-robin shards cover the clips exactly once for
+    even and uneven world sizes, and a rank's step is its clips in launches of at most --clips."""
+    sys.path.insert(0, REPO)
+    import bench
+    for world in (1, 2, 3, 4, 8):
+        parts = [bench.shard(64, world, r) for r in range(world)]
+        assert sorted(sum(parts, [])) == list(range(64)) and max(map(len, parts)) - min(map(len, parts)) <= 1
+        for p in parts:
+            b = bench.batches(len(p), 8)
+            assert sum(b) == len(p) and all(0 < x <= 8 for x in b) and all(x == 8 for x in b[:-1])
+    assert [len(bench.shard(64, 3, r)) for r in range(3)] == [22, 21, 21]
+    assert bench.batches(22, 8) == [8, 8, 6] and bench.batches(21, 8) == [8, 8, 5] and bench.batches(8, 8) == [8]
+    assert bench.batches(0, 8) == []                       # more ranks than clips: that rank only joins the barriers
+
+
+def test_pinned_device_env():
+    """--pin visible: a rank is restricted to ONE device before the runtime starts and addresses it as device 0; an outer
+    HIP_VISIBLE_DEVICES list is honoured."""
+    sys.path.insert(0, REPO)
+    import bench
+    assert bench.pinned_device_env(3) == {"HIP_VISIBLE_DEVICES": "3", "SF_BENCH_DEVICE": "0"}
+    assert bench.pinned_device_env(1, "4,5,6,7") == {"HIP_VISIBLE_DEVICES": "5", "SF_BENCH_DEVICE": "0"}
+
+
+def test_timed_steps_reports_own_time():
+    sys.path.insert(0, REPO)
+    import bench
+    own = []
+    dt = bench.timed_steps(lambda: time.sleep(0.002), steps=3, warmup=1, world=1, sync_fn=lambda: None, barrier_fn=lambda: None,
+                           allreduce_max_fn=lambda x: x, own=own)
+    assert len(own) == 1 and 0.005 <= own[0] <= dt

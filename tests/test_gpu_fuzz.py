@@ -469,15 +469,14 @@ def test_two_product_mode_gelu_accuracy(dev):
 
 
 @pytest.mark.parametrize("preset", ["config2_fp16", "fp32_class"])
-def test_two_chain_schedule_is_bitwise_the_one_chain_schedule(dev, preset, monkeypatch):
-    """The engine runs the sections without a concurrent branch as two half-batch chains on two streams (SF_SPLIT_SOLO,
+def test_two_chain_schedule_is_bitwise_the_one_chain_schedule(dev, preset):
+    """The engine runs the sections without a concurrent branch as two half-batch chains on two streams (EngineOptions.split_solo,
     default 2).  Clips are independent and a kernel's arithmetic does not depend on the batch it is launched with, so the
     flows must be bit-identical to the single-chain schedule -- graph and eager, B = 2 and 4.  (The automatic split-K of
     small grids is switched off for the comparison: it is not available inside the chains -- one scratch buffer -- and
     changes the summation order of the GEMMs it applies to at this test's small shape.)"""
     from streamflow_amd import presets, synthetic as syn
-    from streamflow_amd.engine import HotPathEngine
-    monkeypatch.setenv("SF_AUTO_SPLITK", "0")
+    from streamflow_amd.engine import EngineOptions, HotPathEngine
     T, h, w, iters = 3, 24, 32, 3
     P = syn.make_params(7, T)
     kw = presets.engine_kwargs(preset)
@@ -485,8 +484,7 @@ def test_two_chain_schedule_is_bitwise_the_one_chain_schedule(dev, preset, monke
         fmaps, cnets = syn.make_features(40 + B, B, T, h, w)
         outs = {}
         for chains in ("0", "2", "4"):
-            monkeypatch.setenv("SF_SPLIT_SOLO", chains)
-            eng = HotPathEngine(P, device=dev, T=T, use_graph=graph, **kw)
+            eng = HotPathEngine(P, device=dev, T=T, use_graph=graph, options=EngineOptions(auto_split_k=False, split_solo=int(chains)), **kw)
             for _ in range(2):
                 ups = eng.forward(fmaps.to(dev), cnets.to(dev), iters=iters)[0]
             outs[chains] = [u.clone() for u in ups]

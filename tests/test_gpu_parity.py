@@ -477,20 +477,18 @@ def test_gma_flash_kernel_vs_float64(dev, P, qkp, stats):
 
 
 @pytest.mark.parametrize("qkp", [1, 2, 3])
-def test_engine_flash_mode_vs_golden(golden, dev, qkp, monkeypatch):
+def test_engine_flash_mode_vs_golden(golden, dev, qkp):
     """The whole loop with the fused GMA aggregation (gma_mode='flash': no attention matrix at all) against the
     reference forward, for every logit precision; the 15-iteration small-shape run bounds the accumulated effect."""
     from oracle import streamflow_oracle as orc
     from streamflow_amd import synthetic as syn
     from streamflow_amd.engine import HotPathEngine
-    monkeypatch.setenv("SF_GMA_MODE", "flash")
-    monkeypatch.setenv("SF_FLASH_QKP", str(qkp))
     tag = "forward_T4"
     g = golden(tag)
     B, T, H, W, iters, seed, use_init = cases.FORWARD_CASES[tag]
     P, fmaps, cnets, finit, iters = cases.forward_inputs(tag)
     for graph in (False, True):
-        eng = HotPathEngine(P, device=dev, T=T, use_graph=graph)
+        eng = HotPathEngine(P, device=dev, T=T, use_graph=graph, gma_mode="flash", flash_qk_products=qkp)
         ups, _ = eng.forward(fmaps.to(dev), cnets.to(dev), iters=iters)
         pl = eng.plan(B, H // 8, W // 8, 256)
         assert pl.flash and pl.attn.numel() <= pl.n * pl.P
@@ -501,7 +499,7 @@ def test_engine_flash_mode_vs_golden(golden, dev, qkp, monkeypatch):
     P = syn.make_params(5, T)
     fmaps, cnets = syn.make_features(5, B, T, h, w)
     ups_o, _ = orc.hotpath_forward(fmaps, cnets, P, 15)
-    eng = HotPathEngine(P, device=dev, T=T)
+    eng = HotPathEngine(P, device=dev, T=T, gma_mode="flash", flash_qk_products=qkp)
     ups, _ = eng.forward(fmaps.to(dev), cnets.to(dev), iters=15)
     e = max(orc.epe(u.cpu(), o) for u, o in zip(ups, ups_o))
     print(f"flash GMA, qk_products={qkp}: 15-iteration EPE vs oracle = {e:.3e}")
@@ -723,8 +721,7 @@ def test_dwconv_two_product_mode(dev, hw, k):
 def test_skblock_pw_fold_vs_float64(dev, k, C, hw):
     """f16x2 mode: x4 = gelu(x3 + pw(x3)) is computed as gelu((W + I) x3) with x3 handed over in fp16 rows by the
     depthwise kernel (engine.run_skblock).  The whole block against torch in float64, with the fold and without
-    (SF_PW_FOLD=0): both within the mode's error, and the fold no worse than 2x the plain path."""
-    import os
+    (Ctx.pw_fold = False): both within the mode's error, and the fold no worse than 2x the plain path."""
     import torch.nn.functional as F
     from streamflow_amd import ops
     from streamflow_amd.engine import SKBlockWeights, run_skblock
@@ -753,21 +750,11 @@ def test_skblock_pw_fold_vs_float64(dev, k, C, hw):
     X = Planes.of(x.view(n, C, P).to(dev))
     mk = lambda rows: Planes.of(torch.zeros(n, rows + 8, P, device=dev))
     errs = {}
-    prev = ops.set_precision("f16x2")
-    keep = os.environ.get("SF_PW_FOLD")
-    try:
-        for fold in ("1", "0"):
-            os.environ["SF_PW_FOLD"] = fold
-            y = torch.full((n, Co, P), float("nan"), device=dev)
-            run_skblock(W, X, Planes.of(y), mk(Cm), mk(C), mk(C), h, w)
-            torch.cuda.synchronize()
-            errs[fold] = (y.double().cpu() - ref).abs().max().item()
-    finally:
-        ops.set_precision(prev)
-        if keep is None:
-            os.environ.pop("SF_PW_FOLD", None)
-        else:
-            os.environ["SF_PW_FOLD"] = keep
+    for fold in ("1", "0"):
+        y = torch.full((n, Co, P), float("nan"), device=dev)
+        run_skblock(W, X, Planes.of(y), mk(Cm), mk(C), mk(C), h, w, cx=ops.Ctx(ops.PRECISION_F16X2, pw_fold=(fold == "1")))
+        torch.cuda.synchronize()
+        errs[fold] = (y.double().cpu() - ref).abs().max().item()
     scale = ref.abs().max().item()
     assert errs["0"] < 4e-3 * scale and errs["1"] < 4e-3 * scale, (errs, scale)
     assert errs["1"] < 2.0 * errs["0"] + 1e-6, errs

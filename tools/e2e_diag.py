@@ -19,10 +19,8 @@ fnet, cnet = Twins_CSC().to(dev), Twins_CSC().to(dev)
 fnet.load_state_dict({k: v for k, v in ef.items()}, strict=True); cnet.load_state_dict({k: v for k, v in ec.items()}, strict=True)
 feats = {}
 for enc_prec, koct in (("f16x3", "1"), ("f16x2", "1"), ("f16x2", "0"), ("fp32", "1")):
-    os.environ["SF_ENCODER_KOCT"] = koct
-    prev = ops.set_precision(enc_prec)
-    fm, cn = fnet(imgs.to(dev)), cnet(imgs[:, :-1].to(dev))
-    ops.set_precision(prev)
+    fnet.koct_handover = cnet.koct_handover = koct == "1"
+    fm, cn = fnet(imgs.to(dev), precision=enc_prec), cnet(imgs[:, :-1].to(dev), precision=enc_prec)
     rel = lambda a, b: ((a.cpu() - b).abs().max() / b.abs().max()).item()
     print(f"encoder {enc_prec} koct={koct}: fmap max err / max |f| = {rel(fm, fm_o):.2e} (max |f| {fm_o.abs().max():.2f}), cnet {rel(cn, cn_o):.2e}")
     feats[(enc_prec, koct)] = (fm, cn)
