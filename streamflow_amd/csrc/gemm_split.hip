@@ -704,7 +704,11 @@ int gemm_bstat_launch(const SfGemm& g, hipStream_t st);
 
 int gemm_split_dispatch(const SfGemm& g, hipStream_t st) {
     // automatic split-K through caller-provided scratch
-    if (g.k_splits == 0 && g.split_ws && !g.conv3x3 && !g.c_f16 && !g.r_f16) {  // (no split-K form for the 3x3 conv / fp16 output)
+    // (not for problems the activation-stationary kernel takes: it cuts small grids into row ranges instead, and a k-octet
+    // operand with M <= 96 has no tiled kernel to split)
+    const bool to_bstat = g.algo != SF_ALGO_TILED && gemm_bstat_ok(g) &&
+                          (g.algo == SF_ALGO_BSTAT || g.c_f16 == 2 || (g.b_layout == SF_LAYOUT_F16_KOCT && (g.M + 127) / 128 * 128 * 4 > g.M * 5));
+    if (g.k_splits == 0 && g.split_ws && !g.conv3x3 && !g.c_f16 && !g.r_f16 && !to_bstat) {  // (no split-K form for the 3x3 conv / fp16 output)
         const int ks = auto_splits(g.M, g.N, g.K, g.batch);
         const int64_t slab = (int64_t)g.batch * g.M * g.N;
         if (ks > 1 && g.split_ws_floats >= ks * slab) {
@@ -746,7 +750,11 @@ int gemm_split_dispatch_inner(const SfGemm& g, hipStream_t st) {
     // waste more than a quarter of the MFMAs
     // output / residual format rules: checked for EVERY operand layout (the fp16-in -> fp16-out hand-over is the common case)
     // activation-stationary kernel (gemm_bstat.hip) wherever it applies: K <= 640 held in registers, weights streamed
-    if (g.algo != SF_ALGO_TILED && gemm_bstat_ok(g)) return gemm_bstat_launch(g, st);
+    // (SF_ALGO_AUTO: where the result leaves as k-octets only -- the FFN hiddens, x4, the temporal MLP hidden: its software-
+    // pipelined GELU form runs 1.15-1.3x the tiled kernels; with fp32 planes to write, the tiled kernels' transposed 16-byte
+    // stores still win -- and where the tiled family has no kernel at all: a k-octet operand with fewer than 97 rows)
+    const bool bstat_auto = g.c_f16 == 2 || (g.b_layout == SF_LAYOUT_F16_KOCT && (g.M + 127) / 128 * 128 * 4 > g.M * 5);
+    if ((g.algo == SF_ALGO_BSTAT || (g.algo == SF_ALGO_AUTO && bstat_auto)) && gemm_bstat_ok(g)) return gemm_bstat_launch(g, st);
     if (g.algo == SF_ALGO_BSTAT) return fail(SF_ERR_UNSUPPORTED, "sf_gemm: SF_ALGO_BSTAT cannot run this problem (see include/streamflow_hip.h)");
     if (const int rc = check_output_formats(g); rc != SF_OK) return rc;
     if (g.b_layout == SF_LAYOUT_F16_KOCT) {

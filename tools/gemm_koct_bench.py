@@ -30,19 +30,25 @@ for M, K in shapes:
         Ma = (M + 7) // 8 * 8
         Y = Planes(torch.zeros(n * Ma * P // 2, device=dev), 0, Ma * P, n, M, P, f16=True, koct=True)
         epi = ops.EPI_GELU
+    elif mode == "dw1":                                         # an SK block's ffn*.2: residual + GELU + depthwise 1 x 1 + GELU, fp32 planes out
+        Y = Planes.of(torch.empty(n, M, P, device=dev))
+        epi = ops.EPI_RES_GELU_DW1
     else:
         Y = Planes.of(torch.empty(n, M, P, device=dev))
         epi = ops.EPI_GELU if mode == "gelu" else ops.EPI_NONE
     if mode == "koct" and not (ops.uses_dma_tile(M) if ALGO == 1 else ops.takes_koct(M, K)):
         continue
-    if ALGO == 2 and K > 640:
+    if ALGO == 2 and (K > 640 or (mode == "dw1" and K > 384)):
         continue
+    kw = {}
+    if mode == "dw1":
+        kw = dict(R=Planes.of(torch.randn(n, M, P, device=dev)), dw_w=torch.randn(M, device=dev) * 0.3, dw_b=torch.randn(M, device=dev) * 0.1)
     for _ in range(3):
-        ops.gemm(W, X, Y, epi, algo=ALGO)
+        ops.gemm(W, X, Y, epi, algo=ALGO, **kw)
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
     for _ in range(10):
-        ops.gemm(W, X, Y, epi, algo=ALGO)
+        ops.gemm(W, X, Y, epi, algo=ALGO, **kw)
     e.record(); torch.cuda.synchronize()
     us = s.elapsed_time(e) * 100
     tot += us
