@@ -393,6 +393,7 @@ __global__ __launch_bounds__(kThreads, (PM == 1 && NKS <= 16 && RES == 0) ? 4 : 
     // "row rb + e + 4 khalf < M" as  k4 < (M - rb - e)  with the right side forced into a scalar register: written the other
     // way round, hipcc hoists one per-lane constant PER (tile, group, element) out of the m-loop -- 40 VGPRs of them
     auto rows_left = [&](int r) { return __builtin_amdgcn_readfirstlane(g.M - r); };
+    auto rows_left8 = [&](int r) { return __builtin_amdgcn_readfirstlane((g.M + 7) / 8 * 8 - r); };      // up to the end of the last octet
     // CF = SfGemm.c_f16 (0: fp32 planes, 2: k-octets, 3: both); results that leave as fp16 ONLY take the polynomial GELU of the
     // two-product modes, like the tiled kernels.  The bias is already in the accumulators (m-step start).
     auto epilogue = [&](int m, auto epi_tag, auto cf_tag) {
@@ -439,7 +440,9 @@ __global__ __launch_bounds__(kThreads, (PM == 1 && NKS <= 16 && RES == 0) ? 4 : 
                         for (int e = 0; e < 4; ++e) h[e] = (_Float16)o[e];
                         const int so = (rb >> 3) * ldc4 * 4;
                         // CF = 3: rows >= M of a last octet belong to someone else (flow rows of the motion features)
-                        const bool full = (CF == 2) ? (k4 < rows_left(rb)) : (k4 < rows_left(rb + 3));
+                        // CF = 2: every row of the last octet is written (finite: zero weight rows give gelu(bias = 0)) -- the consumer
+                        // multiplies rows M .. 8 ceil(M / 8) - 1 by zero weights, and 0 x (whatever the buffer held) must not be NaN
+                        const bool full = (CF == 2) ? (k4 < rows_left8(rb)) : (k4 < rows_left(rb + 3));
                         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, h), rc16, full ? lane_k16 : kOob, so, 0);
                         if (CF == 3 && (g.M & 3) && rb + 8 > g.M && rb < g.M) {           // (wave-uniform) partial last group: row by row
 #pragma unroll
@@ -639,6 +642,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bstat_gk_kernel(const BsArgs
     const int lane_k16 = (n < g.N) ? n * 16 + khalf * 8 : kOob;
     const int k4 = 4 * khalf, ldc16 = (int)g.ldc * 16;
     auto rows_left = [&](int r) { return __builtin_amdgcn_readfirstlane(g.M - r); };
+    auto rows_left8 = [&](int r) { return __builtin_amdgcn_readfirstlane((g.M + 7) / 8 * 8 - r); };      // up to the end of the last octet
 
     // rows tau * 32 + 8 j + 4 khalf + 0..3 of `acc` for NG consecutive groups j0 ..: gelu(alpha * acc) -> fp16 -> 8-byte stores.
     // CH = pairs of values whose GELU chains run interleaved (K = 640: one group = two pairs at a time, for the registers)
@@ -669,7 +673,8 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bstat_gk_kernel(const BsArgs
                 const int rb = tau * 32 + 8 * (J0 + jj);
                 u32x2 o;
                 o[0] = hw[2 * jj]; o[1] = hw[2 * jj + 1];
-                __builtin_amdgcn_raw_buffer_store_b64(o, rc16, (k4 < rows_left(rb)) ? lane_k16 : kOob, (rb >> 3) * ldc16, 0);
+                // (every row of the last octet is written: see the kernel above)
+                __builtin_amdgcn_raw_buffer_store_b64(o, rc16, (k4 < rows_left8(rb)) ? lane_k16 : kOob, (rb >> 3) * ldc16, 0);
             }
         }
     };

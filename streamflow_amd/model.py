@@ -68,12 +68,13 @@ class SKFlow_MF8(nn.Module):
     def preset_name(self) -> str:
         """Arithmetic configuration of the refinement loop, chosen the way the reference chooses its own: `args.preset`
         names one of streamflow_amd.presets explicitly; otherwise `args.mixed_precision` (the reference's autocast switch,
-        evaluate_mf.py:1106, streamflow.py:106,118,135) selects the reduced-precision class (`config2_mixed`) and its absence
+        evaluate_mf.py:1106, streamflow.py:106,118,135) selects the reduced-precision class (`config2_fp16`: split weights in every
+        layer; the mixed preset of the benchmark is opt-in by name) and its absence
         the fp32-class arithmetic (`fp32_class`)."""
         from . import presets
         name = getattr(self.args, "preset", None)
         if name is None:
-            name = presets.BENCH_PRESET if getattr(self.args, "mixed_precision", False) else "fp32_class"
+            name = presets.MODEL_MIXED_PRESET if getattr(self.args, "mixed_precision", False) else "fp32_class"
         if name not in presets.PRESETS:
             raise RuntimeError(f"unknown preset {name!r} (have {list(presets.PRESETS)})")
         return name

@@ -23,6 +23,7 @@ def _koct(x, dev, ops):
     n, K, P = x.shape
     Ka = (K + 7) // 8 * 8
     Y = Planes(torch.zeros(n * Ka * P // 2 + 8, device=dev), 0, Ka * P, n, K, P, f16=True, koct=True)
+    Y.base.view(torch.float16).fill_(1000.0)              # rows K .. Ka - 1 of the last octet: finite garbage (contract: zero weights there)
     ops.pack_koct(Planes.of(x.to(dev).contiguous()), Y)
     return Y
 
@@ -94,7 +95,8 @@ def test_bstat_random(dev, seed):
     Mo = (M + 7) // 8 * 8
     y32 = torch.full((n, M, P), float("nan"), device=dev)
     if cfmt == 2:
-        Y = Planes(torch.zeros(n * Mo * P // 2 + 8, device=dev), 0, Mo * P, n, M, P, f16=True, koct=True)
+        # (NaN-filled: every row of the last octet must come out finite -- the next layer multiplies the rows past M by zero weights)
+        Y = Planes(torch.full((n * Mo * P // 2 + 8,), float("nan"), device=dev), 0, Mo * P, n, M, P, f16=True, koct=True)
     else:
         Y = Planes.of(y32)
         if cfmt == 3:
@@ -120,6 +122,9 @@ def test_bstat_random(dev, seed):
         err = (y32.double().cpu() - ref).abs().max().item()
         assert err < 3e-5 * scale, tag + (err,)
     if cfmt >= 2:
+        if cfmt == 2:
+            whole = Y.base.view(torch.float16)[: n * Mo * P].view(n, Mo // 8, P, 8)
+            assert bool(torch.isfinite(whole.float()).all()), tag
         got = (Y if cfmt == 2 else Y.shadow).tensor().double().cpu()
         # fp16 storage: one rounding (2^-11) (+ the polynomial GELU of the k-octet-only output: 5.2e-5)
         err = (got - ref).abs()

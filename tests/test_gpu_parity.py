@@ -292,8 +292,8 @@ def test_preset_selected_through_reference_args(dev):
     import streamflow_amd as sfa
     from streamflow_amd import ops, presets, synthetic as syn
     P = syn.make_params(2, 4)
-    for kw, want in ((dict(), "fp32_class"), (dict(mixed_precision=True), presets.BENCH_PRESET),
-                     (dict(preset="config2_fp16"), "config2_fp16")):
+    for kw, want in ((dict(), "fp32_class"), (dict(mixed_precision=True), presets.MODEL_MIXED_PRESET),
+                     (dict(preset="config2_fp16"), "config2_fp16"), (dict(preset="config2_mixed"), "config2_mixed")):
         m = sfa.SKFlow_MF8(sfa.default_args(T=4, Encoder="InjectEncoder", **kw))
         m.load_state_dict(dict(P), strict=True)
         assert m.preset_name() == want
@@ -303,7 +303,8 @@ def test_preset_selected_through_reference_args(dev):
         assert eng.single_layers == tuple(cfg.get("single_layers", ()))
         n_dw = sum(getattr(eng.W, b).dw_single for b in eng.W.SK_BLOCKS)
         assert sum(pl.single for pl in eng.W.layers().values()) + n_dw == len(cfg.get("single_layers", ()))
-    assert sfa.StreamFlowT4(None, Encoder="InjectEncoder").preset_name() == presets.BENCH_PRESET
+    assert sfa.StreamFlowT4(None, Encoder="InjectEncoder").preset_name() == presets.MODEL_MIXED_PRESET == "config2_fp16"
+    assert sfa.StreamFlowT4(None, Encoder="InjectEncoder", preset=presets.BENCH_PRESET).preset_name() == "config2_mixed"
     with pytest.raises(RuntimeError, match="unknown preset"):
         sfa.SKFlow_MF8(sfa.default_args(T=4, Encoder="InjectEncoder", preset="nope")).engine(dev)
 
@@ -372,7 +373,7 @@ def test_engine_on_non_current_device():
         assert max(orc.epe(u.cpu(), o) for u, o in zip(ups, ups_o)) <= 1e-3
 
 
-@pytest.mark.parametrize("preset", ["fp32_class", "config2_fp16"])
+@pytest.mark.parametrize("preset", ["fp32_class", "config2_fp16", "config2_mixed"])
 def test_kitti_shape_T2_vs_oracle(dev, preset):
     """BASELINE config 3: KITTI shape 376x1248 -> 47x156 grid (odd height, width not a multiple of 32, pooled levels of
     odd width 39 / 19), T=2 (one pair, single-token temporal block, 128->2 flow head), corr build + lookup + 2 iterations
@@ -605,7 +606,7 @@ def test_spring_shape_one_pair_vs_oracle(dev):
     P = syn.make_params(19, T)
     fmaps, cnets = syn.make_features(19, B, T, h, w)
     ups_o, _ = orc.hotpath_forward(fmaps, cnets, P, iters)
-    for name in ("fp32_class", "config2_fp16"):
+    for name in ("fp32_class", "config2_fp16", "config2_mixed"):
         eng = HotPathEngine(P, device=dev, T=T, **presets.engine_kwargs(name))
         ups, _ = eng.forward(fmaps.to(dev), cnets.to(dev), iters=iters)
         pl = eng.plan(B, h, w, 256)
@@ -888,11 +889,14 @@ def test_twins_csc_encoder_vs_reference(golden, dev, tag, precision):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mixed", [False, True])
-def test_real_frames_end_to_end_with_twins_encoder(dev, mixed):
+def test_real_frames_end_to_end_with_twins_encoder(dev):
     """No stand-in anywhere: frames in 0..255 -> Twins_CSC fnet / cnet -> refinement loop -> flows, through the
-    reference's SKFlow_MF8 signature; against the CPU oracles chained the same way (encoder oracle -> hot-path oracle).
-    mixed: args.mixed_precision = True -- encoders AND loop in the bench preset's arithmetic (fp16 hand-over everywhere)."""
+    reference's SKFlow_MF8 signature; against the CPU oracles chained the same way (encoder oracle -> hot-path oracle), in the
+    three presets (encoders AND loop in the preset's arithmetic, fp16 hand-over everywhere in the config-2 presets).
+    The random-weight network over these frames is ill-conditioned (features up to |f| = 19, flows of 20-60 px).  The fp32 class
+    stays inside the ABSOLUTE 1e-3 px budget even so.  The deviation of the fp16-activation class is proportional to the flow:
+    its bound is 1e-3 of the mean flow magnitude, and the mixed preset may be at most 8x the all-split preset's deviation
+    (measured 4.4x) -- a regression of the single-product layer set on ill-conditioned inputs stays visible."""
     from oracle import streamflow_oracle as orc, twins_oracle as two
     from streamflow_amd import synthetic as syn
     from streamflow_amd.model import SKFlow_MF8, default_args
@@ -901,21 +905,21 @@ def test_real_frames_end_to_end_with_twins_encoder(dev, mixed):
     sd = dict(hot)
     sd.update({"fnet." + k: v for k, v in ef.items()})
     sd.update({"cnet." + k: v for k, v in ec.items()})
-    model = SKFlow_MF8(default_args(T=T, mixed_precision=mixed)).to(dev)
-    model.load_state_dict(sd, strict=True)
     frames = [(syn.randn(24, f"frame{t}", (B, 3, H, W)).sigmoid() * 255.0) for t in range(T)]
-    ups = model([f.to(dev) for f in frames], iters=iters, test_mode=True)
     imgs = 2 * (torch.stack(frames, dim=1) / 255.0) - 1.0
     fmaps = two.twins_csc_forward(imgs, ef)
     cnets = two.twins_csc_forward(imgs[:, :-1], ec)
     ups_o, _ = orc.hotpath_forward(fmaps, cnets, hot, iters)
-    assert len(ups) == T - 1 and ups[0].shape == (B, 2, H, W)
-    for i in range(T - 1):
-        e = orc.epe(ups[i].cpu(), ups_o[i])
-        mag = ups_o[i].norm(dim=1).mean().item()
-        print(f"real frames -> Twins_CSC -> loop [mixed_precision={mixed}], pair {i}: EPE vs chained oracles = {e:.3e} "
-              f"(mean |flow| {mag:.1f} px)")
-        # The random-weight network over these frames produces flows of ~60 px.  The fp32 class stays inside the absolute 1e-3 px
-        # budget even so; the deviation of the fp16-activation class is proportional to the flow (measured 1e-4 |flow| for
-        # config2_fp16, 4e-4 |flow| for config2_mixed at this shape: DESIGN.md 5c), so its bound here is relative
-        assert e <= (1e-3 * max(1.0, mag) if mixed else 1e-3), (i, e, mag)
+    mag = float(torch.stack([o.norm(dim=1).mean() for o in ups_o]).mean())
+    worst = {}
+    for preset in ("fp32_class", "config2_fp16", "config2_mixed"):
+        model = SKFlow_MF8(default_args(T=T, preset=preset)).to(dev)
+        model.load_state_dict(sd, strict=True)
+        ups = model([f.to(dev) for f in frames], iters=iters, test_mode=True)
+        assert len(ups) == T - 1 and ups[0].shape == (B, 2, H, W)
+        worst[preset] = max(orc.epe(u.cpu(), o) for u, o in zip(ups, ups_o))
+        print(f"real frames -> Twins_CSC -> loop [{preset}]: max EPE vs chained oracles = {worst[preset]:.3e} (mean |flow| {mag:.1f} px)")
+        del model
+    assert worst["fp32_class"] <= 1e-3, worst
+    assert worst["config2_fp16"] <= 1e-3 * max(1.0, mag) and worst["config2_mixed"] <= 1e-3 * max(1.0, mag), (worst, mag)
+    assert worst["config2_mixed"] <= 8.0 * worst["config2_fp16"], worst
