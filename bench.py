@@ -34,6 +34,7 @@ WORKLOADS = {
     "sintel": (440, 1024, 4, 15),
     "demo256": (256, 256, 4, 4),
     "kitti": (376, 1248, 2, 15),
+    "kitti_w160": (376, 1280, 2, 15),  # experiment: KITTI with a 160-cell grid row (640-byte volume rows = whole cache lines)
     "spring": (1088, 1920, 4, 15),     # 1080p padded to /8: 136x240 grid, N = 32640 (use --clips 1; 17 GB of volumes)
 }
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: exact-fp32 MFMA = fp32 vector peak
@@ -227,6 +228,74 @@ def spawn_ranks(n: int, argv, script: str = None) -> int:
     return rc
 
 
+def corr_only(args, dev, cfg, H, W, T, iters):
+    """BASELINE.json config 3: the all-pairs volume + pyramid build and the pyramid lookups alone.
+    One step = one build of every (clip, pair) volume + `iters` lookups at fresh sub-pixel coordinates (the ratio of the
+    real loop).  Bytes are the algorithmic ones of section 8(d): build = both feature maps read once + every pyramid cell
+    written once; lookup = 4 levels x 10 x 10 footprint cells + coordinates + 324 fp32 output channels per pixel."""
+    from streamflow_amd import ops, synthetic as syn
+    from streamflow_amd.ops import Planes
+    h, w, B, pairs, D = H // 8, W // 8, args.clips, T - 1, 256
+    N, n = h * w, args.clips * (T - 1)
+    f16 = cfg["corr_dtype"] == "f16"
+    cx = ops.Ctx(precision=ops._PRECISION_NAMES[cfg["precision"]], shadows=False)
+    fmaps = syn.make_features(1000, B, T, h, w)[0].to(dev)
+    strides = [N * (h >> l) * (w >> l) for l in range(4)]
+    if f16:                # the shipped fp16 path: blocked volumes, features handed over as fp16 k-octets only (engine.py)
+        vol = ops.new_blocked_volume(n, h, w, dev)
+        ws = torch.empty(max(ops.corr_build_blocked_ws_bytes(n, D, h, w), 16), dtype=torch.uint8, device=dev)
+    else:
+        lvls = [torch.empty(n * s, dtype=torch.float32, device=dev) for s in strides]
+        ws = torch.empty(max(ops.corr_build_ws_bytes(B, pairs, D, h, w), 16), dtype=torch.uint8, device=dev)
+    g = torch.Generator().manual_seed(7)
+    ys, xs = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing="ij")
+    grid = torch.stack([xs, ys])[None]                                        # (x, y) like coords_grid (utils.py)
+    coords = [Planes.of((grid + 4.0 * torch.randn(n, 2, h, w, generator=g)).reshape(n, 2, N).contiguous().to(dev))
+              for _ in range(iters)]
+    out = Planes.of(torch.empty(n, 324, N, device=dev))
+    out_k = ops.new_shadow(out, dev) if f16 else None
+
+    def step():
+        if f16:
+            ops.corr_build_blocked(fmaps.data_ptr(), fmaps.data_ptr() + 4 * D * N, T * D * N, D * N, vol, B, pairs, D, ws=ws)
+            for c in coords:
+                ops.corr_lookup_blocked(vol, c, None, out_k, B, pairs)
+            return
+        ops.corr_build(fmaps.data_ptr(), fmaps.data_ptr() + 4 * D * N, T * D * N, D * N, lvls, strides, B, pairs, D, h, w,
+                       ws=ws, cx=cx)
+        for c in coords:
+            ops.corr_lookup(lvls, strides, c, out, B, pairs, h, w, cx=cx)
+
+    step()
+    torch.cuda.synchronize()
+    dt = timed_steps(step, args.steps, args.warmup, 1, torch.cuda.synchronize, lambda: None, lambda x: x)
+    ops.PROFILER = ops.Profiler()
+    step()
+    prof = ops.PROFILER.summary()
+    ops.PROFILER = None
+    b, l = prof["corr_build"], prof["corr_lookup"]
+    gb = lambda d: d["bytes"] / d["ms"] / 1e6
+    tot_bytes, tot_ms = b["bytes"] + l["bytes"], b["ms"] + l["ms"]
+    cell = 2 if f16 else 4
+    return {
+        "metric": "corr_build_lookup_gbps", "value": tot_bytes / tot_ms / 1e6, "unit": "GB/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": ("fp16 cells (blocked layout, k-octet feature hand-over), single f16 product" if f16 else f"fp32 cells, {cfg['precision']} arithmetic"),
+        "data": "synthetic",
+        "config": {"workload": f"{args.workload}_{H}x{W}_T{T}_corr_only", "clips_per_step": B, "pairs_per_clip": pairs,
+                   "feature_grid": [h, w], "lookups_per_step": iters, "volume_bytes_per_pair": cell * sum(strides),
+                   "preset": args.preset or "default"},
+        "roofline": {"kernel": "corr_build + corr_lookup", "bound": "hbm", "achieved": tot_bytes / tot_ms / 1e6,
+                     "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": tot_bytes / tot_ms / 1e6 / PEAK_HBM_GBPS, "traffic": None,
+                     "build": {"avg_us": 1e3 * b["ms"] / b["launches"], "gbps": gb(b), "tflops": b["flops"] / b["ms"] / 1e9,
+                               "algorithmic_bytes": b["bytes"] / b["launches"]},
+                     "lookup": {"avg_us": 1e3 * l["ms"] / l["launches"], "gbps": gb(l),
+                                "algorithmic_bytes": l["bytes"] / l["launches"]},
+                     "method": "HIP events around every launch of one instrumented step on the launch stream; bytes of SURVEY.md "
+                               "section 8(d) at the element size of the stored volume"},
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -272,6 +341,10 @@ def main():
     ap.add_argument("--streams", type=int, default=1,
                     help="experiment: split the clips of a step over S engines replayed concurrently on S streams "
                          "(fills the partial last round of one engine's launches with the other's workgroups)")
+    ap.add_argument("--corr-only", action="store_true",
+                    help="BASELINE.json config 3: ONLY the correlation build (all-pairs volume + 4-level pyramid) and the "
+                         "pyramid lookups of the workload (one build + `iters` lookups per step), reported in GB/s against "
+                         "the HBM roof; use with --workload kitti --preset fp32_class for the full-resolution fp32 volume")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-runs", type=int, default=3, help="timed whole-clip runs of the CPU oracle (median reported)")
     ap.add_argument("--no-kernel-breakdown", action="store_true")
@@ -332,6 +405,10 @@ def main():
     H, W, T, iters = WORKLOADS[args.workload]
     h, w, B = H // 8, W // 8, args.clips
     pairs = T - 1
+    if args.corr_only:
+        assert world == 1, "--corr-only is a single-GPU line"
+        print(json.dumps(corr_only(args, dev, cfg, H, W, T, iters)), flush=True)
+        return
     params = syn.make_params(0, T)
     strong = args.total_clips > 0
     my_batches = batches(len(shard(args.total_clips, world, rank)), B) if strong else [B]

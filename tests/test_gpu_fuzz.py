@@ -681,3 +681,53 @@ def test_koct_gemm_dispatch_branches_vs_float64(dev, M, K, single, epi):
         ref, tol = v, 5e-5
     err = (got.double() - ref).abs().max().item()
     assert err <= tol, (M, K, single, epi, err)
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_two_engines_two_threads_match_their_serial_runs(dev, graph):
+    """No process-wide launch state: two engines with DIFFERENT presets (arithmetic class, volume format, GMA path, hand-over
+    formats) driven concurrently from two host threads, each on its own stream, give bit for bit the flows each gives alone.
+    Eager launches interleave call by call (every launch takes its precision / formats from the engine's own context);
+    graph engines are captured one after the other and then replayed concurrently."""
+    import threading
+    from streamflow_amd import presets, synthetic as syn
+    from streamflow_amd.engine import HotPathEngine
+    T, h, w, iters, B = 3, 24, 32, 3, 2
+    P = syn.make_params(11, T)
+    jobs = []
+    for i, preset in enumerate(("config2_mixed", "fp32_class")):
+        eng = HotPathEngine(P, device=dev, T=T, use_graph=graph, **presets.engine_kwargs(preset))
+        fm, cn = syn.make_features(70 + i, B, T, h, w)
+        fm, cn = fm.to(dev), cn.to(dev)
+        for _ in range(2):                                        # serial reference (second run: graph replay)
+            ref = [u.clone() for u in eng.forward(fm, cn, iters=iters)[0]]
+        jobs.append((eng, fm, cn, ref))
+    torch.cuda.synchronize()
+    results, errors = [None, None], []
+    gate = threading.Barrier(2)
+
+    def run(i):
+        try:
+            eng, fm, cn, _ = jobs[i]
+            torch.cuda.set_device(dev)
+            st = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(st):
+                gate.wait(timeout=60)
+                for _ in range(4):
+                    ups = eng.forward(fm, cn, iters=iters)[0]
+                results[i] = [u.clone() for u in ups]
+            st.synchronize()
+        except Exception as e:                                    # noqa: BLE001 -- reported by the main thread
+            errors.append((i, repr(e)))
+
+    th = [threading.Thread(target=run, args=(i,)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    torch.cuda.synchronize()
+    assert not errors, errors
+    for i in range(2):
+        assert results[i] is not None
+        for a, b in zip(results[i], jobs[i][3]):
+            assert torch.equal(a, b), ("engine", i, "graph", graph)
