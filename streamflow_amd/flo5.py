@@ -1,6 +1,6 @@
 """``.flo5``: Spring's flow container -- an HDF5 file with ONE dataset ``flow`` (float32 [H, W, 2], gzip level 5), as
 the reference writes and reads it through h5py (core/utils/frame_utils.py:31-47 ``writeFlo5File``, :130-135
-``readFlo5Flow``).  h5py / libhdf5 are not in this image, so this is a small codec for exactly that subset of the
+``readFlo5Flow``).  h5py / libhdf5 are not importable from this package's interpreter, so this is a small codec for exactly that subset of the
 published HDF5 File Format Specification (version 1.1 structures, what libhdf5 emits with ``libver='earliest'``,
 h5py's default):
 
@@ -12,8 +12,10 @@ h5py's default):
 * filter pipeline v1 / v2 with deflate (id 1) and shuffle (id 2); other filters raise.
 
 ``write_flo5`` emits the same structures (one chunked, deflate-compressed dataset under the root group).
-PARITY UNPINNED: no HDF5 library exists here to cross-read the files; the tests are a write -> read round trip plus
-byte-level checks of the structures against the specification's field tables.
+Parity is pinned both ways against the real library (h5py 3.3.0 / HDF5 1.10.6 of the build container's conda interpreter,
+which is not this package's python): the reader decodes, bit for bit, the files under tests/golden/flo5 that h5py wrote with
+the reference's own call (tests/golden/make_flo5_golden.py), and files from ``write_flo5`` open in h5py with the same values,
+gzip level 5 (tests/test_flow_io_cpu.py); plus the round trips and byte-level structure checks.
 """
 from __future__ import annotations
 

@@ -1,4 +1,6 @@
 """CPU: .flo codec, KITTI uint16 arithmetic and the evaluation metrics (reference frame_utils.py / evaluate_mf.py)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -316,3 +318,51 @@ def test_png_reader_all_filter_types(tmp_path):
     (tmp_path / "bad.png").write_bytes(bytes(bad))
     with pytest.raises(IOError):
         flow_io.read_png(str(tmp_path / "bad.png"))
+
+
+GOLD5 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "flo5")
+H5PY_PYTHON = "/opt/conda/bin/python3.9"            # the build container's interpreter that has h5py 3.3.0 / HDF5 1.10.6
+
+
+def test_flo5_reader_against_files_written_by_h5py():
+    """Parity pin of the .flo5 reader: the fixtures under tests/golden/flo5 were written by the real h5py with the reference's
+    own call (frame_utils.py:46-47, gzip level 5, automatic chunking; plus contiguous float64 and shuffled custom chunks) by
+    tests/golden/make_flo5_golden.py -- bytes this package did not produce.  Bit-exact, NaNs (invalid pixels) included."""
+    from streamflow_amd import flow_io
+    exp = np.load(os.path.join(GOLD5, "expected.npz"))
+    assert len(exp.files) >= 6
+    for name in exp.files:
+        got = flow_io.read_flo5(os.path.join(GOLD5, name + ".flo5"))
+        assert got.dtype == exp[name].dtype and got.shape == exp[name].shape, name
+        assert np.array_equal(got.view(np.uint8), exp[name].view(np.uint8)), name          # bit patterns, NaN payloads too
+
+
+@pytest.mark.skipif(not os.path.exists(H5PY_PYTHON), reason="needs the build container's h5py interpreter")
+def test_flo5_writer_output_opens_in_h5py(tmp_path):
+    """The other direction: files from write_flo5 are read back by the real libhdf5 (same values, gzip level 5, chunked)."""
+    import subprocess
+    from streamflow_amd import flow_io
+    rng = np.random.default_rng(5)
+    paths, sums = [], []
+    for i, (h, w) in enumerate(((1, 1), (37, 53), (136, 240))):
+        flow = (rng.standard_normal((h, w, 2)) * 9).astype(np.float32)
+        if h > 1:
+            flow[rng.random((h, w)) < 0.05] = np.nan
+        p = str(tmp_path / f"w{i}.flo5")
+        flow_io.write_flo5(p, flow)
+        paths.append(p)
+        sums.append(float(np.nansum(flow.astype(np.float64))))
+    code = ("import sys, h5py, numpy as np\n"
+            "for p in sys.argv[1:]:\n"
+            "    with h5py.File(p, 'r') as f:\n"
+            "        d = f['flow']; a = d[()]\n"
+            "        print(a.shape[0], a.shape[1], a.shape[2], a.dtype, d.compression, d.compression_opts, repr(float(np.nansum(a.astype(np.float64)))))\n")
+    out = subprocess.run([H5PY_PYTHON, "-c", code] + paths, capture_output=True, text=True, timeout=120,
+                         env={"PATH": "/usr/bin:/bin"})
+    assert out.returncode == 0, out.stderr[-500:]
+    lines = out.stdout.strip().splitlines()
+    assert len(lines) == 3
+    for line, (h, w), s in zip(lines, ((1, 1), (37, 53), (136, 240)), sums):
+        f = line.split()
+        assert (int(f[0]), int(f[1]), int(f[2])) == (h, w, 2) and f[3] == "float32" and f[4] == "gzip" and f[5] == "5"
+        assert float(f[6]) == s
