@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SF_VERSION 110
+#define SF_VERSION 111
 
 enum {
     SF_OK = 0,
@@ -275,6 +275,14 @@ int sf_softmax_rows(float* x, int64_t rows, int cols, void* out_f16, void* strea
 int sf_dwconv_res_gelu(const float* x, int64_t x_img_stride, const float* wgt, const float* bias, void* y,
                        int64_t y_img_stride, int y_f16, int n_img, int C, int h, int w, int ksize, int precision,
                        void* stream);
+/* The same layer with x ALSO as fp16 rows [img][c][h][w] (both strides in halves): the config-2 hand-over of an SK block's
+ * x2 (written by sf_gemm with c_f16 = 1) and x3.  precision SF_PRECISION_F16X2 or SF_PRECISION_F16 only.  The convolution
+ * input and the residual are the fp16 value itself (what the two-product arithmetic multiplies anyway; the residual loses
+ * the 2^-12 relative rounding of x2, which x3's own fp16 rounding already has).  Rows of whole, 16-byte aligned octets
+ * (w % 8 == 0) are staged HBM/L2 -> LDS by DMA, double-buffered over the images of a workgroup; other widths through
+ * registers. */
+int sf_dwconv_res_gelu_f16in(const void* x_f16, int64_t x_img_stride, const float* wgt, const float* bias, void* y_f16,
+                             int64_t y_img_stride, int n_img, int C, int h, int w, int ksize, int precision, void* stream);
 
 /* ---- LayerNorm over channels of channel-major planes (update.py:462-463,481-483) --------------
  * x,y [n_img][C][P] (image strides given in floats), normalises each (img,p) column over C.

@@ -69,6 +69,7 @@ SIGNATURES = {
     "sf_softmax_rows": (_i, [_vp, _i64, _i, _vp, _vp]),
     "sf_splitk_combine": (_i, [_vp, _i64, _i, _i64, _vp, _i64, _vp, _vp, _i64, _i, _i64, _vp]),
     "sf_dwconv_res_gelu": (_i, [_vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "sf_dwconv_res_gelu_f16in": (_i, [_vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _vp]),
     "sf_layernorm_cm": (_i, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _i, _i, _i, _f, _vp]),
     "sf_temporal_attn": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "sf_pack_koct": (_i, [_vp, _i64, _i, _i, _i, _vp, _i64, _vp]),

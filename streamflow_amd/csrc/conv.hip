@@ -163,6 +163,7 @@ struct DwmArgs {
     int w16;          // w rounded up to 16
     int stride16;     // LDS row stride in 16-byte units (= 8 halfs)
     int vec_ok;       // rows are 16-byte aligned: float4 staging loads
+    int plane_bytes;  // bytes of one staged LDS plane (kIn = 2: rounded up to whole 4-KB DMA pieces)
 #ifdef SF_DW_TIMERS
     long long* ts;    // SF_DW_TS_BUF: per-workgroup phase cycles (tools/dwconv_one.py)
 #endif
@@ -187,22 +188,64 @@ struct DwmArgs {
 #ifndef SF_DW_MINWG
 #define SF_DW_MINWG 2
 #endif
-template <int KS, bool kOutF16, int kProd>
+#ifndef SF_DW_DMA_WGS
+#define SF_DW_DMA_WGS 768      // workgroups aimed at by the double-buffered fp16-input form (tools/build_variant.sh to A/B)
+#endif
+// kIn: format of x.  0: fp32 planes (staged through registers and split into hi + lo fp16 planes).  1 / 2: fp16 ROWS (the
+// config-2 hand-over of x2: the value IS its hi half, lo = 0, so conv input and residual are exact in fp16).  1 stages
+// through registers like 0 (any width); 2 -- rows of whole octets, 16-byte aligned -- moves the strip HBM/L2 -> LDS with
+// buffer_load ... lds, no registers, no ds_write, and DOUBLE-BUFFERED: the strip of image i + 1 lands in the second plane
+// (the `lo` plane of the other forms) while the tiles of image i are computed, one barrier per image.
+template <int KS, bool kOutF16, int kProd, int kIn = 0>
 __global__ __launch_bounds__(256, kProd == 1 ? 3 : ((KS == 15 && kProd == 2) ? SF_DW_MINWG : 2)) void dwconv_mfma_kernel(const DwmArgs g) {
     using namespace sf_split;
+    static_assert(kIn == 0 || kProd <= 2, "fp16 input: two- and one-product forms only");
+    typedef __attribute__((address_space(3))) void* lds_ptr;
     constexpr int R = KS / 2;
     constexpr int WZ = 64;                                      // zero-padded weight row: w[ky][j - 24]
     constexpr int TG = SF_DW_TG;                                // adjacent column tiles a wave works on together
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, kg = lane >> 4;
     const int c = blockIdx.x, ys = blockIdx.y * g.strip_h;
     const int rows_in = g.strip_h + KS - 1;
     const int noct = (g.w16 + 16) / 8;                          // octets per staged row: columns -8 .. w16 + 7
-    const int plane_bytes = rows_in * g.stride16 * 16;
+    const int plane_bytes = g.plane_bytes;
     char* hi = lds;
     char* lo = lds + plane_bytes;
     float* wz = reinterpret_cast<float*>(lds + 2 * plane_bytes);
+    const int img0 = blockIdx.z * g.imgs_per_wg;
+    const int img_end = min(img0 + g.imgs_per_wg, g.n_img);
+
+    // ---- kIn = 2: the DMA image of a strip.  LDS slot s (16 bytes) = row s / stride16, octet s % stride16 of the staged
+    // strip; a slot outside the plane (halo rows / columns, pad octets) gets an out-of-range offset and reads as zero.
+    // The offsets do not depend on the image: computed once.
+    constexpr int kMaxPieces = 8;                               // 8 x 256 slots x 16 B = 32 KB >= any plane the host allows
+    constexpr int kOobOff = 1 << 30;
+    int vo[kMaxPieces];
+    const int npieces = plane_bytes >> 12;
+    if constexpr (kIn == 2) {
+#pragma unroll
+        for (int p = 0; p < kMaxPieces; ++p) {
+            const int sl = p * 256 + tid;
+            const int row = sl / g.stride16, co = sl - row * g.stride16;
+            const int gy = ys - R + row, gx = co * 8 - 8;
+            const bool ok = row < rows_in && co < noct && gy >= 0 && gy < g.h && gx >= 0 && gx + 8 <= g.w;
+            vo[p] = ok ? (gy * g.w + gx) * 2 : kOobOff;
+        }
+    }
+    auto issue_strip = [&](int img, char* buf) {                // one resource per (image, channel) plane: the range check zeroes the halo
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<_Float16*>(reinterpret_cast<const _Float16*>(g.x) + img * g.x_img_stride + (int64_t)c * g.h * g.w), 0,
+            g.h * g.w * 2, 0x00020000);
+#pragma unroll
+        for (int p = 0; p < kMaxPieces; ++p)
+            if (p < npieces)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(buf + (p * 256 + wave * 64) * 16), 16, vo[p], 0, 0, 0);
+    };
+    if constexpr (kIn == 2) {
+        if (img0 < img_end) issue_strip(img0, hi);
+    }
 
     // ---- the channel's Toeplitz fragments -> registers --------------------------------------------------
     for (int i = tid; i < KS * WZ; i += 256) {
@@ -228,20 +271,32 @@ __global__ __launch_bounds__(256, kProd == 1 ? 3 : ((KS == 15 && kProd == 2) ? S
     const int ntx = g.w16 / 16, nty = g.strip_h / 16;
     const int ngroups = nty * ((ntx + TG - 1) / TG);            // groups of up to TG adjacent column tiles
 
-    const int img0 = blockIdx.z * g.imgs_per_wg;
-    const int img_end = min(img0 + g.imgs_per_wg, g.n_img);
+    const int my_groups = (ngroups - wave + 3) / 4;             // groups this wave works on per image
     for (int img = img0; img < img_end; ++img) {
         const float* __restrict__ xp = g.x + img * g.x_img_stride + (int64_t)c * g.h * g.w;
+        const _Float16* __restrict__ xh = reinterpret_cast<const _Float16*>(g.x) + img * g.x_img_stride + (int64_t)c * g.h * g.w;
+        // kIn = 2: the plane this image was staged into / the one the next image goes to
+        const char* hb = (kIn == 2) ? lds + ((img - img0) & 1) * plane_bytes : hi;
         // kOutF16: y holds fp16 planes, its strides count halves
         void* yp = kOutF16 ? (void*)(reinterpret_cast<_Float16*>(g.y) + img * g.y_img_stride + (int64_t)c * g.h * g.w)
                            : (void*)(g.y + img * g.y_img_stride + (int64_t)c * g.h * g.w);
         const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(yp, 0, g.h * g.w * (kOutF16 ? 2 : 4), 0x00020000);
-        // LDS-only barriers: the previous image's output stores stay in flight (a __syncthreads would drain them)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                           // previous image's tiles are done with the LDS planes
 #ifdef SF_DW_TIMERS
         const long long t0 = __builtin_readcyclecounter();
 #endif
+        if constexpr (kIn == 2) {
+            // this wave's pieces of the strip have landed: they are older than the 16 output stores of its last tile group of
+            // the previous image, which stay in flight (vmcnt retires in order); a wave without a group has no stores
+            static_assert(TG == 4, "the wait below counts the TG * 4 = 16 stores of one tile group");
+            if (img > img0 && my_groups > 0) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                       // everyone's pieces; and the other plane is no longer read
+            if (img + 1 < img_end) issue_strip(img + 1, lds + (((img - img0) & 1) ^ 1) * plane_bytes);
+        } else {
+        // LDS-only barriers: the previous image's output stores stay in flight (a __syncthreads would drain them)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                           // previous image's tiles are done with the LDS planes
         // ---- stage + split the strip (rows ys-R .., columns -8 ..), zero padded: one octet = 8 consecutive columns
         // of one row = one A-fragment slot; FU octets per thread at a time, all their loads issued before any is used
         constexpr int FU = SF_DW_FU;
@@ -259,7 +314,7 @@ __global__ __launch_bounds__(256, kProd == 1 ? 3 : ((KS == 15 && kProd == 2) ? S
 #if defined(SF_DW_ABLATE) && SF_DW_ABLATE == 2
                 if (false) {
 #else
-                if (rowok && g.vec_ok && gx >= 0 && gx + 8 <= g.w) {
+                if (kIn == 0 && rowok && g.vec_ok && gx >= 0 && gx + 8 <= g.w) {
 #endif
                     const float4 q0 = *reinterpret_cast<const float4*>(xp + gy * g.w + gx);
                     const float4 q1 = *reinterpret_cast<const float4*>(xp + gy * g.w + gx + 4);
@@ -271,7 +326,7 @@ __global__ __launch_bounds__(256, kProd == 1 ? 3 : ((KS == 15 && kProd == 2) ? S
 #if defined(SF_DW_ABLATE) && SF_DW_ABLATE == 2
                         v[u][i] = (float)(idx + i) * 1e-4f;
 #else
-                        v[u][i] = (rowok && gx + i >= 0 && gx + i < g.w) ? xp[gy * g.w + gx + i] : 0.f;
+                        v[u][i] = (rowok && gx + i >= 0 && gx + i < g.w) ? (kIn == 0 ? xp[gy * g.w + gx + i] : (float)xh[gy * g.w + gx + i]) : 0.f;
 #endif
                 }
             }
@@ -285,6 +340,7 @@ __global__ __launch_bounds__(256, kProd == 1 ? 3 : ((KS == 15 && kProd == 2) ? S
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        }
 #ifdef SF_DW_TIMERS
         const long long t1 = __builtin_readcyclecounter();
         t_stage += t1 - t0;
@@ -311,7 +367,7 @@ __global__ __launch_bounds__(256, kProd == 1 ? 3 : ((KS == 15 && kProd == 2) ? S
             f16x8 ah[2][TG], al[2][TG];
 #pragma unroll
             for (int j = 0; j < TG; ++j) {
-                ah[0][j] = *reinterpret_cast<const f16x8*>(hi + offj[j]);
+                ah[0][j] = *reinterpret_cast<const f16x8*>(hb + offj[j]);
                 if constexpr (kProd == 3) al[0][j] = *reinterpret_cast<const f16x8*>(lo + offj[j]);
             }
 #if defined(SF_DW_ABLATE) && SF_DW_ABLATE == 3
@@ -325,7 +381,7 @@ __global__ __launch_bounds__(256, kProd == 1 ? 3 : ((KS == 15 && kProd == 2) ? S
                 if (ky + 1 < KS) {
 #pragma unroll
                     for (int j = 0; j < TG; ++j) {
-                        ah[nxt][j] = *reinterpret_cast<const f16x8*>(hi + offj[j] + (ky + 1) * row_step);
+                        ah[nxt][j] = *reinterpret_cast<const f16x8*>(hb + offj[j] + (ky + 1) * row_step);
                         if constexpr (kProd == 3) al[nxt][j] = *reinterpret_cast<const f16x8*>(lo + offj[j] + (ky + 1) * row_step);
                     }
                 }
@@ -352,8 +408,8 @@ __global__ __launch_bounds__(256, kProd == 1 ? 3 : ((KS == 15 && kProd == 2) ? S
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
                         const int xo = xoff0 + (r + u) * row_step + min(j, ntx - 1 - tx0) * 32;
-                        const float xv = (float)*reinterpret_cast<const _Float16*>(hi + xo) +
-                                         (float)*reinterpret_cast<const _Float16*>(lo + xo);
+                        float xv = (float)*reinterpret_cast<const _Float16*>(hb + xo);
+                        if constexpr (kIn != 2) xv += (float)*reinterpret_cast<const _Float16*>(lo + xo);
                         t[u] = xv + (acc[j][r + u] + bv);
                     }
                     const sf::f32x2 a = sf::gelu2<(kProd <= 2) && kOutF16 && SF_GEMM_FAST_GELU>(t);   // polynomial GELU where the result leaves as fp16
@@ -389,9 +445,9 @@ __global__ __launch_bounds__(256, kProd == 1 ? 3 : ((KS == 15 && kProd == 2) ? S
 
 }  // namespace
 
-extern "C" int sf_dwconv_res_gelu(const float* x, int64_t x_img_stride, const float* wgt, const float* bias, void* y_,
-                                  int64_t y_img_stride, int y_f16, int n_img, int C, int h, int w, int ksize,
-                                  int precision, void* stream) {
+static int dwconv_dispatch(const void* x_, int x_f16, int64_t x_img_stride, const float* wgt, const float* bias, void* y_,
+                    int64_t y_img_stride, int y_f16, int n_img, int C, int h, int w, int ksize, int precision, void* stream) {
+    const float* x = static_cast<const float*>(x_);
     float* y = static_cast<float*>(y_);
     SF_REQUIRE(x && wgt && bias && y, "sf_dwconv_res_gelu: null pointer");
     SF_REQUIRE(y_f16 == 0 || y_f16 == 1, "sf_dwconv_res_gelu: y_f16 must be 0 or 1");
@@ -403,6 +459,8 @@ extern "C" int sf_dwconv_res_gelu(const float* x, int64_t x_img_stride, const fl
     // 128 channels x 24 images); K = 15 runs 1.45x faster on the matrix cores
     const bool two = precision != SF_PRECISION_FP32 && precision != SF_PRECISION_F16X3;
     const bool one = two && precision == SF_PRECISION_F16;       // weights rounded once to fp16 as well
+    SF_REQUIRE(!x_f16 || (two && y_f16), "sf_dwconv_res_gelu_f16in: fp16 input is the f16x2 / f16 hand-over (fp16 output, "
+                                         "SF_PRECISION_F16X2 or SF_PRECISION_F16)");
     // K = 7 in the two-product modes also runs on the matrix cores (7 x 2 MFMAs per tile against 49 FMAs per output)
     if (precision != SF_PRECISION_FP32 && (ksize == 15 || two)) {
         DwmArgs m;
@@ -416,13 +474,21 @@ extern "C" int sf_dwconv_res_gelu(const float* x, int64_t x_img_stride, const fl
         int strip = h16;
         while (strip > 16 && (size_t)2 * (strip + ksize - 1) * m.stride16 * 16 > 60 * 1024) strip -= 16;
         m.strip_h = strip;
-        const size_t lds = (size_t)2 * (strip + ksize - 1) * m.stride16 * 16 + (size_t)ksize * 64 * sizeof(float);
+        m.plane_bytes = (strip + ksize - 1) * m.stride16 * 16;
+        // fp16 rows of whole, 16-byte aligned octets: the DMA-staged, double-buffered form (whole 4-KB pieces per plane)
+        const bool dma = x_f16 && (w % 8 == 0) && (x_img_stride % 8 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) &&
+                         sf::ceil_div(m.plane_bytes, 4096) <= 8;
+        const bool dma_fits = (size_t)2 * sf::ceil_div(m.plane_bytes, 4096) * 4096 + (size_t)ksize * 64 * sizeof(float) <= 64 * 1024;
+        const bool use_dma = dma && dma_fits;
+        if (use_dma) m.plane_bytes = sf::ceil_div(m.plane_bytes, 4096) * 4096;
+        const size_t lds = (size_t)2 * m.plane_bytes + (size_t)ksize * 64 * sizeof(float);
         SF_REQUIRE(lds <= 64 * 1024, "sf_dwconv_res_gelu: width %d too large for the matrix-core kernel", w);
         m.vec_ok = ((w & 3) == 0) && ((x_img_stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
         // several images of a channel per workgroup (the Toeplitz fragments are built once), but keep >= ~2048 workgroups
         const int strips = sf::ceil_div(h, strip);
         // (4096 / 8192 / 16384 workgroups measured within +-3 % of 2048 on every layer shape of the update block)
-        constexpr int target_wgs = 2048;
+        // (the double-buffered form hides an image's staging behind the previous image's tiles: more images per workgroup)
+        const int target_wgs = use_dma ? SF_DW_DMA_WGS : 2048;
         int groups = sf::ceil_div(target_wgs, C * strips);
         if (groups > n_img) groups = n_img;
         if (groups < 1) groups = 1;
@@ -432,6 +498,19 @@ extern "C" int sf_dwconv_res_gelu(const float* x, int64_t x_img_stride, const fl
 #endif
         dim3 grid(C, strips, sf::ceil_div(n_img, m.imgs_per_wg));
         SF_REQUIRE(strips <= 65535 && grid.z <= 65535, "sf_dwconv_res_gelu: grid too large");
+        if (x_f16) {
+#define SF_DW_F16IN(KS_, PR_)                                                                                            \
+    do {                                                                                                                 \
+        if (use_dma) hipLaunchKernelGGL((dwconv_mfma_kernel<KS_, true, PR_, 2>), grid, dim3(256), lds, (hipStream_t)stream, m); \
+        else hipLaunchKernelGGL((dwconv_mfma_kernel<KS_, true, PR_, 1>), grid, dim3(256), lds, (hipStream_t)stream, m);   \
+    } while (0)
+            if (ksize == 7 && one) SF_DW_F16IN(7, 1);
+            else if (ksize == 7) SF_DW_F16IN(7, 2);
+            else if (one) SF_DW_F16IN(15, 1);
+            else SF_DW_F16IN(15, 2);
+#undef SF_DW_F16IN
+            return sf::check_launch("sf_dwconv_res_gelu_f16in");
+        }
         if (ksize == 7) {
             if (one && y_f16) hipLaunchKernelGGL((dwconv_mfma_kernel<7, true, 1>), grid, dim3(256), lds, (hipStream_t)stream, m);
             else if (one) hipLaunchKernelGGL((dwconv_mfma_kernel<7, false, 1>), grid, dim3(256), lds, (hipStream_t)stream, m);
@@ -477,4 +556,18 @@ extern "C" int sf_dwconv_res_gelu(const float* x, int64_t x_img_stride, const fl
     else
         hipLaunchKernelGGL((dwconv_res_gelu_kernel<7, false>), grid, dim3(threads), lds, (hipStream_t)stream, g);
     return sf::check_launch("sf_dwconv_res_gelu");
+}
+
+extern "C" int sf_dwconv_res_gelu(const float* x, int64_t x_img_stride, const float* wgt, const float* bias, void* y,
+                                  int64_t y_img_stride, int y_f16, int n_img, int C, int h, int w, int ksize,
+                                  int precision, void* stream) {
+    return dwconv_dispatch(x, 0, x_img_stride, wgt, bias, y, y_img_stride, y_f16, n_img, C, h, w, ksize, precision, stream);
+}
+
+// x as fp16 ROWS [img][C][h*w] (x_img_stride in halves), y as fp16 rows: the config-2 hand-over of an SK block's x2 and x3
+// (precision SF_PRECISION_F16X2 or SF_PRECISION_F16).  The conv input and the residual are the fp16 value itself.
+extern "C" int sf_dwconv_res_gelu_f16in(const void* x_f16, int64_t x_img_stride, const float* wgt, const float* bias,
+                                        void* y_f16, int64_t y_img_stride, int n_img, int C, int h, int w, int ksize,
+                                        int precision, void* stream) {
+    return dwconv_dispatch(x_f16, 1, x_img_stride, wgt, bias, y_f16, y_img_stride, 1, n_img, C, h, w, ksize, precision, stream);
 }

@@ -43,6 +43,7 @@ class EngineOptions:
     hidden_f16: bool = True          # GEMM-to-GEMM tensors as fp16 in the f16x2 / f16 modes
     hidden_koct: bool = True         # ... as k-octet planes where the consumer takes them
     pw_fold: bool = True             # pw residual folded into the weights (x3 handed over in fp16)
+    x2_f16: bool = True              # ... and x2 (ffn1.2 -> depthwise) as fp16 rows too (changes x3 by <= its own fp16 rounding)
     flash_stats: bool = True         # fused GMA: softmax statistics computed once per clip
     max_plans: int = 4               # buffer sets (and graphs) kept, least recently used evicted
 
@@ -142,9 +143,14 @@ def run_skblock(W: SKBlockWeights, X: Planes, Y: Planes, hid: Planes, xa: Planes
     hidden = _handover(cx, hid, X.n_img, W.c_mid, X.P, consumer_rows=C)             # ffn1.0 -> ffn1.2
     ops.gemm(W.ffn1_0, X, hidden, EPI_GELU, cx=cx)
     # x1 = gelu(x + ffn1(x)); x2 = gelu(x1 + dw1x1(x1))  (both fused in the epilogue)
+    fold = hidden_f16_ok(cx, X.P) and cx.pw_fold
+    if fold and cx.x2_f16:
+        # x2 has ONE reader, the depthwise layer, whose two-product arithmetic multiplies fp16(x2) anyway: handed over as fp16
+        # rows (half the bytes out of this GEMM and into the depthwise kernel, which then stages its strips by DMA)
+        a = _scratch(xa, X.n_img, C, f16=True)
     ops.gemm(W.ffn1_2, hidden, a, EPI_RES_GELU_DW1, R=X, dw_w=W.dw1_w, dw_b=W.dw1_b, cx=cx)
     # x4 is read by ffn2.0 only: the same GEMM-to-GEMM hand-over as the hidden activations (x2 in `xa` is dead by now)
-    if hidden_f16_ok(cx, X.P) and cx.pw_fold:
+    if fold:
         # x3 in fp16 rows straight out of the depthwise kernel, residual folded into the pw weights: the pw GEMM reads half
         # the bytes, has a residual-free epilogue and may therefore write k-octets
         b16 = _scratch(xb, X.n_img, C, f16=True)
@@ -417,7 +423,7 @@ class HotPathEngine:
         return ops.Ctx(precision=self.precision,
                        split_ws=pl.splitws.tensor().view(-1) if self.auto_split_k else None,
                        shadows=o.shadows, shadow_fused=o.shadow_fused, flash_stats=o.flash_stats,
-                       hidden_f16=o.hidden_f16, hidden_koct=o.hidden_koct, pw_fold=o.pw_fold)
+                       hidden_f16=o.hidden_f16, hidden_koct=o.hidden_koct, pw_fold=o.pw_fold, x2_f16=o.x2_f16)
 
     def _attention_rows(self, cx: ops.Ctx, pl: _Plan, i0: int, rows: int) -> None:
         """attn[:, :rows, :] = softmax(scale * q[:, i0:i0+rows]^T k)   (gma.py:53-65) for every image."""

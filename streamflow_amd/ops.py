@@ -55,7 +55,7 @@ class Ctx:
     precision: PRECISION_*.  split_ws: scratch that lets sf_gemm split K for small grids (None: never).
     shadows / shadow_fused: use and maintain Planes.shadow; producers write the k-octet copy in their own epilogue.
     flash_stats: the fused GMA kernel uses the softmax statistics stored once per clip.
-    hidden_f16 / hidden_koct / pw_fold: hand-over formats inside an SK block (engine.run_skblock)."""
+    hidden_f16 / hidden_koct / pw_fold / x2_f16: hand-over formats inside an SK block (engine.run_skblock)."""
     precision: int
     split_ws: Optional[torch.Tensor] = None
     shadows: bool = True
@@ -64,6 +64,7 @@ class Ctx:
     hidden_f16: bool = True
     hidden_koct: bool = True
     pw_fold: bool = True
+    x2_f16: bool = True
 
     def no_split(self) -> "Ctx":
         """The same context without the split-K scratch (ONE buffer: only one stream may use it at a time)."""
@@ -444,17 +445,24 @@ def splitk_combine(partial: torch.Tensor, split_stride: int, k_splits: int, part
 def dwconv_res_gelu(X: Planes, wgt: torch.Tensor, bias: torch.Tensor, Y: Planes, h: int, w: int, k: int,
                     single: bool = False, cx: Optional[Ctx] = None) -> None:
     """Y = gelu(X + dwconv_KxK(X) + bias).  Y may be fp16 row planes (Planes.f16, not koct): the hand-over to a GEMM.
+    X may be fp16 row planes too (f16x2 / f16 arithmetic, fp16 Y): sf_dwconv_res_gelu_f16in.
     single (f16x2 mode only): the weights enter the products as ONE fp16 value (a single-product layer)."""
     PRECISION = _cx(cx).precision
-    assert X.rows == Y.rows == wgt.shape[0] and X.P == h * w and not X.f16 and not Y.koct
+    assert X.rows == Y.rows == wgt.shape[0] and X.P == h * w and not X.koct and not Y.koct
     if DEBUG_RANGE and PRECISION != PRECISION_FP32:
         _check_range(X, f"sf_dwconv_res_gelu C{X.rows} k{k}")
     prec = PRECISION_F16 if (single and PRECISION == PRECISION_F16X2) else PRECISION
-    _launch("dwconv%d" % k, 2.0 * k * k * X.n_img * X.rows * h * w, (6.0 if Y.f16 else 8.0) * X.n_img * X.rows * h * w,
-            lambda: _lib.check(_lib.load().sf_dwconv_res_gelu(X.ptr, X.img_stride, wgt.data_ptr(), bias.data_ptr(),
-                                                              Y.ptr, Y.img_stride, int(Y.f16), X.n_img, X.rows, h, w, k,
-                                                              prec, _lib.stream()),
-                               "sf_dwconv_res_gelu"),
+    if X.f16:
+        assert Y.f16, "fp16 input needs fp16 output"
+        call = lambda: _lib.check(_lib.load().sf_dwconv_res_gelu_f16in(X.ptr, X.img_stride, wgt.data_ptr(), bias.data_ptr(),
+                                                                       Y.ptr, Y.img_stride, X.n_img, X.rows, h, w, k, prec,
+                                                                       _lib.stream()), "sf_dwconv_res_gelu_f16in")
+    else:
+        call = lambda: _lib.check(_lib.load().sf_dwconv_res_gelu(X.ptr, X.img_stride, wgt.data_ptr(), bias.data_ptr(),
+                                                                 Y.ptr, Y.img_stride, int(Y.f16), X.n_img, X.rows, h, w, k,
+                                                                 prec, _lib.stream()), "sf_dwconv_res_gelu")
+    _launch("dwconv%d" % k, 2.0 * k * k * X.n_img * X.rows * h * w,
+            ((2.0 if X.f16 else 4.0) + (2.0 if Y.f16 else 4.0)) * X.n_img * X.rows * h * w, call,
             # matrix-core work: banded Toeplitz GEMMs (32 / 15 of the algorithmic flops) for K = 15 in the split modes, 2 or 3
             # products; the fp32 and 7 x 7 stencils run on the VALU
             products=((32.0 / 15.0) * _products(prec)) if (k == 15 and PRECISION != PRECISION_FP32) else 0.0)

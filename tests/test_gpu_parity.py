@@ -718,6 +718,53 @@ def test_dwconv_two_product_mode(dev, hw, k):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("single", [False, True])
+@pytest.mark.parametrize("k", [15, 7])
+@pytest.mark.parametrize("hw,n_img,C", [((55, 128), 24, 40), ((55, 128), 5, 3), ((23, 37), 3, 6), ((16, 24), 7, 4), ((70, 56), 9, 2),
+                                        ((136, 240), 3, 2)])
+def test_dwconv_f16_input(dev, hw, n_img, C, k, single):
+    """sf_dwconv_res_gelu_f16in: x2 handed over as fp16 ROWS (config-2 presets).  Widths of whole octets take the DMA-staged,
+    double-buffered form (several images per workgroup: 24 x 40 planes; strips: the 136-row grid); other widths the register
+    form.  Against float64 on the SAME fp16 input values the error is the weight split's and the fp16 rounding of the
+    output; and the result equals (to that rounding) what the fp32-input kernel gives for the same values.  The output buffer
+    is NaN-filled: every cell of every image must be written."""
+    import torch.nn.functional as F
+    from streamflow_amd import ops
+    from streamflow_amd.ops import Planes
+    h, w = hw
+    g = torch.Generator().manual_seed(k * 100 + h + n_img)
+    x16 = (torch.randn(n_img, C, h * w, generator=g) * 2).half()
+    wgt = torch.randn(C, k, k, generator=g) / k
+    b = torch.randn(C, generator=g) * 0.1
+    xs = x16.to(dev).contiguous()
+    X16 = Planes(xs.view(-1).view(torch.float32), 0, C * h * w, n_img, C, h * w, f16=True)   # (even number of halves per image)
+    ys = torch.full((n_img, C, h * w), float("nan"), dtype=torch.float16, device=dev)
+    Y16 = Planes(ys.view(-1).view(torch.float32), 0, C * h * w, n_img, C, h * w, f16=True)
+    cx = ops.Ctx(precision=ops.PRECISION_F16X2)
+    ops.dwconv_res_gelu(X16, wgt.to(dev).contiguous(), b.to(dev), Y16, h, w, k, single=single, cx=cx)
+    torch.cuda.synchronize()
+    got = ys.double().cpu().view(n_img, C, h, w)
+    assert bool(torch.isfinite(got).all())
+    xd = x16.double().view(n_img, C, h, w)
+    wd = (wgt.half() if single else wgt).double()
+    pre = xd + F.conv2d(xd, wd.view(C, 1, k, k), b.double(), padding=k // 2, groups=C)
+    ref = F.gelu(pre)
+    # fp16 result: half an ulp of the value + the polynomial GELU (5.2e-5 absolute, 1.1e-5 relative) and the split error of the
+    # fp32 result before rounding
+    tol = 2.0 ** -11 * ref.abs() * 1.03 + 8e-5
+    bad = (got - ref).abs() > tol
+    assert not bool(bad.any()), (hw, n_img, C, k, single, float((got - ref).abs().max()), int(bad.sum()))
+    # the fp32-input kernel on the same values
+    Xf = Planes.of(x16.float().to(dev).contiguous())
+    yf = torch.full((n_img, C, h * w), float("nan"), dtype=torch.float16, device=dev)
+    Yf = Planes(yf.view(-1).view(torch.float32), 0, C * h * w, n_img, C, h * w, f16=True)
+    ops.dwconv_res_gelu(Xf, wgt.to(dev).contiguous(), b.to(dev), Yf, h, w, k, single=single, cx=cx)
+    torch.cuda.synchronize()
+    d = (ys.float() - yf.float()).abs()
+    assert bool((d <= 2.0 ** -10 * yf.float().abs() + 1e-6).all()), float(d.max())
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("k,C,hw", [(15, 256, (55, 128)), (7, 640, (55, 128)), (15, 324, (22, 36))])
 def test_skblock_pw_fold_vs_float64(dev, k, C, hw):
     """f16x2 mode: x4 = gelu(x3 + pw(x3)) is computed as gelu((W + I) x3) with x3 handed over in fp16 rows by the

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Depthwise conv + residual + GELU alone (timing).  argv: C n_img k [precision] [f16out] [single]"""
+"""Depthwise conv + residual + GELU alone (timing).  argv: C n_img k [precision] [f16out] [single] [f16in]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -11,6 +11,9 @@ h, w = 55, 128
 dev = torch.device("cuda:0")
 X = Planes.of(torch.randn(n, C, h * w, device=dev)); Y = Planes.of(torch.empty(n, C, h * w, device=dev))
 single = "single" in sys.argv
+if "f16in" in sys.argv:                 # x as fp16 rows (sf_dwconv_res_gelu_f16in; needs f16out and f16x2)
+    xs = torch.randn(n, C, h * w, device=dev).half().contiguous()
+    X = Planes(xs.view(-1).view(torch.float32), 0, C * h * w, n, C, h * w, f16=True)
 if "f16out" in sys.argv:
     Y = Planes(torch.empty(n * C * h * w // 2, device=dev), 0, C * h * w, n, C, h * w, f16=True)
 wgt = (torch.randn(C, k, k, device=dev) / k).contiguous(); b = torch.randn(C, device=dev) * 0.1
@@ -33,5 +36,5 @@ for _ in range(reps):
     ops.dwconv_res_gelu(X, wgt, b, Y, h, w, k, single=single)
 e.record(); torch.cuda.synchronize()
 us = s.elapsed_time(e) * 1e3 / reps
-print(f"dwconv{k} C={C} n={n} {ops.precision_name()}: {us:.1f} us  {2.0 * k * k * n * C * h * w / us / 1e6:.1f} TF-equivalent  {(6.0 if Y.f16 else 8.0) * n * C * h * w / us / 1e3:.0f} GB/s")
+print(f"dwconv{k} C={C} n={n} {ops.precision_name()}: {us:.1f} us  {2.0 * k * k * n * C * h * w / us / 1e6:.1f} TF-equivalent  {((2.0 if X.f16 else 4.0) + (2.0 if Y.f16 else 4.0)) * n * C * h * w / us / 1e3:.0f} GB/s")
 
