@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SF_VERSION 111
+#define SF_VERSION 112
 
 enum {
     SF_OK = 0,
@@ -297,6 +297,9 @@ int sf_layernorm_cm(const float* x, int64_t x_img_stride, const float* gamma, co
  * out_koct (optional, C % 32 == 0): the result as fp16 k-octet planes [B*TT][C/8][P][8] (SF_LAYOUT_F16_KOCT); out may
  * then be NULL. */
 int sf_temporal_attn(const float* qkv, float* out, void* out_koct, int B, int TT, int C, int P, void* stream);
+/* The same with qkv as fp16 ROWS [B*TT][3C][P] (what sf_gemm writes with c_f16 = 1): the config-2 hand-over -- the qkv GEMM
+ * writes and this kernel reads half the bytes; scores, softmax and the weighted sum stay fp32. */
+int sf_temporal_attn_f16in(const void* qkv_f16, float* out, void* out_koct, int B, int TT, int C, int P, void* stream);
 
 /* ---- fp32 planes -> fp16 k-octet planes (no reference counterpart: an operand format of sf_gemm) -----------------
  * x [n_img][rows][P] fp32 (x_img_stride in floats) -> y [n_img][ceil(rows/8)][P][8] IEEE fp16 (y_img_stride in halves),

@@ -72,6 +72,7 @@ SIGNATURES = {
     "sf_dwconv_res_gelu_f16in": (_i, [_vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _vp]),
     "sf_layernorm_cm": (_i, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _i, _i, _i, _f, _vp]),
     "sf_temporal_attn": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "sf_temporal_attn_f16in": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "sf_pack_koct": (_i, [_vp, _i64, _i, _i, _i, _vp, _i64, _vp]),
     "sf_context_split": (_i, [_vp, _vp, _i64, _vp, _i64, _i, _i, _i, _vp]),
     "sf_flow_update": (_i, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _vp]),

@@ -254,8 +254,9 @@ __global__ __launch_bounds__(kBlock) void layernorm_cm_split_kernel(const float*
 // thread then holds the full softmax weights of its pixel and produces its slice of the output channels.
 // All global accesses are 256-byte rows (64 lanes x consecutive pixels of one channel plane).
 constexpr int kTaPix = 64;
-template <int TT>
-__global__ __launch_bounds__(kBlock) void temporal_attn_kernel(const float* qkv, float* out, _Float16* out16, int C, int P) {
+// TIn = float (fp32 planes) or _Float16 (fp16 rows: the qkv GEMM's c_f16 = 1 hand-over of the config-2 presets).
+template <int TT, typename TIn>
+__global__ __launch_bounds__(kBlock) void temporal_attn_kernel(const TIn* qkv, float* out, _Float16* out16, int C, int P) {
     __shared__ float red[4][TT * TT][kTaPix];
     const int px = threadIdx.x & (kTaPix - 1), cg = threadIdx.x >> 6;
     const int p = blockIdx.x * kTaPix + px;
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(kBlock) void temporal_attn_kernel(const float* qkv,
     const int b = blockIdx.y;
     const int cpt = C / 4, c0 = cg * cpt;
     const int64_t img = (int64_t)3 * C * P;      // one token image of qkv
-    const float* base = qkv + (int64_t)b * TT * img + pc;
+    const TIn* base = qkv + (int64_t)b * TT * img + pc;
     float s[TT][TT];
 #pragma unroll
     for (int t = 0; t < TT; ++t)
@@ -275,8 +276,8 @@ __global__ __launch_bounds__(kBlock) void temporal_attn_kernel(const float* qkv,
         float q[TT], k[TT];
 #pragma unroll
         for (int t = 0; t < TT; ++t) {
-            q[t] = base[t * img + (int64_t)c * P];
-            k[t] = base[t * img + (int64_t)(C + c) * P];
+            q[t] = (float)base[t * img + (int64_t)c * P];
+            k[t] = (float)base[t * img + (int64_t)(C + c) * P];
         }
 #pragma unroll
         for (int t = 0; t < TT; ++t)
@@ -318,7 +319,7 @@ __global__ __launch_bounds__(kBlock) void temporal_attn_kernel(const float* qkv,
             for (int i = 0; i < 8; ++i) {
                 float v[TT];
 #pragma unroll
-                for (int u = 0; u < TT; ++u) v[u] = base[u * img + (int64_t)(2 * C + c8 + i) * P];
+                for (int u = 0; u < TT; ++u) v[u] = (float)base[u * img + (int64_t)(2 * C + c8 + i) * P];
 #pragma unroll
                 for (int t = 0; t < TT; ++t) {
                     float o = 0.f;
@@ -337,7 +338,7 @@ __global__ __launch_bounds__(kBlock) void temporal_attn_kernel(const float* qkv,
     for (int c = c0; c < c0 + cpt; ++c) {
         float v[TT];
 #pragma unroll
-        for (int u = 0; u < TT; ++u) v[u] = base[u * img + (int64_t)(2 * C + c) * P];
+        for (int u = 0; u < TT; ++u) v[u] = (float)base[u * img + (int64_t)(2 * C + c) * P];
 #pragma unroll
         for (int t = 0; t < TT; ++t) {
             float o = 0.f;
@@ -569,7 +570,8 @@ extern "C" int sf_layernorm_cm(const float* x, int64_t x_img_stride, const float
     return sf::check_launch("sf_layernorm_cm");
 }
 
-extern "C" int sf_temporal_attn(const float* qkv, float* out, void* out_koct, int B, int TT, int C, int P, void* stream) {
+template <typename TIn>
+static int temporal_attn_launch(const TIn* qkv, float* out, void* out_koct, int B, int TT, int C, int P, void* stream) {
     SF_REQUIRE(qkv && (out || out_koct) && B > 0 && C > 0 && P > 0, "sf_temporal_attn: bad args");
     SF_REQUIRE(C % 4 == 0, "sf_temporal_attn: C must be a multiple of 4");
     SF_REQUIRE(!out_koct || (C % 32 == 0 && (reinterpret_cast<uintptr_t>(out_koct) & 15) == 0),
@@ -578,16 +580,26 @@ extern "C" int sf_temporal_attn(const float* qkv, float* out, void* out_koct, in
     dim3 grid(sf::ceil_div(P, kTaPix), B), block(kBlock);
     hipStream_t st = (hipStream_t)stream;
     switch (TT) {
-        case 1: hipLaunchKernelGGL(temporal_attn_kernel<1>, grid, block, 0, st, qkv, out, out16, C, P); break;
-        case 2: hipLaunchKernelGGL(temporal_attn_kernel<2>, grid, block, 0, st, qkv, out, out16, C, P); break;
-        case 3: hipLaunchKernelGGL(temporal_attn_kernel<3>, grid, block, 0, st, qkv, out, out16, C, P); break;
-        case 4: hipLaunchKernelGGL(temporal_attn_kernel<4>, grid, block, 0, st, qkv, out, out16, C, P); break;
-        case 5: hipLaunchKernelGGL(temporal_attn_kernel<5>, grid, block, 0, st, qkv, out, out16, C, P); break;
-        case 6: hipLaunchKernelGGL(temporal_attn_kernel<6>, grid, block, 0, st, qkv, out, out16, C, P); break;
-        case 7: hipLaunchKernelGGL(temporal_attn_kernel<7>, grid, block, 0, st, qkv, out, out16, C, P); break;
+        case 1: hipLaunchKernelGGL((temporal_attn_kernel<1, TIn>), grid, block, 0, st, qkv, out, out16, C, P); break;
+        case 2: hipLaunchKernelGGL((temporal_attn_kernel<2, TIn>), grid, block, 0, st, qkv, out, out16, C, P); break;
+        case 3: hipLaunchKernelGGL((temporal_attn_kernel<3, TIn>), grid, block, 0, st, qkv, out, out16, C, P); break;
+        case 4: hipLaunchKernelGGL((temporal_attn_kernel<4, TIn>), grid, block, 0, st, qkv, out, out16, C, P); break;
+        case 5: hipLaunchKernelGGL((temporal_attn_kernel<5, TIn>), grid, block, 0, st, qkv, out, out16, C, P); break;
+        case 6: hipLaunchKernelGGL((temporal_attn_kernel<6, TIn>), grid, block, 0, st, qkv, out, out16, C, P); break;
+        case 7: hipLaunchKernelGGL((temporal_attn_kernel<7, TIn>), grid, block, 0, st, qkv, out, out16, C, P); break;
         default: return sf::fail(SF_ERR_UNSUPPORTED, "sf_temporal_attn: T-1=%d tokens not supported (1..7)", TT);
     }
     return sf::check_launch("sf_temporal_attn");
+}
+
+extern "C" int sf_temporal_attn(const float* qkv, float* out, void* out_koct, int B, int TT, int C, int P, void* stream) {
+    return temporal_attn_launch<float>(qkv, out, out_koct, B, TT, C, P, stream);
+}
+
+// qkv as fp16 ROWS [img][3 C][P] (the qkv GEMM's c_f16 = 1 output in the config-2 presets): q, k, v enter the scores and
+// the weighted sum as the fp16 values they are; scores, softmax and accumulation in fp32 as above.
+extern "C" int sf_temporal_attn_f16in(const void* qkv_f16, float* out, void* out_koct, int B, int TT, int C, int P, void* stream) {
+    return temporal_attn_launch<_Float16>(static_cast<const _Float16*>(qkv_f16), out, out_koct, B, TT, C, P, stream);
 }
 
 extern "C" int sf_upsample_flow(const float* flow, const float* mask, float* out, int n, int h, int w, void* stream) {

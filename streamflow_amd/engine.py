@@ -546,8 +546,10 @@ class HotPathEngine:
             ko = lambda buf, M: (lambda t: t if t.koct else buf)(_handover(cs, buf, pl.n, HDIM, P, consumer_rows=M))
             ln, att = ko(pl.ln128, W.qkv.M), ko(pl.att128, W.proj.M)
             ops.layernorm_cm(pl.mf, W.ln1_w, W.ln1_b, ln)
-            ops.gemm(W.qkv, ln, pl.qkv, EPI_NONE, cx=cs)
-            ops.temporal_attn(pl.qkv, att, Bc, Pn, HDIM)
+            # qkv has ONE reader, the attention core: fp16 rows where the fp16 hand-over is active (EPE-neutral)
+            qkv = _scratch(pl.qkv, pl.n, 3 * HDIM, f16=True) if (hidden_f16_ok(cs, P) and cs.x2_f16) else pl.qkv
+            ops.gemm(W.qkv, ln, qkv, EPI_NONE, cx=cs)
+            ops.temporal_attn(qkv, att, Bc, Pn, HDIM)
             ops.gemm(W.proj, att, pl.tx128, EPI_RES, R=pl.mf, cx=cs)
             ln = ko(pl.ln128, W.fc1.M)
             ops.layernorm_cm(pl.tx128, W.ln2_w, W.ln2_b, ln)

@@ -483,11 +483,12 @@ def layernorm_cm(X: Planes, gamma: torch.Tensor, beta: torch.Tensor, Y: Planes, 
 @on_tensor_device
 def temporal_attn(QKV: Planes, OUT: Planes, B: int, TT: int, C_: int) -> None:
     assert QKV.img_stride == 3 * C_ * QKV.P and OUT.img_stride == C_ * OUT.P and QKV.n_img == B * TT
-    assert not OUT.f16 or OUT.koct
+    assert (not OUT.f16 or OUT.koct) and not QKV.koct
     ko = OUT.f16                                          # fp16 k-octet planes: the hand-over to the proj GEMM
-    _launch("temporal_attn", 0, (14.0 if ko else 16.0) * QKV.n_img * C_ * QKV.P,
-            lambda: _lib.check(_lib.load().sf_temporal_attn(QKV.ptr, None if ko else OUT.ptr, OUT.ptr if ko else None,
-                                                            B, TT, C_, QKV.P, _lib.stream()), "sf_temporal_attn"))
+    fn = _lib.load().sf_temporal_attn_f16in if QKV.f16 else _lib.load().sf_temporal_attn     # (fp16 rows: the qkv GEMM's c_f16 = 1)
+    _launch("temporal_attn", 0, ((6.0 if QKV.f16 else 12.0) + (2.0 if ko else 4.0)) * QKV.n_img * C_ * QKV.P,
+            lambda: _lib.check(fn(QKV.ptr, None if ko else OUT.ptr, OUT.ptr if ko else None,
+                                  B, TT, C_, QKV.P, _lib.stream()), "sf_temporal_attn"))
 
 
 @on_tensor_device

@@ -389,6 +389,24 @@ def test_layernorm_and_temporal_attn_koct_outputs(dev, P):
     ops.temporal_attn(Planes.of(qkv), sh2, n // TT, TT, C)
     torch.cuda.synchronize()
     assert close(sh2.tensor().float(), out)
+    # qkv as fp16 rows (sf_temporal_attn_f16in, the config-2 hand-over): float64 attention over the SAME fp16 values, and the
+    # fp32-input kernel fed those values, for both output formats (NaN-filled first)
+    q16 = qkv.half().contiguous()
+    Q16 = Planes(q16.view(-1).view(torch.float32), 0, 3 * C * P, n, 3 * C, P, f16=True)
+    out_h = torch.full((n, C, P), float("nan"), device=dev)
+    ops.temporal_attn(Q16, Planes.of(out_h), n // TT, TT, C)
+    sh3 = ops.new_shadow(Planes.of(out_h), dev)
+    sh3.base.view(torch.float16).fill_(float("nan"))
+    ops.temporal_attn(Q16, sh3, n // TT, TT, C)
+    out_f = torch.empty(n, C, P, device=dev)
+    ops.temporal_attn(Planes.of(q16.float()), Planes.of(out_f), n // TT, TT, C)
+    torch.cuda.synchronize()
+    qd = q16.double().view(n // TT, TT, 3, C, P)
+    att = torch.softmax(torch.einsum("btcp,bucp->bptu", qd[:, :, 0], qd[:, :, 1]) / C ** 0.5, dim=-1)
+    ref_a = torch.einsum("bptu,bucp->btcp", att, qd[:, :, 2]).reshape(n, C, P)
+    assert (out_h.double() - ref_a).abs().max().item() < 2e-5
+    assert (out_h - out_f).abs().max().item() < 2e-6
+    assert close(sh3.tensor().float(), out_h)
 
 
 @pytest.mark.parametrize("preset", ["config2_fp16", "fp32_class"])
