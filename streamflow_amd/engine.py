@@ -43,6 +43,7 @@ class EngineOptions:
     hidden_f16: bool = True          # GEMM-to-GEMM tensors as fp16 in the f16x2 / f16 modes
     hidden_koct: bool = True         # ... as k-octet planes where the consumer takes them
     pw_fold: bool = True             # pw residual folded into the weights (x3 handed over in fp16)
+    koct_io: bool = True             # motion-encoder tensors between SK blocks as fp16 k-octets only (no fp32 planes)
     x2_f16: bool = True              # ... and x2 (ffn1.2 -> depthwise) as fp16 rows too (changes x3 by <= its own fp16 rounding)
     flash_stats: bool = True         # fused GMA: softmax statistics computed once per clip
     max_plans: int = 4               # buffer sets (and graphs) kept, least recently used evicted
@@ -239,7 +240,7 @@ class _Plan:
 
     def __init__(self, W: HotPathWeights, Bc: int, h: int, w: int, D: int, device, attn_chunk_rows: int = 0,
                  attn_f16: bool = False, corr_f16: bool = False, flash: Optional[bool] = None, shadows: bool = False,
-                 corr_blocked: bool = False):
+                 corr_blocked: bool = False, koct_io: bool = False):
         Pn = W.pairs
         n, P = Bc * Pn, h * w
         self.Bc, self.Pn, self.h, self.w, self.n, self.P, self.D = Bc, Pn, h, w, n, P, D
@@ -299,17 +300,25 @@ class _Plan:
                 ("splitws", 1024)]                                # scratch for sf_gemm's automatic split-K
         if self.corr_blocked:
             spec = [(nm, r) for nm, r in spec if nm != "corr"]          # no fp32 planes of the correlation features at all
+        # tensors of the motion encoder that are ONLY input / output of SK blocks (cor = convc1's output, cat(cor, flo), convf1's
+        # output) exist as fp16 k-octet planes alone in the fp16 hand-over modes: their producers write 2 instead of 6 bytes per
+        # element, the next block takes operand AND residual from the k-octets (SfGemm.r_f16 = 2).  EPE-neutral
+        self.koct_io = bool(koct_io and shadows)
+        koct_only = {"cor256": 256, "cat256": 256, "f128": 128} if self.koct_io else {}
+        spec = [(nm, r) for nm, r in spec if nm not in koct_only]
         ws = Workspace(sum(n * r * P + 64 for _, r in spec), device)
         self.ws = ws
         for name, r in spec:
             setattr(self, name, ws.take(n, r, P))
         if self.corr_blocked:
             self.corr = ops.new_shadow(Planes(ws.buf, 0, COR_PLANES * P, n, COR_PLANES, P), device)   # k-octet planes only
+        for name, r in koct_only.items():
+            setattr(self, name, ops.new_shadow(Planes(ws.buf, 0, r * P, n, r, P), device))
         # f16x2 mode: the SK blocks' INPUT tensors keep an fp16 k-octet copy next to the fp32 planes (ops.Planes.shadow):
         # the first GEMM of a block reads the copy by LDS-DMA, its residual epilogue and every other kernel the planes
         self.shadows = bool(shadows)
         if self.shadows:
-            for name in ("cor256", "cat256", "concat") + (() if self.corr_blocked else ("corr",)):
+            for name in (() if self.koct_io else ("cor256", "cat256")) + ("concat",) + (() if self.corr_blocked else ("corr",)):
                 setattr(self, name, replace(getattr(self, name), shadow=ops.new_shadow(getattr(self, name), device)))
         self.nets = self.concat.slice(0, 128)
         self.inps = self.concat.slice(128, 256)
@@ -412,7 +421,7 @@ class HotPathEngine:
                        flash=flash, shadows=(self.options.shadows and (h * w) % 4 == 0 and
                                              self.precision in (ops.PRECISION_F16X2, ops.PRECISION_F16) and
                                              self.options.hidden_f16),
-                       corr_blocked=self.corr_blocked)
+                       corr_blocked=self.corr_blocked, koct_io=self.options.koct_io)
         self._plans[key] = pl                                        # (re)insert as most recent
         return pl
 

@@ -1,10 +1,12 @@
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out/r04e
-timeout 900 python -m pytest tests/test_gpu_fuzz.py -q -k "temporal_attn" 2>&1 | tail -4
-timeout 900 python bench.py --no-cpu-baseline --gemm-shapes > gpurun_out/r04e/bench_qkv.json 2>/dev/null; python - <<'P'
+timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -12
+timeout 900 python bench.py --gemm-shapes > gpurun_out/r04e/bench_kio.json 2>/dev/null; python - <<'P'
 import json
-d=json.loads(open('gpurun_out/r04e/bench_qkv.json').read().strip().splitlines()[-1])
+d=json.loads(open('gpurun_out/r04e/bench_kio.json').read().strip().splitlines()[-1])
 print(d['value'], d['ms_per_step'], d['config2_fp16_mode']['value'], d['single_clip']['value'])
+print([round(s['epe_px']*1e4,2) for s in d['epe_vs_oracle']['samples']], 'hard', round(d['epe_hard_case']['value'],4))
 k=d['kernels']
-for n in ('gemm','dwconv15','dwconv7','gma_flash','temporal_attn','gemm M384 K128 b24 e0','layernorm'): print(n, round(k[n]['ms_per_step'],3), k[n]['launches_per_step'], round(k[n]['avg_us'] or 0,1))
+f=lambda x: 0.0 if x is None else float(x)
+rows=[(f(v.get('ms_per_step')),n,int(f(v.get('launches_per_step'))),f(v.get('avg_us')), f(v.get('gbps_algorithmic'))) for n,v in k.items()]
+for r in sorted(rows,reverse=True)[:40]: print("  %7.3f ms  %-34s x%-4d %8.1f us  %7.0f GB/s"%r)
 P
-timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
