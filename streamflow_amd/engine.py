@@ -421,7 +421,8 @@ class HotPathEngine:
                        flash=flash, shadows=(self.options.shadows and (h * w) % 4 == 0 and
                                              self.precision in (ops.PRECISION_F16X2, ops.PRECISION_F16) and
                                              self.options.hidden_f16),
-                       corr_blocked=self.corr_blocked, koct_io=self.options.koct_io)
+                       corr_blocked=self.corr_blocked,
+                       koct_io=self.options.koct_io and self.options.hidden_koct)   # (k-octet-only blocks need k-octet producers)
         self._plans[key] = pl                                        # (re)insert as most recent
         return pl
 

@@ -749,3 +749,29 @@ def test_two_engines_two_threads_match_their_serial_runs(dev, graph):
         assert results[i] is not None
         for a, b in zip(results[i], jobs[i][3]):
             assert torch.equal(a, b), ("engine", i, "graph", graph)
+
+
+@pytest.mark.parametrize("opts", ["koct_io=0", "x2_f16=0", "koct_io=0,x2_f16=0,pw_fold=0", "hidden_koct=0", "shadows=0"])
+def test_handover_switches_stay_within_the_class(dev, opts):
+    """EngineOptions hand-over switches (A/B knobs): every combination computes the same network in the same arithmetic class --
+    flows within the config-2 budget of the oracle AND close to the default engine's (the switches change where an activation
+    is rounded to fp16, not what is computed)."""
+    from oracle import streamflow_oracle as orc
+    from streamflow_amd import presets, synthetic as syn
+    from streamflow_amd.engine import EngineOptions, HotPathEngine
+    T, h, w, iters, B = 3, 24, 32, 4, 2
+    P = syn.make_params(5, T)
+    fm, cn = syn.make_features(55, B, T, h, w)
+    ups_o, _ = orc.hotpath_forward(fm, cn, P, iters)
+    kw = presets.engine_kwargs("config2_mixed")
+    spec = dict(item.split("=") for item in opts.split(","))
+    alt = EngineOptions(**{k: (v != "0") for k, v in spec.items()})
+    outs = []
+    for options in (EngineOptions(), alt):
+        eng = HotPathEngine(P, device=dev, T=T, use_graph=False, options=options, **kw)
+        ups = eng.forward(fm.to(dev), cn.to(dev), iters=iters)[0]
+        outs.append([u.cpu() for u in ups])
+    e_def = max(orc.epe(u, o) for u, o in zip(outs[0], ups_o))
+    e_alt = max(orc.epe(u, o) for u, o in zip(outs[1], ups_o))
+    d = max(orc.epe(a, b) for a, b in zip(outs[0], outs[1]))
+    assert e_def <= 1e-3 and e_alt <= 1e-3 and d <= 1e-3, (opts, e_def, e_alt, d)
