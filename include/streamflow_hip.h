@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SF_VERSION 112
+#define SF_VERSION 113
 
 enum {
     SF_OK = 0,
@@ -254,6 +254,12 @@ int sf_gma_flash_aggregate(void* ws, int64_t ws_bytes, const float* v, int64_t v
                            int64_t mf_img_stride, const float* gamma, float* out, int64_t out_img_stride,
                            void* out_koct, int64_t out_koct_img_stride, int n_img, int P, int qk_products, int use_stats,
                            void* stream);
+/* The same with v as fp16 ROWS [n_img][128][P] (v_img_stride in halves: sf_gemm's c_f16 = 1 output of the to_v layer in the
+ * config-2 presets): v enters the second contraction as fp16 either way, the to_v GEMM writes and the pack reads half the bytes. */
+int sf_gma_flash_aggregate_f16v(void* ws, int64_t ws_bytes, const void* v_f16, int64_t v_img_stride, const float* mf,
+                                int64_t mf_img_stride, const float* gamma, float* out, int64_t out_img_stride,
+                                void* out_koct, int64_t out_koct_img_stride, int n_img, int P, int qk_products,
+                                int use_stats, void* stream);
 
 /* ---- row softmax (gma.py:63): x [rows][cols] ----------------------------------------------------
  * out_f16 == NULL: in place.  Otherwise the weights are written as IEEE fp16 to out_f16 [rows][cols] (x is then

@@ -88,17 +88,18 @@ __global__ __launch_bounds__(256) void flash_pack_qk_kernel(const float* qk, int
 }
 
 // ---- pack v: planes [img][HD][P] fp32 -> fp16 [(key/8)][HD][8], keys of each 16-group in accumulator-register order ----
-__global__ __launch_bounds__(256) void flash_pack_v_kernel(const float* v, int64_t v_img_stride, char* ws, int P, int Ppad) {
+template <typename TIn>       // float planes, or _Float16 rows (the to_v GEMM's c_f16 = 1 output: half the bytes in)
+__global__ __launch_bounds__(256) void flash_pack_v_kernel(const TIn* v, int64_t v_img_stride, char* ws, int P, int Ppad) {
     const int o = blockIdx.x * 32 + (threadIdx.x & 31);            // key octet
     const int d = blockIdx.y * 8 + (threadIdx.x >> 5), img = blockIdx.z;
     if (o * 8 >= Ppad) return;
     const int khalf = o & 1, base = (o >> 1) * 16 + 4 * khalf;     // keys base + {0,1,2,3, 8,9,10,11}
-    const float* row = v + (int64_t)img * v_img_stride + (int64_t)d * P;
+    const TIn* row = v + (int64_t)img * v_img_stride + (int64_t)d * P;
     f16x8 h;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int key = base + (i & 3) + 8 * (i >> 2);
-        h[i] = (_Float16)((key < P) ? row[key] : 0.f);
+        h[i] = (key < P) ? (_Float16)row[key] : (_Float16)0.f;
     }
     char* dst = ws + (int64_t)img * img_ws_bytes(Ppad) + 4 * plane_bytes(Ppad) + ((int64_t)o * HD + d) * 16;
     *reinterpret_cast<f16x8*>(dst) = h;
@@ -387,12 +388,13 @@ extern "C" int sf_gma_flash_pack_qk(const float* qk, int64_t qk_img_stride, void
     return sf::check_launch("sf_gma_flash_pack_qk");
 }
 
-extern "C" int sf_gma_flash_aggregate(void* ws, int64_t ws_bytes, const float* v, int64_t v_img_stride, const float* mf,
+static int flash_aggregate(void* ws, int64_t ws_bytes, const void* v_, int v_f16, int64_t v_img_stride, const float* mf,
                                       int64_t mf_img_stride, const float* gamma, float* out, int64_t out_img_stride,
                                       void* out_koct, int64_t out_koct_img_stride, int n_img, int P, int qk_products,
                                       int use_stats, void* stream) {
     SF_REQUIRE(!out_koct || ((reinterpret_cast<uintptr_t>(out_koct) & 15) == 0 && (out_koct_img_stride & 7) == 0),
                "sf_gma_flash_aggregate: out_koct must be 16-byte aligned, its image stride a multiple of 8 halves");
+    const float* v = static_cast<const float*>(v_);
     SF_REQUIRE(ws && v && mf && gamma && out, "sf_gma_flash_aggregate: null pointer");
     SF_REQUIRE(n_img > 0 && P > 0 && n_img <= 65535, "sf_gma_flash_aggregate: bad dims");
     SF_REQUIRE(qk_products >= 1 && qk_products <= 3, "sf_gma_flash_aggregate: qk_products must be 1, 2 or 3");
@@ -400,8 +402,12 @@ extern "C" int sf_gma_flash_aggregate(void* ws, int64_t ws_bytes, const float* v
                "sf_gma_flash_aggregate: workspace too small or misaligned");
     const int Ppad = sf::ceil_div(P, BQ) * BQ;
     SF_REQUIRE(2 * plane_bytes(Ppad) < ((int64_t)1 << 31), "sf_gma_flash_aggregate: image too large");
-    hipLaunchKernelGGL(flash_pack_v_kernel, dim3(sf::ceil_div(Ppad / 8, 32), HD / 8, n_img), dim3(256), 0, (hipStream_t)stream,
-                       v, v_img_stride, (char*)ws, P, Ppad);
+    if (v_f16)
+        hipLaunchKernelGGL(flash_pack_v_kernel<_Float16>, dim3(sf::ceil_div(Ppad / 8, 32), HD / 8, n_img), dim3(256), 0,
+                           (hipStream_t)stream, static_cast<const _Float16*>(v_), v_img_stride, (char*)ws, P, Ppad);
+    else
+        hipLaunchKernelGGL(flash_pack_v_kernel<float>, dim3(sf::ceil_div(Ppad / 8, 32), HD / 8, n_img), dim3(256), 0,
+                           (hipStream_t)stream, v, v_img_stride, (char*)ws, P, Ppad);
     FlashArgs g;
     g.ws = (const char*)ws; g.mf = mf; g.gamma = gamma; g.out = out;
     g.out16 = static_cast<_Float16*>(out_koct); g.out16_img_stride = out_koct_img_stride;
@@ -423,4 +429,22 @@ extern "C" int sf_gma_flash_aggregate(void* ws, int64_t ws_bytes, const float* v
         hipLaunchKernelGGL(flash_combine_kernel, dim3(sf::ceil_div(P, 256), HD / 8, n_img), dim3(256), 0, (hipStream_t)stream, g.part,
                            g.nsplit, mf, mf_img_stride, out, out_img_stride, g.out16, g.out16_img_stride, P, Ppad);
     return sf::check_launch("sf_gma_flash_aggregate");
+}
+
+extern "C" int sf_gma_flash_aggregate(void* ws, int64_t ws_bytes, const float* v, int64_t v_img_stride, const float* mf,
+                                      int64_t mf_img_stride, const float* gamma, float* out, int64_t out_img_stride,
+                                      void* out_koct, int64_t out_koct_img_stride, int n_img, int P, int qk_products,
+                                      int use_stats, void* stream) {
+    return flash_aggregate(ws, ws_bytes, v, 0, v_img_stride, mf, mf_img_stride, gamma, out, out_img_stride, out_koct,
+                           out_koct_img_stride, n_img, P, qk_products, use_stats, stream);
+}
+
+// v as fp16 ROWS [n_img][128][P] (v_img_stride in halves): what sf_gemm writes with c_f16 = 1 -- the values enter the
+// second contraction as fp16 either way.
+extern "C" int sf_gma_flash_aggregate_f16v(void* ws, int64_t ws_bytes, const void* v_f16, int64_t v_img_stride,
+                                           const float* mf, int64_t mf_img_stride, const float* gamma, float* out,
+                                           int64_t out_img_stride, void* out_koct, int64_t out_koct_img_stride, int n_img,
+                                           int P, int qk_products, int use_stats, void* stream) {
+    return flash_aggregate(ws, ws_bytes, v_f16, 1, v_img_stride, mf, mf_img_stride, gamma, out, out_img_stride, out_koct,
+                           out_koct_img_stride, n_img, P, qk_products, use_stats, stream);
 }

@@ -567,13 +567,15 @@ class HotPathEngine:
             ops.gemm(W.fc1, ln, h256, EPI_GELU, cx=cs)
             ops.gemm(W.fc2, h256, pl.mft, EPI_RES, R=pl.tx128, cx=cs)
         # a7: global aggregation  mfg = mf + gamma * attn @ to_v(mf)   (gma.py:91-104), main stream
-        ops.gemm(W.to_v, pl.mf, pl.v128, EPI_NONE, cx=cx)
+        # v has ONE reader, the pack of the fused kernel (which rounds it to fp16): fp16 rows where the fp16 hand-over is active
+        v128 = _scratch(pl.v128, pl.n, HDIM, f16=True) if (pl.flash and hidden_f16_ok(cx, P) and cx.x2_f16) else pl.v128
+        ops.gemm(W.to_v, pl.mf, v128, EPI_NONE, cx=cx)
         ks = self.attn_k_splits if self.precision != ops.PRECISION_FP32 else 1
         attn_ptr, attn_lay = ((pl.attn16.data_ptr(), LAYOUT_F16_K_MINOR) if pl.attn16 is not None
                               else (pl.attn.data_ptr(), LAYOUT_K_MINOR))
         if pl.flash:
             # fused recompute (K6' of SURVEY.md): one kernel, online softmax, logits never written
-            ops.gma_flash_aggregate(pl.flash_ws, pl.v128, pl.mf, W.gamma, pl.mfg, self.flash_qk_products, use_stats=True, cx=cx)
+            ops.gma_flash_aggregate(pl.flash_ws, v128, pl.mf, W.gamma, pl.mfg, self.flash_qk_products, use_stats=True, cx=cx)
         elif pl.attn_rows < P:
             # high-resolution path: recompute the attention rows chunk by chunk (K6' of SURVEY.md)
             for i0 in range(0, P, pl.attn_rows):

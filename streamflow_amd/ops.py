@@ -595,12 +595,14 @@ def gma_flash_aggregate(ws: torch.Tensor, V: Planes, MF: Planes, gamma: torch.Te
     statistics stored by gma_flash_pack_qk(..., stats_qk_products=qk_products) are used instead of an online softmax."""
     cx = _cx(cx)
     use_stats = bool(use_stats) and cx.flash_stats
-    assert V.rows == MF.rows == OUT.rows == 128 and V.n_img == MF.n_img == OUT.n_img
+    assert V.rows == MF.rows == OUT.rows == 128 and V.n_img == MF.n_img == OUT.n_img and not V.koct
     n, P = V.n_img, V.P
+    fn = _lib.load().sf_gma_flash_aggregate_f16v if V.f16 else _lib.load().sf_gma_flash_aggregate     # (v as fp16 rows)
     # algorithmic: the two contractions; bytes: v, mf in, out (q/k/v tiles are re-read from L2 by every query tile)
     sh = OUT.shadow if (OUT.shadow is not None and cx.shadows and cx.shadow_fused) else None
-    _launch("gma_flash", 4.0 * n * P * P * 128, 4.0 * n * 128 * P * 3 + 2.0 * n * 128 * P * (2 if sh is None else 3),
-            lambda: _lib.check(_lib.load().sf_gma_flash_aggregate(
+    _launch("gma_flash", 4.0 * n * P * P * 128,
+            (2.0 if V.f16 else 4.0) * n * 128 * P + 4.0 * n * 128 * P * 2 + 2.0 * n * 128 * P * (2 if sh is None else 3),
+            lambda: _lib.check(fn(
                 ws.data_ptr(), ws.numel(), V.ptr, V.img_stride, MF.ptr, MF.img_stride, gamma.data_ptr(), OUT.ptr,
                 OUT.img_stride, None if sh is None else sh.ptr, 0 if sh is None else sh.img_stride, n, P,
                 int(qk_products), int(use_stats), _lib.stream()), "sf_gma_flash_aggregate"), products=(qk_products + 1) / 2.0)

@@ -475,6 +475,17 @@ def test_gma_flash_kernel_vs_float64(dev, P, qkp, stats):
     torch.cuda.synchronize()
     assert torch.equal(out2, out)
     assert torch.equal(sh.tensor().float(), out.half().float())
+    # v as fp16 rows (sf_gma_flash_aggregate_f16v, the to_v GEMM's c_f16 = 1 hand-over): the pack rounds v to fp16 anyway, so
+    # feeding the rounded values through either entry point gives bit-identical results (P even: fp16 rows in a float buffer)
+    if P % 2 == 0:
+        v16 = v.half().to(dev).contiguous()
+        V16 = Planes(v16.view(-1).view(torch.float32), 0, 128 * P, n, 128, P, f16=True)
+        o_h = torch.full((n, 128, P), float("nan"), device=dev)
+        o_f = torch.full((n, 128, P), float("nan"), device=dev)
+        ops.gma_flash_aggregate(ws, V16, Planes.of(mf.to(dev)), gamma.to(dev), Planes.of(o_h), qkp, use_stats=stats)
+        ops.gma_flash_aggregate(ws, Planes.of(v16.float()), Planes.of(mf.to(dev)), gamma.to(dev), Planes.of(o_f), qkp, use_stats=stats)
+        torch.cuda.synchronize()
+        assert torch.equal(o_h, o_f) and torch.equal(o_h, out)
 
 
 @pytest.mark.parametrize("qkp", [1, 2, 3])
