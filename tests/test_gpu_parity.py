@@ -929,6 +929,31 @@ def test_bench_two_ranks_self_launched(dev):
 
 
 @pytest.mark.gpu
+def test_bench_strong_scaling_three_ranks(dev):
+    """BASELINE config 4's mode at toy size, end to end: `bench.py --gpus 3 --total-clips 5 --clips 2` -- the SAME 5 clips at any
+    N, round-robined over the ranks (2 / 2 / 1 clips, the uneven case), each rank's share run in launches of at most 2 clips;
+    `scaling` = "strong", per-rank times in the JSON line, value = total flow fields / max-over-ranks time.  The three ranks
+    share this box's one GPU and rendezvous over gloo."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--share-device", "--dist-backend", "gloo",
+                        "--workload", "demo256", "--total-clips", "5", "--clips", "2", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 3 and d["scaling"] == "strong"
+    assert d["config"]["clips_per_step_all_gpus"] == 5 and d["config"]["clips_per_rank"] == [2, 2, 1]
+    assert len(d["per_rank_ms_per_step"]) == 3 and max(d["per_rank_ms_per_step"]) <= d["ms_per_step"] * 1.001
+    assert abs(d["value"] - 5 * 3 * 2 / (d["ms_per_step"] * 2 / 1e3)) / d["value"] < 1e-6      # 5 clips x 3 pairs x 2 steps
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("tag", list(cases.TWINS_CASES))
 def test_twins_csc_encoder_vs_reference(golden, dev, tag, precision):
     """f1: the Twins_CSC encoder on the HIP kernels (sf_gemm for every Linear / strided conv, sf_layernorm_cm,
