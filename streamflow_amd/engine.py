@@ -44,7 +44,7 @@ class EngineOptions:
     hidden_koct: bool = True         # ... as k-octet planes where the consumer takes them
     pw_fold: bool = True             # pw residual folded into the weights (x3 handed over in fp16)
     koct_io: bool = True             # motion-encoder tensors between SK blocks as fp16 k-octets only (no fp32 planes)
-    x2_f16: bool = True              # ... and x2 (ffn1.2 -> depthwise) as fp16 rows too (changes x3 by <= its own fp16 rounding)
+    x2_f16: bool = True              # single-reader tensors as fp16 ROWS: x2 (ffn1.2 -> depthwise), qkv (-> temporal attention), v (-> GMA pack)
     flash_stats: bool = True         # fused GMA: softmax statistics computed once per clip
     max_plans: int = 4               # buffer sets (and graphs) kept, least recently used evicted
 
