@@ -43,6 +43,9 @@ template <int PM> struct StageK { static constexpr int value = (PM == 1) ? 8 : 4
 #define SF_BSTAT_RING 3
 #endif
 constexpr int RING = SF_BSTAT_RING;    // weight stages in LDS
+#ifndef SF_BSTAT_STORE_SLACK
+#define SF_BSTAT_STORE_SLACK 1
+#endif
 constexpr int kParamRows = 1024;       // rows of the LDS copy of bias / depthwise scale / shift
 constexpr int kOob = 1 << 30;          // byte offset beyond every buffer range (host-checked spans < 2^30)
 
@@ -690,8 +693,9 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bstat_gk_kernel(const BsArgs
     const char* sp_base = smem + lane * 16;
     f32x16 acc0, acc1 = {};
     // one tile: MFMAs into `cur`, the epilogue of the previous tile (`prev`, tile tau - 1) between them
-    auto phase = [&](f32x16& cur, const f32x16& prev, int tau, auto prev_tag) {
+    auto phase = [&](f32x16& cur, const f32x16& prev, int tau, auto prev_tag, auto pp_tag) {
         constexpr bool kPrev = decltype(prev_tag)::value;
+        constexpr bool kPrevPrev = decltype(pp_tag)::value;        // the phase before this one had an epilogue (stores) too
         using std::integral_constant;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -702,7 +706,16 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bstat_gk_kernel(const BsArgs
         static_for<0, NS>([&](auto s_tag) {
             constexpr int s = decltype(s_tag)::value;
             SF_BS_STAMP(tm)
-            wait_vm<P * (RING - 2)>();                             // this wave's pieces of the stage have landed (see issue order)
+            // this wave's pieces of the stage have landed.  Younger than them in the in-order queue: the refill issued at the end of the
+            // previous stage (P pieces) AND the epilogue stores of the previous stage (one 8-byte store per group) -- counting those too
+            // leaves them in flight for a whole stage instead of draining them here (SF_BSTAT_STORE_SLACK)
+            {
+                constexpr int kB = 4 / NS, kR = 4 % NS;
+                constexpr int sp = (s > 0) ? s - 1 : NS - 1;
+                constexpr bool had = (s > 0) ? kPrev : kPrevPrev;
+                constexpr int kSt = (SF_BSTAT_STORE_SLACK && had) ? kB + (sp < kR ? 1 : 0) : 0;
+                wait_vm<P * (RING - 2) + kSt>();
+            }
             SF_BS_STAMP(tw)
             __builtin_amdgcn_s_barrier();                          // ... everyone's; nobody reads the previous slot any more
             SF_BS_STAMP(tb)
@@ -752,15 +765,22 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bstat_gk_kernel(const BsArgs
     using std::integral_constant;
     int tau = t_beg;
     if (tau < t_end) {
-        phase(acc0, acc1, tau, integral_constant<bool, false>{});
+        using T_ = integral_constant<bool, true>;
+        using F_ = integral_constant<bool, false>;
+        phase(acc0, acc1, tau, F_{}, F_{});
         ++tau;
+        if (tau + 1 < t_end) {                                     // (the first pair: the phase before it stored nothing)
+            phase(acc1, acc0, tau, T_{}, F_{});
+            phase(acc0, acc1, tau + 1, T_{}, T_{});
+            tau += 2;
+        }
         while (tau + 1 < t_end) {                                  // two tiles per trip: the accumulators swap roles
-            phase(acc1, acc0, tau, integral_constant<bool, true>{});
-            phase(acc0, acc1, tau + 1, integral_constant<bool, true>{});
+            phase(acc1, acc0, tau, T_{}, T_{});
+            phase(acc0, acc1, tau + 1, T_{}, T_{});
             tau += 2;
         }
         if (tau < t_end) {
-            phase(acc1, acc0, tau, integral_constant<bool, true>{});
+            phase(acc1, acc0, tau, T_{}, F_{});                    // (conservative: this may be the second phase)
             epi_groups(acc1, tau, integral_constant<int, 0>{}, integral_constant<int, 2>{});
             epi_groups(acc1, tau, integral_constant<int, 2>{}, integral_constant<int, 2>{});
         } else {
