@@ -805,6 +805,7 @@ int launch_gk(const BsArgs& a, dim3 grid, hipStream_t st) {
     if (nks <= 8) hipLaunchKernelGGL((gemm_bstat_gk_kernel<8, PM>), grid, dim3(kThreads), 0, st, a);
     else if (nks <= 16) hipLaunchKernelGGL((gemm_bstat_gk_kernel<16, PM>), grid, dim3(kThreads), 0, st, a);
     else if (nks <= 24) hipLaunchKernelGGL((gemm_bstat_gk_kernel<24, PM>), grid, dim3(kThreads), 0, st, a);
+    else if (nks <= 32) hipLaunchKernelGGL((gemm_bstat_gk_kernel<32, PM>), grid, dim3(kThreads), 0, st, a);   // (K = 486: 31 k-steps)
     else hipLaunchKernelGGL((gemm_bstat_gk_kernel<40, PM>), grid, dim3(kThreads), 0, st, a);
     return sf::check_launch("sf_gemm(B-stationary, pipelined GELU)");
 }
