@@ -13,6 +13,7 @@ independent, so N GPUs run N replicas with no data-path collective (torch.distri
 barrier and the max-over-ranks timing the contract asks for).
 """
 import argparse
+import datetime
 import glob
 import json
 import os
@@ -25,6 +26,38 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+
+
+def _load_launch():
+    # streamflow_amd/launch.py by path: importing the package would import torch, and the placement below must happen first
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("sf_launch", os.path.join(ROOT, "streamflow_amd", "launch.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+launch = _load_launch()
+# A rank of an N > 1 run (spawned by this file or by torch.distributed.run) takes its share of the host cores NOW, before torch
+# and OpenMP size their thread pools from the affinity mask: the cores of its GPU's NUMA node,
+# split evenly between the ranks on that node
+RANK_CPUS = launch.pin_rank_cpus(int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def _argv_option(name: str, default: str) -> str:
+    for a, b in zip(sys.argv[1:], sys.argv[2:] + [""]):
+        if a == name:
+            return b
+        if a.startswith(name + "="):
+            return a.split("=", 1)[1]
+    return default
+
+
+if (int(os.environ.get("WORLD_SIZE", "1")) > 1 and "SF_BENCH_DEVICE" not in os.environ and "--share-device" not in sys.argv
+        and _argv_option("--pin", os.environ.get("SF_BENCH_PIN", "visible")) == "visible"):
+    # a rank under an external launcher (torch.distributed.run): restrict it to ITS device before the HIP runtime is even loaded
+    os.environ["SF_BENCH_OUTER_VISIBLE"] = os.environ.get("HIP_VISIBLE_DEVICES", "")
+    os.environ.update(launch.pinned_device_env(int(os.environ.get("LOCAL_RANK", "0")), os.environ.get("HIP_VISIBLE_DEVICES")))
 
 import torch
 import torch.distributed as dist
@@ -127,26 +160,40 @@ def cpu_baseline(samples, iters: int, pairs: int):
             "s_per_clip": clip}, ups
 
 
-def hard_case_epe(preset_cfg, dev):
+HARD_SEEDS = (21, 11, 12, 13, 31, 32)      # == tests/cases.py HARD_SEEDS (seed 21: hot params 21, frames 24, Twins 22 / 23)
+
+
+def hard_case_epe(preset_cfg, dev, seeds=HARD_SEEDS):
     """frames -> random-init Twins_CSC features -> loop at 128 x 192, 4 iterations (tests/test_gpu_parity.py::
-    test_real_frames_end_to_end_with_twins_encoder: an ill-conditioned input, flows of 20-60 px) against the chained CPU oracles:
-    the deviation of the fp16-activation arithmetic class is relative to the flow, so both forms are reported."""
+    test_hard_case_sweep_vs_oracle: ill-conditioned inputs, flows of 4-40 px) against the chained CPU oracles, on SIX weight / frame
+    seeds: `value` is the MAXIMUM; the deviation of the fp16-activation arithmetic class is relative to the flow,
+    so both forms are reported per seed."""
     from oracle import streamflow_oracle as orc, twins_oracle as two
     from streamflow_amd import synthetic as syn
     from streamflow_amd.engine import HotPathEngine
     B, T, H, W, iters = 1, 4, 128, 192, 4
-    hot = syn.make_params(21, T)
-    frames = torch.stack([(syn.randn(24, f"frame{t}", (B, 3, H, W)).sigmoid() * 255.0) for t in range(T)], dim=1)
-    imgs = 2 * (frames / 255.0) - 1.0
-    fm = two.twins_csc_forward(imgs, syn.make_twins_params(22))
-    cn = two.twins_csc_forward(imgs[:, :-1], syn.make_twins_params(23))
-    ups_o, _ = orc.hotpath_forward(fm, cn, hot, iters)
-    eng = HotPathEngine(hot, device=dev, T=T, **preset_cfg)
-    ups, _ = eng.forward(fm.to(dev).contiguous(), cn.to(dev).contiguous(), iters=iters)
-    e = max(orc.epe(u.cpu(), o) for u, o in zip(ups, ups_o))
-    mag = float(torch.stack([o.norm(dim=1).mean() for o in ups_o]).mean())
-    return {"value": e, "unit": "px", "mean_flow_px": round(mag, 2), "relative_to_flow": e / mag,
-            "note": "exact (oracle) Twins_CSC features of random frames, 128 x 192, 4 iterations; HIP loop vs the CPU oracle loop"}
+    per = []
+    for seed in seeds:
+        ps, fs, a, b = (21, 24, 22, 23) if seed == 21 else (seed, 100 + seed, 200 + seed, 300 + seed)
+        hot = syn.make_params(ps, T)
+        frames = torch.stack([(syn.randn(fs, f"frame{t}", (B, 3, H, W)).sigmoid() * 255.0) for t in range(T)], dim=1)
+        imgs = 2 * (frames / 255.0) - 1.0
+        fm = two.twins_csc_forward(imgs, syn.make_twins_params(a))
+        cn = two.twins_csc_forward(imgs[:, :-1], syn.make_twins_params(b))
+        ups_o, _ = orc.hotpath_forward(fm, cn, hot, iters)
+        eng = HotPathEngine(hot, device=dev, T=T, **preset_cfg)
+        ups, _ = eng.forward(fm.to(dev).contiguous(), cn.to(dev).contiguous(), iters=iters)
+        e = max(orc.epe(u.cpu(), o) for u, o in zip(ups, ups_o))
+        mag = float(torch.stack([o.norm(dim=1).mean() for o in ups_o]).mean())
+        per.append({"seed": seed, "epe_px": e, "mean_flow_px": round(mag, 2), "relative_to_flow": e / mag})
+        del eng
+    worst = max(per, key=lambda p: p["epe_px"])
+    return {"value": worst["epe_px"], "unit": "px", "mean_flow_px": worst["mean_flow_px"],
+            "relative_to_flow": max(p["relative_to_flow"] for p in per),
+            "within_1e-3_of_max(1,flow)": all(p["epe_px"] <= 1e-3 * max(1.0, p["mean_flow_px"]) for p in per),
+            "seeds": per,
+            "note": "MAX over six weight / frame seeds: exact (oracle) Twins_CSC features of random frames, 128 x 192, 4 iterations; "
+                    "HIP loop vs the CPU oracle loop; relative_to_flow = the worst seed's EPE / mean flow"}
 
 
 def mfma_busy_from_profiles(kernel_family):
@@ -160,9 +207,25 @@ def mfma_busy_from_profiles(kernel_family):
         with open(files[-1]) as f:
             d = json.load(f)
         v = d.get(kernel_family)
-        return {"value": v, "source": os.path.relpath(files[-1], ROOT)} if v is not None else None
+        if v is None:
+            return None
+        if d.get("_csrc_sha") != csrc_sha():
+            return {"value": None, "source": os.path.relpath(files[-1], ROOT),
+                    "note": f"taken on other kernel sources (csrc hash {d.get('_csrc_sha')} != {csrc_sha()}): not quoted"}
+        return {"value": v, "source": os.path.relpath(files[-1], ROOT)}
     except (OSError, ValueError):
         return None
+
+
+def csrc_sha() -> str:
+    """Hash of the kernel sources (streamflow_amd/csrc/*.hip, *.h): PMC traffic files are only valid for the sources they were
+    profiled on (tools/traffic_json.py stores it as _csrc_sha)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "streamflow_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "streamflow_amd", "csrc", "*.h"))):
+        with open(f, "rb") as fh:
+            h.update(os.path.basename(f).encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
 
 
 def newest_traffic_file(workload=None):
@@ -178,12 +241,7 @@ def newest_traffic_file(workload=None):
     return files[-1] if files else None
 
 
-def pinned_device_env(local_rank: int, visible=None) -> dict:
-    """Environment that restricts a rank to ONE GPU before it initialises the runtime: the local_rank-th of the devices this
-    process may see (HIP_VISIBLE_DEVICES of the parent, if set).  The rank then addresses it as device 0 (SF_BENCH_DEVICE)."""
-    devs = [d for d in visible.split(",") if d != ""] if visible else None
-    dev = devs[local_rank % len(devs)] if devs else str(local_rank)
-    return {"HIP_VISIBLE_DEVICES": dev, "SF_BENCH_DEVICE": "0"}
+pinned_device_env = launch.pinned_device_env
 
 
 def _free_port() -> int:
@@ -198,14 +256,23 @@ def spawn_ranks(n: int, argv, script: str = None) -> int:
     GPU, wait for them, return the worst exit code.  Rank 0 inherits stdout and prints the one JSON line."""
     port = _free_port()
     procs = []
-    # SF_BENCH_PIN=visible: every child sees exactly ONE device (HIP_VISIBLE_DEVICES = its local rank, set before the child
-    # initialises the GPU: SURVEY.md 8e) and uses device index 0; default: all devices visible, device index = LOCAL_RANK
-    pin = os.environ.get("SF_BENCH_PIN", "index")
+    # pin = visible (default; --pin / SF_BENCH_PIN): every child sees exactly ONE device (HIP_VISIBLE_DEVICES = its local rank,
+    # set before the child initialises the GPU: SURVEY.md 8e) and uses device index 0; index: all devices visible, device index
+    # = LOCAL_RANK.  Each child also takes its own share of the host cores when it starts (launch.pin_rank_cpus above).
+    pin = os.environ.get("SF_BENCH_PIN", "visible")
+    for a, b in zip(argv, list(argv)[1:] + [""]):
+        if a == "--pin":
+            pin = b
+        elif a.startswith("--pin="):
+            pin = a.split("=", 1)[1]
+    if "--share-device" in argv:
+        pin = "index"                               # (dry runs on fewer devices than ranks)
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         if pin == "visible":
             env.update(pinned_device_env(r, os.environ.get("HIP_VISIBLE_DEVICES")))
+            env["SF_BENCH_OUTER_VISIBLE"] = os.environ.get("HIP_VISIBLE_DEVICES", "")
         procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + list(argv), env=env))
     rc = 0
     try:
@@ -306,9 +373,9 @@ def main():
                     help="STRONG scaling: this many clips in total per step at every --gpus N (BASELINE.json config 4: 64), "
                          "round-robined over the ranks and run in launches of --clips; 0 (default) = weak scaling, "
                          "--clips per GPU per step")
-    ap.add_argument("--pin", default=os.environ.get("SF_BENCH_PIN", "index"), choices=["index", "visible"],
-                    help="how a rank takes its GPU: index = cuda:LOCAL_RANK with every device visible; visible = "
-                         "HIP_VISIBLE_DEVICES restricted to its one device before the runtime starts (SURVEY.md 8e)")
+    ap.add_argument("--pin", default=os.environ.get("SF_BENCH_PIN", "visible"), choices=["index", "visible"],
+                    help="how a rank takes its GPU: visible (default) = HIP_VISIBLE_DEVICES restricted to its one device "
+                         "before the runtime starts (SURVEY.md 8e); index = cuda:LOCAL_RANK with every device visible")
     ap.add_argument("--clips", type=int, default=8,
                     help="clips per GPU per step, batched through every launch (default 8 = the per-GPU share of "
                          "BASELINE.json's 8-GPU 'Sintel-shape batch=64' configuration; 1 = single-clip latency)")
@@ -317,10 +384,11 @@ def main():
                     help="run the mask head every iteration as the reference literally does (outputs identical; "
                          "the default skips the 14 mask heads whose results test_mode discards)")
     ap.add_argument("--preset", default=None, choices=["config2_mixed", "config2_fp16", "fp32_class"],
-                    help="named arithmetic configuration (streamflow_amd/presets.py); default config2_fp16 = BASELINE.json "
-                         "configuration 2 ('bf16'): activations fp16 into split-precision weights, fp16 correlation "
-                         "volumes, fused fp16 GMA aggregation, fp32 accumulation everywhere.  fp32_class = the library "
-                         "default (split precision everywhere, fp32 volumes).  --precision / --corr-dtype / --gma override")
+                    help="named arithmetic configuration (streamflow_amd/presets.py); default = presets.BENCH_PRESET.  config2_fp16 = "
+                         "BASELINE.json configuration 2 ('bf16'): activations fp16 into split-precision weights, fp16 correlation "
+                         "volumes, fused fp16 GMA aggregation, fp32 accumulation everywhere; config2_mixed = the same with single "
+                         "fp16 weights in the layers where that was measured invisible; fp32_class = the library default (split "
+                         "precision everywhere, fp32 volumes).  --precision / --corr-dtype / --gma override")
     ap.add_argument("--precision", default=None, choices=["f16x3", "fp32", "f16x2", "f16"],
                     help="f16x3: split-fp16 MFMA with fp32 accumulation (fp32-class accuracy); fp32: exact fp32 MFMA; "
                          "f16x2: weights split, activations rounded once to fp16")
@@ -345,6 +413,9 @@ def main():
                     help="BASELINE.json config 3: ONLY the correlation build (all-pairs volume + 4-level pyramid) and the "
                          "pyramid lookups of the workload (one build + `iters` lookups per step), reported in GB/s against "
                          "the HBM roof; use with --workload kitti --preset fp32_class for the full-resolution fp32 volume")
+    ap.add_argument("--placement-only", default=None, metavar="DIR",
+                    help="dry run of the rank placement: every rank writes {rank, device environment, host cores} to DIR/rankN.json "
+                         "and exits before touching the GPU (tests/test_distributed_cpu.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-runs", type=int, default=3, help="timed whole-clip runs of the CPU oracle (median reported)")
     ap.add_argument("--no-kernel-breakdown", action="store_true")
@@ -361,8 +432,15 @@ def main():
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
     if args.gpus > 1 and world == 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE=1")
+    if args.placement_only:
+        with open(os.path.join(args.placement_only, f"rank{rank}.json"), "w") as f:
+            json.dump({"rank": rank, "local_rank": local_rank, "world": world, "cpus": sorted(os.sched_getaffinity(0)),
+                       "HIP_VISIBLE_DEVICES": os.environ.get("HIP_VISIBLE_DEVICES"), "SF_BENCH_DEVICE": os.environ.get("SF_BENCH_DEVICE"),
+                       "torch_threads": torch.get_num_threads()}, f)
+        return
     if args.pin == "visible" and world > 1 and "SF_BENCH_DEVICE" not in os.environ and not args.share_device:
         # under an external launcher: restrict this rank to its device now -- nothing has initialised the GPU yet
+        os.environ["SF_BENCH_OUTER_VISIBLE"] = os.environ.get("HIP_VISIBLE_DEVICES", "")
         os.environ.update(pinned_device_env(local_rank, os.environ.get("HIP_VISIBLE_DEVICES")))
     if "SF_BENCH_DEVICE" in os.environ and not args.share_device:
         local_rank = int(os.environ["SF_BENCH_DEVICE"])
@@ -373,7 +451,8 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1:
         if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            # RCCL carries only the barrier and the max-over-ranks of the timing (no data-path collective)
+            dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=600))
         else:
             # gloo announces its connections on stdout; rank 0's stdout must carry exactly one JSON line
             sys.stdout.flush()
@@ -466,12 +545,13 @@ def main():
     own = []
     dt = timed_steps(step, args.steps, args.warmup, world, torch.cuda.synchronize, barrier, allreduce_max, own=own)
     log(f"timed region: {args.steps} steps in {dt:.3f}s (this rank: {own[0]:.3f}s)")
-    per_rank = [own[0]]
+    per_rank, rank_cores = [own[0]], [len(RANK_CPUS)]
     if world > 1:
-        t_own = torch.tensor([own[0]], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
+        t_own = torch.tensor([own[0], float(len(RANK_CPUS))], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
         t_all = [torch.zeros_like(t_own) for _ in range(world)]
         dist.all_gather(t_all, t_own)
-        per_rank = [float(t.item()) for t in t_all]
+        per_rank = [float(t[0].item()) for t in t_all]
+        rank_cores = [int(t[1].item()) for t in t_all]
     clips_all = args.total_clips if strong else world * B
     fields = clips_all * pairs * args.steps
     result = {
@@ -479,6 +559,9 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
         "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
         "per_rank_ms_per_step": [round(1e3 * t / args.steps, 3) for t in per_rank],
+        # spread of the ranks' own times (each up to its device sync, before the closing barrier) relative to their mean: what
+        # the slowest rank costs the job
+        "imbalance": round((max(per_rank) - min(per_rank)) / (sum(per_rank) / len(per_rank)), 4),
         "dtype": {"fp32": "fp32", "f16x3": "f16x3-split (fp32 accumulate)",
                   "f16x2": ("f16x2 (weights hi+lo, activations fp16; fp32 accumulate)" if not cfg.get("single_layers") else
                             f"f16x2 / f16 mixed (activations fp16; weights fp16 in {len(cfg['single_layers'])} of the 45 "
@@ -489,7 +572,8 @@ def main():
                    "clips_per_gpu_per_step": (B if not strong else None), "clips_per_launch": B,
                    "clips_per_step_all_gpus": clips_all,
                    "clips_per_rank": ([len(shard(args.total_clips, world, r)) for r in range(world)] if strong else [B] * world),
-                   "device_pinning": args.pin,
+                   "device_pinning": args.pin if world > 1 else "single device",
+                   "host_cores_per_rank": rank_cores,
                    "flow_fields_per_clip": pairs, "feature_grid": [h, w], "parallelism": f"replicas{world}",
                    "hip_graph": not args.no_graph, "mask_head_every_iteration": bool(args.all_masks),
                    "preset": args.preset or presets.BENCH_PRESET,
@@ -510,7 +594,7 @@ def main():
         eager = HotPathEngine(params, device=dev, T=T, use_graph=False, **cfg)
         eager._plans = eng._plans                       # reuse buffers
         eager.parallel_branches = False                 # serial launches: clean per-kernel durations
-        ops.PROFILE_SHAPES = args.gemm_shapes
+        ops.PROFILE_SHAPES = True                          # GEMM launches by layer shape (folded into one family row below)
         eager.forward(fmaps, cnets, iters=iters, all_masks=args.all_masks)
         reps = 2
         ops.PROFILER = ops.Profiler()
@@ -527,60 +611,102 @@ def main():
                           "tflops": round(d["flops"] / reps / (ms * 1e-3) / 1e12, 2) if d["flops"] else None,
                           "gbps_algorithmic": round(d["bytes"] / reps / (ms * 1e-3) / 1e9, 1) if d["bytes"] else None}
         result["kernels"] = kern
-        if args.gemm_shapes:            # fold the per-shape rows back into one family row for the roofline
-            fam = [k for k in kern if k.startswith("gemm M")]
-            ms = sum(kern[k]["ms_per_step"] for k in fam)
-            fl = sum(summ[k]["flops"] for k in fam) / reps
-            kern["gemm"] = {"launches_per_step": sum(kern[k]["launches_per_step"] for k in fam), "ms_per_step": round(ms, 4),
-                            "avg_us": None, "tflops": round(fl / (ms * 1e-3) / 1e12, 2), "gbps_algorithmic": None}
+        # fold the per-shape rows into one family row (the per-shape rows stay in `kernels` with --gemm-shapes only)
+        famk = [k for k in kern if k.startswith("gemm M")]
+        if famk:
+            ms = sum(kern[k]["ms_per_step"] for k in famk)
+            fl = sum(summ[k]["flops"] for k in famk) / reps
+            by = sum(summ[k]["bytes"] for k in famk) / reps
+            nl = sum(kern[k]["launches_per_step"] for k in famk)
+            kern["gemm"] = {"launches_per_step": nl, "ms_per_step": round(ms, 4), "avg_us": round(1e3 * ms / max(nl, 1), 2),
+                            "tflops": round(fl / (ms * 1e-3) / 1e12, 2), "gbps_algorithmic": round(by / (ms * 1e-3) / 1e9, 1)}
+            if not args.gemm_shapes:
+                for k in famk:
+                    del kern[k]
         dom = max((k for k in kern if not k.startswith("gemm M")), key=lambda k: kern[k]["ms_per_step"])
-        # HBM traffic of every family from the committed rocprofv3 PMC passes (bench.py cannot run the profiler on
-        # itself): newest profiles/rNN*traffic.json
-        traffic, tfile = {}, newest_traffic_file(args.workload)
+        # HBM traffic of every family from the committed rocprofv3 PMC passes (bench.py cannot run the profiler on itself): newest
+        # profiles/rNN*traffic.json -- used ONLY when it was taken on this configuration AND on this kernel source (csrc hash)
+        traffic, tfile, traffic_why = {}, newest_traffic_file(args.workload), None
         if tfile:
             try:
                 with open(tfile) as f:
                     traffic = json.load(f)
             except (OSError, ValueError):
                 traffic = {}
-        d = kern[dom]
-        n_launch = max(d["launches_per_step"], 1)
-        ms = d["ms_per_step"]
-        same = (traffic.get("_workload", "sintel") == args.workload and int(traffic.get("_clips", 8)) == B and
-                traffic.get("_corr_dtype", "f32") == args.corr_dtype and traffic.get("_precision", "f16x3") == args.precision and
-                traffic.get("_preset", args.preset or presets.BENCH_PRESET) == (args.preset or presets.BENCH_PRESET))
-        fam = traffic.get(dom) if same else None           # PMC bytes only describe the configuration they were taken on
-        pmc_bytes = int((fam["fetch_kib_per_launch"] + fam["write_kib_per_launch"]) * 1024) if fam else None
-        alg_bytes = summ[dom]["bytes"] / reps if dom in summ else 0.0
-        alg_flops = summ[dom]["flops"] / reps if dom in summ else sum(summ[k]["flops"] for k in summ if k.startswith("gemm M")) / reps
-        if not alg_bytes and args.gemm_shapes:
-            alg_bytes = sum(summ[k]["bytes"] for k in summ if k.startswith("gemm M")) / reps
-        # which roof binds: time floor of the matrix cores (algorithmic flops x MFMA products per flop / dense peak)
-        # against the time floor of HBM (bytes the family really moves -- PMC when available, else algorithmic)
-        peak_tf = {"fp32": PEAK_FP32_MFMA_TFLOPS, "f16x3": PEAK_F16_MFMA_TFLOPS / 3.0,
-                   "f16x2": PEAK_F16_MFMA_TFLOPS / 2.0, "f16": PEAK_F16_MFMA_TFLOPS}[args.precision]
-        t_mfma = alg_flops / (peak_tf * 1e12) if alg_flops else 0.0
-        t_hbm = (pmc_bytes * n_launch if pmc_bytes else alg_bytes) / (PEAK_HBM_GBPS * 1e9)
-        if alg_flops and t_mfma >= t_hbm:
-            result["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": d["tflops"], "peak": round(peak_tf, 1),
-                                  "unit": "TFLOP/s", "frac": round(d["tflops"] / peak_tf, 4)}
+        same = bool(traffic) and (
+            traffic.get("_workload", "sintel") == args.workload and int(traffic.get("_clips", 8)) == B and
+            traffic.get("_corr_dtype", "f32") == args.corr_dtype and traffic.get("_precision", "f16x3") == args.precision and
+            traffic.get("_preset", args.preset or presets.BENCH_PRESET) == (args.preset or presets.BENCH_PRESET))
+        if not traffic:
+            traffic_why = "no profiles/r*traffic*.json for this workload"
+        elif not same:
+            traffic_why = f"{os.path.relpath(tfile, ROOT)} was taken on another configuration"
+        elif traffic.get("_csrc_sha") != csrc_sha():
+            same, traffic_why = False, (f"{os.path.relpath(tfile, ROOT)} was taken on other kernel sources (csrc hash "
+                                        f"{traffic.get('_csrc_sha')} != {csrc_sha()}): re-run tools/r05/profiles.sh")
+
+        def pmc_bytes_of(name):
+            fam = traffic.get(name) if same else None
+            return int((fam["fetch_kib_per_launch"] + fam["write_kib_per_launch"]) * 1024) if fam else None
+
+        def row(name, members):
+            """Both time floors of one kernel (or family): HBM at the bytes it must move (PMC bytes where valid, else the
+            algorithmic ones) and the matrix cores at the MFMA products it really ISSUES (3 / 2 / 1 per algorithmic product, per
+            layer: a single-product layer is priced as one)."""
+            ms = sum(summ[k]["ms"] for k in members) / reps
+            n = sum(summ[k]["launches"] for k in members) // reps
+            by = sum(summ[k]["bytes"] for k in members) / reps
+            fl = sum(summ[k]["flops"] for k in members) / reps
+            mf = sum(summ[k]["mfma_flops"] for k in members) / reps
+            peak = PEAK_FP32_MFMA_TFLOPS if args.precision == "fp32" else PEAK_F16_MFMA_TFLOPS
+            pmc = pmc_bytes_of(name)
+            t_hbm = (pmc * n if pmc else by) / (PEAK_HBM_GBPS * 1e9)
+            t_mfma = mf / (peak * 1e12)
+            t = ms * 1e-3
+            return {"kernel": name, "launches_per_step": n, "ms_per_step": round(ms, 4), "avg_us": round(1e3 * ms / max(n, 1), 2),
+                    "algorithmic_bytes_per_launch": int(by / max(n, 1)), "algorithmic_flops_per_launch": int(fl / max(n, 1)),
+                    "mfma_flops_issued_per_launch": int(mf / max(n, 1)),
+                    "frac_hbm": round(by / (PEAK_HBM_GBPS * 1e9) / t, 4) if t else None,
+                    "frac_mfma": round(t_mfma / t, 4) if (t and mf) else None,
+                    "bound": "mfma" if t_mfma > t_hbm else "hbm",
+                    "floor_us": {"hbm": round(1e6 * t_hbm / max(n, 1), 2), "mfma": round(1e6 * t_mfma / max(n, 1), 2)},
+                    "traffic": pmc, "_t_hbm": t_hbm, "_t_mfma": t_mfma, "_bytes": by, "_mf": mf, "_fl": fl}
+
+        members = {k: [k] for k in summ if not k.startswith("gemm M")}
+        shape_rows = [k for k in summ if k.startswith("gemm M")]
+        if shape_rows:
+            members["gemm"] = shape_rows
+        fam = row(dom, members[dom])
+        peak_tf = PEAK_FP32_MFMA_TFLOPS if args.precision == "fp32" else PEAK_F16_MFMA_TFLOPS
+        t = fam["ms_per_step"] * 1e-3
+        if fam["bound"] == "mfma":
+            ach = fam["_mf"] / t / 1e12
+            result["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 1), "peak": peak_tf, "unit": "TFLOP/s",
+                                  "frac": round(ach / peak_tf, 4)}
         else:
-            gbps = alg_bytes / (ms * 1e-3) / 1e9 if ms else 0.0
-            result["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": round(gbps, 1), "peak": PEAK_HBM_GBPS,
-                                  "unit": "GB/s", "frac": round(gbps / PEAK_HBM_GBPS, 4)}
-        mfma_fl = (summ[dom]["mfma_flops"] if dom in summ else sum(summ[k]["mfma_flops"] for k in summ if k.startswith("gemm M"))) / reps
+            ach = fam["_bytes"] / t / 1e9
+            result["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                                  "frac": round(ach / PEAK_HBM_GBPS, 4)}
+        # the five most expensive kernels of the step, one row each (GEMM launches by layer shape): name, time, algorithmic
+        # bytes / flops, the fraction of BOTH roofs
+        rows = [row(k, [k]) for k in summ if k != "gemm"]
+        rows.sort(key=lambda r: -r["ms_per_step"])
+        strip = lambda r: {k: v for k, v in r.items() if not k.startswith("_")}
         result["roofline"].update({
-            "frac_mfma": round(mfma_fl / (ms * 1e-3) / (PEAK_F16_MFMA_TFLOPS * 1e12), 4) if args.precision != "fp32" else None,
-            "mfma_tflops_issued": round(mfma_fl / (ms * 1e-3) / 1e12, 1),
+            "frac_hbm": fam["frac_hbm"], "frac_mfma": fam["frac_mfma"],
+            "algorithmic_tflops": round(fam["_fl"] / t / 1e12, 1), "mfma_tflops_issued": round(fam["_mf"] / t / 1e12, 1),
             "mfma_busy": mfma_busy_from_profiles(dom),
-            "traffic": pmc_bytes, "launches_per_step": n_launch, "avg_launch_us": round(1e3 * ms / n_launch, 2),
-            "algorithmic_bytes_per_launch": int(alg_bytes / n_launch), "algorithmic_tflops": d["tflops"],
-            "floor_ms_per_step": {"mfma": round(1e3 * t_mfma, 2), "hbm": round(1e3 * t_hbm, 2)},
-            "method": "family totals of one instrumented step (HIP events around every launch on the launch stream): "
-                      "achieved = algorithmic bytes (operands read once + result written once) or flops / summed "
-                      "duration; bound = the larger of the two time floors, the HBM floor priced with the PMC bytes",
-            "traffic_note": (f"bytes per launch, mean over the family: 2 x FETCH_SIZE + WRITE_SIZE from separate rocprofv3 "
-                             f"--pmc passes of this workload ({os.path.relpath(tfile, ROOT)})") if pmc_bytes else None})
+            "traffic": fam["traffic"], "traffic_note": traffic_why if fam["traffic"] is None else (
+                f"bytes per launch, mean over the family: 2 x FETCH_SIZE + WRITE_SIZE from separate rocprofv3 --pmc passes of this "
+                f"workload on these kernel sources ({os.path.relpath(tfile, ROOT)})"),
+            "launches_per_step": fam["launches_per_step"], "avg_launch_us": fam["avg_us"],
+            "algorithmic_bytes_per_launch": fam["algorithmic_bytes_per_launch"],
+            "floor_ms_per_step": {"mfma": round(1e3 * fam["_t_mfma"], 2), "hbm": round(1e3 * fam["_t_hbm"], 2)},
+            "per_kernel": [strip(r) for r in rows[:5]],
+            "method": "one instrumented step (HIP events around every launch on the launch stream), family totals: HBM floor = bytes "
+                      "(PMC where valid for this source, else algorithmic: operands read once + result written once) / 8 TB/s; MFMA "
+                      "floor = issued MFMA flops (algorithmic flops x products of each layer: 1 for single-weight layers, 2 for hi+lo, "
+                      "3 for f16x3) / dense f16 peak; bound = the larger floor; achieved / frac are stated against that roof"})
         # north-star sub-metric: corr build + lookup against the HBM roofline (algorithmic bytes, SURVEY 8d)
         cb, cl = kern.get("corr_build"), kern.get("corr_lookup")
         if cb and cl:
@@ -594,6 +720,8 @@ def main():
                                        "bytes": "SURVEY.md section 8(d), element size of the stored volume: per pair build = 2 N 256 4 + N cells e, "
                                                 "lookup = N (4 100 e + 8 + 324 4) -- the k-octet hand-over and the blocked layout's padding "
                                                 "are NOT counted"}
+            if not same:
+                result["roofline_corr"]["traffic"], result["roofline_corr"]["traffic_note"] = None, traffic_why
             if same and traffic.get("corr_build") and traffic.get("corr_lookup"):
                 real = 1024.0 * ((traffic["corr_build"]["fetch_kib_per_launch"] + traffic["corr_build"]["write_kib_per_launch"]) * cb["launches_per_step"] +
                                  (traffic["corr_lookup"]["fetch_kib_per_launch"] + traffic["corr_lookup"]["write_kib_per_launch"]) * cl["launches_per_step"])

@@ -95,7 +95,10 @@ __device__ __forceinline__ void wait_vm_epi(int e) {
         case 32: wait_vm<P + 32>(); break;
         case 40: wait_vm<P + 40>(); break;
         case 48: wait_vm<P + 48>(); break;
-        default: wait_vm<(P + 56 > 63 ? 63 : P + 56)>(); break;      // e >= 56
+        default:                                                     // e >= 56 (a smaller count than P + e only waits longer);
+            if (e >= 56) wait_vm<(P + 56 > 63 ? 63 : P + 56)>();     // anything else is not an epilogue size this file produces:
+            else wait_vm<P>();                                       // wait for the pieces AND whatever is behind them
+            break;
     }
 }
 
@@ -860,12 +863,42 @@ bool gemm_bstat_ok(const SfGemm& g) {
         return false;
     if (g.b_layout == SF_LAYOUT_F16_KOCT && ((reinterpret_cast<uintptr_t>(g.B) & 15) || (g.strideB & 7) || (g.b_group_stride & 7) || g.ldb < g.N))
         return false;
-    if ((int64_t)g.ldb * 16 * 8 >= ((int64_t)1 << 30)) return false;    // 32-bit offsets of the operand loads
+    // argument rules the tiled family checks in check_output_formats(): a problem that breaks them must not become a GPU fault
+    // here -- return false, the tiled path then rejects it with its error message
+    if (g.r_f16 != 0 && g.r_f16 != 2) return false;
+    if (needs_r && (!g.R || g.ldr < g.N)) return false;
+    if (g.epilogue == SF_EPI_RES_GELU_DW1 && (!g.dw_w || !g.dw_b)) return false;
+    if (g.epilogue == SF_EPI_AXPY && !g.gamma) return false;
+    if (g.r_f16 == 2 && ((reinterpret_cast<uintptr_t>(g.R) & 15) || (g.strideR & 7))) return false;
+    if (g.c_f16 != 2 && (!g.C || g.ldc < g.N)) return false;
+    if (g.c_f16 == 3 && !g.C16) return false;
+    // 32-bit buffer ranges and offsets: every span the kernel turns into a descriptor range or a scalar offset stays under kOob = 2^30
+    // (an out-of-range lane is given the offset 2^30 and must fall outside EVERY range), computed in 64 bits
+    {
+        const int64_t lim = (int64_t)1 << 30;
+        const int64_t noct = (g.K + 7) / 8, moct = (g.M + 7) / 8;
+        int64_t bspan;
+        if (g.b_layout == SF_LAYOUT_F16_KOCT)
+            bspan = (g.b_group > 0 ? (int64_t)((g.K - 1) / g.b_group) * g.b_group_stride * 2 + (int64_t)((g.b_group + 7) / 8) * g.ldb * 16
+                                   : noct * (int64_t)g.ldb * 16);
+        else
+            bspan = (g.b_group > 0 ? (int64_t)((g.K - 1) / g.b_group) * g.b_group_stride + (int64_t)(g.b_group - 1) * g.ldb + g.N
+                                   : (int64_t)(g.K - 1) * g.ldb + g.N) * (g.b_layout == SF_LAYOUT_F16_K_MAJOR ? 2 : 4);
+        if (bspan >= lim) return false;
+        if (g.c_f16 != 2 && ((int64_t)(g.M - 1) * g.ldc + g.N) * 4 >= lim) return false;
+        if (g.c_f16 >= 2 && moct * (int64_t)g.ldc * 16 >= lim) return false;
+        if (needs_r) {
+            const int64_t mr = g.M - 1;
+            const int64_t rspan = (g.r_f16 == 2) ? moct * (int64_t)g.ldr * 16
+                                : ((g.r_group > 0 ? (mr / g.r_group) * g.r_group_stride + (mr % g.r_group) * (int64_t)g.ldr : mr * (int64_t)g.ldr) + g.N) * 4;
+            if (rspan >= lim) return false;
+        }
+    }
     return true;
 }
 
 int gemm_bstat_launch(const SfGemm& g, hipStream_t st) {
-    BsArgs a;
+    BsArgs a{};
     a.g = g;
     const int sk = (g.precision == SF_PRECISION_F16) ? 128 : 64;        // k extent of a weight stage
     const int kp = (g.K + 127) / 128 * 128;                             // extent of the planes (a_k_pad = 128)
@@ -891,6 +924,15 @@ int gemm_bstat_launch(const SfGemm& g, hipStream_t st) {
     }
     a.n_main = n_main;
     a.msplit = f;
+    // vector memory operations one epilogue of gemm_bstat_kernel leaves BEHIND the next m-step's first weight pieces (per wave):
+    // 16 TM fp32 row stores and / or 4 TM k-octet stores, + the residual loads of the next m-step (16 TM fp32 / 4 TM k-octets).
+    // The row-by-row tail stores of an `M % 4 != 0` fp32 + k-octet output are not counted: wait for everything there.
+    {
+        const bool needs_r = g.epilogue == SF_EPI_RES || g.epilogue == SF_EPI_RES_GELU || g.epilogue == SF_EPI_RES_GELU_DW1 ||
+                             g.epilogue == SF_EPI_AXPY;
+        a.e_ops = (g.c_f16 == 2 ? 0 : 16 * TM) + (g.c_f16 >= 2 ? 4 * TM : 0) + (!needs_r ? 0 : (g.r_f16 == 2 ? 4 * TM : 16 * TM));
+        if (g.c_f16 == 3 && (g.M & 3)) a.e_ops = 0;
+    }
     const int64_t grid_x = n_main + (wgs - n_main) * f;
 #ifdef SF_BSTAT_TIMERS
     a.ts = getenv("SF_GEMM_TS_BUF") ? (long long*)strtoull(getenv("SF_GEMM_TS_BUF"), nullptr, 0) : nullptr;

@@ -125,6 +125,7 @@ def test_pinned_device_env():
     HIP_VISIBLE_DEVICES list is honoured."""
     sys.path.insert(0, REPO)
     import bench
+    assert bench.launch.pinned_device_env is bench.pinned_device_env
     assert bench.pinned_device_env(3) == {"HIP_VISIBLE_DEVICES": "3", "SF_BENCH_DEVICE": "0"}
     assert bench.pinned_device_env(1, "4,5,6,7") == {"HIP_VISIBLE_DEVICES": "5", "SF_BENCH_DEVICE": "0"}
 
@@ -136,3 +137,61 @@ def test_timed_steps_reports_own_time():
     dt = bench.timed_steps(lambda: time.sleep(0.002), steps=3, warmup=1, world=1, sync_fn=lambda: None, barrier_fn=lambda: None,
                            allreduce_max_fn=lambda x: x, own=own)
     assert len(own) == 1 and 0.005 <= own[0] <= dt
+
+
+def test_rank_cpu_sets_numa_and_fallback():
+    """Host cores of the local ranks (streamflow_amd/launch.py): disjoint, inside the allowed mask, on the NUMA node of the rank's
+    GPU when the topology is known; an even split otherwise; single cores round-robin when there are fewer cores than ranks."""
+    sys.path.insert(0, REPO)
+    import bench
+    L = bench.launch
+    assert L.parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    # 8 GPUs, 4 per socket, 2 x 64 cores of which the job may use every second one
+    allowed = list(range(0, 128, 2))
+    sets = L.rank_cpu_sets(8, allowed, [0, 0, 0, 0, 1, 1, 1, 1], {0: range(0, 64), 1: range(64, 128)})
+    assert all(len(s) == 8 for s in sets) and len(set(sum(sets, []))) == 64 and set(sum(sets, [])) <= set(allowed)
+    assert all(max(s) < 64 for s in sets[:4]) and all(min(s) >= 64 for s in sets[4:])
+    # unknown topology (numa_node = -1) or a node without allowed cores: even split of the mask
+    for nodes, cpus in (([-1] * 8, {}), ([0] * 8, {0: range(200, 208)}), (None, None)):
+        sets = L.rank_cpu_sets(8, range(16), nodes, cpus)
+        assert sets == [[2 * r, 2 * r + 1] for r in range(8)]
+    assert L.rank_cpu_sets(4, [5, 9]) == [[5], [9], [5], [9]]
+    assert L.rank_cpu_sets(1, range(4)) == [[0, 1, 2, 3]] and L.rank_cpu_sets(0, range(4)) == []
+
+
+def test_eight_spawned_ranks_get_disjoint_cores_and_devices(tmp_path):
+    """`python bench.py --gpus 8 --placement-only DIR`: the launcher starts 8 children; each restricts itself to ONE device
+    (HIP_VISIBLE_DEVICES = its local rank, addressed as device 0) and to its own host cores before torch is imported, and exits
+    without touching the GPU.  Also the external-launcher form (RANK / LOCAL_RANK / WORLD_SIZE set by torch.distributed.run)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                                                             "HIP_VISIBLE_DEVICES", "SF_BENCH_PIN", "SF_BENCH_DEVICE")}
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "8", "--placement-only", str(tmp_path)],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    recs = [json.load(open(tmp_path / f"rank{i}.json")) for i in range(8)]
+    assert [d["HIP_VISIBLE_DEVICES"] for d in recs] == [str(i) for i in range(8)] and all(d["SF_BENCH_DEVICE"] == "0" for d in recs)
+    ncpu = len(os.sched_getaffinity(0))
+    cores = [tuple(d["cpus"]) for d in recs]
+    assert all(len(c) == max(1, ncpu // 8) for c in cores)
+    if ncpu >= 8:
+        assert len(set(sum(map(list, cores), []))) == 8 * (ncpu // 8)                 # pairwise disjoint
+    assert all(d["torch_threads"] <= len(d["cpus"]) for d in recs)                     # thread pools sized from the rank's mask
+    # external launcher: one rank of 8, outer device list honoured
+    d2 = tmp_path / "ext"
+    d2.mkdir()
+    env2 = dict(env, RANK="5", LOCAL_RANK="5", WORLD_SIZE="8", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999", HIP_VISIBLE_DEVICES="0,1,2,3,4,6,7,5")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "8", "--placement-only", str(d2)],
+                       capture_output=True, text=True, timeout=600, env=env2)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rec = json.load(open(d2 / "rank5.json"))
+    assert rec["HIP_VISIBLE_DEVICES"] == "6" and rec["SF_BENCH_DEVICE"] == "0" and len(rec["cpus"]) == max(1, ncpu // 8)
+    # --pin index keeps every device visible
+    d3 = tmp_path / "idx"
+    d3.mkdir()
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "8", "--pin", "index", "--placement-only", str(d3)],
+                       capture_output=True, text=True, timeout=600, env=dict(env, RANK="2", LOCAL_RANK="2", WORLD_SIZE="8",
+                                                                             MASTER_ADDR="127.0.0.1", MASTER_PORT="29999"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert json.load(open(d3 / "rank2.json"))["HIP_VISIBLE_DEVICES"] is None

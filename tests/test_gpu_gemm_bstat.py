@@ -211,3 +211,37 @@ def test_bstat_refuses_what_it_cannot_run(dev):
         ops.gemm(A, Planes.of(x), Planes.of(y))                                 # (auto: the tiled kernel takes it)
     finally:
         ops.set_precision(prev)
+
+
+@pytest.mark.parametrize("M,K,P", [(192, 128, 7040), (640, 96, 2048), (324, 192, 7040)])
+@pytest.mark.parametrize("epi_name", ["none", "res_gelu"])
+def test_bstat_general_kernel_short_k_many_msteps(dev, M, K, P, epi_name):
+    """gemm_bstat_kernel (the non-pipelined form) with k-octet-only output, >= 3 m-steps and a short K: the first two stages of
+    every m-step wait with a count that includes the previous epilogue's stores (BsArgs.e_ops, ADVICE r4: the field was left
+    uninitialised once) -- a wrong count reads a weight stage before its DMA pieces have landed.  Repeated launches, exact
+    reference."""
+    from streamflow_amd import _lib, ops
+    from streamflow_amd.ops import PackedLinear, Planes
+    epi = ops.EPI_NONE if epi_name == "none" else ops.EPI_RES_GELU
+    n = 3
+    g = torch.Generator().manual_seed(M * 7 + K)
+    Wt = torch.randn(M, K, generator=g) / K ** 0.5
+    bias = torch.randn(M, generator=g) * 0.1
+    X = torch.randn(n, K, P, generator=g)
+    R = torch.randn(n, M, P, generator=g)
+    A = PackedLinear(Wt.view(M, K, 1, 1), bias, dev)
+    Xp = _koct(X, dev, ops)
+    Rp = Planes.of(R.to(dev)) if epi == ops.EPI_RES_GELU else None
+    Mo = (M + 7) // 8 * 8
+    v = torch.einsum("mk,zkp->zmp", _weights_eff(A, M, K, False), X.half().double()) + bias.double()[None, :, None]
+    ref = v if epi == ops.EPI_NONE else F.gelu(R.double() + v)
+    prev = ops.set_precision("f16x2")
+    try:
+        for rep in range(6):
+            Y = Planes(torch.full((n * Mo * P // 2 + 8,), float("nan"), device=dev), 0, Mo * P, n, M, P, f16=True, koct=True)
+            ops.gemm(A, Xp, Y, epi, R=Rp, algo=_lib.ALGO_BSTAT)
+            got = Y.tensor().double().cpu()
+            err = (got - ref).abs()
+            assert bool((err <= 2.0 ** -11 * ref.abs() * 1.01 + 8e-5).all()), (M, K, P, epi_name, rep, err.max().item())
+    finally:
+        ops.set_precision(prev)
