@@ -307,7 +307,10 @@ def corr_only(args, dev, cfg, H, W, T, iters):
     f16 = cfg["corr_dtype"] == "f16"
     cx = ops.Ctx(precision=ops._PRECISION_NAMES[cfg["precision"]], shadows=False)
     fmaps = syn.make_features(1000, B, T, h, w)[0].to(dev)
-    strides = [N * (h >> l) * (w >> l) for l in range(4)]
+    pitch = None if f16 else ops.corr_pitch(h, w)             # fp32 maps: line-aligned rows (KITTI), as the engine lays them out
+    if args.dense_volumes:
+        pitch = None
+    strides = [N * (h >> l) * (pitch[l] if pitch else (w >> l)) for l in range(4)]
     if f16:                # the shipped fp16 path: blocked volumes, features handed over as fp16 k-octets only (engine.py)
         vol = ops.new_blocked_volume(n, h, w, dev)
         ws = torch.empty(max(ops.corr_build_blocked_ws_bytes(n, D, h, w), 16), dtype=torch.uint8, device=dev)
@@ -329,9 +332,9 @@ def corr_only(args, dev, cfg, H, W, T, iters):
                 ops.corr_lookup_blocked(vol, c, None, out_k, B, pairs)
             return
         ops.corr_build(fmaps.data_ptr(), fmaps.data_ptr() + 4 * D * N, T * D * N, D * N, lvls, strides, B, pairs, D, h, w,
-                       ws=ws, cx=cx)
+                       ws=ws, cx=cx, pitch=pitch)
         for c in coords:
-            ops.corr_lookup(lvls, strides, c, out, B, pairs, h, w, cx=cx)
+            ops.corr_lookup(lvls, strides, c, out, B, pairs, h, w, cx=cx, pitch=pitch)
 
     step()
     torch.cuda.synchronize()
@@ -351,6 +354,7 @@ def corr_only(args, dev, cfg, H, W, T, iters):
         "data": "synthetic",
         "config": {"workload": f"{args.workload}_{H}x{W}_T{T}_corr_only", "clips_per_step": B, "pairs_per_clip": pairs,
                    "feature_grid": [h, w], "lookups_per_step": iters, "volume_bytes_per_pair": cell * sum(strides),
+                   "map_row_pitch_cells": list(pitch) if pitch else "dense (the reference's [N, h_l, w_l])",
                    "preset": args.preset or "default"},
         "roofline": {"kernel": "corr_build + corr_lookup", "bound": "hbm", "achieved": tot_bytes / tot_ms / 1e6,
                      "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": tot_bytes / tot_ms / 1e6 / PEAK_HBM_GBPS, "traffic": None,
@@ -416,6 +420,8 @@ def main():
     ap.add_argument("--placement-only", default=None, metavar="DIR",
                     help="dry run of the rank placement: every rank writes {rank, device environment, host cores} to DIR/rankN.json "
                          "and exits before touching the GPU (tests/test_distributed_cpu.py)")
+    ap.add_argument("--dense-volumes", action="store_true",
+                    help="--corr-only, fp32 volumes: keep the reference's dense [N, h_l, w_l] maps instead of line-aligned row pitches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-runs", type=int, default=3, help="timed whole-clip runs of the CPU oracle (median reported)")
     ap.add_argument("--no-kernel-breakdown", action="store_true")
@@ -797,8 +803,8 @@ def main():
             dtr = (time.perf_counter() - t0) / 5
             result["fp32_class_mode"] = {"value": B * pairs / dtr, "unit": "flow-fields/s", "ms_per_step": 1e3 * dtr,
                                          "config": presets.engine_kwargs("fp32_class"),
-                                         "note": "same workload, split precision f16x3 in every contraction, fp32 volumes, "
-                                                 "materialised fp16 attention matrix (EPE vs oracle ~2e-5 px)"}
+                                         "note": "same workload, split precision f16x3 in every contraction, fp32 volumes, fused GMA "
+                                                 "with fp16 q / k / v (EPE vs oracle ~2e-5 px)"}
             del ref_eng
             torch.cuda.empty_cache()
         except RuntimeError as e:

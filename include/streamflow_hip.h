@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SF_VERSION 113
+#define SF_VERSION 114
 
 enum {
     SF_OK = 0,
@@ -70,6 +70,17 @@ int sf_corr_build_pyramid(const float* f1, const float* f2, int64_t f_clip_strid
  * per pixel so that the build kernel can DMA operand tiles straight into LDS.  Not needed (may be NULL / 0) for
  * SF_PRECISION_FP32.  Contents are scratch: dead once the call's kernels have run. */
 int64_t sf_corr_build_ws_bytes(int B, int pairs, int D, int h, int w);
+/* The same build into PITCHED maps (fp32 and fp16 cells): level l of (pair t, clip b, source pixel i) is (h>>l) rows of
+ * lvl_pitch[l] cells at lvl{l} + t*lvl_pair_stride[l] + (b*h*w + i)*(h>>l)*lvl_pitch[l]; cell (y, x), x < w>>l, at y*lvl_pitch[l] + x.
+ * lvl_pitch: HOST array of 4 row pitches in cells, w>>l <= lvl_pitch[l] <= w rounded up to 32; NULL = the reference's dense layout
+ * (== sf_corr_build_pyramid).  Why: core/corr.py:13-21 keeps [N, h_l, w_l] maps; at KITTI's 156-cell rows (624 bytes) every
+ * 128-byte store run of the build straddles two cache lines.  A pitch of a multiple of 32 cells puts every row on a line
+ * boundary; the pad cells x >= w>>l of a row are WRITTEN (unspecified values) so that whole lines are written; the reference's
+ * [N, 1, h_l, w_l] tensor is the strided view [..., :w_l] of the pitched one (streamflow_amd.corr.CorrBlock.corr_pyramid). */
+int sf_corr_build_pyramid_pitched(const float* f1, const float* f2, int64_t f_clip_stride, int64_t f_pair_stride,
+                                  float* lvl0, float* lvl1, float* lvl2, float* lvl3,
+                                  const int64_t* lvl_pair_stride, const int32_t* lvl_pitch, int B, int pairs, int D, int h, int w,
+                                  int num_levels, int precision, void* split_ws, int64_t split_ws_bytes, void* stream);
 
 /* ---- a3: CorrBlock.__call__  (core/corr.py:23-44) ----------------------------------------------
  * Image index img = b*pairs + t.  coords [B*pairs][2][h][w] (ch0 = x, ch1 = y)  ->
@@ -86,6 +97,11 @@ int sf_corr_lookup(const float* lvl0, const float* lvl1, const float* lvl2, cons
                    const int64_t* lvl_pair_stride, const float* coords, float* out, int64_t out_img_stride,
                    void* out_koct, int64_t out_koct_img_stride, int B, int pairs, int h, int w, int num_levels,
                    int radius, int vol_precision, void* stream);
+/* Lookup in the pitched maps of sf_corr_build_pyramid_pitched (fp32 cells only; lvl_pitch as there, NULL = dense). */
+int sf_corr_lookup_pitched(const float* lvl0, const float* lvl1, const float* lvl2, const float* lvl3,
+                           const int64_t* lvl_pair_stride, const int32_t* lvl_pitch, const float* coords, float* out,
+                           int64_t out_img_stride, void* out_koct, int64_t out_koct_img_stride, int B, int pairs, int h, int w,
+                           int num_levels, int radius, int vol_precision, void* stream);
 
 /* ---- a1 + a2 + a3 in the BLOCKED fp16 volume layout (core/corr.py:7-54; csrc/corr_blocked.hip) --------------------------
  * Same mathematics as sf_corr_build_pyramid(SF_PRECISION_F16) / sf_corr_lookup, different memory layout: ONE buffer per

@@ -55,6 +55,10 @@ SIGNATURES = {
                                    _vp, _i64, _vp]),
     "sf_corr_build_ws_bytes": (_i64, [_i, _i, _i, _i, _i]),
     "sf_corr_lookup": (_i, [_vp, _vp, _vp, _vp, C.POINTER(_i64), _vp, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "sf_corr_build_pyramid_pitched": (_i, [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, C.POINTER(_i64), C.POINTER(C.c_int32),
+                                           _i, _i, _i, _i, _i, _i, _i, _vp, _i64, _vp]),
+    "sf_corr_lookup_pitched": (_i, [_vp, _vp, _vp, _vp, C.POINTER(_i64), C.POINTER(C.c_int32), _vp, _vp, _i64, _vp, _i64,
+                                    _i, _i, _i, _i, _i, _i, _i, _vp]),
     "sf_corr_blocked_geometry": (_i, [_i, _i, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                       C.POINTER(_i64)]),
     "sf_corr_blocked_bytes": (_i64, [_i, _i, _i]),

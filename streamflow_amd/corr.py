@@ -44,11 +44,16 @@ class CorrBlock:
         if layout == "blocked":
             self.vol = ops.new_blocked_volume(B, h, w, f1.device)
             ops.corr_build_blocked(f1.data_ptr(), f2.data_ptr(), D * N, 0, self.vol, B, 1, D)
-            self._pyr = None
+            self._pyr = self._store = self.pitch = None
             return
-        lv = [torch.empty(B * N, 1, h >> l, w >> l, dtype=dtype, device=f1.device) for l in range(4)]
-        ops.corr_build(f1.data_ptr(), f2.data_ptr(), D * N, 0, lv, None, B, 1, D, h, w)
-        self._pyr = lv
+        # fp32 maps whose rows would straddle cache lines are kept with a row pitch of a multiple of 32 cells (ops.corr_pitch:
+        # KITTI's 156-cell rows); `corr_pyramid` is then the strided [..., :w_l] view of the pitched tensors: the reference's
+        # shape and values (corr.py:13-21), no copy
+        self.pitch = ops.corr_pitch(h, w) if dtype == torch.float32 else None
+        pw = self.pitch or tuple(w >> l for l in range(4))
+        self._store = [torch.empty(B * N, 1, h >> l, pw[l], dtype=dtype, device=f1.device) for l in range(4)]
+        ops.corr_build(f1.data_ptr(), f2.data_ptr(), D * N, 0, self._store, None, B, 1, D, h, w, pitch=self.pitch)
+        self._pyr = [t[..., : w >> l] for l, t in enumerate(self._store)]
 
     @property
     def corr_pyramid(self):
@@ -67,7 +72,7 @@ class CorrBlock:
         if self.vol is not None:
             ops.corr_lookup_blocked(self.vol, Planes.of(c), Planes.of(out), None, B, 1)
         else:
-            ops.corr_lookup(self.corr_pyramid, None, Planes.of(c), Planes.of(out), B, 1, h, w)
+            ops.corr_lookup(self._store, None, Planes.of(c), Planes.of(out), B, 1, h, w, pitch=self.pitch)
         return out
 
     @staticmethod

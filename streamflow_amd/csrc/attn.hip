@@ -109,6 +109,9 @@ __device__ __forceinline__ float xor32(float v) {          // value of lane ^ 32
     return __shfl_xor(v, 32, 64);
 }
 
+#ifndef SF_FLASH_PRIO
+#define SF_FLASH_PRIO 0   // 1: s_setprio(1) around the two MFMA clusters of a tile (A/B knob, tools/build_variant.sh)
+#endif
 #ifndef SF_FLASH_V1
 #define SF_FLASH_V1 1     // one-product kernel: ONE V stage (48 KB of LDS, 3 workgroups per CU) instead of two (64 KB, 2 per CU)
 #endif
@@ -207,6 +210,9 @@ __global__ __launch_bounds__(256, (QKP == 3) ? 1 : ((QKP == 1 && SF_FLASH_V1) ? 
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[sub][r] = kUseStats ? -st_m : 0.f;     // (a lane holds ONE query: its -max is the start value)
         }
+#if SF_FLASH_PRIO
+        __builtin_amdgcn_s_setprio(1);                            // (experiment: MFMA clusters at raised priority, guide T5)
+#endif
 #pragma unroll
         for (int ks = 0; ks < HD / 16; ++ks) {
 #pragma unroll
@@ -221,6 +227,9 @@ __global__ __launch_bounds__(256, (QKP == 3) ? 1 : ((QKP == 1 && SF_FLASH_V1) ? 
                 s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[ks], s[sub], 0, 0, 0);
             }
         }
+#if SF_FLASH_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         // ---- online softmax for this lane's query ----
         if ((t + 1) * BJ > P) {                                   // last tile with padded keys (workgroup-uniform)
 #pragma unroll
@@ -284,6 +293,9 @@ __global__ __launch_bounds__(256, (QKP == 3) ? 1 : ((QKP == 1 && SF_FLASH_V1) ? 
             __builtin_amdgcn_s_barrier();
         }
         // ---- O^T += V^T P^T ----
+#if SF_FLASH_PRIO
+        __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
@@ -292,6 +304,9 @@ __global__ __launch_bounds__(256, (QKP == 3) ? 1 : ((QKP == 1 && SF_FLASH_V1) ? 
                 o[td] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[kk], o[td], 0, 0, 0);
             }
         }
+#if SF_FLASH_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
     }
 
     // ---- epilogue: out[d][q] = mf[d][q] + gamma * O^T[d][q] / rowsum ----

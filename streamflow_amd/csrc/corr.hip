@@ -700,6 +700,7 @@ struct LookupArgs {
     int64_t lvl_pair_stride[4];
     int B, pairs, h, w, N;
     int hl[4], wl[4];
+    int pl[4];                   // row pitch of the maps in cells (== wl for the reference's dense layout)
     _Float16* out16;             // optional fp16 k-octet copy of `out` ([41 octets][N][8] per image), fp16-volume kernel only
     int64_t out16_img_stride;    // halves
 };
@@ -712,7 +713,7 @@ __global__ __launch_bounds__(kThreads) void corr_lookup_kernel(const LookupArgs 
     const int l = blockIdx.y, img = blockIdx.z;
     const int b = img / g.pairs, pair = img % g.pairs;
     const int p0 = blockIdx.x * LP;
-    const int hl = g.hl[l], wl = g.wl[l];
+    const int hl = g.hl[l], wl = g.wl[l], pl = g.pl[l];
     const float inv = 1.0f / (float)(1 << l);
     if (tid < LP) {
         const int p = p0 + tid;
@@ -731,13 +732,13 @@ __global__ __launch_bounds__(kThreads) void corr_lookup_kernel(const LookupArgs 
         sfy[tid] = cy - fy0;
     }
     __syncthreads();
-    const float* vol = g.lvl[l] + pair * g.lvl_pair_stride[l] + ((int64_t)b * g.N + p0) * hl * wl;
+    const float* vol = g.lvl[l] + pair * g.lvl_pair_stride[l] + ((int64_t)b * g.N + p0) * hl * pl;
     for (int idx = tid; idx < LP * FP * FP; idx += kThreads) {
         const int pix = idx / (FP * FP), cell = idx % (FP * FP);
         const int yy = sy0[pix] - RAD + cell / FP, xx = sx0[pix] - RAD + cell % FP;
         float v = 0.f;
         if (p0 + pix < g.N && yy >= 0 && yy < hl && xx >= 0 && xx < wl)
-            v = vol[(int64_t)pix * hl * wl + yy * wl + xx];
+            v = vol[(int64_t)pix * hl * pl + yy * pl + xx];
         win[pix * WSTRIDE + cell] = v;
     }
     __syncthreads();
@@ -927,7 +928,27 @@ extern "C" int sf_corr_build_pyramid(const float* f1, const float* f2, int64_t f
                                      const int64_t* lvl_pair_stride, int B, int pairs, int D, int h, int w,
                                      int num_levels, int precision, void* split_ws, int64_t split_ws_bytes,
                                      void* stream) {
+    return sf_corr_build_pyramid_pitched(f1, f2, f_clip_stride, f_pair_stride, lvl0, lvl1, lvl2, lvl3, lvl_pair_stride, nullptr,
+                                         B, pairs, D, h, w, num_levels, precision, split_ws, split_ws_bytes, stream);
+}
+
+// Row pitch of the volume maps (cells): lvl_pitch[l] >= w >> l, map of one source pixel = (h >> l) rows of lvl_pitch[l] cells.
+// The reference's dense [N, h_l, w_l] layout (lvl_pitch = NULL) puts a KITTI row (156 fp32 cells = 624 bytes) across cache-line
+// boundaries with a different phase in every row and map: the build's 128-byte store runs straddle two lines each (1.56 TB/s
+// against 2.6 at Sintel's 512-byte rows).  With a pitch of a multiple of 32 cells every row starts on a line;
+// the pad cells of a row are WRITTEN (their target pixels lie outside the image: zero features, the stored value is 0 at level
+// 0 and a don't-care partial mean above it) so that every line is written whole; lookups never read them.
+extern "C" int sf_corr_build_pyramid_pitched(const float* f1, const float* f2, int64_t f_clip_stride, int64_t f_pair_stride,
+                                             float* lvl0, float* lvl1, float* lvl2, float* lvl3,
+                                             const int64_t* lvl_pair_stride, const int32_t* lvl_pitch, int B, int pairs, int D,
+                                             int h, int w, int num_levels, int precision, void* split_ws,
+                                             int64_t split_ws_bytes, void* stream) {
     SF_REQUIRE(f1 && f2 && lvl0 && lvl1 && lvl2 && lvl3, "sf_corr_build_pyramid: null pointer");
+    if (lvl_pitch) {
+        for (int l = 0; l < 4; ++l)
+            SF_REQUIRE(lvl_pitch[l] >= (w >> l) && lvl_pitch[l] <= sf::ceil_div(w, 32) * 32,
+                       "sf_corr_build_pyramid_pitched: lvl_pitch[%d] = %d must lie in [w >> l, w rounded up to 32]", l, lvl_pitch[l]);
+    }
     SF_REQUIRE(B > 0 && pairs > 0 && D > 0 && h > 0 && w > 0, "sf_corr_build_pyramid: bad dims");
     SF_REQUIRE(pairs == 1 || lvl_pair_stride, "sf_corr_build_pyramid: pairs > 1 needs lvl_pair_stride");
     SF_REQUIRE(num_levels == 4, "sf_corr_build_pyramid: num_levels must be 4 (got %d)", num_levels);
@@ -950,7 +971,8 @@ extern "C" int sf_corr_build_pyramid(const float* f1, const float* f2, int64_t f
     g.f_clip_stride = f_clip_stride; g.f_pair_stride = f_pair_stride;
     g.B = B; g.pairs = pairs; g.D = D; g.h = h; g.w = w; g.N = h * w;
     for (int l = 0; l < 4; ++l) {
-        g.hl[l] = h >> l; g.wl[l] = w >> l;
+        // (the store side uses wl as row pitch AND as column guard: with a pitch the pad columns are stored too, see above)
+        g.hl[l] = h >> l; g.wl[l] = lvl_pitch ? lvl_pitch[l] : (w >> l);
         g.lvl_pair_stride[l] = (pairs > 1) ? lvl_pair_stride[l] : 0;
     }
     g.pcols = sf::ceil_div(w, PC);
@@ -1011,7 +1033,17 @@ extern "C" int sf_corr_lookup(const float* lvl0, const float* lvl1, const float*
                               const int64_t* lvl_pair_stride, const float* coords, float* out,
                               int64_t out_img_stride, void* out_koct, int64_t out_koct_img_stride, int B, int pairs,
                               int h, int w, int num_levels, int radius, int vol_precision, void* stream) {
+    return sf_corr_lookup_pitched(lvl0, lvl1, lvl2, lvl3, lvl_pair_stride, nullptr, coords, out, out_img_stride, out_koct,
+                                  out_koct_img_stride, B, pairs, h, w, num_levels, radius, vol_precision, stream);
+}
+
+// lvl_pitch: row pitch (cells) of the maps written by sf_corr_build_pyramid_pitched; NULL = dense (fp32 volumes only)
+extern "C" int sf_corr_lookup_pitched(const float* lvl0, const float* lvl1, const float* lvl2, const float* lvl3,
+                                      const int64_t* lvl_pair_stride, const int32_t* lvl_pitch, const float* coords, float* out,
+                                      int64_t out_img_stride, void* out_koct, int64_t out_koct_img_stride, int B, int pairs,
+                                      int h, int w, int num_levels, int radius, int vol_precision, void* stream) {
     SF_REQUIRE(lvl0 && lvl1 && lvl2 && lvl3 && coords && out, "sf_corr_lookup: null pointer");
+    SF_REQUIRE(!lvl_pitch || vol_precision != SF_PRECISION_F16, "sf_corr_lookup_pitched: pitched maps are fp32 volumes only");
     SF_REQUIRE(B > 0 && pairs > 0 && h > 0 && w > 0, "sf_corr_lookup: bad dims");
     SF_REQUIRE(pairs == 1 || lvl_pair_stride, "sf_corr_lookup: pairs > 1 needs lvl_pair_stride");
     SF_REQUIRE(num_levels == 4 && radius == RAD, "sf_corr_lookup: only num_levels=4, radius=4 (got %d, %d)",
@@ -1027,6 +1059,8 @@ extern "C" int sf_corr_lookup(const float* lvl0, const float* lvl1, const float*
     g.B = B; g.pairs = pairs; g.h = h; g.w = w; g.N = h * w;
     for (int l = 0; l < 4; ++l) {
         g.hl[l] = h >> l; g.wl[l] = w >> l;
+        g.pl[l] = lvl_pitch ? lvl_pitch[l] : g.wl[l];
+        SF_REQUIRE(g.pl[l] >= g.wl[l], "sf_corr_lookup_pitched: lvl_pitch[%d] < level width", l);
         g.lvl_pair_stride[l] = (pairs > 1) ? lvl_pair_stride[l] : 0;
     }
     if (vol_precision == SF_PRECISION_F16) {

@@ -14,21 +14,19 @@ from .utils import InputPadder
 
 
 def group_clips(n_frames: int, T: int = 4) -> List[Tuple[int, List[bool]]]:
-    """[(first frame of the window, keep[k] for each of its T-1 pairs)] -- the demo's window/flag schedule."""
-    if n_frames < T:
-        raise ValueError(f"need at least T={T} frames, got {n_frames}")
-    out = []
-    i = 0
-    while True:
-        if i + T <= n_frames:
-            start, flags = i, list(range(i, i + T))
-        else:
-            start = n_frames - T
-            flags = [-1 if j < i else j for j in range(start, n_frames)]
-        out.append((start, [flags[k] != -1 for k in range(T - 1)]))
-        if i + T >= n_frames:
-            break
-        i += T - 1
+    """[(first frame of the window, keep[k] for each of its T-1 pairs)] -- the demo's window / flag schedule, in closed form:
+    `full = (n - 1) // (T - 1)` whole windows start at 0, T - 1, 2 (T - 1), ... and keep every pair; if pairs are left over
+    (`(n - 1) % (T - 1) != 0`) ONE more window is aligned to the end of the video (start n - T) and keeps only the pairs that start
+    at or behind frame `full * (T - 1)`, the first one no earlier window has produced."""
+    if T < 2 or n_frames < T:
+        raise ValueError(f"need at least T={T} >= 2 frames, got {n_frames}")
+    step = T - 1
+    full = (n_frames - 1) // step
+    out = [(s * step, [True] * step) for s in range(full)]
+    done = full * step                                   # pairs 0 .. done - 1 are covered
+    if done < n_frames - 1:
+        start = n_frames - T
+        out.append((start, [start + k >= done for k in range(step)]))
     return out
 
 

@@ -46,6 +46,7 @@ class EngineOptions:
     koct_io: bool = True             # motion-encoder tensors between SK blocks as fp16 k-octets only (no fp32 planes)
     x2_f16: bool = True              # single-reader tensors as fp16 ROWS: x2 (ffn1.2 -> depthwise), qkv (-> temporal attention), v (-> GMA pack)
     flash_stats: bool = True         # fused GMA: softmax statistics computed once per clip
+    setup_overlap: bool = True       # the context chain of the setup (split, to_qk, GMA pack / statistics) beside the volume build
     max_plans: int = 4               # buffer sets (and graphs) kept, least recently used evicted
 
     @staticmethod
@@ -251,7 +252,9 @@ class _Plan:
             raise RuntimeError(f"feature grid {h}x{w}: coarsest pyramid level would be 1 pixel wide; the reference "
                                "is undefined there (needs images >= 128 px per side)")
         dims = [(h >> l, w >> l) for l in range(4)]
-        self.lvl_pair_stride = [Bc * P * hl * wl for hl, wl in dims]
+        # fp32 maps: rows padded to whole cache lines where the dense layout would straddle them (ops.corr_pitch)
+        self.corr_pitch = None if corr_f16 else ops.corr_pitch(h, w)
+        self.lvl_pair_stride = [Bc * P * hl * (self.corr_pitch[l] if self.corr_pitch else wl) for l, (hl, wl) in enumerate(dims)]
         # blocked fp16 volumes (csrc/corr_blocked.hip): one buffer, 8 x 8-cell blocks = cache lines; the lookup then hands
         # the correlation features over as fp16 k-octets ONLY (operand and residual of convc1's first block)
         self.corr_blocked = bool(corr_blocked and corr_f16 and shadows)
@@ -340,6 +343,19 @@ class _Plan:
         self.cnets_in = None
         self.graph = None
         self.graph_key = None
+
+
+def _level_maps(self, l: int) -> torch.Tensor:
+    """Level l of the row-major volumes as [pairs, clips * N, h_l, w_l] -- per pair the reference's corr_pyramid[l] (corr.py:13-21)
+    without its singleton dimension -- a strided VIEW of the (possibly row-pitched, _Plan.corr_pitch) storage."""
+    if self.lvls is None:
+        raise RuntimeError("level_maps: blocked volumes (use plan.vol.levels())")
+    hl, wl = self.h >> l, self.w >> l
+    pit = self.corr_pitch[l] if self.corr_pitch else wl
+    return self.lvls[l].view(self.Pn, self.Bc * self.P, hl, pit)[..., :wl]
+
+
+_Plan.level_maps = _level_maps
 
 
 class HotPathEngine:
@@ -454,24 +470,34 @@ class HotPathEngine:
         W = self.W
         Bc, Pn, h, w, P, n, D = pl.Bc, pl.Pn, pl.h, pl.w, pl.P, pl.n, pl.D
         T = Pn + 1
+        # The context chain (split -> to_qk -> GMA pack + softmax statistics / attention matrix) reads only `cnets` and the volume
+        # build only `fmaps`: two independent chains, the context chain on the side stream (options.setup_overlap)
+        main = torch.cuda.current_stream()
+        side = self._side if (self.parallel_branches and self.options.setup_overlap) else main
+        cs = cx.no_split() if side is not main else cx
+        if side is not main:
+            side.wait_stream(main)
+        with torch.cuda.stream(side):
+            # streamflow.py:119-122: nets = tanh(.), inps = relu(.)
+            ops.context_split(cnets, pl.nets, pl.inps, HDIM)
+            ops.refresh_shadow(pl.nets, cs)
+            ops.refresh_shadow(pl.inps, cs)
+            # a6: attn = softmax(scale * q k^T) over the context features (gma.py:53-65), computed once
+            ops.gemm(W.to_qk, pl.inps, pl.qk, EPI_NONE, cx=cs)
+            if pl.flash:
+                # q, k are constant over the loop: packed once, and the softmax statistics of every query with them
+                ops.gma_flash_pack_qk(pl.qk, pl.flash_ws, float(HDIM) ** -0.5, stats_qk_products=self.flash_qk_products, cx=cs)
+            elif pl.attn_rows == P:
+                self._attention_rows(cs, pl, 0, P)
         # a1+a2: all pairs, one launch.  pair t = (frame t, frame t+1)
         if pl.corr_blocked:
             ops.corr_build_blocked(fmaps.data_ptr(), fmaps.data_ptr() + 4 * D * P, T * D * P, D * P, pl.vol, Bc, Pn, D,
                                    ws=pl.corr_ws)
         else:
             ops.corr_build(fmaps.data_ptr(), fmaps.data_ptr() + 4 * D * P, T * D * P, D * P, pl.lvls, pl.lvl_pair_stride,
-                           Bc, Pn, D, h, w, ws=pl.corr_ws, cx=cx)
-        # streamflow.py:119-122: nets = tanh(.), inps = relu(.)
-        ops.context_split(cnets, pl.nets, pl.inps, HDIM)
-        ops.refresh_shadow(pl.nets, cx)
-        ops.refresh_shadow(pl.inps, cx)
-        # a6: attn = softmax(scale * q k^T) over the context features (gma.py:53-65), computed once
-        ops.gemm(W.to_qk, pl.inps, pl.qk, EPI_NONE, cx=cx)
-        if pl.flash:
-            # q, k are constant over the loop: packed once, and the softmax statistics of every query with them
-            ops.gma_flash_pack_qk(pl.qk, pl.flash_ws, float(HDIM) ** -0.5, stats_qk_products=self.flash_qk_products, cx=cx)
-        elif pl.attn_rows == P:
-            self._attention_rows(cx, pl, 0, P)
+                           Bc, Pn, D, h, w, ws=pl.corr_ws, cx=cx, pitch=pl.corr_pitch)
+        if side is not main:
+            main.wait_stream(side)
 
     def _iteration(self, cx: ops.Ctx, pl: _Plan, with_mask: bool) -> None:
         W = self.W
@@ -504,7 +530,7 @@ class HotPathEngine:
         if pl.corr_blocked:
             ops.corr_lookup_blocked(pl.vol, pl.coords1, None, pl.corr, Bc, Pn)
         else:
-            ops.corr_lookup(pl.lvls, pl.lvl_pair_stride, pl.coords1, pl.corr, Bc, Pn, h, w, cx=cx)
+            ops.corr_lookup(pl.lvls, pl.lvl_pair_stride, pl.coords1, pl.corr, Bc, Pn, h, w, cx=cx, pitch=pl.corr_pitch)
         # image ranges of the chains: whole clips when the clip count divides, else (a single clip, an odd batch) two
         # ranges of images -- every block but the flow head works image by image
         nch = self.split_solo if (self.split_solo in (2, 4) and side is not main) else 1
@@ -702,7 +728,10 @@ class HotPathEngine:
             pl.cnets_in = torch.empty_like(cnets)
         pl.fmaps_in.copy_(fmaps)
         pl.cnets_in.copy_(cnets)
-        key = key + (self.precision, self.options, self.gma_mode, self.flash_qk_products, self.corr_f16, self.single_layers)
+        # (the schedule reads these MUTABLE attributes -- bench.py / tests assign eng.parallel_branches etc. after construction:
+        # the values in force at capture time are part of the key)
+        key = key + (self.precision, self.options, self.gma_mode, self.flash_qk_products, self.corr_f16, self.single_layers,
+                     self.parallel_branches, self.split_solo, self.auto_split_k, self.attn_chunk_rows, self.attn_k_splits)
         if pl.graph is None or pl.graph_key != key:
             # warm-up outside capture, then capture the whole clip as one graph.  The loop state (coords1, flow)
             # is re-initialised by the caller before every replay, so the graph itself is stateless.

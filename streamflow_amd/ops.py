@@ -676,13 +676,27 @@ def corr_build_ws_bytes(B: int, pairs: int, D: int, h: int, w: int) -> int:
     return int(_lib.load().sf_corr_build_ws_bytes(B, pairs, D, h, w))
 
 
+def corr_pitch(h: int, w: int) -> Optional[tuple]:
+    """Row pitch (cells) of the fp32 volume maps of an h x w feature grid, or None where the reference's dense [N, h_l, w_l] layout
+    already starts every level-0 row on a cache line (w % 32 == 0: Sintel 128, Spring 240 is NOT): every level's rows are rounded
+    up to 32 cells = 128 bytes (sf_corr_build_pyramid_pitched; DESIGN.md section 12.7: KITTI's 156-cell rows)."""
+    if w % 32 == 0:
+        return None
+    return tuple(((w >> l) + 31) // 32 * 32 for l in range(4))
+
+
+def _pitch_arg(pitch):
+    return None if pitch is None else (C.c_int32 * 4)(*[int(p) for p in pitch])
+
+
 @on_tensor_device
 def corr_build(f1_ptr: int, f2_ptr: int, clip_stride: int, pair_stride: int, lvls: Sequence[torch.Tensor],
                lvl_pair_stride: Optional[Sequence[int]], B: int, pairs: int, D: int, h: int, w: int,
-               ws: Optional[torch.Tensor] = None, cx: Optional[Ctx] = None) -> None:
+               ws: Optional[torch.Tensor] = None, cx: Optional[Ctx] = None, pitch: Optional[Sequence[int]] = None) -> None:
     """ws: scratch of corr_build_ws_bytes() bytes for the split-precision / fp16 builds (allocated here when omitted).
     The dtype of `lvls` selects the volume format: float32 (arithmetic = the package precision, fp32 or f16x3) or
-    float16 (SF_PRECISION_F16: single f16 products, fp16 cells)."""
+    float16 (SF_PRECISION_F16: single f16 products, fp16 cells).  pitch: row pitch of the maps in cells per level (corr_pitch),
+    None = dense."""
     N = h * w
     vol16 = lvls[0].dtype == torch.float16
     assert all(t.dtype == lvls[0].dtype for t in lvls) and lvls[0].dtype in (torch.float16, torch.float32)
@@ -694,16 +708,17 @@ def corr_build(f1_ptr: int, f2_ptr: int, clip_stride: int, pair_stride: int, lvl
     # algorithmic bytes per (clip, pair): both feature maps read once + every pyramid cell written once
     nbytes = B * pairs * (2.0 * N * D * 4 + (2.0 if vol16 else 4.0) * N * cells)
     _launch("corr_build", 2.0 * N * N * D * B * pairs, nbytes, lambda: _lib.check(
-        _lib.load().sf_corr_build_pyramid(
+        _lib.load().sf_corr_build_pyramid_pitched(
             f1_ptr, f2_ptr, clip_stride, pair_stride, lvls[0].data_ptr(), lvls[1].data_ptr(), lvls[2].data_ptr(),
-            lvls[3].data_ptr(), pair_strides(lvl_pair_stride), B, pairs, D, h, w, 4, prec,
+            lvls[3].data_ptr(), pair_strides(lvl_pair_stride), _pitch_arg(pitch), B, pairs, D, h, w, 4, prec,
             ws.data_ptr() if need else None, need, _lib.stream()),
         "sf_corr_build_pyramid"), products=_products(prec))
 
 
 @on_tensor_device
 def corr_lookup(lvls: Sequence[torch.Tensor], lvl_pair_stride: Optional[Sequence[int]], coords: Planes,
-                out: Planes, B: int, pairs: int, h: int, w: int, cx: Optional[Ctx] = None) -> None:
+                out: Planes, B: int, pairs: int, h: int, w: int, cx: Optional[Ctx] = None,
+                pitch: Optional[Sequence[int]] = None) -> None:
     assert out.rows == 324 and out.n_img == B * pairs and coords.img_stride == 2 * h * w
     N = h * w
     vol16 = lvls[0].dtype == torch.float16
@@ -713,9 +728,9 @@ def corr_lookup(lvls: Sequence[torch.Tensor], lvl_pair_stride: Optional[Sequence
     sh = out.shadow if (out.shadow is not None and cx.shadows and vol16 and cx.shadow_fused) else None
     # (footprints + coords + the 324 fp32 output channels; the k-octet copy is extra traffic)
     nbytes = B * pairs * (N * 4 * 100 * (2.0 if vol16 else 4.0) + N * 2 * 4.0 + N * 324 * 4.0)
-    _launch("corr_lookup", 0, nbytes, lambda: _lib.check(_lib.load().sf_corr_lookup(
+    _launch("corr_lookup", 0, nbytes, lambda: _lib.check(_lib.load().sf_corr_lookup_pitched(
         lvls[0].data_ptr(), lvls[1].data_ptr(), lvls[2].data_ptr(), lvls[3].data_ptr(),
-        pair_strides(lvl_pair_stride), coords.ptr, out.ptr, out.img_stride,
+        pair_strides(lvl_pair_stride), _pitch_arg(pitch), coords.ptr, out.ptr, out.img_stride,
         None if sh is None else sh.ptr, 0 if sh is None else sh.img_stride, B, pairs, h, w, 4, 4,
         PRECISION_F16 if vol16 else PRECISION_FP32, _lib.stream()), "sf_corr_lookup"))
     if sh is None:

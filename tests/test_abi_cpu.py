@@ -26,6 +26,14 @@ def test_every_declared_symbol_is_exported(lib):
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
     assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
+    # ... and nothing else: the dynamic symbol table (`nm -D`) holds exactly the declared sf_* entry points
+    import shutil
+    import subprocess
+    nm = shutil.which("nm") or shutil.which("llvm-nm") or "/opt/rocm/lib/llvm/bin/llvm-nm"
+    if os.path.exists(nm):
+        syms = subprocess.run([nm, "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+        exported = {ln.split()[-1] for ln in syms.splitlines() if ln.split() and ln.split()[-1].startswith("sf_")}
+        assert exported == declared, exported ^ declared
     version = int(re.search(r"#define SF_VERSION (\d+)", hdr).group(1))
     assert lib.sf_version() == version >= 101
 

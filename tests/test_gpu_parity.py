@@ -226,8 +226,8 @@ def test_sintel_shape_vs_oracle(dev, precision):
     ups = [u.cpu() for u in ups]
     pl = eng.plan(B, h, w, 256)
     N = h * w
-    l0 = pl.lvls[0][: N * N].view(N, h, w)
-    l1 = pl.lvls[1][: N * (h // 2) * (w // 2)].view(N, h // 2, w // 2)
+    l0 = pl.level_maps(0)[0]
+    l1 = pl.level_maps(1)[0]
     pooled = l0[:, : 2 * (h // 2), :].reshape(N, h // 2, 2, w // 2, 2).mean(dim=(2, 4))
     assert (pooled - l1).abs().max().item() < 1e-5
     if pl.attn16 is not None:            # split precisions keep the attention weights in fp16 (engine._Plan)
@@ -390,7 +390,7 @@ def test_kitti_shape_T2_vs_oracle(dev, preset):
     if preset == "fp32_class":
         pyr = orc.corr_pyramid(fmaps[:, 0], fmaps[:, 1])
         for l in range(4):
-            got = pl.lvls[l].view(pyr[l].shape).cpu()
+            got = pl.level_maps(l)[0].reshape(pyr[l].shape).cpu()        # (strided view of the row-pitched maps: 156 -> 160 cells)
             assert (got - pyr[l]).abs().max().item() < 5e-5, f"level {l}"
     else:
         pyr = orc.corr_pyramid(fmaps[:, 0].half().float(), fmaps[:, 1].half().float())
@@ -542,9 +542,9 @@ def test_spring_shape_smoke(dev):
         assert torch.isfinite(u).all()
     N = h * w
     i = 12345                                           # one source pixel of pair 0
-    l0 = pl.lvls[0][i * N:(i + 1) * N].view(h, w)
-    l1 = pl.lvls[1][i * (N // 4):(i + 1) * (N // 4)].view(h // 2, w // 2)
-    assert (l0.view(h // 2, 2, w // 2, 2).mean(dim=(1, 3)) - l1).abs().max().item() < 1e-5
+    l0 = pl.level_maps(0)[0][i]
+    l1 = pl.level_maps(1)[0][i]
+    assert (l0.reshape(h // 2, 2, w // 2, 2).mean(dim=(1, 3)) - l1).abs().max().item() < 1e-5
     ref = (fmaps[0, 0].reshape(256, N)[:, i].to(dev) @ fmaps[0, 1].reshape(256, N).to(dev)) / 16.0
     assert (l0.reshape(-1) - ref).abs().max().item() < 1e-3
 

@@ -20,5 +20,5 @@ for f in sorted(busy):
         out[f] = round(busy[f] / (act[f] * 128.0), 4)
 for kv in sys.argv[2:]:
     k, v = kv.split("=", 1)
-    out[k] = int(v) if v.isdigit() else v
+    out[k] = int(v) if (v.isdigit() and k != "_csrc_sha") else v
 print(json.dumps(out, indent=1))

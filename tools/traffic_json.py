@@ -47,7 +47,7 @@ def main():
                   "fetch_size_raw_kib": round(ft[f] / nf, 1), "launches_profiled": nf}
     for kv in sys.argv[3:]:
         k, v = kv.split("=", 1)
-        out[k] = int(v) if v.isdigit() else v
+        out[k] = int(v) if (v.isdigit() and k != "_csrc_sha") else v
     print(json.dumps(out, indent=1))
 
 
