@@ -276,6 +276,15 @@ int sf_gma_flash_aggregate_f16v(void* ws, int64_t ws_bytes, const void* v_f16, i
                                 int64_t mf_img_stride, const float* gamma, float* out, int64_t out_img_stride,
                                 void* out_koct, int64_t out_koct_img_stride, int n_img, int P, int qk_products,
                                 int use_stats, void* stream);
+/* to_v (core/gma.py:93: v = to_v(fmap), 1x1 conv 128 -> 128, no bias) AND the v pack in one launch: v = fp16(alpha * W_v x) written
+ * straight into the packed v planes of ws, from operands in the formats they already have -- x_koct: the k-octet fp16 copy of the
+ * motion features [16][ldx][8] per image (SF_LAYOUT_F16_KOCT; x_koct_img_stride in halves, ldx = pixels per octet row >= P);
+ * w_hi / w_lo: the split weight planes [128 / 8][lda_h = 128][8] of sf_gemm's SF_LAYOUT_SPLIT_F16 (products = 1: w_hi alone,
+ * 2: w_hi + w_lo); alpha: 1 / the weights' power-of-two pre-scale.  A following sf_gma_flash_aggregate* call takes v == NULL
+ * ("the v planes of ws are current").  The activation enters as fp16 (the config-2 arithmetic class). */
+int sf_gma_flash_project_v(void* ws, int64_t ws_bytes, const void* x_koct, int64_t x_koct_img_stride, int64_t ldx,
+                           const void* w_hi, const void* w_lo, int lda_h, float alpha, int products, int n_img, int P,
+                           void* stream);
 
 /* ---- row softmax (gma.py:63): x [rows][cols] ----------------------------------------------------
  * out_f16 == NULL: in place.  Otherwise the weights are written as IEEE fp16 to out_f16 [rows][cols] (x is then

@@ -71,6 +71,7 @@ SIGNATURES = {
     "sf_gma_flash_pack_qk": (_i, [_vp, _i64, _vp, _i64, _i, _i, _f, _i, _vp]),
     "sf_gma_flash_aggregate": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _vp]),
     "sf_gma_flash_aggregate_f16v": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _vp]),
+    "sf_gma_flash_project_v": (_i, [_vp, _i64, _vp, _i64, _i64, _vp, _vp, _i, _f, _i, _i, _i, _vp]),
     "sf_softmax_rows": (_i, [_vp, _i64, _i, _vp, _vp]),
     "sf_splitk_combine": (_i, [_vp, _i64, _i, _i64, _vp, _i64, _vp, _vp, _i64, _i, _i64, _vp]),
     "sf_dwconv_res_gelu": (_i, [_vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _i, _vp]),

@@ -27,9 +27,9 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vector
          "-Rpass-analysis=kernel-resource-usage"]
 # kernels that may not use scratch memory (substring of the demangled name): everything that shows up in the top rows of the
 # step's kernel table (profiles/r*_kernel_stats_sintel_serial.md)
-HOT_KERNELS = ("gemm_bstat", "gemm_bdirect_kernel", "gma_flash_kernel", "dwconv_mfma_kernel", "corr_lookup_blocked_kernel",
-               "corr_build_blocked_kernel", "temporal_block_kernel", "temporal_attn_kernel", "layernorm_cm_split_kernel",
-               "flash_pack_v_kernel", "ffn_pair_kernel")
+HOT_KERNELS = ("gemm_bstat", "gemm_bdirect_kernel", "gma_flash_kernel", "flash_project_v_kernel", "dwconv_mfma_kernel",
+               "corr_lookup_blocked_kernel", "corr_build_blocked_kernel", "temporal_attn_kernel", "layernorm_cm_split_kernel",
+               "flash_pack_v_kernel")
 
 
 def hipcc() -> str:

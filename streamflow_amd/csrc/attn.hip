@@ -105,6 +105,70 @@ __global__ __launch_bounds__(256) void flash_pack_v_kernel(const TIn* v, int64_t
     *reinterpret_cast<f16x8*>(dst) = h;
 }
 
+// ---- to_v and the v pack in one kernel (gma.py:93 + the pack above) --------------------------------------------------------
+// V^T[key][d] = sum_c x[c][key] W_v[d][c] with the KEYS as MFMA rows: the C/D layout then leaves a lane (column d, k-half) with
+// the 16 keys (r & 3) + 8 (r >> 2) + 4 khalf of its 32-key block -- registers 0..7 / 8..15 ARE the two packed key octets
+// (keys 16 g + 4 khalf + {0,1,2,3, 8,9,10,11}) of the v planes: no transposition, one 16-byte store per 8 registers, 512
+// contiguous bytes per half wave.  Operands in the formats they already have: x = the k-octet fp16 copy of the motion features
+// (A fragment = one 16-byte load), W_v = the split weight planes [c / 8][128][8] (B fragment: staged once per workgroup in LDS).
+// Replaces a GEMM launch (fp16 rows out) + the pack launch (rows in, octets out) on the critical path of every iteration.
+template <int PM>
+__global__ __launch_bounds__(256) void flash_project_v_kernel(const char* x_koct, int64_t x_img_stride_bytes, int ldx,
+                                                              const char* w_hi, const char* w_lo, float alpha, char* ws, int P,
+                                                              int Ppad) {
+    constexpr int WPLANE = (HD / 8) * HD * 16;                       // 32 KB: [16 c-octets][128 d][8]
+    __shared__ __attribute__((aligned(1024))) char smem[PM * WPLANE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int khalf = lane >> 5, l31 = lane & 31;
+    const int img = blockIdx.y, p0 = blockIdx.x * BQ + wave * 32;
+    const __amdgpu_buffer_rsrc_t rwh = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(w_hi), 0, WPLANE, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rwl = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(PM == 2 ? w_lo : w_hi), 0, WPLANE, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < WPLANE / 4096; ++i) {                        // 1-KB pieces, wave w takes pieces w, w + 4, ...
+        const int piece = wave + 4 * i;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rwh, (lds_ptr)(smem + piece * 1024), 16, lane * 16, piece * 1024, 0, 0);
+        if (PM == 2)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rwl, (lds_ptr)(smem + WPLANE + piece * 1024), 16, lane * 16, piece * 1024, 0, 0);
+    }
+    // A fragments: c-octet 2 ks + khalf of key p0 + l31 (keys >= P: zeros -- the padded keys of the v planes must be 0)
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(x_koct) + (int64_t)img * x_img_stride_bytes, 0, (HD / 8) * ldx * 16, 0x00020000);
+    const int p = p0 + l31;
+    f16x8 a[HD / 16];
+#pragma unroll
+    for (int ks = 0; ks < HD / 16; ++ks)
+        a[ks] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(
+            rx, (p < P) ? ((2 * ks + khalf) * ldx + p) * 16 : (int)0x80000000u, 0, 0));
+    f32x16 acc[HD / 32];
+#pragma unroll
+    for (int td = 0; td < HD / 32; ++td)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[td][r] = 0.f;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < HD / 16; ++ks)
+#pragma unroll
+        for (int td = 0; td < HD / 32; ++td) {
+            const int off = ((2 * ks + khalf) * HD + td * 32 + l31) * 16;
+            if (PM == 2) acc[td] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks], *reinterpret_cast<const f16x8*>(smem + WPLANE + off), acc[td], 0, 0, 0);
+            acc[td] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks], *reinterpret_cast<const f16x8*>(smem + off), acc[td], 0, 0, 0);
+        }
+    if (p0 >= Ppad) return;                                          // (wave-uniform; grid covers Ppad exactly: never taken)
+    char* dst = ws + (int64_t)img * img_ws_bytes(Ppad) + 4 * plane_bytes(Ppad);
+#pragma unroll
+    for (int td = 0; td < HD / 32; ++td)
+#pragma unroll
+        for (int grp = 0; grp < 2; ++grp) {
+            f16x8 h;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) h[i] = (_Float16)(alpha * acc[td][8 * grp + i]);
+            const int o = 2 * (p0 / 16 + grp) + khalf;               // key octet of the v planes
+            *reinterpret_cast<f16x8*>(dst + ((int64_t)o * HD + td * 32 + l31) * 16) = h;
+        }
+}
+
 __device__ __forceinline__ float xor32(float v) {          // value of lane ^ 32
     return __shfl_xor(v, 32, 64);
 }
@@ -410,14 +474,15 @@ static int flash_aggregate(void* ws, int64_t ws_bytes, const void* v_, int v_f16
     SF_REQUIRE(!out_koct || ((reinterpret_cast<uintptr_t>(out_koct) & 15) == 0 && (out_koct_img_stride & 7) == 0),
                "sf_gma_flash_aggregate: out_koct must be 16-byte aligned, its image stride a multiple of 8 halves");
     const float* v = static_cast<const float*>(v_);
-    SF_REQUIRE(ws && v && mf && gamma && out, "sf_gma_flash_aggregate: null pointer");
+    SF_REQUIRE(ws && mf && gamma && out, "sf_gma_flash_aggregate: null pointer");       // (v == NULL: sf_gma_flash_project_v packed it)
     SF_REQUIRE(n_img > 0 && P > 0 && n_img <= 65535, "sf_gma_flash_aggregate: bad dims");
     SF_REQUIRE(qk_products >= 1 && qk_products <= 3, "sf_gma_flash_aggregate: qk_products must be 1, 2 or 3");
     SF_REQUIRE(ws_bytes >= sf_gma_flash_ws_bytes(n_img, P) && (reinterpret_cast<uintptr_t>(ws) & 15) == 0,
                "sf_gma_flash_aggregate: workspace too small or misaligned");
     const int Ppad = sf::ceil_div(P, BQ) * BQ;
     SF_REQUIRE(2 * plane_bytes(Ppad) < ((int64_t)1 << 31), "sf_gma_flash_aggregate: image too large");
-    if (v_f16)
+    if (!v_) {}                                               // the v planes of ws are current (sf_gma_flash_project_v)
+    else if (v_f16)
         hipLaunchKernelGGL(flash_pack_v_kernel<_Float16>, dim3(sf::ceil_div(Ppad / 8, 32), HD / 8, n_img), dim3(256), 0,
                            (hipStream_t)stream, static_cast<const _Float16*>(v_), v_img_stride, (char*)ws, P, Ppad);
     else
@@ -444,6 +509,28 @@ static int flash_aggregate(void* ws, int64_t ws_bytes, const void* v_, int v_f16
         hipLaunchKernelGGL(flash_combine_kernel, dim3(sf::ceil_div(P, 256), HD / 8, n_img), dim3(256), 0, (hipStream_t)stream, g.part,
                            g.nsplit, mf, mf_img_stride, out, out_img_stride, g.out16, g.out16_img_stride, P, Ppad);
     return sf::check_launch("sf_gma_flash_aggregate");
+}
+
+extern "C" int sf_gma_flash_project_v(void* ws, int64_t ws_bytes, const void* x_koct, int64_t x_koct_img_stride, int64_t ldx,
+                                      const void* w_hi, const void* w_lo, int lda_h, float alpha, int products, int n_img, int P,
+                                      void* stream) {
+    SF_REQUIRE(ws && x_koct && w_hi && (products == 1 || w_lo), "sf_gma_flash_project_v: null pointer");
+    SF_REQUIRE(products == 1 || products == 2, "sf_gma_flash_project_v: products must be 1 (w_hi) or 2 (w_hi + w_lo)");
+    SF_REQUIRE(n_img > 0 && P > 0 && n_img <= 65535 && ldx >= P && lda_h == HD, "sf_gma_flash_project_v: bad dims (to_v is 128 x 128)");
+    SF_REQUIRE(ws_bytes >= sf_gma_flash_ws_bytes(n_img, P) && (reinterpret_cast<uintptr_t>(ws) & 15) == 0,
+               "sf_gma_flash_project_v: workspace too small or misaligned");
+    SF_REQUIRE(((reinterpret_cast<uintptr_t>(x_koct) | reinterpret_cast<uintptr_t>(w_hi) | reinterpret_cast<uintptr_t>(w_lo)) & 15) == 0 &&
+                   (x_koct_img_stride & 7) == 0 && (int64_t)(HD / 8) * ldx * 16 < ((int64_t)1 << 30),
+               "sf_gma_flash_project_v: operands must be 16-byte aligned (image stride %% 8 halves), image < 1 GiB");
+    const int Ppad = sf::ceil_div(P, BQ) * BQ;
+    dim3 grid(Ppad / BQ, n_img);
+    if (products == 2)
+        hipLaunchKernelGGL(flash_project_v_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, (const char*)x_koct,
+                           x_koct_img_stride * 2, (int)ldx, (const char*)w_hi, (const char*)w_lo, alpha, (char*)ws, P, Ppad);
+    else
+        hipLaunchKernelGGL(flash_project_v_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, (const char*)x_koct,
+                           x_koct_img_stride * 2, (int)ldx, (const char*)w_hi, (const char*)w_hi, alpha, (char*)ws, P, Ppad);
+    return sf::check_launch("sf_gma_flash_project_v");
 }
 
 extern "C" int sf_gma_flash_aggregate(void* ws, int64_t ws_bytes, const float* v, int64_t v_img_stride, const float* mf,

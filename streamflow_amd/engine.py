@@ -46,6 +46,7 @@ class EngineOptions:
     koct_io: bool = True             # motion-encoder tensors between SK blocks as fp16 k-octets only (no fp32 planes)
     x2_f16: bool = True              # single-reader tensors as fp16 ROWS: x2 (ffn1.2 -> depthwise), qkv (-> temporal attention), v (-> GMA pack)
     flash_stats: bool = True         # fused GMA: softmax statistics computed once per clip
+    project_v: bool = True           # fused GMA, fp16 activations: to_v + the v pack as one launch (sf_gma_flash_project_v)
     setup_overlap: bool = True       # the context chain of the setup (split, to_qk, GMA pack / statistics) beside the volume build
     max_plans: int = 4               # buffer sets (and graphs) kept, least recently used evicted
 
@@ -595,7 +596,13 @@ class HotPathEngine:
         # a7: global aggregation  mfg = mf + gamma * attn @ to_v(mf)   (gma.py:91-104), main stream
         # v has ONE reader, the pack of the fused kernel (which rounds it to fp16): fp16 rows where the fp16 hand-over is active
         v128 = _scratch(pl.v128, pl.n, HDIM, f16=True) if (pl.flash and hidden_f16_ok(cx, P) and cx.x2_f16) else pl.v128
-        ops.gemm(W.to_v, pl.mf, v128, EPI_NONE, cx=cx)
+        # fused recompute path with fp16 activations: to_v and the v pack are ONE launch from mf's k-octet copy (options.project_v)
+        project = pl.flash and self.options.project_v and ops.gma_flash_project_ok(W.to_v, pl.mf, cx)
+        if project:
+            ops.gma_flash_project_v(pl.flash_ws, W.to_v, pl.mf, cx=cx)
+            v128 = None
+        else:
+            ops.gemm(W.to_v, pl.mf, v128, EPI_NONE, cx=cx)
         ks = self.attn_k_splits if self.precision != ops.PRECISION_FP32 else 1
         attn_ptr, attn_lay = ((pl.attn16.data_ptr(), LAYOUT_F16_K_MINOR) if pl.attn16 is not None
                               else (pl.attn.data_ptr(), LAYOUT_K_MINOR))

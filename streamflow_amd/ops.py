@@ -588,13 +588,39 @@ def gma_flash_pack_qk(QK: Planes, ws: torch.Tensor, scale: float, stats_qk_produ
             products=(sq + 1) / 2.0 if sq else 1.0)
 
 
+def gma_flash_project_ok(A: "PackedLinear", X: Planes, cx: Optional[Ctx] = None) -> bool:
+    """Can to_v + the v pack run as ONE launch (sf_gma_flash_project_v)?  fp16-activation arithmetic, a 128 x 128 weight, and the
+    k-octet copy of the motion features at hand."""
+    cx = _cx(cx)
+    return (cx.precision in (PRECISION_F16X2, PRECISION_F16) and cx.shadows and A.M == 128 and A.K == 128 and A.bias is None and
+            X.shadow is not None and X.rows == 128)
+
+
 @on_tensor_device
-def gma_flash_aggregate(ws: torch.Tensor, V: Planes, MF: Planes, gamma: torch.Tensor, OUT: Planes, qk_products: int = 3,
+def gma_flash_project_v(ws: torch.Tensor, A: "PackedLinear", X: Planes, cx: Optional[Ctx] = None) -> None:
+    """v = to_v(X) (gma.py:93) written straight into the packed v planes of the fused kernel's workspace; X.shadow (the k-octet
+    fp16 copy) is the operand.  The following gma_flash_aggregate call passes V=None."""
+    cx = _cx(cx)
+    sh = X.shadow
+    assert gma_flash_project_ok(A, X, cx) and sh.f16 and sh.koct
+    products = 1 if (cx.precision == PRECISION_F16 or A.single) else 2
+    n, P = X.n_img, X.P
+    _launch("gma_project_v", 2.0 * 128 * 128 * n * P, 4.0 * n * 128 * P,
+            lambda: _lib.check(_lib.load().sf_gma_flash_project_v(
+                ws.data_ptr(), ws.numel(), sh.ptr, sh.img_stride, sh.P, A.hi.data_ptr(), A.lo.data_ptr(), A.lda_h,
+                1.0 / A.split_scale, products, n, P, _lib.stream()), "sf_gma_flash_project_v"), products=float(products))
+
+
+@on_tensor_device
+def gma_flash_aggregate(ws: torch.Tensor, V: Optional[Planes], MF: Planes, gamma: torch.Tensor, OUT: Planes, qk_products: int = 3,
                         use_stats: bool = False, cx: Optional[Ctx] = None) -> None:
     """OUT = MF + gamma * softmax(scale q k^T) V, fused (no N x N tensor); q, k come packed in ws.  use_stats: the softmax
-    statistics stored by gma_flash_pack_qk(..., stats_qk_products=qk_products) are used instead of an online softmax."""
+    statistics stored by gma_flash_pack_qk(..., stats_qk_products=qk_products) are used instead of an online softmax.
+    V=None: the v planes of ws were written by gma_flash_project_v."""
     cx = _cx(cx)
     use_stats = bool(use_stats) and cx.flash_stats
+    if V is None:
+        V = Planes(MF.base, 0, 0, MF.n_img, 128, MF.P, f16=True)             # placeholder: pointer 0 is passed below
     assert V.rows == MF.rows == OUT.rows == 128 and V.n_img == MF.n_img == OUT.n_img and not V.koct
     n, P = V.n_img, V.P
     fn = _lib.load().sf_gma_flash_aggregate_f16v if V.f16 else _lib.load().sf_gma_flash_aggregate     # (v as fp16 rows)
@@ -603,7 +629,7 @@ def gma_flash_aggregate(ws: torch.Tensor, V: Planes, MF: Planes, gamma: torch.Te
     _launch("gma_flash", 4.0 * n * P * P * 128,
             (2.0 if V.f16 else 4.0) * n * 128 * P + 4.0 * n * 128 * P * 2 + 2.0 * n * 128 * P * (2 if sh is None else 3),
             lambda: _lib.check(fn(
-                ws.data_ptr(), ws.numel(), V.ptr, V.img_stride, MF.ptr, MF.img_stride, gamma.data_ptr(), OUT.ptr,
+                ws.data_ptr(), ws.numel(), (V.ptr if V.img_stride else None), V.img_stride, MF.ptr, MF.img_stride, gamma.data_ptr(), OUT.ptr,
                 OUT.img_stride, None if sh is None else sh.ptr, 0 if sh is None else sh.img_stride, n, P,
                 int(qk_products), int(use_stats), _lib.stream()), "sf_gma_flash_aggregate"), products=(qk_products + 1) / 2.0)
     if sh is None:

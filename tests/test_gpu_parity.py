@@ -488,6 +488,61 @@ def test_gma_flash_kernel_vs_float64(dev, P, qkp, stats):
         assert torch.equal(o_h, o_f) and torch.equal(o_h, out)
 
 
+@pytest.mark.parametrize("P", [64, 323, 1000, 7040])
+@pytest.mark.parametrize("single", [False, True])
+def test_gma_flash_project_v_vs_gemm_and_float64(dev, P, single):
+    """sf_gma_flash_project_v (to_v + the v pack in one launch, gma.py:93) against (a) float64 on the same fp16-rounded features and
+    (b) the two-launch path it replaces (sf_gemm to fp16 rows -> pack inside sf_gma_flash_aggregate): the packed v planes must give
+    the same aggregation result up to the summation order of one 128-term dot product and one fp16 rounding of v.  P = 323 / 1000:
+    padded keys must be exact zeros (the workspace is poisoned first)."""
+    from dataclasses import replace
+    from streamflow_amd import ops
+    from streamflow_amd.ops import PackedLinear, Planes
+    gen = torch.Generator().manual_seed(P + 7 * int(single))
+    n = 3
+    x = torch.randn(n, 128, P, generator=gen)
+    Wv = torch.randn(128, 128, generator=gen) / 128 ** 0.5
+    qk = torch.randn(n, 256, P, generator=gen)
+    mf = torch.randn(n, 128, P, generator=gen)
+    gamma = torch.tensor([0.61]).to(dev)
+    A = PackedLinear(Wv.view(128, 128, 1, 1), None, dev)
+    A.single = single
+    X = Planes.of(x.to(dev).contiguous())
+    sh = ops.new_shadow(X, dev)
+    ops.pack_koct(X, sh)
+    X = replace(X, shadow=sh)
+    cx = ops.Ctx(precision=ops.PRECISION_F16X2)
+    assert ops.gma_flash_project_ok(A, X, cx)
+    ws = torch.empty(ops.gma_flash_ws_bytes(n, P), dtype=torch.uint8, device=dev)
+    ws.fill_(0x7e)                                            # (0x7e7e = a large finite fp16 / NaN-free poison: padded keys must be rewritten)
+    ops.gma_flash_pack_qk(Planes.of(qk.to(dev)), ws, 128 ** -0.5, stats_qk_products=1, cx=cx)
+    out_f = torch.full((n, 128, P), float("nan"), device=dev)
+    ops.gma_flash_project_v(ws, A, X, cx=cx)
+    ops.gma_flash_aggregate(ws, None, Planes.of(mf.to(dev)), gamma, Planes.of(out_f), 1, use_stats=True, cx=cx)
+    # the two-launch path: GEMM in the same arithmetic (fp16 activations, hi + lo or hi weights) to fp16 rows, then the pack
+    Pe = P + (P % 2)
+    v16 = torch.zeros(n * 128 * Pe // 2 + 8, device=dev)
+    if P % 2 == 0:
+        V16 = Planes(v16, 0, 128 * P, n, 128, P, f16=True)
+        ops.gemm(A, X, V16, ops.EPI_NONE, cx=cx)
+        out_g = torch.full((n, 128, P), float("nan"), device=dev)
+        ops.gma_flash_aggregate(ws, V16, Planes.of(mf.to(dev)), gamma, Planes.of(out_g), 1, use_stats=True, cx=cx)
+        torch.cuda.synchronize()
+        d = (out_f - out_g).abs().max().item()
+        print(f"project_v P={P} single={single}: fused vs gemm + pack: {d:.2e}")
+        assert d < 2e-3, d                                     # (one fp16 ulp of v values of ~3 = 2e-3, weighted by softmax rows)
+    torch.cuda.synchronize()
+    hi = A.hi.float().permute(1, 0, 2).reshape(128, 128).double().cpu()
+    lo = A.lo.float().permute(1, 0, 2).reshape(128, 128).double().cpu()
+    W_eff = (hi if single else hi + lo) / A.split_scale
+    v64 = torch.einsum("dc,ncp->ndp", W_eff, x.half().double()).half().double()           # v enters P V as fp16
+    attn = torch.softmax(128 ** -0.5 * torch.einsum("ndi,ndj->nij", qk[:, :128].half().double(), qk[:, 128:].half().double()), dim=-1)
+    ref = mf.double() + 0.61 * torch.einsum("nij,ndj->ndi", attn, v64)
+    err = (out_f.double().cpu() - ref).abs().max().item()
+    print(f"project_v P={P} single={single}: max abs err vs float64 = {err:.2e}")
+    assert err < 3e-3, (P, single, err)
+
+
 @pytest.mark.parametrize("qkp", [1, 2, 3])
 def test_engine_flash_mode_vs_golden(golden, dev, qkp):
     """The whole loop with the fused GMA aggregation (gma_mode='flash': no attention matrix at all) against the
