@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SF_VERSION 114
+#define SF_VERSION 115
 
 enum {
     SF_OK = 0,
@@ -285,6 +285,32 @@ int sf_gma_flash_aggregate_f16v(void* ws, int64_t ws_bytes, const void* v_f16, i
 int sf_gma_flash_project_v(void* ws, int64_t ws_bytes, const void* x_koct, int64_t x_koct_img_stride, int64_t ldx,
                            const void* w_hi, const void* w_lo, int lda_h, float alpha, int products, int n_img, int P,
                            void* stream);
+
+/* ---- a8: one FFN pair of an SK block in ONE launch (core/update.py:14-16, 30-36; csrc/ffn_pair.hip) ---------------------------
+ * y = W2 gelu(W1 x + b1) + b2 with the 1.5 C hidden tensor kept in registers (the two-launch form writes and re-reads it).
+ * X: the input as fp16 k-octet planes [K1/8][ldx][8] per image (SF_LAYOUT_F16_KOCT; strideX in halves), N pixels, `batch` images.
+ * wstream: both layers' weights as ONE stream of 1-KB MFMA fragments in consumption order, built by the host
+ *   (streamflow_amd.ops.PackedPair): per 32 hidden rows  2 * ceil(K1/32) * pm1 fragments of W1 (16 rows x 32 k each: lane
+ *   (row, kq) = 8 halves W1[row][32 s + 8 kq ..]; with pm = 2 the `lo` fragment precedes the `hi` one), then ceil(M2/16) * pm2
+ *   fragments of W2 whose 32 columns are ordered  k = 8 kq + i <-> hidden row 4 kq + i (i < 4) | 16 + 4 kq + i - 4 (i >= 4),
+ *   zero-padded to sf_ffn_pair_frags(K1, M2, pm1, pm2) fragments.  Weights pre-scaled by a power of two per layer (alpha1 / alpha2
+ *   undo it; bias1 / bias2 carry the same scale), rows / columns beyond H, K1, M2 zero.
+ * mode 0 (an ffn2 pair): out = y, or gelu(y) with gelu_out, to C (fp32 planes [M2][ldc], optional) and / or C16 (fp16 k-octet
+ *   planes [M2/8][ldc16][8], optional; c16_partial: rows >= M2 of the last octet are not written).
+ * mode 1 (an ffn1 pair, M2 == K1): x1 = gelu(x + y); x2 = gelu(x1 + dw_w * x1 + dw_b)  (update.py:31-32: residual, then the
+ *   depthwise 1x1 layer of conv_list); C16 = x2 as fp16 ROWS [M2][ldc16].  The residual is the fp16 operand itself.
+ * Shapes built: the SK blocks of the update block (C = 128 / 256 / 324; see the dispatch table in csrc/ffn_pair.hip). */
+typedef struct SfFfnPair {
+    const void* X; int64_t strideX; int64_t ldx;
+    const void* wstream; int64_t wstream_bytes;
+    const float* bias1; const float* bias2; const float* dw_w; const float* dw_b;
+    float* C; int64_t strideC; int64_t ldc;
+    void* C16; int64_t strideC16; int64_t ldc16;
+    int32_t N, batch, K1, H, M2, pm1, pm2, mode, gelu_out, c16_partial;
+    float alpha1, alpha2;
+} SfFfnPair;
+int sf_ffn_pair(const SfFfnPair* p, void* stream);
+int sf_ffn_pair_frags(int K1, int M2, int pm1, int pm2);
 
 /* ---- row softmax (gma.py:63): x [rows][cols] ----------------------------------------------------
  * out_f16 == NULL: in place.  Otherwise the weights are written as IEEE fp16 to out_f16 [rows][cols] (x is then

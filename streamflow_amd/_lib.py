@@ -45,6 +45,19 @@ class SfGemm(C.Structure):
     ]
 
 
+class SfFfnPair(C.Structure):
+    _fields_ = [
+        ("X", _vp), ("strideX", _i64), ("ldx", _i64),
+        ("wstream", _vp), ("wstream_bytes", _i64),
+        ("bias1", _vp), ("bias2", _vp), ("dw_w", _vp), ("dw_b", _vp),
+        ("C", _vp), ("strideC", _i64), ("ldc", _i64),
+        ("C16", _vp), ("strideC16", _i64), ("ldc16", _i64),
+        ("N", C.c_int32), ("batch", C.c_int32), ("K1", C.c_int32), ("H", C.c_int32), ("M2", C.c_int32),
+        ("pm1", C.c_int32), ("pm2", C.c_int32), ("mode", C.c_int32), ("gelu_out", C.c_int32), ("c16_partial", C.c_int32),
+        ("alpha1", _f), ("alpha2", _f),
+    ]
+
+
 # name -> (restype, argtypes); must list every symbol of include/streamflow_hip.h
 SIGNATURES = {
     "sf_version": (_i, []),
@@ -72,6 +85,8 @@ SIGNATURES = {
     "sf_gma_flash_aggregate": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _vp]),
     "sf_gma_flash_aggregate_f16v": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _vp]),
     "sf_gma_flash_project_v": (_i, [_vp, _i64, _vp, _i64, _i64, _vp, _vp, _i, _f, _i, _i, _i, _vp]),
+    "sf_ffn_pair": (_i, [C.POINTER(SfFfnPair), _vp]),
+    "sf_ffn_pair_frags": (_i, [_i, _i, _i, _i]),
     "sf_softmax_rows": (_i, [_vp, _i64, _i, _vp, _vp]),
     "sf_splitk_combine": (_i, [_vp, _i64, _i, _i64, _vp, _i64, _vp, _vp, _i64, _i, _i64, _vp]),
     "sf_dwconv_res_gelu": (_i, [_vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _i, _vp]),

@@ -46,6 +46,7 @@ class EngineOptions:
     koct_io: bool = True             # motion-encoder tensors between SK blocks as fp16 k-octets only (no fp32 planes)
     x2_f16: bool = True              # single-reader tensors as fp16 ROWS: x2 (ffn1.2 -> depthwise), qkv (-> temporal attention), v (-> GMA pack)
     flash_stats: bool = True         # fused GMA: softmax statistics computed once per clip
+    ffn_pairs: bool = True           # the SK blocks' ffn1 / ffn2 pairs as one launch each where the shape is built (sf_ffn_pair)
     project_v: bool = True           # fused GMA, fp16 activations: to_v + the v pack as one launch (sf_gma_flash_project_v)
     setup_overlap: bool = True       # the context chain of the setup (split, to_qk, GMA pack / statistics) beside the volume build
     max_plans: int = 4               # buffer sets (and graphs) kept, least recently used evicted
@@ -82,6 +83,9 @@ class SKBlockWeights:
         self.pw_res = PackedLinear(wpw + eye, g("pw.bias"), device)
         self.ffn2_0 = PackedLinear(g("ffn2.0.weight"), g("ffn2.0.bias"), device)
         self.ffn2_2 = PackedLinear(g("ffn2.2.weight"), g("ffn2.2.bias"), device)
+        # the two FFNs as single launches (update.py:14-16: nn.Sequential(conv, GELU, conv)); weight streams are built on first use
+        self.pair1 = ops.PackedPair(self.ffn1_0, self.ffn1_2)
+        self.pair2 = ops.PackedPair(self.ffn2_0, self.ffn2_2)
         self.c_in, self.c_mid, self.c_out = self.ffn1_0.K, self.ffn1_0.M, self.ffn2_2.M
         f32 = lambda t: t.detach().to(device=device, dtype=torch.float32).contiguous()
         w0 = g("conv_list.0.weight")
@@ -143,15 +147,20 @@ def run_skblock(W: SKBlockWeights, X: Planes, Y: Planes, hid: Planes, xa: Planes
     C = W.c_in
     assert X.rows == C and Y.rows == W.c_out and X.n_img == Y.n_img
     a, b = _scratch(xa, X.n_img, C), _scratch(xb, X.n_img, C)
-    hidden = _handover(cx, hid, X.n_img, W.c_mid, X.P, consumer_rows=C)             # ffn1.0 -> ffn1.2
-    ops.gemm(W.ffn1_0, X, hidden, EPI_GELU, cx=cx)
-    # x1 = gelu(x + ffn1(x)); x2 = gelu(x1 + dw1x1(x1))  (both fused in the epilogue)
     fold = hidden_f16_ok(cx, X.P) and cx.pw_fold
     if fold and cx.x2_f16:
         # x2 has ONE reader, the depthwise layer, whose two-product arithmetic multiplies fp16(x2) anyway: handed over as fp16
         # rows (half the bytes out of this GEMM and into the depthwise kernel, which then stages its strips by DMA)
         a = _scratch(xa, X.n_img, C, f16=True)
-    ops.gemm(W.ffn1_2, hidden, a, EPI_RES_GELU_DW1, R=X, dw_w=W.dw1_w, dw_b=W.dw1_b, cx=cx)
+    # x1 = gelu(x + ffn1(x)); x2 = gelu(x1 + dw1x1(x1))  (both fused in the epilogue)
+    if cx.ffn_pairs and a.f16 and X.f16 and X.koct and ops.ffn_pair_ok(W.pair1, X, 1, cx):
+        # the block input exists as k-octets only (operand AND residual): the whole ffn1 + epilogue is one launch, the 1.5 C
+        # hidden tensor stays in registers (csrc/ffn_pair.hip)
+        ops.ffn_pair(W.pair1, X, a, 1, dw_w=W.dw1_w, dw_b=W.dw1_b, cx=cx)
+    else:
+        hidden = _handover(cx, hid, X.n_img, W.c_mid, X.P, consumer_rows=C)         # ffn1.0 -> ffn1.2
+        ops.gemm(W.ffn1_0, X, hidden, EPI_GELU, cx=cx)
+        ops.gemm(W.ffn1_2, hidden, a, EPI_RES_GELU_DW1, R=X, dw_w=W.dw1_w, dw_b=W.dw1_b, cx=cx)
     # x4 is read by ffn2.0 only: the same GEMM-to-GEMM hand-over as the hidden activations (x2 in `xa` is dead by now)
     if fold:
         # x3 in fp16 rows straight out of the depthwise kernel, residual folded into the pw weights: the pw GEMM reads half
@@ -166,6 +175,9 @@ def run_skblock(W: SKBlockWeights, X: Planes, Y: Planes, hid: Planes, xa: Planes
         # pw GEMMs 15-20 % slower -- more than their consumers gained)
         a4 = _handover(cx, xa, X.n_img, C, X.P, consumer_rows=W.c_mid, allow_koct=False)
         ops.gemm(W.pw, b, a4, EPI_RES_GELU, R=b, cx=cx)                         # x4 = gelu(x3 + pw(x3))
+    if cx.ffn_pairs and a4.f16 and a4.koct and ops.ffn_pair_ok(W.pair2, a4, 0, cx) and (not Y.f16 or Y.koct):
+        ops.ffn_pair(W.pair2, a4, Y, 0, gelu_out=final_gelu, cx=cx)                 # y = ffn2(x4): one launch
+        return
     hidden = _handover(cx, hid, X.n_img, W.c_mid, X.P, consumer_rows=W.c_out)       # ffn2.0 -> ffn2.2
     ops.gemm(W.ffn2_0, a4, hidden, EPI_GELU, cx=cx)
     ops.gemm(W.ffn2_2, hidden, Y, EPI_GELU if final_gelu else EPI_NONE, cx=cx)
@@ -416,6 +428,17 @@ class HotPathEngine:
         # layers whose weights are used as ONE fp16 value in the f16x2 mode (see presets.py: chosen by measured EPE)
         self.single_layers = tuple(single_layers or ())
         self.W.set_single("all" if self.single_layers == ("all",) else self.single_layers)
+        # the FFN pairs' weight streams are built NOW (device-synchronous), not lazily inside a forward: a forward enqueues on several
+        # streams (and may be a graph capture) -- a stream built on one of them would be read by another before it exists
+        if self.options.ffn_pairs and self.precision in (ops.PRECISION_F16X2, ops.PRECISION_F16):
+            cxp = ops.Ctx(precision=self.precision)
+            with torch.cuda.device(self.device):
+                for b in HotPathWeights.SK_BLOCKS:
+                    blk = getattr(self.W, b)
+                    for pair in (blk.pair1, blk.pair2):
+                        if (pair.K1, pair.M2) in ops.PAIR_SHAPES[0] | ops.PAIR_SHAPES[1]:
+                            pair.stream(*pair.products(cxp))
+                torch.cuda.synchronize(self.device)
         self.use_graph = use_graph
         self._plans: Dict[Tuple[int, int, int, int], _Plan] = {}
         self.max_plans = int(self.options.max_plans)
@@ -450,7 +473,8 @@ class HotPathEngine:
         return ops.Ctx(precision=self.precision,
                        split_ws=pl.splitws.tensor().view(-1) if self.auto_split_k else None,
                        shadows=o.shadows, shadow_fused=o.shadow_fused, flash_stats=o.flash_stats,
-                       hidden_f16=o.hidden_f16, hidden_koct=o.hidden_koct, pw_fold=o.pw_fold, x2_f16=o.x2_f16)
+                       hidden_f16=o.hidden_f16, hidden_koct=o.hidden_koct, pw_fold=o.pw_fold, x2_f16=o.x2_f16,
+                       ffn_pairs=o.ffn_pairs)
 
     def _attention_rows(self, cx: ops.Ctx, pl: _Plan, i0: int, rows: int) -> None:
         """attn[:, :rows, :] = softmax(scale * q[:, i0:i0+rows]^T k)   (gma.py:53-65) for every image."""

@@ -65,6 +65,7 @@ class Ctx:
     hidden_koct: bool = True
     pw_fold: bool = True
     x2_f16: bool = True
+    ffn_pairs: bool = True      # an SK block's ffn1 / ffn2 as ONE launch where sf_ffn_pair has the shape (csrc/ffn_pair.hip)
 
     def no_split(self) -> "Ctx":
         """The same context without the split-K scratch (ONE buffer: only one stream may use it at a time)."""
@@ -302,6 +303,128 @@ class PackedLinear:
         self.bias_split = None if self.bias is None else (self.bias * self.split_scale).contiguous()
         # achieved split accuracy relative to the largest weight (reported, used by tests)
         self.split_error = float(((hi.float() + lo.float()) - wm).abs().max() / max(wmax * self.split_scale, 1e-30))
+
+
+class PackedPair:
+    """The two 1x1 convolutions of an SK block's FFN (update.py:14-16: conv -> GELU -> conv) as ONE weight stream for
+    sf_ffn_pair (csrc/ffn_pair.hip): 1-KB MFMA fragments in consumption order, built per (products of layer 1, products of
+    layer 2) on first use.  `first` / `second` are the layers' PackedLinear objects (their `single` flags, scales and biases
+    are the source of truth: the pair computes exactly what the two sf_gemm launches compute)."""
+
+    S = 16                                               # fragments per stage (csrc/ffn_pair.hip)
+
+    def __init__(self, first: "PackedLinear", second: "PackedLinear"):
+        assert first.M == second.K and not first.conv3x3 and not second.conv3x3
+        self.first, self.second = first, second
+        self.K1, self.H, self.M2 = first.K, first.M, second.M
+        self._streams = {}
+
+    def products(self, cx: "Ctx"):
+        one = cx.precision == PRECISION_F16
+        return (1 if (one or self.first.single) else 2), (1 if (one or self.second.single) else 2)
+
+    @staticmethod
+    def _split(A: "PackedLinear", rows: int, cols: int):
+        """(hi, lo) fp16 images of split_scale * W, zero-padded to [rows, cols] (the same rounding as PackedLinear.hi / .lo)."""
+        w = torch.zeros(rows, cols, dtype=torch.float32, device=A.wt.device)
+        w[: A.M, : A.K] = A.wt[: A.K, : A.M].t() * A.split_scale
+        hi = w.to(torch.float16)
+        return hi, (w - hi.float()).to(torch.float16)
+
+    def stream(self, pm1: int, pm2: int) -> torch.Tensor:
+        key = (pm1, pm2)
+        if key in self._streams:
+            return self._streams[key]
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("PackedPair.stream: weight stream requested for the first time inside a graph capture; build it "
+                               "before (HotPathEngine does at construction)")
+        nk1, nt2, hp = (self.K1 + 31) // 32, (self.M2 + 15) // 16, (self.H + 31) // 32
+        fpad = int(_lib.load().sf_ffn_pair_frags(self.K1, self.M2, pm1, pm2))
+        h1, l1 = self._split(self.first, hp * 32, nk1 * 32)
+        h2, l2 = self._split(self.second, nt2 * 16, hp * 32)
+        dev = h1.device
+        # layer 1: fragment (m, u, s, plane) = rows 32 m + 16 u .. + 15, k 32 s .. + 31; lane (row, kq) holds k = 8 kq .. + 7
+        planes1 = [l1, h1] if pm1 == 2 else [h1]
+        f1 = torch.stack([w.view(hp, 2, 16, nk1, 4, 8) for w in planes1], dim=0)          # [plane, m, u, row, s, kq, i]
+        f1 = f1.permute(1, 2, 4, 0, 5, 3, 6).reshape(hp, 2 * nk1 * pm1, 64 * 8)          # [m][(u, s, plane)][(kq, row), i]
+        # layer 2: fragment (m, t, plane) = rows 16 t .. + 15, hidden rows 32 m .. + 31 in the order the layer-1 accumulators
+        # hold them: k = 8 kq + i  <->  4 kq + i (i < 4) | 16 + 4 kq + i - 4 (i >= 4)
+        kq = torch.arange(4, device=dev).view(4, 1)
+        i = torch.arange(8, device=dev).view(1, 8)
+        perm = torch.where(i < 4, 4 * kq + i, 16 + 4 * kq + i - 4).reshape(-1)             # [32] hidden row of (kq, i)
+        planes2 = [l2, h2] if pm2 == 2 else [h2]
+        f2 = torch.stack([w.view(nt2, 16, hp, 32)[..., perm].reshape(nt2, 16, hp, 4, 8) for w in planes2], dim=0)
+        f2 = f2.permute(3, 1, 0, 4, 2, 5).reshape(hp, nt2 * pm2, 64 * 8)                  # [m][(t, plane)][(kq, row), i]
+        pad = torch.zeros(hp, fpad - f1.shape[1] - f2.shape[1], 64 * 8, dtype=torch.float16, device=dev)
+        st = torch.cat([f1, f2, pad], dim=1).contiguous().view(-1)
+        assert st.numel() * 2 == hp * fpad * 1024
+        self._streams[key] = st
+        return st
+
+
+# (K1, M2) of the shapes csrc/ffn_pair.hip is built for, by mode (0: an ffn2 pair, 1: an ffn1 pair)
+PAIR_SHAPES = {1: {(128, 128), (256, 256), (324, 324)}, 0: {(128, 64), (256, 192), (256, 126), (324, 256)}}
+
+
+def ffn_pair_ok(pair: Optional[PackedPair], X: Planes, mode: int, cx: Optional["Ctx"] = None) -> bool:
+    """Does sf_ffn_pair run this FFN?  fp16-activation arithmetic with k-octet hand-over, an ungrouped k-octet operand (the
+    planes themselves or their copy), one of the built shapes."""
+    cx = _cx(cx)
+    if pair is None or cx.precision not in (PRECISION_F16X2, PRECISION_F16) or not (cx.shadows and cx.hidden_f16 and cx.hidden_koct):
+        return False
+    src = X if (X.f16 and X.koct) else X.shadow
+    if src is None or src.group or X.group or X.P % 4:
+        return False
+    pm = pair.products(cx)
+    return (pair.K1, pair.M2) in PAIR_SHAPES[mode] and pm in ((1, 1), (2, 1), (2, 2))
+
+
+@on_tensor_device
+def ffn_pair(pair: PackedPair, X: Planes, Y: Planes, mode: int, dw_w: Optional[torch.Tensor] = None,
+             dw_b: Optional[torch.Tensor] = None, gelu_out: bool = False, cx: Optional["Ctx"] = None) -> None:
+    """mode 0: Y = ffn(X) [gelu'ed with gelu_out]: Y fp16 k-octet planes, or fp32 planes (+ their k-octet copy Y.shadow).
+    mode 1: Y (fp16 ROWS) = gelu(x1 + dw_w * x1 + dw_b), x1 = gelu(X + ffn(X))  (update.py:31-32).  X: k-octet planes or planes
+    with a k-octet copy."""
+    cx = _cx(cx)
+    assert ffn_pair_ok(pair, X, mode, cx)
+    src = X if (X.f16 and X.koct) else X.shadow
+    pm1, pm2 = pair.products(cx)
+    st = pair.stream(pm1, pm2)
+    g = _lib.SfFfnPair()
+    g.X, g.strideX, g.ldx = src.ptr, src.img_stride, src.P
+    g.wstream, g.wstream_bytes = st.data_ptr(), st.numel() * 2
+    A1, A2 = pair.first, pair.second
+    g.bias1 = None if A1.bias_split is None else A1.bias_split.data_ptr()
+    g.bias2 = None if A2.bias_split is None else A2.bias_split.data_ptr()
+    g.alpha1, g.alpha2 = 1.0 / A1.split_scale, 1.0 / A2.split_scale
+    g.N, g.batch, g.K1, g.H, g.M2 = X.P, X.n_img, pair.K1, pair.H, pair.M2
+    g.pm1, g.pm2, g.mode, g.gelu_out = pm1, pm2, int(mode), int(bool(gelu_out))
+    assert Y.n_img == X.n_img and Y.P == X.P and Y.rows == pair.M2 and Y.group == 0
+    out_bytes = 2.0
+    if mode == 1:
+        assert Y.f16 and not Y.koct and dw_w is not None and dw_b is not None
+        g.dw_w, g.dw_b = dw_w.data_ptr(), dw_b.data_ptr()
+        g.C16, g.strideC16, g.ldc16 = Y.ptr, Y.img_stride, Y.P
+    elif Y.f16:
+        assert Y.koct
+        g.C16, g.strideC16, g.ldc16 = Y.ptr, Y.img_stride, Y.P
+    else:
+        g.C, g.strideC, g.ldc = Y.ptr, Y.img_stride, Y.P
+        out_bytes = 4.0
+        if Y.shadow is not None and cx.shadows:
+            sh = Y.shadow
+            g.C16, g.strideC16, g.ldc16 = sh.ptr, sh.img_stride, sh.P
+            g.c16_partial = 1 if pair.M2 % 8 else 0
+            out_bytes = 6.0
+    n, P = X.n_img, X.P
+    flops = 2.0 * n * P * (pair.K1 * pair.H + pair.H * pair.M2)
+    mf = 2.0 * n * P * (pair.K1 * pair.H * pm1 + pair.H * pair.M2 * pm2)
+    nbytes = n * P * (2.0 * pair.K1 * (2 if mode == 1 else 1) + out_bytes * pair.M2) + 2.0 * (pair.K1 * pair.H * pm1 + pair.H * pair.M2 * pm2)
+    name = "ffn_pair" if not PROFILE_SHAPES else f"ffn_pair K{pair.K1} H{pair.H} M{pair.M2} b{n} m{mode}"
+    _launch(name, flops, nbytes, lambda: _lib.check(_lib.load().sf_ffn_pair(C.byref(g), _lib.stream()), "sf_ffn_pair"),
+            products=mf / flops)
+    if g.C and not g.C16:
+        refresh_shadow(Y, cx)
 
 
 def new_shadow(X: Planes, device) -> Planes:
