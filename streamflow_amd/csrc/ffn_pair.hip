@@ -24,6 +24,7 @@
 //         depthwise K x K kernel's input); the residual x is re-read from the k-octet input (the operand itself).
 #include "sf_common.h"
 
+#include <cstdlib>
 #include <type_traits>
 
 namespace {
@@ -47,7 +48,16 @@ constexpr int RING = SF_PAIR_RING;
 constexpr int kOob = 1 << 30;                              // byte offset beyond every buffer range (host-checked spans < 2^30)
 constexpr int kMaxH = 608, kMaxM2 = 384;                   // hidden rows whose bias is kept in LDS; output rows (24 tiles)
 
+#ifdef SF_PAIR_TIMERS
+#define SF_PT_STAMP(acc_) { const long long t_ = __builtin_readcyclecounter(); acc_ += t_ - tprev; tprev = t_; }
+#else
+#define SF_PT_STAMP(acc_)
+#endif
+
 struct PairArgs {
+#ifdef SF_PAIR_TIMERS
+    long long* ts;        // SF_PAIR_TS_BUF: per-wave phase cycle sums (tools/ffn_pair_timers.py; -DSF_PAIR_TIMERS builds only)
+#endif
     SfFfnPair p;
     int ntile;            // pixel tiles per image
     int hp;               // hidden row pairs of 16 = ceil(H / 32)
@@ -97,6 +107,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 8) ? 4 : ((NK1 > 8 && MODE == 1) ? 
                                                      s * kStage + piece * 1024, 0, 0);
         }
     };
+#ifdef SF_PAIR_TIMERS
+    const long long ts0 = __builtin_readcyclecounter();
+    long long t_issue = 0, t_mma = 0, t_drain = 0, t_bar = 0, tprev = ts0;
+#endif
     const int nstage = a.hp * NSTG;
 #pragma unroll
     for (int i = 0; i < RING - 1; ++i)
@@ -124,6 +138,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 8) ? 4 : ((NK1 > 8 && MODE == 1) ? 
 #pragma unroll
     for (int t = 0; t < NT2; ++t) acc2[t] = *reinterpret_cast<const f32x4*>(sb2 + 16 * t + 4 * kq);
 
+#ifdef SF_PAIR_TIMERS
+    const long long ts1 = __builtin_readcyclecounter();
+    tprev = ts1;
+#endif
     int gs = 0, slot = 0;                                         // global stage index, its ring slot
     for (int m = 0; m < a.hp; ++m) {
         f32x4 a1[2];
@@ -135,6 +153,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8) ? 4 : ((NK1 > 8 && MODE == 1) ? 
             // stage gs + RING - 1 goes into the slot every wave finished reading before the barrier that ended the previous stage
             // (issued past the end too -- out of range: zeros -- so that the counted wait below sees the same queue every trip)
             issue_stage(gs + RING - 1, slot == 0 ? RING - 1 : slot - 1);
+            SF_PT_STAMP(t_issue)
             const char* sp = smem + slot * kStage + lane * 16;
             static_for<0, S>([&](auto i_tag) {
                 constexpr int i = decltype(i_tag)::value, f = st * S + i;
@@ -163,9 +182,12 @@ __global__ __launch_bounds__(NW * 64, (NW == 8) ? 4 : ((NK1 > 8 && MODE == 1) ? 
             // the barrier first, and a read that was only issued (hipcc sinks the last MFMAs and their lgkmcnt waits below the
             // s_barrier -- the builtin is no memory barrier to it) then races with the refill's DMA.  Seen as run-to-run differences
             // (tests/test_gpu_ffn_pair.py::test_ffn_pair_is_deterministic) with both ring depths; the explicit drain removed them.
+            SF_PT_STAMP(t_mma)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             wait_vm<PCS * (RING - 2)>();                           // this wave's pieces of the NEXT stage have landed (later ones fly on) ...
+            SF_PT_STAMP(t_drain)
             __builtin_amdgcn_s_barrier();                          // ... everyone's; nobody reads this stage's slot any more
+            SF_PT_STAMP(t_bar)
             asm volatile("" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             ++gs;
@@ -173,6 +195,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 8) ? 4 : ((NK1 > 8 && MODE == 1) ? 
         });
     }
 
+#ifdef SF_PAIR_TIMERS
+    const long long ts2 = __builtin_readcyclecounter();
+#endif
     wait_vm<0>();                                                  // (pieces requested past the end must land before the LDS is released)
     if constexpr (MODE == 1) {                                     // the depthwise 1x1 parameters into the (now idle) ring
         __syncthreads();
@@ -276,6 +301,14 @@ __global__ __launch_bounds__(NW * 64, (NW == 8) ? 4 : ((NK1 > 8 && MODE == 1) ? 
         }
         }
     }
+#ifdef SF_PAIR_TIMERS
+    if (a.ts && lane == 0 && blockIdx.x < 8192) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        long long* d = a.ts + ((int64_t)blockIdx.x * NW + wave) * 8;
+        d[0] = ts1 - ts0; d[1] = t_issue; d[2] = t_mma; d[3] = t_drain; d[4] = t_bar; d[5] = ts2 - ts1; d[6] = __builtin_readcyclecounter() - ts2;
+        d[7] = nstage;
+    }
+#endif
 }
 
 template <int NK1, int NT2, int MODE, int NW>
@@ -326,6 +359,9 @@ extern "C" int sf_ffn_pair(const SfFfnPair* p, void* stream) {
         SF_REQUIRE(g.ldc16 >= g.N && ((int64_t)(g.M2 - 1) * g.ldc16 + g.N) * 2 < lim, "sf_ffn_pair: C16 rows: ldc16 >= N, image < 1 GiB");
     }
     PairArgs a;
+#ifdef SF_PAIR_TIMERS
+    a.ts = getenv("SF_PAIR_TS_BUF") ? (long long*)strtoull(getenv("SF_PAIR_TS_BUF"), nullptr, 0) : nullptr;
+#endif
     a.p = g;
     a.ntile = 0;
     a.hp = (g.H + 31) / 32;

@@ -175,7 +175,10 @@ def run_skblock(W: SKBlockWeights, X: Planes, Y: Planes, hid: Planes, xa: Planes
         # pw GEMMs 15-20 % slower -- more than their consumers gained)
         a4 = _handover(cx, xa, X.n_img, C, X.P, consumer_rows=W.c_mid, allow_koct=False)
         ops.gemm(W.pw, b, a4, EPI_RES_GELU, R=b, cx=cx)                         # x4 = gelu(x3 + pw(x3))
-    if cx.ffn_pairs and a4.f16 and a4.koct and ops.ffn_pair_ok(W.pair2, a4, 0, cx) and (not Y.f16 or Y.koct):
+    # (ffn2 pairs with hi + lo weights measured no faster than their two launches at C >= 256 -- 144 vs ~135 us at 256 -> 384 -> 192:
+    # twice the MFMAs on 16 x 16 x 32 tiles, whose fragment reads bind -- so those stay on the 32 x 32 x 16 kernels)
+    pair2_pays = W.c_in <= 128 or W.pair2.products(cx) == (1, 1)
+    if (cx.ffn_pairs and pair2_pays and a4.f16 and a4.koct and ops.ffn_pair_ok(W.pair2, a4, 0, cx) and (not Y.f16 or Y.koct)):
         ops.ffn_pair(W.pair2, a4, Y, 0, gelu_out=final_gelu, cx=cx)                 # y = ffn2(x4): one launch
         return
     hidden = _handover(cx, hid, X.n_img, W.c_mid, X.P, consumer_rows=W.c_out)       # ffn2.0 -> ffn2.2
