@@ -155,7 +155,58 @@ def build(force: bool = False, verbose: bool = True) -> str:
     return LIB
 
 
+ASAN_OBJ = os.path.join(CSRC, "build_asan")
+ASAN_LIB = os.path.join(HERE, "libstreamflow_hip_asan.so")
+
+
+def asan_runtime() -> str:
+    """The AddressSanitizer runtime of hipcc's clang (to LD_PRELOAD into the python that loads the instrumented library)."""
+    clang = os.path.join(os.path.dirname(os.path.realpath(hipcc())), "..", "lib", "llvm", "bin", "clang")
+    if not os.path.exists(clang):
+        clang = "/opt/rocm/lib/llvm/bin/clang"
+    return subprocess.run([clang, "-print-file-name=libclang_rt.asan-x86_64.so"], capture_output=True, text=True).stdout.strip()
+
+
+def build_asan(force: bool = False, verbose: bool = True) -> str:
+    """The same sources with the HOST side instrumented (-Xarch_host -fsanitize=address,undefined): the sf_* argument checks, the
+    launch planning (grid shaping, dispatch tables, workspace sizes) and the error paths run under the sanitizers on a CPU-only box
+    (kernel launches there fail with 'no device' AFTER the planning code has run).  Device code is unchanged: GPU AddressSanitizer
+    is not available on this pool.  -> streamflow_amd/libstreamflow_hip_asan.so; tests/test_host_sanitizer_cpu.py"""
+    os.makedirs(ASAN_OBJ, exist_ok=True)
+    cc = hipcc()
+    flags = ["--offload-arch=gfx950", "-O1", "-g", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-Wno-unused-function",
+             "-Xarch_host", "-fsanitize=address,undefined", "-Xarch_host", "-fno-omit-frame-pointer", "-Xarch_host", "-fno-sanitize-recover=undefined"]
+    jobs = []
+    for src in SOURCES:
+        s, o = os.path.join(CSRC, src), os.path.join(ASAN_OBJ, src.replace(".hip", ".o"))
+        if force or _stale(o, [s] + HEADERS):
+            jobs.append((s, o))
+
+    def one(job):
+        s, o = job
+        cmd = [cc] + flags + ["-c", s, "-o", o]
+        if verbose:
+            print("[build-asan]", " ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc (asan) failed for {s}:\n{r.stderr[-4000:]}")
+        return o
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(one, jobs))
+    objs = [os.path.join(ASAN_OBJ, s.replace(".hip", ".o")) for s in SOURCES]
+    if force or jobs or _stale(ASAN_LIB, objs):
+        r = subprocess.run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fsanitize=address,undefined", "-shared-libsan"] + objs +
+                           ["-o", ASAN_LIB], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link (asan) failed:\n{r.stderr[-4000:]}")
+    return ASAN_LIB
+
+
 if __name__ == "__main__":
+    if "--asan" in sys.argv:
+        print(build_asan(force="--force" in sys.argv))
+        sys.exit(0)
     print(build(force="--force" in sys.argv))
     if "--resources" in sys.argv:
         print(resources_markdown())

@@ -44,6 +44,9 @@ constexpr int kStage = S * 1024;
 #define SF_PAIR_RING 3                                     // stages in flight + 1: the ring of the weight stream (A/B knob)
 #endif
 constexpr int RING = SF_PAIR_RING;
+#ifndef SF_PAIR_ONE_LOADER
+#define SF_PAIR_ONE_LOADER 0
+#endif
 
 constexpr int kOob = 1 << 30;                              // byte offset beyond every buffer range (host-checked spans < 2^30)
 constexpr int kMaxH = 608, kMaxM2 = 384;                   // hidden rows whose bias is kept in LDS; output rows (24 tiles)
@@ -152,7 +155,17 @@ __global__ __launch_bounds__(NW * 64, (NW == 8) ? 4 : ((NK1 > 8 && MODE == 1) ? 
             constexpr int st = decltype(st_tag)::value;
             // stage gs + RING - 1 goes into the slot every wave finished reading before the barrier that ended the previous stage
             // (issued past the end too -- out of range: zeros -- so that the counted wait below sees the same queue every trip)
+#if SF_PAIR_ONE_LOADER
+            // (experiment: ONE wave per stage issues all its pieces -- fewer waves queueing on the CU's address path at a time)
+            if (wave == gs % kWaves) {
+#pragma unroll
+                for (int i = 0; i < S; ++i)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(smem + (slot == 0 ? RING - 1 : slot - 1) * kStage + i * 1024), 16,
+                                                             lane * 16, (gs + RING - 1) * kStage + i * 1024, 0, 0);
+            }
+#else
             issue_stage(gs + RING - 1, slot == 0 ? RING - 1 : slot - 1);
+#endif
             SF_PT_STAMP(t_issue)
             const char* sp = smem + slot * kStage + lane * 16;
             static_for<0, S>([&](auto i_tag) {
@@ -184,7 +197,12 @@ __global__ __launch_bounds__(NW * 64, (NW == 8) ? 4 : ((NK1 > 8 && MODE == 1) ? 
             // (tests/test_gpu_ffn_pair.py::test_ffn_pair_is_deterministic) with both ring depths; the explicit drain removed them.
             SF_PT_STAMP(t_mma)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#if SF_PAIR_ONE_LOADER
+            static_assert(!SF_PAIR_ONE_LOADER || RING == 3, "one-loader experiment: ring of 3");
+            if (wave == (gs + kWaves - 1) % kWaves) wait_vm<0>();  // the wave that issued stage gs + 1 (at the top of stage gs - 1)
+#else
             wait_vm<PCS * (RING - 2)>();                           // this wave's pieces of the NEXT stage have landed (later ones fly on) ...
+#endif
             SF_PT_STAMP(t_drain)
             __builtin_amdgcn_s_barrier();                          // ... everyone's; nobody reads this stage's slot any more
             SF_PT_STAMP(t_bar)

@@ -201,9 +201,10 @@ def test_full_checkpoint_contract_with_twins_encoder(tmp_path):
 
 
 def test_mixed_preset_layer_sets():
-    """config2_mixed: exactly the nine layers of the ablation keep split weights, the other 30 contraction
-    layers and the motion encoder's four 15x15 depthwise layers are single-product; every name exists in the engine's
-    layer inventory; the other presets name no single-product layer."""
+    """config2_mixed (profiles/r05_preset_select.jsonl): exactly the 17 layers of the oracle-referenced selection
+    keep split weights, the other 22 contraction layers and two of the 15x15 depthwise layers are single-product; every name exists
+    in the engine's layer inventory; the committed selection record names the same sets; the other presets name no single layer."""
+    import json
     from streamflow_amd import presets
     from streamflow_amd.engine import HotPathWeights
     inventory = set(HotPathWeights.PLAIN_LAYERS) | {f"{b}.{l}" for b in HotPathWeights.SK_BLOCKS for l in HotPathWeights.SK_LAYERS}
@@ -211,10 +212,80 @@ def test_mixed_preset_layer_sets():
     kw = presets.engine_kwargs("config2_mixed")
     single = set(kw["single_layers"])
     gemm_single = single & inventory
-    assert set(presets.MIXED_KEEP_SPLIT) <= inventory and len(presets.MIXED_KEEP_SPLIT) == 9
-    assert gemm_single == inventory - set(presets.MIXED_KEEP_SPLIT) and len(gemm_single) == 30
-    assert single - inventory == {"convc1.dw", "convc2.dw", "convf2.dw", "conv.dw"}
-    assert {"flow_head.ffn2_2", "gru.pw", "qkv"} <= set(presets.MIXED_KEEP_SPLIT)
+    assert set(presets.MIXED_KEEP_SPLIT) <= inventory and len(presets.MIXED_KEEP_SPLIT) == 17
+    assert gemm_single == inventory - set(presets.MIXED_KEEP_SPLIT) and len(gemm_single) == 22
+    assert single - inventory == {"convf2.dw", "conv.dw"}
+    assert {"flow_head.ffn2_2", "gru.pw", "qkv", "fc2", "conv.pw"} <= set(presets.MIXED_KEEP_SPLIT)
+    with open(os.path.join(REPO, "profiles", "r05_preset_select.jsonl")) as f:
+        rec = json.loads(f.read().strip().splitlines()[-1])
+    assert set(rec["keep_split"]) == set(presets.MIXED_KEEP_SPLIT)
+    assert set(rec["single_depthwise"]) == set(presets.MIXED_SINGLE_DEPTHWISE)
+    assert max(e / max(1.0, m) for e, m in zip(rec["epe_selected"][3:], rec["mean_flow_px"][3:])) < 0.6e-3       # hard cases
+    assert all(v["epe_selected"] <= 0.6e-3 * max(1.0, v["mean_flow_px"]) for v in rec["validation_hard"])      # held-out validation
     for name in ("fp32_class", "config2_fp16"):
         assert not presets.engine_kwargs(name).get("single_layers")
     assert presets.BENCH_PRESET == "config2_mixed"
+
+
+def test_ffn_pair_weight_stream_layout(lib):
+    """ops.PackedPair: the fragment stream of sf_ffn_pair (include/streamflow_hip.h SfFfnPair): per 32 hidden rows the layer-1
+    fragments in (k-step, plane, 16-row tile) order, then the layer-2 fragments with their 32 columns in the order the layer-1
+    accumulators hold the hidden rows, zero-padded to whole 16-fragment stages.  Host-only (packing + sf_ffn_pair_frags)."""
+    import random
+    from streamflow_amd import ops
+    torch.manual_seed(0)
+    K1, H, M2 = 324, 486, 256
+    A1 = ops.PackedLinear(torch.randn(H, K1, 1, 1), torch.randn(H), "cpu")
+    A2 = ops.PackedLinear(torch.randn(M2, H, 1, 1), torch.randn(M2), "cpu")
+    pp = ops.PackedPair(A1, A2)
+    rnd = random.Random(1)
+    for pm in ((1, 1), (2, 1), (2, 2)):
+        st = pp.stream(*pm).view(-1, 64, 8)
+        nk1, nt2, hp = (K1 + 31) // 32, (M2 + 15) // 16, (H + 31) // 32
+        fpad = lib.sf_ffn_pair_frags(K1, M2, pm[0], pm[1])
+        assert fpad % 16 == 0 and fpad >= 2 * nk1 * pm[0] + nt2 * pm[1] and st.shape[0] == hp * fpad
+        h1, l1 = pp._split(A1, hp * 32, nk1 * 32)
+        h2, l2 = pp._split(A2, nt2 * 16, hp * 32)
+        assert torch.equal(h1[:H, :K1].float() + l1[:H, :K1].float(), (A1.hi.float() + A1.lo.float()).permute(1, 0, 2).reshape(A1.lda_h, -1)[:H, :K1])
+        for _ in range(300):
+            m, u, s_, lane, i = rnd.randrange(hp), rnd.randrange(2), rnd.randrange(nk1), rnd.randrange(64), rnd.randrange(8)
+            row, kq = lane & 15, lane >> 4
+            for pl in range(pm[0]):
+                W = l1 if (pm[0] == 2 and pl == 0) else h1
+                f = (u * nk1 + s_) * pm[0] + pl
+                assert st[m * fpad + f, lane, i] == W[32 * m + 16 * u + row, 32 * s_ + 8 * kq + i]
+            t = rnd.randrange(nt2)
+            hid = 32 * m + (4 * kq + i if i < 4 else 16 + 4 * kq + i - 4)
+            for pl in range(pm[1]):
+                W = l2 if (pm[1] == 2 and pl == 0) else h2
+                assert st[m * fpad + 2 * nk1 * pm[0] + t * pm[1] + pl, lane, i] == W[16 * t + row, hid]
+        assert not bool(st.view(hp, fpad, -1)[:, 2 * nk1 * pm[0] + nt2 * pm[1]:].any())          # padding fragments are zero
+    assert lib.sf_ffn_pair_frags(256, 256, 3, 1) == 0
+
+
+def test_ffn_pair_argument_validation(lib):
+    """sf_ffn_pair rejects what it cannot run before any launch (dummy, never dereferenced pointers): unbuilt shapes, a short
+    weight stream, misaligned operands, mode 1 without the depthwise parameters."""
+    import ctypes
+    from streamflow_amd import _lib
+    g = _lib.SfFfnPair()
+    g.X, g.strideX, g.ldx = 0x1000, 256 * 64, 64
+    g.wstream, g.wstream_bytes = 0x2000, 1 << 24
+    g.N, g.batch, g.K1, g.H, g.M2, g.pm1, g.pm2, g.mode = 64, 1, 256, 384, 192, 1, 1, 0
+    g.C16, g.strideC16, g.ldc16 = 0x3000, 192 * 64, 64
+    g.alpha1 = g.alpha2 = 1.0
+    bad = dict(K1=640, H=960, M2=128)                                  # the GRU: not built
+    for k, v in bad.items():
+        setattr(g, k, v)
+    assert lib.sf_ffn_pair(ctypes.byref(g), None) != 0 and b"not built" in lib.sf_last_error() or b"H <=" in lib.sf_last_error()
+    g.K1, g.H, g.M2 = 256, 384, 192
+    g.wstream_bytes = 1024
+    assert lib.sf_ffn_pair(ctypes.byref(g), None) != 0 and b"weight stream too small" in lib.sf_last_error()
+    g.wstream_bytes = 1 << 24
+    g.X = 0x1004
+    assert lib.sf_ffn_pair(ctypes.byref(g), None) != 0 and b"16-byte aligned" in lib.sf_last_error()
+    g.X = 0x1000
+    g.mode, g.M2 = 1, 256
+    assert lib.sf_ffn_pair(ctypes.byref(g), None) != 0 and b"mode 1 needs" in lib.sf_last_error()
+    g.mode, g.M2, g.pm1 = 0, 192, 3
+    assert lib.sf_ffn_pair(ctypes.byref(g), None) != 0

@@ -8,6 +8,7 @@ attaches these bytes to a run of the same configuration."""
 import collections, csv, json, re, sys
 
 FAMILY = [(r"corr_build|split_pack|pack_f16", "corr_build"), (r"corr_lookup", "corr_lookup"),
+          (r"flash_project_v", "gma_project_v"), (r"ffn_pair_kernel", "ffn_pair"),
           (r"gma_flash|flash_pack_v", "gma_flash"), (r"flash_pack_qk", "flash_pack_qk"),
           (r"gemm_f16x3_mfma<[^>]*, 1, [13], (true|false)>", "gemm_attn"), (r"gemm_f|gemm_bdirect|gemm_bstat", "gemm"),
           (r"splitk_epilogue", "gemm"), (r"splitk_combine", "splitk_combine"), (r"dwconv_mfma_kernel<7", "dwconv7"), (r"dwconv_mfma", "dwconv15"),
@@ -22,11 +23,17 @@ def family(name):
             return fam
     return None
 
+PACK_V_SEEN = False      # (round 5: with sf_gma_flash_project_v the aggregate call launches the fused kernel alone)
+
+
 def collect(path, counter):
+    global PACK_V_SEEN
     tot, cnt = collections.Counter(), collections.Counter()
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != counter:
             continue
+        if "flash_pack_v" in r["Kernel_Name"]:
+            PACK_V_SEEN = True
         f = family(r["Kernel_Name"])
         if f:
             tot[f] += float(r["Counter_Value"])
@@ -41,7 +48,7 @@ def main():
                     "write = WRITE_SIZE; calibrated on softmax_rows (known bytes)."}
     for f in sorted(set(ft) | set(wt)):
         nf, nw = max(fc[f], 1), max(wc[f], 1)
-        if f in ("corr_build", "gma_flash"):          # pack + main kernel = two launches of one C-ABI call
+        if f == "corr_build" or (f == "gma_flash" and PACK_V_SEEN):     # pack + main kernel = two launches of one C-ABI call
             nf, nw = max(nf // 2, 1), max(nw // 2, 1)
         out[f] = {"fetch_kib_per_launch": round(2.0 * ft[f] / nf, 1), "write_kib_per_launch": round(wt[f] / nw, 1),
                   "fetch_size_raw_kib": round(ft[f] / nf, 1), "launches_profiled": nf}
