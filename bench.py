@@ -73,6 +73,7 @@ WORKLOADS = {
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: exact-fp32 MFMA = fp32 vector peak
 PEAK_F16_MFMA_TFLOPS = 2500.0      # dense f16/bf16 MFMA; the split path spends 3 MFMA flops per algorithmic flop
 PEAK_HBM_GBPS = 8000.0             # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+PEAK_CLOCK_MHZ = 2400.0            # MI355X_MICROARCH.md: max clock (the dense peaks above are quoted at it)
 
 
 def log(msg: str) -> None:
@@ -595,6 +596,37 @@ def main():
                                  "f16": "weights fp16, activations fp16 (1x v_mfma_f32_32x32x16_f16)"}[args.precision]},
     }
 
+    # The clock the chip SUSTAINS under this step (MI355X clocks to its power budget): a one-wave probe on a side stream reads the
+    # shader-cycle counter against the constant 100 MHz counter while the step replays (sf_clock_probe); the same probe on the idle
+    # device next to it.  Quoted beside the roofline, which prices the matrix-core roof at the guide's 2.4 GHz.
+    clock = None
+    if rank == 0 and not args.no_kernel_breakdown and args.streams == 1:
+        side, out = torch.cuda.Stream(device=dev), torch.zeros(4, dtype=torch.int64, device=dev)
+        t_step = dt / args.steps / (len(my_batches) if strong else 1)
+        nrep = max(3, int(0.3 / max(t_step, 1e-4)))
+        step()
+        torch.cuda.synchronize()
+        side.wait_stream(torch.cuda.current_stream())
+        t_sec = time.perf_counter()
+        with torch.cuda.stream(side):
+            ops.clock_probe(out[:2], int(1e6 * 0.85 * nrep * t_step))
+        for _ in range(nrep):
+            step()
+        torch.cuda.synchronize()
+        t_sec = time.perf_counter() - t_sec
+        time.sleep(0.5)
+        with torch.cuda.stream(side):
+            ops.clock_probe(out[2:], 20000)
+        torch.cuda.synchronize()
+        c = [int(v) for v in out.tolist()]
+        clock = {"sustained_mhz": round(100.0 * c[0] / max(c[1], 1), 1), "idle_probe_mhz": round(100.0 * c[2] / max(c[3], 1), 1),
+                 "max_mhz": PEAK_CLOCK_MHZ,
+                 # (probe and replays side by side: the section takes the replays' time, not replays + spin)
+                 "section_ms": round(1e3 * t_sec, 1), "replays_ms": round(1e3 * nrep * t_step, 1),
+                 "method": f"sf_clock_probe on a side stream: shader cycles (s_memtime) / 100 MHz ticks (s_memrealtime) over 85 % of "
+                           f"{nrep} replays of the timed step; idle = the same probe alone for 20 ms after 0.5 s of rest"}
+        log(f"clock under the step: {clock['sustained_mhz']} MHz (idle probe {clock['idle_probe_mhz']} MHz)")
+
     if rank == 0 and not args.no_kernel_breakdown:
         # instrumented eager pass: HIP events around every launch on the launch stream
         eager = HotPathEngine(params, device=dev, T=T, use_graph=False, **cfg)
@@ -702,6 +734,9 @@ def main():
             "frac_hbm": fam["frac_hbm"], "frac_mfma": fam["frac_mfma"],
             "algorithmic_tflops": round(fam["_fl"] / t / 1e12, 1), "mfma_tflops_issued": round(fam["_mf"] / t / 1e12, 1),
             "mfma_busy": mfma_busy_from_profiles(dom),
+            "clock": clock,
+            "frac_mfma_at_sustained_clock": (round(fam["frac_mfma"] * PEAK_CLOCK_MHZ / clock["sustained_mhz"], 4)
+                                             if (clock and fam["frac_mfma"] and clock["sustained_mhz"] > 0) else None),
             "traffic": fam["traffic"], "traffic_note": traffic_why if fam["traffic"] is None else (
                 f"bytes per launch, mean over the family: 2 x FETCH_SIZE + WRITE_SIZE from separate rocprofv3 --pmc passes of this "
                 f"workload on these kernel sources ({os.path.relpath(tfile, ROOT)})"),

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SF_VERSION 115
+#define SF_VERSION 116
 
 enum {
     SF_OK = 0,
@@ -312,6 +312,37 @@ typedef struct SfFfnPair {
 int sf_ffn_pair(const SfFfnPair* p, void* stream);
 int sf_ffn_pair_frags(int K1, int M2, int pm1, int pm2);
 
+/* ---- a10: the temporal transformer block in ONE launch (core/update.py:459-484,502-513 -> timm Block; called at update.py:770;
+ * csrc/temporal.hip) ---------------------------------------------------------------------------------------------------------
+ * tokens of one pixel = its TT = T - 1 frames x C = 128 channels:  x += proj(softmax(C^-1/2 q k^T) v), (q, k, v) = qkv(LN1 x);
+ * x += fc2(gelu(fc1(LN2 x))) -- the unfused form is sf_layernorm_cm, sf_gemm, sf_temporal_attn, sf_gemm, sf_layernorm_cm, sf_gemm,
+ * sf_gemm.  Here every intermediate stays in registers (a wave owns 16 pixels x TT frames).
+ * X16: the tokens as fp16 k-octet planes [C/8][ldx][8] per image, image = clip * TT + frame (strideX in halves); they are the
+ *   operand AND the residual.  B clips of N pixels.
+ * wstream: the four layers' weights as ONE stream of 1-KB fragments (16 rows x 32 k: lane (row, kq) = 8 halves W[row][k(8 kq ..)];
+ *   with pm = 2 the `lo` fragment precedes the `hi` one) in consumption order (streamflow_amd.ops.PackedTemporal):
+ *     q and k rows of qkv: row tile m = 0 .. 15, k-step s = 0 .. 3 (natural column order);
+ *     then for p = 0 .. 3: v row tiles 16 + 2 p, 16 + 2 p + 1 (x 4 k-steps), then proj row tiles 0 .. 7 at k-step p;
+ *     then for h = 0 .. 7: fc1 row tiles 2 h, 2 h + 1 (x 4 k-steps), then fc2 row tiles 0 .. 7 at k-step h;
+ *   the columns of a k-step of proj, fc1 and fc2 are ordered  k = 8 kq + i <-> input row 4 kq + i (i < 4) | 16 + 4 kq + i - 4
+ *   (i >= 4) of that k-step's 32 rows (the accumulator layout of the producing tiles).  sf_temporal_block_frags(pm) fragments.
+ *   Weights pre-scaled by a power of two per layer: alpha_* = 1 / scale; bias_* carry the scale; ss_proj / ss_fc2 = the scale of
+ *   proj / fc2 (the residual enters their accumulators).  qkv has no bias (timm: qkv_bias = False).
+ * Y (fp32 planes [C][ldy], optional) and / or Y16 (their fp16 k-octet copy, optional): image stride strideY floats / strideY16 halves.
+ * Built for C = 128, H = 256 (mlp_ratio 2), TT = 1 .. 3, pm = 1 / 2; anything else: SF_ERR_UNSUPPORTED (the caller keeps the
+ * seven launches).  Arithmetic: activations enter every product as fp16; fp32 accumulation, LayerNorm, softmax and GELU. */
+typedef struct SfTemporalBlock {
+    const void* X16; int64_t strideX, ldx;
+    const void* wstream; int64_t wstream_bytes;
+    const float *ln1_w, *ln1_b, *ln2_w, *ln2_b, *bias_proj, *bias_fc1, *bias_fc2;
+    float* Y; int64_t strideY, ldy;
+    void* Y16; int64_t strideY16, ldy16;
+    int32_t N, B, TT, C, H, pm;
+    float alpha_qkv, alpha_proj, alpha_fc1, alpha_fc2, ss_proj, ss_fc2, eps, scale;
+} SfTemporalBlock;
+int sf_temporal_block(const SfTemporalBlock* p, void* stream);
+int sf_temporal_block_frags(int pm);
+
 /* ---- row softmax (gma.py:63): x [rows][cols] ----------------------------------------------------
  * out_f16 == NULL: in place.  Otherwise the weights are written as IEEE fp16 to out_f16 [rows][cols] (x is then
  * scratch): the attention matrix is re-read by every refinement iteration's attn @ v and that read is HBM-bound,
@@ -366,6 +397,13 @@ int sf_temporal_attn_f16in(const void* qkv_f16, float* out, void* out_koct, int 
  * the loop get their k-octet copy from the producing kernel (SfGemm.C16). */
 int sf_pack_koct(const float* x, int64_t x_img_stride, int n_img, int rows, int P, void* y, int64_t y_img_stride,
                  void* stream);
+
+/* ---- measurement aid (no reference counterpart) -----------------------------------------------------------------
+ * One wave that reads the shader-cycle counter and the constant 100 MHz counter for `spin_us` microseconds (sleeping in
+ * between) and writes out[0] = shader cycles, out[1] = 100 MHz ticks that passed: launched on a side stream while the hot path
+ * replays, it gives the clock the chip SUSTAINS under that load (MI355X clocks to its power budget; bench.py prices the
+ * matrix-core roof at 2.4 GHz as the guide prescribes and quotes this clock next to it).  out: two int64 in device memory. */
+int sf_clock_probe(int64_t* out, int spin_us, void* stream);
 
 /* ---- context split (streamflow.py:119-122): cnets [n_img][2*hdim][P] ->
  * nets = tanh(first half) (written with nets_img_stride), inps = relu(second half). */

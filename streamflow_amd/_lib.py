@@ -58,6 +58,19 @@ class SfFfnPair(C.Structure):
     ]
 
 
+class SfTemporalBlock(C.Structure):
+    _fields_ = [
+        ("X16", _vp), ("strideX", _i64), ("ldx", _i64),
+        ("wstream", _vp), ("wstream_bytes", _i64),
+        ("ln1_w", _vp), ("ln1_b", _vp), ("ln2_w", _vp), ("ln2_b", _vp), ("bias_proj", _vp), ("bias_fc1", _vp), ("bias_fc2", _vp),
+        ("Y", _vp), ("strideY", _i64), ("ldy", _i64),
+        ("Y16", _vp), ("strideY16", _i64), ("ldy16", _i64),
+        ("N", C.c_int32), ("B", C.c_int32), ("TT", C.c_int32), ("C", C.c_int32), ("H", C.c_int32), ("pm", C.c_int32),
+        ("alpha_qkv", _f), ("alpha_proj", _f), ("alpha_fc1", _f), ("alpha_fc2", _f), ("ss_proj", _f), ("ss_fc2", _f),
+        ("eps", _f), ("scale", _f),
+    ]
+
+
 # name -> (restype, argtypes); must list every symbol of include/streamflow_hip.h
 SIGNATURES = {
     "sf_version": (_i, []),
@@ -87,6 +100,8 @@ SIGNATURES = {
     "sf_gma_flash_project_v": (_i, [_vp, _i64, _vp, _i64, _i64, _vp, _vp, _i, _f, _i, _i, _i, _vp]),
     "sf_ffn_pair": (_i, [C.POINTER(SfFfnPair), _vp]),
     "sf_ffn_pair_frags": (_i, [_i, _i, _i, _i]),
+    "sf_temporal_block": (_i, [C.POINTER(SfTemporalBlock), _vp]),
+    "sf_temporal_block_frags": (_i, [_i]),
     "sf_softmax_rows": (_i, [_vp, _i64, _i, _vp, _vp]),
     "sf_splitk_combine": (_i, [_vp, _i64, _i, _i64, _vp, _i64, _vp, _vp, _i64, _i, _i64, _vp]),
     "sf_dwconv_res_gelu": (_i, [_vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _i, _vp]),
@@ -95,6 +110,7 @@ SIGNATURES = {
     "sf_temporal_attn": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "sf_temporal_attn_f16in": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "sf_pack_koct": (_i, [_vp, _i64, _i, _i, _i, _vp, _i64, _vp]),
+    "sf_clock_probe": (_i, [_vp, _i, _vp]),
     "sf_context_split": (_i, [_vp, _vp, _i64, _vp, _i64, _i, _i, _i, _vp]),
     "sf_flow_update": (_i, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _vp]),
     "sf_window_attn": (_i, [_vp, _i64, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _vp]),
@@ -130,7 +146,7 @@ def load() -> C.CDLL:
             raise RuntimeError(f"{LIB_PATH} does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
-    if lib.sf_version() < 109:
+    if lib.sf_version() < 116:
         raise RuntimeError("libstreamflow_hip.so is too old; rebuild")
     _lib = lib
     return lib

@@ -42,6 +42,9 @@ template <int PM> struct StageK { static constexpr int value = (PM == 1) ? 8 : 4
 #ifndef SF_BSTAT_RING
 #define SF_BSTAT_RING 3
 #endif
+#ifndef SF_BSTAT_ALT_ACC
+#define SF_BSTAT_ALT_ACC 0      // (two accumulation chains per tile: measured 0-4 % SLOWER; kept as a switch)
+#endif
 constexpr int RING = SF_BSTAT_RING;    // weight stages in LDS
 #ifndef SF_BSTAT_STORE_SLACK
 #define SF_BSTAT_STORE_SLACK 1
@@ -706,6 +709,14 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bstat_gk_kernel(const BsArgs
 #pragma unroll
             for (int e = 0; e < 4; ++e) cur[4 * j + e] = b4[e];
         }
+#if SF_BSTAT_ALT_ACC
+        // Two accumulation chains per tile (fragments alternate between `cur` and `alt`, summed at the end of the tile): an MFMA that
+        // depends on the one before it AND has other instructions issued in between (here: a fragment read and a share of the previous
+        // tile's epilogue behind every MFMA) waits for that MFMA's write-back -- ~40 cycles on top of the 32 it occupies the pipe
+        // (MI355X_MICROARCH.md, "one EXTRA issue slot between two MFMAs on the SAME accumulator"); with two chains the neighbour is
+        // independent.  With two products `cur` collects the lo products and `alt` the hi ones.
+        f32x16 alt = {};
+#endif
         static_for<0, NS>([&](auto s_tag) {
             constexpr int s = decltype(s_tag)::value;
             SF_BS_STAMP(tm)
@@ -728,6 +739,10 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bstat_gk_kernel(const BsArgs
 #pragma unroll
             for (int i = 0; i < S; ++i) {
                 const f16x8 fr = *reinterpret_cast<const f16x8*>(sp + i * 1024);
+#if SF_BSTAT_ALT_ACC
+                if ((s * S + i) & 1) alt = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr, b[(s * S + i) / PM], alt, 0, 0, 0);
+                else
+#endif
                 cur = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr, b[(s * S + i) / PM], cur, 0, 0, 0);
             }
             // groups of the previous tile's epilogue that belong to this stage: 4 groups spread over the NS stages
@@ -763,6 +778,10 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bstat_gk_kernel(const BsArgs
             __builtin_amdgcn_sched_barrier(0);
             slot = (slot == RING - 1) ? 0 : slot + 1;
         });
+#if SF_BSTAT_ALT_ACC
+#pragma unroll
+        for (int e = 0; e < 16; ++e) cur[e] += alt[e];
+#endif
     };
 
     using std::integral_constant;
@@ -796,7 +815,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bstat_gk_kernel(const BsArgs
 #ifdef SF_BSTAT_TIMERS
     if (a.ts && lane == 0 && blockIdx.x < 4096) {
         long long* d = a.ts + ((int64_t)blockIdx.x * 4 + wave) * 8;
-        d[0] = ts1 - ts0; d[1] = tw; d[2] = tb; d[3] = ti; d[4] = tm; d[5] = te; d[6] = __builtin_readcyclecounter() - ts0;
+        d[0] = ts1 - ts0; d[1] = tw; d[2] = tb; d[3] = ti; d[4] = tm; d[5] = rt0;   /* (gk: start time, 100 MHz) */ d[6] = __builtin_readcyclecounter() - ts0;
         d[7] = __builtin_amdgcn_s_memrealtime() - rt0;
     }
 #endif

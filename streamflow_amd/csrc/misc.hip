@@ -519,6 +519,29 @@ extern "C" int sf_pack_koct(const float* x, int64_t x_img_stride, int n_img, int
     return sf::check_launch("sf_pack_koct");
 }
 
+namespace {
+// One wave that watches the clock: lane 0 reads the shader-cycle counter (s_memtime) and the constant 100 MHz counter
+// (s_memrealtime) until `spin_us` have passed, sleeping in between.
+__global__ __launch_bounds__(64) void clock_probe_kernel(long long* out, long long ticks) {
+    if (threadIdx.x != 0) return;
+    const long long c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
+    long long r = r0;
+    while (r - r0 < ticks) {
+        __builtin_amdgcn_s_sleep(64);
+        r = __builtin_amdgcn_s_memrealtime();
+    }
+    out[0] = __builtin_readcyclecounter() - c0;
+    out[1] = r - r0;
+}
+}  // namespace
+
+extern "C" int sf_clock_probe(int64_t* out, int spin_us, void* stream) {
+    SF_REQUIRE(out && spin_us > 0 && spin_us <= 2000000, "sf_clock_probe: bad args");
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, reinterpret_cast<long long*>(out),
+                       (long long)spin_us * 100);
+    return sf::check_launch("sf_clock_probe");
+}
+
 extern "C" int sf_context_split(const float* cnets, float* nets, int64_t nets_img_stride, float* inps,
                                 int64_t inps_img_stride, int n_img, int hdim, int P, void* stream) {
     SF_REQUIRE(cnets && nets && inps && n_img > 0 && hdim > 0 && P > 0, "sf_context_split: bad args");

@@ -48,6 +48,7 @@ class EngineOptions:
     flash_stats: bool = True         # fused GMA: softmax statistics computed once per clip
     ffn_pairs: bool = True           # the SK blocks' ffn1 / ffn2 pairs as one launch each where the shape is built (sf_ffn_pair)
     project_v: bool = True           # fused GMA, fp16 activations: to_v + the v pack as one launch (sf_gma_flash_project_v)
+    temporal_block: bool = True      # the temporal transformer block as ONE launch (sf_temporal_block) instead of seven
     setup_overlap: bool = True       # the context chain of the setup (split, to_qk, GMA pack / statistics) beside the volume build
     max_plans: int = 4               # buffer sets (and graphs) kept, least recently used evicted
 
@@ -220,6 +221,7 @@ class HotPathWeights:
         self.proj = PackedLinear(sd[tb + ".attn.proj.weight"], sd[tb + ".attn.proj.bias"], device)
         self.fc1 = PackedLinear(sd[tb + ".mlp.fc1.weight"], sd[tb + ".mlp.fc1.bias"], device)
         self.fc2 = PackedLinear(sd[tb + ".mlp.fc2.weight"], sd[tb + ".mlp.fc2.bias"], device)
+        self.temporal = ops.PackedTemporal(self.qkv, self.proj, self.fc1, self.fc2)
 
     SK_BLOCKS = ("convc1", "convc2", "convf2", "conv", "gru", "flow_head")
     SK_LAYERS = ("ffn1_0", "ffn1_2", "pw", "ffn2_0", "ffn2_2")
@@ -442,6 +444,12 @@ class HotPathEngine:
                         if (pair.K1, pair.M2) in ops.PAIR_SHAPES[0] | ops.PAIR_SHAPES[1]:
                             pair.stream(*pair.products(cxp))
                 torch.cuda.synchronize(self.device)
+        if self.options.temporal_block and self.precision in (ops.PRECISION_F16X2, ops.PRECISION_F16) and self.W.temporal.built():
+            pm = self.W.temporal.products(ops.Ctx(precision=self.precision))
+            if pm is not None:
+                with torch.cuda.device(self.device):
+                    self.W.temporal.stream(pm)
+                    torch.cuda.synchronize(self.device)
         self.use_graph = use_graph
         self._plans: Dict[Tuple[int, int, int, int], _Plan] = {}
         self.max_plans = int(self.options.max_plans)
@@ -606,20 +614,24 @@ class HotPathEngine:
         # a10: temporal transformer block over the T-1 tokens of each pixel (update.py:481-484,770), side stream
         fork()
         with on_side():
-            # LayerNorm / attention outputs have ONE reader, a GEMM: in the f16x2 mode they leave as its k-octet operand
-            ko = lambda buf, M: (lambda t: t if t.koct else buf)(_handover(cs, buf, pl.n, HDIM, P, consumer_rows=M))
-            ln, att = ko(pl.ln128, W.qkv.M), ko(pl.att128, W.proj.M)
-            ops.layernorm_cm(pl.mf, W.ln1_w, W.ln1_b, ln)
-            # qkv has ONE reader, the attention core: fp16 rows where the fp16 hand-over is active (EPE-neutral)
-            qkv = _scratch(pl.qkv, pl.n, 3 * HDIM, f16=True) if (hidden_f16_ok(cs, P) and cs.x2_f16) else pl.qkv
-            ops.gemm(W.qkv, ln, qkv, EPI_NONE, cx=cs)
-            ops.temporal_attn(qkv, att, Bc, Pn, HDIM)
-            ops.gemm(W.proj, att, pl.tx128, EPI_RES, R=pl.mf, cx=cs)
-            ln = ko(pl.ln128, W.fc1.M)
-            ops.layernorm_cm(pl.tx128, W.ln2_w, W.ln2_b, ln)
-            h256 = _handover(cs, pl.h256, pl.n, 256, P, consumer_rows=HDIM)        # fc1 -> fc2 only
-            ops.gemm(W.fc1, ln, h256, EPI_GELU, cx=cs)
-            ops.gemm(W.fc2, h256, pl.mft, EPI_RES, R=pl.tx128, cx=cs)
+            if self.options.temporal_block and ops.temporal_block_ok(W.temporal, pl.mf, Pn, cs):
+                # the whole block in one launch from the k-octet copy of the motion features (csrc/temporal.hip)
+                ops.temporal_block(W.temporal, pl.mf, pl.mft, Pn, (W.ln1_w, W.ln1_b), (W.ln2_w, W.ln2_b), cx=cs)
+            else:
+                # LayerNorm / attention outputs have ONE reader, a GEMM: in the f16x2 mode they leave as its k-octet operand
+                ko = lambda buf, M: (lambda t: t if t.koct else buf)(_handover(cs, buf, pl.n, HDIM, P, consumer_rows=M))
+                ln, att = ko(pl.ln128, W.qkv.M), ko(pl.att128, W.proj.M)
+                ops.layernorm_cm(pl.mf, W.ln1_w, W.ln1_b, ln)
+                # qkv has ONE reader, the attention core: fp16 rows where the fp16 hand-over is active (EPE-neutral)
+                qkv = _scratch(pl.qkv, pl.n, 3 * HDIM, f16=True) if (hidden_f16_ok(cs, P) and cs.x2_f16) else pl.qkv
+                ops.gemm(W.qkv, ln, qkv, EPI_NONE, cx=cs)
+                ops.temporal_attn(qkv, att, Bc, Pn, HDIM)
+                ops.gemm(W.proj, att, pl.tx128, EPI_RES, R=pl.mf, cx=cs)
+                ln = ko(pl.ln128, W.fc1.M)
+                ops.layernorm_cm(pl.tx128, W.ln2_w, W.ln2_b, ln)
+                h256 = _handover(cs, pl.h256, pl.n, 256, P, consumer_rows=HDIM)        # fc1 -> fc2 only
+                ops.gemm(W.fc1, ln, h256, EPI_GELU, cx=cs)
+                ops.gemm(W.fc2, h256, pl.mft, EPI_RES, R=pl.tx128, cx=cs)
         # a7: global aggregation  mfg = mf + gamma * attn @ to_v(mf)   (gma.py:91-104), main stream
         # v has ONE reader, the pack of the fused kernel (which rounds it to fp16): fp16 rows where the fp16 hand-over is active
         v128 = _scratch(pl.v128, pl.n, HDIM, f16=True) if (pl.flash and hidden_f16_ok(cx, P) and cx.x2_f16) else pl.v128

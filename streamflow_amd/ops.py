@@ -362,6 +362,111 @@ class PackedPair:
         return st
 
 
+class PackedTemporal:
+    """The four contractions of the temporal transformer block (update.py:459-484 -> timm Block: qkv, proj, fc1, fc2) as ONE weight
+    stream for sf_temporal_block (csrc/temporal.hip): 1-KB MFMA fragments in consumption order (layout: include/streamflow_hip.h).
+    The PackedLinear objects stay the source of truth (rounding, power-of-two scales, biases, `single` flags)."""
+
+    def __init__(self, qkv: "PackedLinear", proj: "PackedLinear", fc1: "PackedLinear", fc2: "PackedLinear"):
+        self.layers = (qkv, proj, fc1, fc2)
+        self.C, self.H = qkv.K, fc1.M
+        self._streams = {}
+
+    def built(self) -> bool:
+        qkv, proj, fc1, fc2 = self.layers
+        return (self.C == 128 and self.H == 256 and qkv.M == 384 and qkv.bias is None and (proj.M, proj.K) == (128, 128) and
+                fc1.K == 128 and (fc2.M, fc2.K) == (128, 256) and not any(l.conv3x3 for l in self.layers))
+
+    def products(self, cx: "Ctx") -> Optional[int]:
+        """MFMA products per element: 1 (fp16 weights) or 2 (hi + lo) -- the kernel takes ONE value for the block; a layer set that
+        mixes the two keeps the unfused launches (None)."""
+        if cx.precision == PRECISION_F16 or all(l.single for l in self.layers):
+            return 1
+        return 2 if not any(l.single for l in self.layers) else None
+
+    def stream(self, pm: int) -> torch.Tensor:
+        if pm in self._streams:
+            return self._streams[pm]
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("PackedTemporal.stream: weight stream requested for the first time inside a graph capture; build it "
+                               "before (HotPathEngine does at construction)")
+        qkv, proj, fc1, fc2 = (PackedPair._split(l, l.M, l.K) for l in self.layers)       # (hi, lo) of scale * W, [M, K] fp16
+        dev = qkv[0].device
+        kq = torch.arange(4, device=dev).view(4, 1)
+        i = torch.arange(8, device=dev).view(1, 8)
+        perm = torch.where(i < 4, 4 * kq + i, 16 + 4 * kq + i - 4).reshape(-1)             # input row of column (kq, i) of a k-step
+        out = []
+
+        def emit(w, m, s, permuted):
+            for plane in ((w[1], w[0]) if pm == 2 else (w[0],)):                           # lo before hi
+                blk = plane[16 * m:16 * m + 16, 32 * s:32 * s + 32]
+                if permuted:
+                    blk = blk[:, perm]
+                out.append(blk.reshape(16, 4, 8).permute(1, 0, 2).reshape(512))           # lane (kq, row): 8 halves
+
+        for m in range(16):                                                                # q and k rows
+            for s in range(4):
+                emit(qkv, m, s, False)
+        for p_ in range(4):                                                                # v two tiles at a time, then proj's k-step
+            for tile in (16 + 2 * p_, 16 + 2 * p_ + 1):
+                for s in range(4):
+                    emit(qkv, tile, s, False)
+            for m in range(8):
+                emit(proj, m, p_, True)
+        for h in range(8):                                                                 # fc1 two tiles at a time, then fc2's k-step
+            for tile in (2 * h, 2 * h + 1):
+                for s in range(4):
+                    emit(fc1, tile, s, True)
+            for m in range(8):
+                emit(fc2, m, h, True)
+        st = torch.cat(out).contiguous()
+        assert st.numel() == int(_lib.load().sf_temporal_block_frags(pm)) * 512
+        self._streams[pm] = st
+        return st
+
+
+def temporal_block_ok(pack: Optional[PackedTemporal], X: Planes, TT: int, cx: Optional["Ctx"] = None) -> bool:
+    """Does sf_temporal_block run this block?  fp16-activation arithmetic with the k-octet copy of the tokens at hand, the built
+    shape (C = 128, hidden 256, <= 3 tokens per pixel), one product count for all four layers."""
+    cx = _cx(cx)
+    if pack is None or cx.precision not in (PRECISION_F16X2, PRECISION_F16) or not (cx.shadows and cx.hidden_f16 and cx.hidden_koct):
+        return False
+    return (pack.built() and pack.products(cx) is not None and 1 <= TT <= 3 and X.shadow is not None and X.rows == 128 and
+            X.group == 0 and X.n_img % TT == 0)
+
+
+@on_tensor_device
+def temporal_block(pack: PackedTemporal, X: Planes, Y: Planes, TT: int, ln1, ln2, eps: float = 1e-5, cx: Optional["Ctx"] = None) -> None:
+    """Y = Block(X) over the TT tokens of every pixel (update.py:481-484): X fp32 planes with a k-octet copy (the operand), image =
+    clip * TT + frame; Y fp32 planes (+ their k-octet copy Y.shadow).  ln1 / ln2 = (weight, bias) of the two LayerNorms."""
+    cx = _cx(cx)
+    assert temporal_block_ok(pack, X, TT, cx)
+    sh = X.shadow
+    assert sh.f16 and sh.koct and not Y.f16 and Y.rows == 128 and Y.n_img == X.n_img and Y.P == X.P and Y.group == 0
+    pm = pack.products(cx)
+    st = pack.stream(pm)
+    qkv, proj, fc1, fc2 = pack.layers
+    g = _lib.SfTemporalBlock()
+    g.X16, g.strideX, g.ldx = sh.ptr, sh.img_stride, sh.P
+    g.wstream, g.wstream_bytes = st.data_ptr(), st.numel() * 2
+    g.ln1_w, g.ln1_b, g.ln2_w, g.ln2_b = ln1[0].data_ptr(), ln1[1].data_ptr(), ln2[0].data_ptr(), ln2[1].data_ptr()
+    g.bias_proj = None if proj.bias_split is None else proj.bias_split.data_ptr()
+    g.bias_fc1 = None if fc1.bias_split is None else fc1.bias_split.data_ptr()
+    g.bias_fc2 = None if fc2.bias_split is None else fc2.bias_split.data_ptr()
+    g.Y, g.strideY, g.ldy = Y.ptr, Y.img_stride, Y.P
+    nbytes = 2.0 + 4.0
+    if Y.shadow is not None and cx.shadows:
+        g.Y16, g.strideY16, g.ldy16 = Y.shadow.ptr, Y.shadow.img_stride, Y.shadow.P
+        nbytes += 2.0
+    g.N, g.B, g.TT, g.C, g.H, g.pm = X.P, X.n_img // TT, TT, 128, 256, pm
+    g.alpha_qkv, g.alpha_proj, g.alpha_fc1, g.alpha_fc2 = (1.0 / l.split_scale for l in pack.layers)
+    g.ss_proj, g.ss_fc2, g.eps, g.scale = proj.split_scale, fc2.split_scale, eps, 128 ** -0.5
+    n, P = X.n_img, X.P
+    flops = 2.0 * n * P * (384 * 128 + 128 * 128 + 256 * 128 + 128 * 256) + 4.0 * n * P * TT * 128
+    _launch("temporal_block", flops, nbytes * n * 128 * P,
+            lambda: _lib.check(_lib.load().sf_temporal_block(C.byref(g), _lib.stream()), "sf_temporal_block"), products=float(pm))
+
+
 # (K1, M2) of the shapes csrc/ffn_pair.hip is built for, by mode (0: an ffn2 pair, 1: an ffn1 pair)
 PAIR_SHAPES = {1: {(128, 128), (256, 256), (324, 324)}, 0: {(128, 64), (256, 192), (256, 126), (324, 256)}}
 
@@ -442,6 +547,12 @@ def pack_koct(X: Planes, Y: Planes) -> None:
     _launch("pack_koct", 0, 6.0 * X.n_img * X.rows * X.P,
             lambda: _lib.check(_lib.load().sf_pack_koct(X.ptr, X.img_stride, X.n_img, X.rows, X.P, Y.ptr, Y.img_stride,
                                                         _lib.stream()), "sf_pack_koct"))
+
+
+def clock_probe(out: torch.Tensor, spin_us: int) -> None:
+    """Enqueue sf_clock_probe on the CURRENT stream: out (int64[2], device) <- (shader cycles, 100 MHz ticks) over spin_us."""
+    assert out.is_cuda and out.dtype == torch.int64 and out.numel() >= 2 and out.is_contiguous()
+    _lib.check(_lib.load().sf_clock_probe(out.data_ptr(), int(spin_us), _lib.stream()), "sf_clock_probe")
 
 
 def refresh_shadow(X: Planes, cx: Optional[Ctx] = None) -> None:

@@ -90,4 +90,15 @@ for ks, prec, C_ in itertools.product((15, 7, 9), (0, 1, 2, 3), (128, 324, 640))
     call(lib.sf_dwconv_res_gelu_f16in, PTR[0], C_ * 7040, PTR[1], PTR[2], PTR[3], C_ * 7040, 24, C_, 55, 128, ks, prec, None)
 call(lib.sf_coords_grid, PTR[0], 8, 55, 128, None)
 call(lib.sf_coords_grid, None, 8, 55, 128, None)
+for TT, pm, Cc, wb in itertools.product((1, 2, 3, 4, 0), (1, 2, 3), (128, 64), (None, 0)):
+    t = _lib.SfTemporalBlock()
+    t.X16, t.strideX, t.ldx, t.wstream = PTR[0], 128 * 7040, 7040, PTR[1]
+    t.wstream_bytes = (lib.sf_temporal_block_frags(pm) * 1024) if wb is None else wb
+    t.ln1_w, t.ln1_b, t.ln2_w, t.ln2_b, t.bias_proj, t.bias_fc1, t.bias_fc2 = PTR[2], PTR[3], PTR[4], PTR[5], PTR[6], PTR[7], PTR[8]
+    t.Y, t.strideY, t.ldy, t.Y16, t.strideY16, t.ldy16 = PTR[9], 640 * 7040, 7040, PTR[10], 640 * 7040, 7040
+    t.N, t.B, t.TT, t.C, t.H, t.pm = 7040, 8, TT, Cc, 256, pm
+    call(lib.sf_temporal_block, C.byref(t), None)
+call(lib.sf_temporal_block, None, None)
+for out, us in ((PTR[0], 1000), (None, 1000), (PTR[0], 0), (PTR[0], 3000000)):
+    call(lib.sf_clock_probe, out, us, None)
 print(f"host sanitizer driver: {calls} calls, {rejected} rejected or failed at the launch, version {lib.sf_version()}")

@@ -289,3 +289,54 @@ def test_ffn_pair_argument_validation(lib):
     assert lib.sf_ffn_pair(ctypes.byref(g), None) != 0 and b"mode 1 needs" in lib.sf_last_error()
     g.mode, g.M2, g.pm1 = 0, 192, 3
     assert lib.sf_ffn_pair(ctypes.byref(g), None) != 0
+
+
+def test_temporal_block_weight_stream_layout_and_validation(lib):
+    """ops.PackedTemporal: the fragment stream of sf_temporal_block (include/streamflow_hip.h SfTemporalBlock) -- q / k rows of qkv,
+    then per proj k-step the two v row tiles and proj's eight, then per fc2 k-step the two fc1 row tiles and fc2's eight; the columns
+    of proj / fc1 / fc2 k-steps in accumulator order; `lo` before `hi`.  Host-only; plus the entry point's argument checks."""
+    import ctypes
+    import random
+    from streamflow_amd import _lib, ops
+    torch.manual_seed(3)
+    Cc, Hh = 128, 256
+    L = [ops.PackedLinear(torch.randn(3 * Cc, Cc, 1, 1), None, "cpu"), ops.PackedLinear(torch.randn(Cc, Cc, 1, 1), torch.randn(Cc), "cpu"),
+         ops.PackedLinear(torch.randn(Hh, Cc, 1, 1), torch.randn(Hh), "cpu"), ops.PackedLinear(torch.randn(Cc, Hh, 1, 1), torch.randn(Cc), "cpu")]
+    pk = ops.PackedTemporal(*L)
+    assert pk.built() and pk.products(ops.Ctx(precision=ops.PRECISION_F16X2)) == 2
+    L[1].single = True
+    assert pk.products(ops.Ctx(precision=ops.PRECISION_F16X2)) is None and pk.products(ops.Ctx(precision=ops.PRECISION_F16)) == 1
+    L[1].single = False
+    planes = [ops.PackedPair._split(l, l.M, l.K) for l in L]                 # (hi, lo) per layer
+    rnd = random.Random(2)
+    perm = lambda kq, i: 4 * kq + i if i < 4 else 16 + 4 * kq + i - 4
+    for pm in (1, 2):
+        st = pk.stream(pm).view(-1, 64, 8)
+        assert st.shape[0] == lib.sf_temporal_block_frags(pm) == 256 * pm
+        pick = lambda layer, pl: planes[layer][1] if (pm == 2 and pl == 0) else planes[layer][0]
+        for _ in range(400):
+            lane, i, pl = rnd.randrange(64), rnd.randrange(8), rnd.randrange(pm)
+            row, kq = lane & 15, lane >> 4
+            m, s_ = rnd.randrange(16), rnd.randrange(4)                     # phase 1: q / k row tile m, k-step s
+            assert st[(m * 4 + s_) * pm + pl, lane, i] == pick(0, pl)[16 * m + row, 32 * s_ + 8 * kq + i]
+            p_, u, mo = rnd.randrange(4), rnd.randrange(2), rnd.randrange(8)   # phase 2, proj k-step p
+            base = 64 * pm + p_ * 16 * pm
+            assert st[base + (u * 4 + s_) * pm + pl, lane, i] == pick(0, pl)[16 * (16 + 2 * p_ + u) + row, 32 * s_ + 8 * kq + i]
+            assert st[base + 8 * pm + mo * pm + pl, lane, i] == pick(1, pl)[16 * mo + row, 32 * p_ + perm(kq, i)]
+            h = rnd.randrange(8)                                             # phase 3, fc2 k-step h
+            base = 128 * pm + h * 16 * pm
+            assert st[base + (u * 4 + s_) * pm + pl, lane, i] == pick(2, pl)[16 * (2 * h + u) + row, 32 * s_ + perm(kq, i)]
+            assert st[base + 8 * pm + mo * pm + pl, lane, i] == pick(3, pl)[16 * mo + row, 32 * h + perm(kq, i)]
+    g = _lib.SfTemporalBlock()
+    g.X16, g.strideX, g.ldx, g.wstream, g.wstream_bytes = 0x1000, 128 * 64, 64, 0x2000, 512 * 1024
+    g.ln1_w = g.ln1_b = g.ln2_w = g.ln2_b = 0x3000
+    g.Y, g.strideY, g.ldy = 0x4000, 128 * 64, 64
+    g.N, g.B, g.TT, g.C, g.H, g.pm = 64, 1, 3, 128, 256, 2
+    g.TT = 4
+    assert lib.sf_temporal_block(ctypes.byref(g), None) != 0 and b"built for" in lib.sf_last_error()
+    g.TT, g.wstream_bytes = 3, 1024
+    assert lib.sf_temporal_block(ctypes.byref(g), None) != 0 and b"weight stream size" in lib.sf_last_error()
+    g.wstream_bytes, g.X16 = 512 * 1024, 0x1004
+    assert lib.sf_temporal_block(ctypes.byref(g), None) != 0 and b"16-byte aligned" in lib.sf_last_error()
+    g.X16, g.Y = 0x1000, None
+    assert lib.sf_temporal_block(ctypes.byref(g), None) != 0 and b"NULL operand" in lib.sf_last_error()

@@ -44,3 +44,10 @@ for name, col in (("prologue (B loads)", 0), ("whole wave", 6)):
     v = t[:, col]
     print(f"  {name:18s}: mean {v.mean().item():8.0f} median {v.median().item():8.0f} min {v.min().item():8.0f} max {v.max().item():8.0f} cycles")
 print(f"  clock {(t[:, 6].sum() / t[:, 7].sum()).item() * 100:.0f} MHz")
+if EPI == 1 and CF == 2:                            # round structure: when do the workgroups start / end (100 MHz real time)
+    t0 = t[:, 5].min()
+    st, en = (t[:, 5] - t0) / 100.0, (t[:, 5] - t0 + t[:, 7]) / 100.0
+    print(f"  kernel span {en.max().item():.1f} us; wave life mean {(en - st).mean().item():.1f} us")
+    edges = [0, 5, 10, 20, 40, 60, 80, 100, 120, 140, 160, 200, 250, 300, 400, 1000]
+    print("  starts per window [us]:", [(edges[i], int(((st >= edges[i]) & (st < edges[i + 1])).sum().item()) // 4) for i in range(len(edges) - 1)])
+    print("  ends   per window [us]:", [(edges[i], int(((en >= edges[i]) & (en < edges[i + 1])).sum().item()) // 4) for i in range(len(edges) - 1)])
