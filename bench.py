@@ -22,6 +22,7 @@ import statistics
 import subprocess
 import sys
 import time
+from dataclasses import replace
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -596,35 +597,40 @@ def main():
                                  "f16": "weights fp16, activations fp16 (1x v_mfma_f32_32x32x16_f16)"}[args.precision]},
     }
 
-    # The clock the chip SUSTAINS under this step (MI355X clocks to its power budget): a one-wave probe on a side stream reads the
-    # shader-cycle counter against the constant 100 MHz counter while the step replays (sf_clock_probe); the same probe on the idle
-    # device next to it.  Quoted beside the roofline, which prices the matrix-core roof at the guide's 2.4 GHz.
+    # The clock the chip SUSTAINS under this step (MI355X clocks to its power budget): a second engine with the same configuration
+    # forks a one-wave probe (sf_clock_probe: shader-cycle counter against the constant 100 MHz counter) as a BRANCH of its captured
+    # graph for 80 % of the step (a probe launched from another stream beside a graph replay shared a hardware queue with it and ran
+    # before or after it); the same probe on the idle device next to it.  Quoted beside the roofline, which prices the matrix-core
+    # roof at the guide's 2.4 GHz.
     clock = None
-    if rank == 0 and not args.no_kernel_breakdown and args.streams == 1:
-        side, out = torch.cuda.Stream(device=dev), torch.zeros(4, dtype=torch.int64, device=dev)
-        t_step = dt / args.steps / (len(my_batches) if strong else 1)
-        nrep = max(3, int(0.3 / max(t_step, 1e-4)))
-        step()
+    if rank == 0 and not args.no_kernel_breakdown and args.streams == 1 and not strong:
+        from streamflow_amd.engine import EngineOptions
+        t_step = dt / args.steps
+        peng = HotPathEngine(params, device=dev, T=T, use_graph=not args.no_graph,
+                             **dict(cfg, options=replace(cfg.get("options") or EngineOptions(), clock_probe_us=int(1e6 * 0.8 * t_step))))
+        for _ in range(3):
+            peng.forward(fmaps, cnets, iters=iters, all_masks=args.all_masks)
         torch.cuda.synchronize()
-        side.wait_stream(torch.cuda.current_stream())
         t_sec = time.perf_counter()
-        with torch.cuda.stream(side):
-            ops.clock_probe(out[:2], int(1e6 * 0.85 * nrep * t_step))
-        for _ in range(nrep):
-            step()
-        torch.cuda.synchronize()
-        t_sec = time.perf_counter() - t_sec
+        reads = []
+        for _ in range(4):
+            peng.forward(fmaps, cnets, iters=iters, all_masks=args.all_masks)
+            torch.cuda.synchronize()
+            c = [int(v) for v in peng.clock_counts.tolist()]
+            reads.append(100.0 * c[0] / max(c[1], 1))
+        t_sec = (time.perf_counter() - t_sec) / 4
         time.sleep(0.5)
-        with torch.cuda.stream(side):
-            ops.clock_probe(out[2:], 20000)
+        idle = torch.zeros(2, dtype=torch.int64, device=dev)
+        ops.clock_probe(idle, 20000)
         torch.cuda.synchronize()
-        c = [int(v) for v in out.tolist()]
-        clock = {"sustained_mhz": round(100.0 * c[0] / max(c[1], 1), 1), "idle_probe_mhz": round(100.0 * c[2] / max(c[3], 1), 1),
-                 "max_mhz": PEAK_CLOCK_MHZ,
-                 # (probe and replays side by side: the section takes the replays' time, not replays + spin)
-                 "section_ms": round(1e3 * t_sec, 1), "replays_ms": round(1e3 * nrep * t_step, 1),
-                 "method": f"sf_clock_probe on a side stream: shader cycles (s_memtime) / 100 MHz ticks (s_memrealtime) over 85 % of "
-                           f"{nrep} replays of the timed step; idle = the same probe alone for 20 ms after 0.5 s of rest"}
+        ci = [int(v) for v in idle.tolist()]
+        clock = {"sustained_mhz": round(statistics.median(reads), 1), "reads_mhz": [round(r, 1) for r in reads],
+                 "idle_probe_mhz": round(100.0 * ci[0] / max(ci[1], 1), 1), "max_mhz": PEAK_CLOCK_MHZ,
+                 "probed_step_ms": round(1e3 * t_sec, 2),
+                 "method": "sf_clock_probe (shader cycles / 100 MHz ticks) as a branch of the step's own graph for 80 % of the step, 4 "
+                           "steps, median; probed_step_ms = that engine's step (the timed engine has no probe); idle = the same probe alone "
+                           "for 20 ms after 0.5 s of rest"}
+        del peng
         log(f"clock under the step: {clock['sustained_mhz']} MHz (idle probe {clock['idle_probe_mhz']} MHz)")
 
     if rank == 0 and not args.no_kernel_breakdown:
@@ -736,7 +742,7 @@ def main():
             "mfma_busy": mfma_busy_from_profiles(dom),
             "clock": clock,
             "frac_mfma_at_sustained_clock": (round(fam["frac_mfma"] * PEAK_CLOCK_MHZ / clock["sustained_mhz"], 4)
-                                             if (clock and fam["frac_mfma"] and clock["sustained_mhz"] > 0) else None),
+                                             if (clock and fam["frac_mfma"] and clock["sustained_mhz"]) else None),
             "traffic": fam["traffic"], "traffic_note": traffic_why if fam["traffic"] is None else (
                 f"bytes per launch, mean over the family: 2 x FETCH_SIZE + WRITE_SIZE from separate rocprofv3 --pmc passes of this "
                 f"workload on these kernel sources ({os.path.relpath(tfile, ROOT)})"),

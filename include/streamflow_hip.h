@@ -299,7 +299,8 @@ int sf_gma_flash_project_v(void* ws, int64_t ws_bytes, const void* x_koct, int64
  *   planes [M2/8][ldc16][8], optional; c16_partial: rows >= M2 of the last octet are not written).
  * mode 1 (an ffn1 pair, M2 == K1): x1 = gelu(x + y); x2 = gelu(x1 + dw_w * x1 + dw_b)  (update.py:31-32: residual, then the
  *   depthwise 1x1 layer of conv_list); C16 = x2 as fp16 ROWS [M2][ldc16].  The residual is the fp16 operand itself.
- * Shapes built: the SK blocks of the update block (C = 128 / 256 / 324; see the dispatch table in csrc/ffn_pair.hip). */
+ * Shapes built: the SK blocks of the update block (C = 128 / 256 / 324) and the flow head (384 / 256 / 128 -> 2 (T - 1) rows); see the
+ * dispatch table in csrc/ffn_pair.hip. */
 typedef struct SfFfnPair {
     const void* X; int64_t strideX; int64_t ldx;
     const void* wstream; int64_t wstream_bytes;
@@ -308,6 +309,9 @@ typedef struct SfFfnPair {
     void* C16; int64_t strideC16; int64_t ldc16;
     int32_t N, batch, K1, H, M2, pm1, pm2, mode, gelu_out, c16_partial;
     float alpha1, alpha2;
+    int32_t x_group; int64_t x_group_stride;   /* x_group > 0: X's K1 rows are x_group-row slices (a multiple of 32 that divides K1) of
+                                                  consecutive groups x_group_stride halves apart -- the flow head's '(B T) C -> B (T C)'
+                                                  view of the hidden state (update.py:775) without a copy; 0: plain planes */
 } SfFfnPair;
 int sf_ffn_pair(const SfFfnPair* p, void* stream);
 int sf_ffn_pair_frags(int K1, int M2, int pm1, int pm2);

@@ -55,6 +55,7 @@ class SfFfnPair(C.Structure):
         ("N", C.c_int32), ("batch", C.c_int32), ("K1", C.c_int32), ("H", C.c_int32), ("M2", C.c_int32),
         ("pm1", C.c_int32), ("pm2", C.c_int32), ("mode", C.c_int32), ("gelu_out", C.c_int32), ("c16_partial", C.c_int32),
         ("alpha1", _f), ("alpha2", _f),
+        ("x_group", C.c_int32), ("x_group_stride", _i64),
     ]
 
 

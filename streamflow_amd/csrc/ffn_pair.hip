@@ -64,6 +64,7 @@ struct PairArgs {
     SfFfnPair p;
     int ntile;            // pixel tiles per image
     int hp;               // hidden row pairs of 16 = ceil(H / 32)
+    int x_span;           // bytes of one image (all its groups) of X as the kernel addresses it
     int64_t w_bytes;      // bytes of the packed weight stream
 };
 
@@ -124,15 +125,20 @@ __global__ __launch_bounds__(NW * 64, (NW == 8) ? 4 : ((NK1 > 8 && MODE == 1) ? 
     for (int i = tid; i < NT2 * 16; i += kThreads) sb2[i] = (i < g.M2 && g.bias2) ? g.bias2[i] : 0.f;
 
     // ---- layer-1 B operand: the K1 channels of this lane's pixel (k-octet 4 s + kq of k-step s) ----
+    // (x_group > 0: the K1 rows are x_group-row slices of consecutive images, '(B T) C -> B (T C)': octet oc lives in group
+    // oc / goct at octet oc % goct; a k-step never straddles a group: x_group % 32 == 0, host-checked)
     const int noct = (g.K1 + 7) / 8;
+    const int goct = g.x_group > 0 ? g.x_group / 8 : noct;         // octets per group (wave-uniform)
+    const int gbytes = g.x_group > 0 ? (int)(g.x_group_stride * 2) : 0;
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char*>(reinterpret_cast<const char*>(g.X)) + (int64_t)z * g.strideX * 2, 0, (int)((int64_t)noct * g.ldx * 16), 0x00020000);
+        const_cast<char*>(reinterpret_cast<const char*>(g.X)) + (int64_t)z * g.strideX * 2, 0, a.x_span, 0x00020000);
     f16x8 b[NK1];
 #pragma unroll
     for (int s = 0; s < NK1; ++s) {
         const int oc = 4 * s + kq;
+        const int og = __builtin_amdgcn_readfirstlane((4 * s) / goct);          // group of the k-step
         b[s] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(
-            rx, (pin && oc < noct) ? (oc * (int)g.ldx + px) * 16 : kOob, 0, 0));
+            rx, (pin && oc < noct) ? ((oc - og * goct) * (int)g.ldx + px) * 16 : kOob, og * gbytes, 0));
     }
     wait_vm<0>();
     __syncthreads();
@@ -289,9 +295,11 @@ __global__ __launch_bounds__(NW * 64, (NW == 8) ? 4 : ((NK1 > 8 && MODE == 1) ? 
         for (int t0 = 0; t0 < NT2; t0 += CH) {
         u32x2 rk[CH];
 #pragma unroll
-        for (int c = 0; c < CH; ++c)
+        for (int c = 0; c < CH; ++c) {
+            const int og = __builtin_amdgcn_readfirstlane((2 * (t0 + c)) / goct);          // (goct is even: the pair of octets shares a group)
             rk[c] = __builtin_amdgcn_raw_buffer_load_b64(rx, (pin && 2 * (t0 + c) + (kq >> 1) < noct) ? vr : kOob,
-                                                         2 * (t0 + c) * (int)g.ldx * 16, 0);
+                                                         og * gbytes + (2 * (t0 + c) - og * goct) * (int)g.ldx * 16, 0);
+        }
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
             const int t = t0 + c;
@@ -365,7 +373,11 @@ extern "C" int sf_ffn_pair(const SfFfnPair* p, void* stream) {
                    (reinterpret_cast<uintptr_t>(g.wstream) & 15) == 0,
                "sf_ffn_pair: X (k-octet planes) and the weight stream must be 16-byte aligned, strideX %% 8 == 0, ldx >= N");
     const int64_t lim = (int64_t)1 << 30;
-    SF_REQUIRE((int64_t)((g.K1 + 7) / 8) * g.ldx * 16 < lim, "sf_ffn_pair: input image larger than 1 GiB");
+    SF_REQUIRE(g.x_group >= 0 && (g.x_group == 0 || (g.x_group % 32 == 0 && g.K1 % g.x_group == 0 && (g.x_group_stride & 7) == 0 && g.x_group_stride >= 0)),
+               "sf_ffn_pair: x_group must be 0 or a multiple of 32 that divides K1, x_group_stride %% 8 == 0");
+    const int64_t x_span = g.x_group > 0 ? (int64_t)(g.K1 / g.x_group - 1) * g.x_group_stride * 2 + (int64_t)(g.x_group / 8) * g.ldx * 16
+                                         : (int64_t)((g.K1 + 7) / 8) * g.ldx * 16;
+    SF_REQUIRE(x_span < lim, "sf_ffn_pair: input image larger than 1 GiB");
     if (g.mode == 0) {
         SF_REQUIRE(g.C || g.C16, "sf_ffn_pair: mode 0 needs C (fp32 planes) and / or C16 (k-octet planes)");
         SF_REQUIRE(!g.C16 || ((reinterpret_cast<uintptr_t>(g.C16) & 15) == 0 && (g.strideC16 & 7) == 0 && g.ldc16 >= g.N &&
@@ -383,6 +395,7 @@ extern "C" int sf_ffn_pair(const SfFfnPair* p, void* stream) {
     a.p = g;
     a.ntile = 0;
     a.hp = (g.H + 31) / 32;
+    a.x_span = (int)x_span;
     const int fpad = sf_ffn_pair_frags(g.K1, g.M2, g.pm1, g.pm2);
     SF_REQUIRE(fpad > 0, "sf_ffn_pair: products must be 1 or 2");
     a.w_bytes = (int64_t)a.hp * fpad * 1024;
@@ -401,6 +414,11 @@ extern "C" int sf_ffn_pair(const SfFfnPair* p, void* stream) {
     SF_PAIR_CASE(8, 12, 0, 8);     // convc2.ffn2   256 -> 384 -> 192
     SF_PAIR_CASE(8, 8, 0, 8);      // conv.ffn2     256 -> 384 -> 126
     SF_PAIR_CASE(11, 16, 0, 4);    // convc1.ffn2   324 -> 486 -> 256
+    // the flow head (update.py:744, 775): its input is the '(B T) C -> B (T C)' view of the hidden state (x_group = 128), T - 1 = 3 / 2 / 1 frames
+    SF_PAIR_CASE(12, 24, 1, 4);    // flow_head.ffn1   384 -> 576 -> 384   (T = 4)
+    SF_PAIR_CASE(12, 1, 0, 8);     // flow_head.ffn2   384 -> 576 -> 6
+    SF_PAIR_CASE(8, 1, 0, 8);      //                  256 -> 384 -> 4     (T = 3; its ffn1 is the 256 -> 384 -> 256 case above)
+    SF_PAIR_CASE(4, 1, 0, 8);      //                  128 -> 192 -> 2     (T = 2)
 #undef SF_PAIR_CASE
     return sf::fail(SF_ERR_UNSUPPORTED, "sf_ffn_pair: shape K1 = %d, M2 = %d, mode %d not built", g.K1, g.M2, g.mode);
 }

@@ -49,6 +49,8 @@ class EngineOptions:
     ffn_pairs: bool = True           # the SK blocks' ffn1 / ffn2 pairs as one launch each where the shape is built (sf_ffn_pair)
     project_v: bool = True           # fused GMA, fp16 activations: to_v + the v pack as one launch (sf_gma_flash_project_v)
     temporal_block: bool = True      # the temporal transformer block as ONE launch (sf_temporal_block) instead of seven
+    clock_probe_us: int = 0          # measurement aid: > 0 forks sf_clock_probe for that long beside every forward (results in
+                                     # engine.clock_counts: shader cycles, 100 MHz ticks); a graph branch like any other
     setup_overlap: bool = True       # the context chain of the setup (split, to_qk, GMA pack / statistics) beside the volume build
     max_plans: int = 4               # buffer sets (and graphs) kept, least recently used evicted
 
@@ -154,8 +156,12 @@ def run_skblock(W: SKBlockWeights, X: Planes, Y: Planes, hid: Planes, xa: Planes
         # rows (half the bytes out of this GEMM and into the depthwise kernel, which then stages its strips by DMA)
         a = _scratch(xa, X.n_img, C, f16=True)
     # x1 = gelu(x + ffn1(x)); x2 = gelu(x1 + dw1x1(x1))  (both fused in the epilogue)
-    if cx.ffn_pairs and a.f16 and X.f16 and X.koct and ops.ffn_pair_ok(W.pair1, X, 1, cx):
-        # the block input exists as k-octets only (operand AND residual): the whole ffn1 + epilogue is one launch, the 1.5 C
+    # (the flow head's pairs pay with enough pixels to fill the chip at 64 per workgroup: 8 clips 63.3 vs 63.8 ms per step, one
+    # clip 220 vs 226 ff/s the other way -- its GEMM launches split M for small grids)
+    head_pairs = X.group and X.shadow is not None and X.n_img * X.P >= 4 * 7040
+    if cx.ffn_pairs and a.f16 and ((X.f16 and X.koct) or head_pairs) and ops.ffn_pair_ok(W.pair1, X, 1, cx):
+        # the block input exists as k-octets only (operand AND residual) -- or it is the flow head's grouped view of the hidden
+        # state, whose k-octet copy is the operand and (round 5) the residual: the whole ffn1 + epilogue is one launch, the 1.5 C
         # hidden tensor stays in registers (csrc/ffn_pair.hip)
         ops.ffn_pair(W.pair1, X, a, 1, dw_w=W.dw1_w, dw_b=W.dw1_b, cx=cx)
     else:
@@ -178,7 +184,7 @@ def run_skblock(W: SKBlockWeights, X: Planes, Y: Planes, hid: Planes, xa: Planes
         ops.gemm(W.pw, b, a4, EPI_RES_GELU, R=b, cx=cx)                         # x4 = gelu(x3 + pw(x3))
     # (ffn2 pairs with hi + lo weights measured no faster than their two launches at C >= 256 -- 144 vs ~135 us at 256 -> 384 -> 192:
     # twice the MFMAs on 16 x 16 x 32 tiles, whose fragment reads bind -- so those stay on the 32 x 32 x 16 kernels)
-    pair2_pays = W.c_in <= 128 or W.pair2.products(cx) == (1, 1)
+    pair2_pays = W.c_in <= 128 or W.pair2.products(cx) == (1, 1) or (W.c_out <= 16 and head_pairs)   # (the flow head: layer 2 is one 16-row tile)
     if (cx.ffn_pairs and pair2_pays and a4.f16 and a4.koct and ops.ffn_pair_ok(W.pair2, a4, 0, cx) and (not Y.f16 or Y.koct)):
         ops.ffn_pair(W.pair2, a4, Y, 0, gelu_out=final_gelu, cx=cx)                 # y = ffn2(x4): one launch
         return
@@ -424,6 +430,9 @@ class HotPathEngine:
         if self.flash_qk_products not in (1, 2, 3):
             raise RuntimeError(f"flash_qk_products must be 1, 2 or 3, got {self.flash_qk_products}")
         self._side = torch.cuda.Stream(device=self.device)
+        if int(self.options.clock_probe_us) > 0:
+            self._probe_stream = torch.cuda.Stream(device=self.device)
+            self.clock_counts = torch.zeros(2, dtype=torch.int64, device=self.device)
         self._chain_streams = [torch.cuda.Stream(device=self.device) for _ in range(3)]
         # Where the main stream has no concurrent branch (corr encoder, motion-encoder tail, GRU + flow head) a batch of an
         # even number of clips is cut in two halves that run as two chains on two streams: a dependent kernel boundary costs
@@ -698,9 +707,17 @@ class HotPathEngine:
 
     def _run(self, pl: _Plan, fmaps: torch.Tensor, cnets: torch.Tensor, iters: int, all_masks: bool) -> None:
         cx = self._ctx(pl)
+        probe = int(self.options.clock_probe_us)
+        if probe > 0:                                   # the clock under THIS forward: a branch of the launch sequence (and of its graph)
+            main = torch.cuda.current_stream()
+            self._probe_stream.wait_stream(main)
+            with torch.cuda.stream(self._probe_stream):
+                ops.clock_probe(self.clock_counts, probe)
         self._setup(cx, pl, fmaps, cnets)
         for it in range(iters):
             self._iteration(cx, pl, with_mask=all_masks or it == iters - 1)
+        if probe > 0:
+            torch.cuda.current_stream().wait_stream(self._probe_stream)
         flow_t = pl.flow.tensor().view(pl.n, 2, pl.h, pl.w)
         mask_t = pl.mask.tensor().view(pl.n, 576, pl.h, pl.w)
         _lib.check(_lib.load().sf_upsample_flow(flow_t.data_ptr(), mask_t.data_ptr(), pl.up.data_ptr(), pl.n, pl.h,

@@ -468,17 +468,18 @@ def temporal_block(pack: PackedTemporal, X: Planes, Y: Planes, TT: int, ln1, ln2
 
 
 # (K1, M2) of the shapes csrc/ffn_pair.hip is built for, by mode (0: an ffn2 pair, 1: an ffn1 pair)
-PAIR_SHAPES = {1: {(128, 128), (256, 256), (324, 324)}, 0: {(128, 64), (256, 192), (256, 126), (324, 256)}}
+PAIR_SHAPES = {1: {(128, 128), (256, 256), (324, 324), (384, 384)},
+               0: {(128, 64), (256, 192), (256, 126), (324, 256), (384, 6), (256, 4), (128, 2)}}
 
 
 def ffn_pair_ok(pair: Optional[PackedPair], X: Planes, mode: int, cx: Optional["Ctx"] = None) -> bool:
-    """Does sf_ffn_pair run this FFN?  fp16-activation arithmetic with k-octet hand-over, an ungrouped k-octet operand (the
-    planes themselves or their copy), one of the built shapes."""
+    """Does sf_ffn_pair run this FFN?  fp16-activation arithmetic with k-octet hand-over, a k-octet operand (the planes themselves
+    or their copy; grouped '(B T) C -> B (T C)' views in groups of a multiple of 32 rows), one of the built shapes."""
     cx = _cx(cx)
     if pair is None or cx.precision not in (PRECISION_F16X2, PRECISION_F16) or not (cx.shadows and cx.hidden_f16 and cx.hidden_koct):
         return False
     src = X if (X.f16 and X.koct) else X.shadow
-    if src is None or src.group or X.group or X.P % 4:
+    if src is None or X.P % 4 or (src.group and (src.group % 32 or pair.K1 % src.group)):
         return False
     pm = pair.products(cx)
     return (pair.K1, pair.M2) in PAIR_SHAPES[mode] and pm in ((1, 1), (2, 1), (2, 2))
@@ -497,6 +498,7 @@ def ffn_pair(pair: PackedPair, X: Planes, Y: Planes, mode: int, dw_w: Optional[t
     st = pair.stream(pm1, pm2)
     g = _lib.SfFfnPair()
     g.X, g.strideX, g.ldx = src.ptr, src.img_stride, src.P
+    g.x_group, g.x_group_stride = src.group, src.group_stride
     g.wstream, g.wstream_bytes = st.data_ptr(), st.numel() * 2
     A1, A2 = pair.first, pair.second
     g.bias1 = None if A1.bias_split is None else A1.bias_split.data_ptr()

@@ -69,6 +69,9 @@ for (K1, H, M2), mode, pm1, pm2, part in itertools.product(((128, 192, 64), (128
     p.N, p.batch, p.K1, p.H, p.M2, p.pm1, p.pm2, p.mode, p.c16_partial = 7040, 24, K1, H, M2, pm1, pm2, mode, part
     p.alpha1 = p.alpha2 = 1.0
     call(lib.sf_ffn_pair, C.byref(p), None)
+    for xg, xs in ((128, 640 * 7040), (48, 640 * 7040), (128, 3), (-8, 0)):          # the flow head's grouped view, and what is not one
+        p.x_group, p.x_group_stride = xg, xs
+        call(lib.sf_ffn_pair, C.byref(p), None)
 
 # correlation, GMA, depthwise, element-wise entry points: good and bad arguments
 strides = (C.c_int64 * 4)(*[8 * 7040 * (55 >> l) * (128 >> l) for l in range(4)])

@@ -8,8 +8,8 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-FFN1 = [(128, 192), (256, 384), (324, 486)]                      # (C, 1.5 C): mode 1, M2 = C
-FFN2 = [(128, 192, 64), (256, 384, 192), (256, 384, 126), (324, 486, 256)]
+FFN1 = [(128, 192), (256, 384), (324, 486), (384, 576)]          # (C, 1.5 C): mode 1, M2 = C
+FFN2 = [(128, 192, 64), (256, 384, 192), (256, 384, 126), (324, 486, 256), (384, 576, 6), (256, 384, 4), (128, 192, 2)]
 
 
 @pytest.fixture(scope="module")
@@ -206,3 +206,49 @@ def test_gma_flash_is_deterministic(dev, qkp):
     torch.cuda.synchronize()
     for o in outs[1:]:
         assert torch.equal(o, outs[0])
+
+
+@pytest.mark.parametrize("pm", [(1, 1), (2, 2)])
+@pytest.mark.parametrize("frames", [1, 2, 3])
+def test_flow_head_pairs_on_the_grouped_view(dev, frames, pm):
+    """The flow head's input is the '(B T) C -> B (T C)' view of the hidden state (update.py:775: 128-row slices of T - 1 consecutive
+    images): sf_ffn_pair addresses it in place (x_group = 128).  Both pairs of the block against the same launches on a gathered,
+    plain copy of that view (bit-identical: same fragments, same order)."""
+    from dataclasses import replace
+    from streamflow_amd import ops
+    from streamflow_amd.ops import Planes
+    B, P, Cg = 3, 1000, 128
+    C, H, M2 = Cg * frames, Cg * frames * 3 // 2, 2 * frames
+    g = torch.Generator().manual_seed(frames * 10 + pm[0])
+    # a wider parent buffer (like the engine's 640-row concat): the hidden state in rows 0 .. 127 of every image
+    rows = 640
+    parent = torch.randn(B * frames, rows, P, generator=g)
+    par16 = _koct(parent, dev, ops)                                            # k-octet copy of the whole parent
+    img16 = par16.img_stride
+    Xg = Planes(par16.base, par16.off, frames * img16, B, C, P, f16=True, koct=True, group=Cg, group_stride=img16)
+    plain = parent[:, :Cg].reshape(B, frames * Cg, P).contiguous()
+    Xp = _koct(plain, dev, ops)
+    cx = ops.Ctx(precision=ops.PRECISION_F16X2)
+    # ffn1 pair (mode 1)
+    A1, A2, pair, b1, b2, g2 = _layers(C, H, C, 3 + frames, dev, pm)
+    dw_w, dw_b = (torch.randn(C, generator=g2) * 0.5).to(dev), (torch.randn(C, generator=g2) * 0.1).to(dev)
+    assert ops.ffn_pair_ok(pair, Xg, 1, cx) and ops.ffn_pair_ok(pair, Xp, 1, cx)
+    outs = []
+    for X in (Xg, Xp):
+        Y = Planes(torch.full((B * C * P // 2 + 8,), float("nan"), device=dev), 0, C * P, B, C, P, f16=True)
+        ops.ffn_pair(pair, X, Y, 1, dw_w=dw_w, dw_b=dw_b, cx=cx)
+        outs.append(Y.tensor().clone())
+    assert bool(torch.isfinite(outs[0]).all()) and torch.equal(outs[0], outs[1])
+    # ffn2 pair (mode 0, 2 (T - 1) output rows, fp32 planes)
+    A1, A2, pair, b1, b2, g2 = _layers(C, H, M2, 5 + frames, dev, pm)
+    assert ops.ffn_pair_ok(pair, Xg, 0, cx)
+    outs = []
+    for X in (Xg, Xp):
+        y = torch.full((B, M2, P), float("nan"), device=dev)
+        ops.ffn_pair(pair, X, Planes.of(y), 0, cx=cx)
+        outs.append(y.clone())
+    assert bool(torch.isfinite(outs[0]).all()) and torch.equal(outs[0], outs[1])
+    x16 = plain.half().double()
+    hid = F.gelu(torch.einsum("hk,nkp->nhp", _weff(A1, pm[0] == 1), x16) + b1.double()[None, :, None]).half().double()
+    ref = torch.einsum("mh,nhp->nmp", _weff(A2, pm[1] == 1), hid) + b2.double()[None, :, None]
+    assert (outs[0].double().cpu() - ref).abs().max().item() < 2e-3 * max(1.0, ref.abs().max().item())
