@@ -185,6 +185,8 @@ def run_skblock(W: SKBlockWeights, X: Planes, Y: Planes, hid: Planes, xa: Planes
     # (ffn2 pairs with hi + lo weights measured no faster than their two launches at C >= 256 -- 144 vs ~135 us at 256 -> 384 -> 192:
     # twice the MFMAs on 16 x 16 x 32 tiles, whose fragment reads bind -- so those stay on the 32 x 32 x 16 kernels)
     pair2_pays = W.c_in <= 128 or W.pair2.products(cx) == (1, 1) or (W.c_out <= 16 and head_pairs)   # (the flow head: layer 2 is one 16-row tile)
+    if X.n_img * X.P < 4 * 7040 and not X.group:            # (a small launch is latency-bound: one launch instead of two, +0.7 % on a single clip)
+        pair2_pays = True
     if (cx.ffn_pairs and pair2_pays and a4.f16 and a4.koct and ops.ffn_pair_ok(W.pair2, a4, 0, cx) and (not Y.f16 or Y.koct)):
         ops.ffn_pair(W.pair2, a4, Y, 0, gelu_out=final_gelu, cx=cx)                 # y = ffn2(x4): one launch
         return
