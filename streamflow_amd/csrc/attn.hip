@@ -24,6 +24,10 @@
 // logits).  P and V are single fp16 (the materialised path already stores the attention matrix in fp16).
 #include "sf_common.h"
 
+#ifndef SF_FLASH_XCD_MAP
+#define SF_FLASH_XCD_MAP 1
+#endif
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -195,7 +199,15 @@ __global__ __launch_bounds__(256, (QKP == 3) ? 1 : ((QKP == 1 && SF_FLASH_V1) ? 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int khalf = lane >> 5, l31 = lane & 31;
+    // (query tile, image) from the linear workgroup id such that every XCD walks whole images: the K / V planes of an image (3.6 MB at
+    // the Sintel grid) are read by all its query tiles and live in ONE XCD's L2 instead of eight (round 5; FETCH_SIZE of the kernel
+    // 889 -> see profiles: the requests went to the Infinity Cache before)
+#if SF_FLASH_XCD_MAP
+    const int wg_lin = sf::xcd_linear_id((int)(blockIdx.x + gridDim.x * blockIdx.y), (int)(gridDim.x * gridDim.y));
+    const int img = wg_lin / (int)gridDim.x, q0 = (wg_lin % (int)gridDim.x) * BQ;
+#else
     const int img = blockIdx.y, q0 = blockIdx.x * BQ;
+#endif
     const int P = g.P, Ppad = g.Ppad;
     const int plane = (int)plane_bytes(Ppad);                       // < 2 GiB (host-checked)
     const char* ws = g.ws + (int64_t)img * img_ws_bytes(Ppad);

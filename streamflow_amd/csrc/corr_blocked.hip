@@ -400,6 +400,9 @@ constexpr int LP = 32;                          // source pixels per workgroup
 constexpr int NCH = 324, NOCT = 41;
 constexpr int TROW = NOCT * 8;                  // halves per pixel in the transpose buffer (656 bytes: 16-byte aligned rows,
                                                 // 164 dwords = 36 mod 64: the 16-byte read-back of 16 pixels is conflict-free)
+#ifndef SF_LOOKB_W2_ALWAYS
+#define SF_LOOKB_W2_ALWAYS 0
+#endif
 #ifndef SF_LOOKB_WAVES
 #define SF_LOOKB_WAVES 4                        // waves per SIMD the register budget is sized for
 #endif
@@ -473,7 +476,13 @@ __global__ __launch_bounds__(kThreads, SF_LOOKB_WAVES) void corr_lookup_blocked_
         Foot f;
         f.w0 = __builtin_amdgcn_raw_buffer_load_b128(rv, piece(0), 0, 0);
         f.w1 = __builtin_amdgcn_raw_buffer_load_b128(rv, piece(1), 0, 0);
-        f.w2 = __builtin_amdgcn_raw_buffer_load_b32(rv, piece(2), 0, 0);      // rows 16, 17: only needed when ys % 8 == 7
+        // rows 16, 17 (a third block row) are part of the footprint only when ys % 8 == 7: requested only then -- an unconditional
+        // 4-byte request pulled two more 128-byte lines per level into L2 for seven footprints of eight (round 5)
+#if SF_LOOKB_W2_ALWAYS
+        f.w2 = __builtin_amdgcn_raw_buffer_load_b32(rv, piece(2), 0, 0);
+#else
+        f.w2 = __builtin_amdgcn_raw_buffer_load_b32(rv, ((ys & 7) == 7) ? piece(2) : kDrop, 0, 0);
+#endif
         return f;
     };
 

@@ -956,6 +956,35 @@ def test_bench_contract_line(dev):
     assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
     assert set(d["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"} and d["cpu_baseline"]["kind"] == "port"
     assert d["epe_vs_oracle"]["value"] <= 1e-3
+    # the clock under the step, measured by a probe that is a branch of the step's own graph: a plausible shader clock
+    c = d["roofline"]["clock"]
+    assert 500.0 < c["sustained_mhz"] <= 2600.0 and 500.0 < c["idle_probe_mhz"] <= 2600.0 and len(c["reads_mhz"]) == 4
+
+
+@pytest.mark.gpu
+def test_clock_probe_branch_leaves_the_results_alone(dev):
+    """EngineOptions.clock_probe_us forks sf_clock_probe beside the forward (eager and as a branch of the captured graph): same flows
+    bit for bit, a plausible clock in engine.clock_counts, and the forward lasts at least the probe's spin."""
+    import time
+    from streamflow_amd import presets, synthetic as syn
+    from streamflow_amd.engine import EngineOptions, HotPathEngine
+    T, B, h, w = 4, 2, 32, 48
+    params = syn.make_params(3, T)
+    fm, cn = (t.to(dev) for t in syn.make_features(77, B, T, h, w))
+    kw = presets.engine_kwargs("config2_mixed")
+    ref = [f.clone() for f in HotPathEngine(params, device=dev, T=T, use_graph=True, **kw).forward(fm, cn, iters=3)[0]]
+    for graph in (False, True):
+        eng = HotPathEngine(params, device=dev, T=T, use_graph=graph, options=EngineOptions(clock_probe_us=20000), **kw)
+        for _ in range(2):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            out = eng.forward(fm, cn, iters=3)[0]
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        assert all(torch.equal(a, b) for a, b in zip(ref, out))
+        cyc, ticks = (int(v) for v in eng.clock_counts.tolist())
+        assert ticks >= 20000 * 100 and 500.0 < 100.0 * cyc / ticks <= 2600.0
+        assert dt >= 0.02
 
 
 @pytest.mark.gpu
