@@ -347,6 +347,25 @@ typedef struct SfTemporalBlock {
 int sf_temporal_block(const SfTemporalBlock* p, void* stream);
 int sf_temporal_block_frags(int pm);
 
+/* ---- f2: mask head, second layer + convex upsampling in ONE launch (core/update.py:756-759,777 + core/models/streamflow.py:82-93;
+ * csrc/mask_upsample.hip) ------------------------------------------------------------------------------------------------------
+ * out[n][c][8 y + i][8 x + j] = sum_k softmax_k(mask[n][64 k + 8 i + j][y][x]) * 8 flow[n][c][y + k / 3 - 1][x + k % 3 - 1]  (0 outside),
+ * mask = alpha * (W x + bias) with W the 576 x 256 weights of mask.2 and alpha = 0.25 / (the weights' power-of-two pre-scale): the
+ * unfused form is sf_gemm (mask.2) + sf_upsample_flow, with the 576-channel mask written and read back in between.
+ * X16: relu(mask.0(net)) as fp16 k-octet planes [256/8][ldx][8] per image (strideX in halves) -- sf_gemm's c_f16 = 3 copy;
+ * wstream: the weights as 1-KB fragments (16 rows x 32 k, lane (row, kq) = 8 halves W[row][32 s + 8 kq ..]; pm = 2: `lo` before `hi`)
+ *   in the order row tile 0 .. 35, k-step 0 .. 7 (streamflow_amd.ops.PackedMask): sf_mask_upsample_frags(pm) fragments;
+ * bias: 576 floats carrying the pre-scale (or NULL); flow [n][2][h][w] fp32; out [n][2][8h][8w] fp32, 16-byte aligned. */
+typedef struct SfMaskUpsample {
+    const void* X16; int64_t strideX, ldx;
+    const void* wstream; int64_t wstream_bytes;
+    const float* bias; const float* flow; float* out;
+    int32_t n_img, h, w, K, M, pm;
+    float alpha;
+} SfMaskUpsample;
+int sf_mask_upsample(const SfMaskUpsample* p, void* stream);
+int sf_mask_upsample_frags(int pm);
+
 /* ---- row softmax (gma.py:63): x [rows][cols] ----------------------------------------------------
  * out_f16 == NULL: in place.  Otherwise the weights are written as IEEE fp16 to out_f16 [rows][cols] (x is then
  * scratch): the attention matrix is re-read by every refinement iteration's attn @ v and that read is HBM-bound,

@@ -72,6 +72,16 @@ class SfTemporalBlock(C.Structure):
     ]
 
 
+class SfMaskUpsample(C.Structure):
+    _fields_ = [
+        ("X16", _vp), ("strideX", _i64), ("ldx", _i64),
+        ("wstream", _vp), ("wstream_bytes", _i64),
+        ("bias", _vp), ("flow", _vp), ("out", _vp),
+        ("n_img", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("K", C.c_int32), ("M", C.c_int32), ("pm", C.c_int32),
+        ("alpha", _f),
+    ]
+
+
 # name -> (restype, argtypes); must list every symbol of include/streamflow_hip.h
 SIGNATURES = {
     "sf_version": (_i, []),
@@ -103,6 +113,8 @@ SIGNATURES = {
     "sf_ffn_pair_frags": (_i, [_i, _i, _i, _i]),
     "sf_temporal_block": (_i, [C.POINTER(SfTemporalBlock), _vp]),
     "sf_temporal_block_frags": (_i, [_i]),
+    "sf_mask_upsample": (_i, [C.POINTER(SfMaskUpsample), _vp]),
+    "sf_mask_upsample_frags": (_i, [_i]),
     "sf_softmax_rows": (_i, [_vp, _i64, _i, _vp, _vp]),
     "sf_splitk_combine": (_i, [_vp, _i64, _i, _i64, _vp, _i64, _vp, _vp, _i64, _i, _i64, _vp]),
     "sf_dwconv_res_gelu": (_i, [_vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _i, _vp]),

@@ -49,6 +49,7 @@ class EngineOptions:
     ffn_pairs: bool = True           # the SK blocks' ffn1 / ffn2 pairs as one launch each where the shape is built (sf_ffn_pair)
     project_v: bool = True           # fused GMA, fp16 activations: to_v + the v pack as one launch (sf_gma_flash_project_v)
     temporal_block: bool = True      # the temporal transformer block as ONE launch (sf_temporal_block) instead of seven
+    mask_upsample: bool = True       # mask head's second layer + convex upsampling as ONE launch (sf_mask_upsample): the mask is never written
     clock_probe_us: int = 0          # measurement aid: > 0 forks sf_clock_probe for that long beside every forward (results in
                                      # engine.clock_counts: shader cycles, 100 MHz ticks); a graph branch like any other
     setup_overlap: bool = True       # the context chain of the setup (split, to_qk, GMA pack / statistics) beside the volume build
@@ -230,6 +231,7 @@ class HotPathWeights:
         self.fc1 = PackedLinear(sd[tb + ".mlp.fc1.weight"], sd[tb + ".mlp.fc1.bias"], device)
         self.fc2 = PackedLinear(sd[tb + ".mlp.fc2.weight"], sd[tb + ".mlp.fc2.bias"], device)
         self.temporal = ops.PackedTemporal(self.qkv, self.proj, self.fc1, self.fc2)
+        self.mask_pack = ops.PackedMask(self.mask2)
 
     SK_BLOCKS = ("convc1", "convc2", "convf2", "conv", "gru", "flow_head")
     SK_LAYERS = ("ffn1_0", "ffn1_2", "pw", "ffn2_0", "ffn2_2")
@@ -347,7 +349,7 @@ class _Plan:
         # the first GEMM of a block reads the copy by LDS-DMA, its residual epilogue and every other kernel the planes
         self.shadows = bool(shadows)
         if self.shadows:
-            for name in (() if self.koct_io else ("cor256", "cat256")) + ("concat",) + (() if self.corr_blocked else ("corr",)):
+            for name in (() if self.koct_io else ("cor256", "cat256")) + ("concat", "m256") + (() if self.corr_blocked else ("corr",)):
                 setattr(self, name, replace(getattr(self, name), shadow=ops.new_shadow(getattr(self, name), device)))
         self.nets = self.concat.slice(0, 128)
         self.inps = self.concat.slice(128, 256)
@@ -455,6 +457,10 @@ class HotPathEngine:
                         if (pair.K1, pair.M2) in ops.PAIR_SHAPES[0] | ops.PAIR_SHAPES[1]:
                             pair.stream(*pair.products(cxp))
                 torch.cuda.synchronize(self.device)
+        if self.options.mask_upsample and self.precision in (ops.PRECISION_F16X2, ops.PRECISION_F16) and self.W.mask_pack.built():
+            with torch.cuda.device(self.device):
+                self.W.mask_pack.stream(self.W.mask_pack.products(ops.Ctx(precision=self.precision)))
+                torch.cuda.synchronize(self.device)
         if self.options.temporal_block and self.precision in (ops.PRECISION_F16X2, ops.PRECISION_F16) and self.W.temporal.built():
             pm = self.W.temporal.products(ops.Ctx(precision=self.precision))
             if pm is not None:
@@ -546,7 +552,7 @@ class HotPathEngine:
         if side is not main:
             main.wait_stream(side)
 
-    def _iteration(self, cx: ops.Ctx, pl: _Plan, with_mask: bool) -> None:
+    def _iteration(self, cx: ops.Ctx, pl: _Plan, with_mask: bool, fuse_mask: bool = False) -> None:
         W = self.W
         Bc, Pn, h, w, P, n = pl.Bc, pl.Pn, pl.h, pl.w, pl.P, pl.n
         sk = lambda Wt, X, Y, fg=False: run_skblock(Wt, X, Y, pl.hid, pl.xa, pl.xb, h, w, fg, cx=cx)
@@ -702,7 +708,8 @@ class HotPathEngine:
             sk(W.flow_head, pl.nets_grouped, pl.delta_fh)
         if with_mask:                                               # update.py:756-759,777
             ops.gemm(W.mask0, pl.nets, pl.m256, EPI_RELU, hw=(h, w), cx=cx)
-            ops.gemm(W.mask2, pl.m256, pl.mask, EPI_NONE, alpha=0.25, cx=cx)
+            if not fuse_mask:                                       # (fused: mask.2 runs inside sf_mask_upsample, after the loop)
+                ops.gemm(W.mask2, pl.m256, pl.mask, EPI_NONE, alpha=0.25, cx=cx)
         # streamflow.py:138 + :133 for the next iteration
         ops.flow_update(pl.coords1, pl.delta, pl.flow, pl.mf.slice(HDIM - 2, HDIM, unshadowed=True), n, h, w,
                         koct=pl.mf.shadow, koct_row=HDIM - 2, cx=cx)   # (+ the flow rows of mf's k-octet copy)
@@ -716,11 +723,16 @@ class HotPathEngine:
             with torch.cuda.stream(self._probe_stream):
                 ops.clock_probe(self.clock_counts, probe)
         self._setup(cx, pl, fmaps, cnets)
+        # only the last iteration's mask is used (test mode): its second layer + the convex upsampling are one launch then
+        fuse = (self.options.mask_upsample and not all_masks and iters > 0 and ops.mask_upsample_ok(self.W.mask_pack, pl.m256, cx))
         for it in range(iters):
-            self._iteration(cx, pl, with_mask=all_masks or it == iters - 1)
+            self._iteration(cx, pl, with_mask=all_masks or it == iters - 1, fuse_mask=fuse)
         if probe > 0:
             torch.cuda.current_stream().wait_stream(self._probe_stream)
         flow_t = pl.flow.tensor().view(pl.n, 2, pl.h, pl.w)
+        if fuse:
+            ops.mask_upsample(self.W.mask_pack, pl.m256, flow_t, pl.up, pl.h, pl.w, cx=cx)
+            return
         mask_t = pl.mask.tensor().view(pl.n, 576, pl.h, pl.w)
         _lib.check(_lib.load().sf_upsample_flow(flow_t.data_ptr(), mask_t.data_ptr(), pl.up.data_ptr(), pl.n, pl.h,
                                                 pl.w, _lib.stream()), "sf_upsample_flow")

@@ -425,6 +425,62 @@ class PackedTemporal:
         return st
 
 
+class PackedMask:
+    """mask.2 (update.py:758: Conv1x1 256 -> 576) as the weight stream of sf_mask_upsample (csrc/mask_upsample.hip): row tile 0 .. 35,
+    k-step 0 .. 7, `lo` before `hi`."""
+
+    def __init__(self, layer: "PackedLinear"):
+        self.layer = layer
+        self._streams = {}
+
+    def built(self) -> bool:
+        return (self.layer.M, self.layer.K) == (576, 256) and not self.layer.conv3x3
+
+    def products(self, cx: "Ctx") -> int:
+        return 1 if (cx.precision == PRECISION_F16 or self.layer.single) else 2
+
+    def stream(self, pm: int) -> torch.Tensor:
+        if pm in self._streams:
+            return self._streams[pm]
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("PackedMask.stream: weight stream requested for the first time inside a graph capture")
+        hi, lo = PackedPair._split(self.layer, 576, 256)
+        planes = [lo, hi] if pm == 2 else [hi]
+        f = torch.stack([w.view(36, 16, 8, 4, 8) for w in planes], dim=0)                   # [plane, tile, row, s, kq, i]
+        st = f.permute(1, 3, 0, 4, 2, 5).reshape(-1).contiguous()                           # [tile][s][plane][(kq, row), i]
+        assert st.numel() == int(_lib.load().sf_mask_upsample_frags(pm)) * 512
+        self._streams[pm] = st
+        return st
+
+
+def mask_upsample_ok(pack: Optional[PackedMask], M256: Planes, cx: Optional["Ctx"] = None) -> bool:
+    cx = _cx(cx)
+    return (pack is not None and pack.built() and cx.precision in (PRECISION_F16X2, PRECISION_F16) and cx.shadows and
+            M256.shadow is not None and M256.rows == 256 and M256.group == 0)
+
+
+@on_tensor_device
+def mask_upsample(pack: PackedMask, M256: Planes, flow: torch.Tensor, out: torch.Tensor, h: int, w: int,
+                  cx: Optional["Ctx"] = None) -> None:
+    """out [n, 2, 8h, 8w] = convex upsampling of flow [n, 2, h, w] with mask = 0.25 * mask.2(M256) (streamflow.py:82-93), the mask
+    never written: M256 = relu(mask.0(net)) as planes with a k-octet copy (the operand)."""
+    cx = _cx(cx)
+    assert mask_upsample_ok(pack, M256, cx) and M256.P == h * w and flow.is_contiguous() and out.is_contiguous()
+    sh, A = M256.shadow, pack.layer
+    pm = pack.products(cx)
+    st = pack.stream(pm)
+    g = _lib.SfMaskUpsample()
+    g.X16, g.strideX, g.ldx = sh.ptr, sh.img_stride, sh.P
+    g.wstream, g.wstream_bytes = st.data_ptr(), st.numel() * 2
+    g.bias = None if A.bias_split is None else A.bias_split.data_ptr()
+    g.flow, g.out = flow.data_ptr(), out.data_ptr()
+    g.n_img, g.h, g.w, g.K, g.M, g.pm = M256.n_img, h, w, 256, 576, pm
+    g.alpha = 0.25 / A.split_scale
+    n, P = M256.n_img, h * w
+    _launch("mask_upsample", 2.0 * 576 * 256 * n * P, (2.0 * 256 + 4.0 * 2 + 4.0 * 128) * n * P,
+            lambda: _lib.check(_lib.load().sf_mask_upsample(C.byref(g), _lib.stream()), "sf_mask_upsample"), products=float(pm))
+
+
 def temporal_block_ok(pack: Optional[PackedTemporal], X: Planes, TT: int, cx: Optional["Ctx"] = None) -> bool:
     """Does sf_temporal_block run this block?  fp16-activation arithmetic with the k-octet copy of the tokens at hand, the built
     shape (C = 128, hidden 256, <= 3 tokens per pixel), one product count for all four layers."""

@@ -102,6 +102,14 @@ for TT, pm, Cc, wb in itertools.product((1, 2, 3, 4, 0), (1, 2, 3), (128, 64), (
     t.N, t.B, t.TT, t.C, t.H, t.pm = 7040, 8, TT, Cc, 256, pm
     call(lib.sf_temporal_block, C.byref(t), None)
 call(lib.sf_temporal_block, None, None)
+for pm, M, wb, hh in itertools.product((1, 2, 3), (576, 512), (None, 0), (55, 0)):
+    m = _lib.SfMaskUpsample()
+    m.X16, m.strideX, m.ldx, m.wstream = PTR[0], 256 * 7040, 7040, PTR[1]
+    m.wstream_bytes = (lib.sf_mask_upsample_frags(pm) * 1024) if wb is None else wb
+    m.bias, m.flow, m.out = PTR[2], PTR[3], PTR[4]
+    m.n_img, m.h, m.w, m.K, m.M, m.pm, m.alpha = 24, hh, 128, 256, M, pm, 0.25
+    call(lib.sf_mask_upsample, C.byref(m), None)
+call(lib.sf_mask_upsample, None, None)
 for out, us in ((PTR[0], 1000), (None, 1000), (PTR[0], 0), (PTR[0], 3000000)):
     call(lib.sf_clock_probe, out, us, None)
 print(f"host sanitizer driver: {calls} calls, {rejected} rejected or failed at the launch, version {lib.sf_version()}")
