@@ -312,6 +312,8 @@ typedef struct SfFfnPair {
     int32_t x_group; int64_t x_group_stride;   /* x_group > 0: X's K1 rows are x_group-row slices (a multiple of 32 that divides K1) of
                                                   consecutive groups x_group_stride halves apart -- the flow head's '(B T) C -> B (T C)'
                                                   view of the hidden state (update.py:775) without a copy; 0: plain planes */
+    const float* R32; int64_t strideR32, ldr32, r32_group_stride;   /* mode 1, optional: the residual x from fp32 planes [M2][ldr32]
+                                                  (grouped like X: groups r32_group_stride floats apart) instead of the fp16 operand */
 } SfFfnPair;
 int sf_ffn_pair(const SfFfnPair* p, void* stream);
 int sf_ffn_pair_frags(int K1, int M2, int pm1, int pm2);

@@ -56,6 +56,7 @@ class SfFfnPair(C.Structure):
         ("pm1", C.c_int32), ("pm2", C.c_int32), ("mode", C.c_int32), ("gelu_out", C.c_int32), ("c16_partial", C.c_int32),
         ("alpha1", _f), ("alpha2", _f),
         ("x_group", C.c_int32), ("x_group_stride", _i64),
+        ("R32", _vp), ("strideR32", _i64), ("ldr32", _i64), ("r32_group_stride", _i64),
     ]
 
 

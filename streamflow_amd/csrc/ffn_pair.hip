@@ -65,6 +65,7 @@ struct PairArgs {
     int ntile;            // pixel tiles per image
     int hp;               // hidden row pairs of 16 = ceil(H / 32)
     int x_span;           // bytes of one image (all its groups) of X as the kernel addresses it
+    int r32_span;         // ... of the fp32 residual planes (mode 1 with R32)
     int64_t w_bytes;      // bytes of the packed weight stream
 };
 
@@ -82,7 +83,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 template <int NK1, int NT2, int PM1, int PM2, int MODE, int NW>
-__global__ __launch_bounds__(NW * 64, (NW == 8) ? 4 : ((NK1 > 8 && MODE == 1) ? 2 : 3)) void ffn_pair_kernel(const PairArgs a) {
+__global__ __launch_bounds__(NW * 64, (NW == 8) ? 4 : ((NK1 > 8 && MODE >= 1) ? 2 : 3)) void ffn_pair_kernel(const PairArgs a) {
     const SfFfnPair& g = a.p;
     constexpr int kWaves = NW, kThreads = NW * 64, kPxWg = NW * kPxWave;
     constexpr int NA = 2 * NK1 * PM1, NB = NT2 * PM2, F = NA + NB, NSTG = (F + S - 1) / S;
@@ -223,7 +224,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 8) ? 4 : ((NK1 > 8 && MODE == 1) ? 
     const long long ts2 = __builtin_readcyclecounter();
 #endif
     wait_vm<0>();                                                  // (pieces requested past the end must land before the LDS is released)
-    if constexpr (MODE == 1) {                                     // the depthwise 1x1 parameters into the (now idle) ring
+    constexpr bool kR32 = MODE == 2;                               // MODE 2 = mode 1 with the residual from fp32 planes (SfFfnPair.R32)
+    if constexpr (MODE >= 1) {                                     // the depthwise 1x1 parameters into the (now idle) ring
         __syncthreads();
         for (int i = tid; i < NT2 * 16; i += kThreads) {
             sdw[i] = (i < g.M2) ? g.dw_w[i] : 0.f;
@@ -287,6 +289,11 @@ __global__ __launch_bounds__(NW * 64, (NW == 8) ? 4 : ((NK1 > 8 && MODE == 1) ? 
         char* c16 = reinterpret_cast<char*>(g.C16) + (int64_t)z * g.strideC16 * 2;
         const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(c16, 0, (int)(((int64_t)(g.M2 - 1) * g.ldc16 + g.N) * 2), 0x00020000);
         // residual x (update.py:31: x + ffn1(x)): rows 16 t + 4 kq .. + 3 = half an octet of the input planes, all tiles requested first
+        const __amdgpu_buffer_rsrc_t rr32 = __builtin_amdgcn_make_buffer_rsrc(
+            kR32 ? const_cast<char*>(reinterpret_cast<const char*>(g.R32)) + (int64_t)z * g.strideR32 * 4 : nullptr, 0, kR32 ? a.r32_span : 0,
+            0x00020000);
+        const int vr32 = (4 * kq * (int)g.ldr32 + px) * 4;
+        const int g32bytes = (int)(g.r32_group_stride * 4);
         const int vr = ((kq >> 1) * (int)g.ldx + px) * 16 + 8 * (kq & 1);
         const int vrow = (4 * kq * (int)g.ldc16 + px) * 2;                                // fp16 rows: + (16 t + e) rows
         // (tiles in chunks of CH: the residual of a chunk is requested before its first GELU, not all NT2 tiles at once: registers)
@@ -294,11 +301,24 @@ __global__ __launch_bounds__(NW * 64, (NW == 8) ? 4 : ((NK1 > 8 && MODE == 1) ? 
 #pragma unroll
         for (int t0 = 0; t0 < NT2; t0 += CH) {
         u32x2 rk[CH];
+        f32x4 rf[CH];                                             // (R32: the residual from the fp32 planes instead of the fp16 operand)
+        if constexpr (kR32) {
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                const int og = __builtin_amdgcn_readfirstlane((2 * (t0 + c)) / goct);
+                const int rowg = 16 * (t0 + c) - og * goct * 8;                            // first row of the tile inside its group
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    rf[c][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                        rr32, (pin && 16 * (t0 + c) + 4 * kq + e < g.M2) ? vr32 : kOob, og * g32bytes + (rowg + e) * (int)g.ldr32 * 4, 0));
+            }
+        } else {
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
             const int og = __builtin_amdgcn_readfirstlane((2 * (t0 + c)) / goct);          // (goct is even: the pair of octets shares a group)
             rk[c] = __builtin_amdgcn_raw_buffer_load_b64(rx, (pin && 2 * (t0 + c) + (kq >> 1) < noct) ? vr : kOob,
                                                          og * gbytes + (2 * (t0 + c) - og * goct) * (int)g.ldx * 16, 0);
+        }
         }
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
@@ -311,7 +331,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 8) ? 4 : ((NK1 > 8 && MODE == 1) ? 
                 const f16x2 rh = __builtin_bit_cast(f16x2, ru);
                 f32x2 v, r, w2, b2;
                 v[0] = g.alpha2 * acc2[t][2 * q]; v[1] = g.alpha2 * acc2[t][2 * q + 1];
-                r[0] = (float)rh[0]; r[1] = (float)rh[1];
+                r[0] = kR32 ? rf[c][2 * q] : (float)rh[0];
+                r[1] = kR32 ? rf[c][2 * q + 1] : (float)rh[1];
                 w2[0] = dww[2 * q]; w2[1] = dww[2 * q + 1];
                 b2[0] = dwb[2 * q]; b2[1] = dwb[2 * q + 1];
                 const f32x2 x1 = sf::gelu_poly2(r + v);
@@ -396,6 +417,15 @@ extern "C" int sf_ffn_pair(const SfFfnPair* p, void* stream) {
     a.ntile = 0;
     a.hp = (g.H + 31) / 32;
     a.x_span = (int)x_span;
+    a.r32_span = 0;
+    if (g.R32) {
+        SF_REQUIRE(g.mode == 1 && g.ldr32 >= g.N && (reinterpret_cast<uintptr_t>(g.R32) & 3) == 0 && g.r32_group_stride >= 0,
+                   "sf_ffn_pair: R32 (fp32 residual planes) is a mode-1 option, ldr32 >= N");
+        const int64_t rows_g = g.x_group > 0 ? g.x_group : g.M2;
+        const int64_t sp = (g.x_group > 0 ? (int64_t)(g.M2 / g.x_group - 1) * g.r32_group_stride : 0) * 4 + ((rows_g - 1) * g.ldr32 + g.N) * 4;
+        SF_REQUIRE(sp < lim, "sf_ffn_pair: residual image larger than 1 GiB");
+        a.r32_span = (int)sp;
+    }
     const int fpad = sf_ffn_pair_frags(g.K1, g.M2, g.pm1, g.pm2);
     SF_REQUIRE(fpad > 0, "sf_ffn_pair: products must be 1 or 2");
     a.w_bytes = (int64_t)a.hp * fpad * 1024;
@@ -403,8 +433,9 @@ extern "C" int sf_ffn_pair(const SfFfnPair* p, void* stream) {
                (long long)a.w_bytes);
     hipStream_t st = (hipStream_t)stream;
     const int nk1 = (g.K1 + 31) / 32, nt2 = (g.M2 + 15) / 16;
+    const int kmode = (g.mode == 1 && g.R32) ? 2 : g.mode;           // (kernel MODE 2: mode 1 with the fp32 residual)
 #define SF_PAIR_CASE(NK1_, NT2_, MODE_, NW_) \
-    if (nk1 == NK1_ && nt2 == NT2_ && g.mode == MODE_) return launch_pm<NK1_, NT2_, MODE_, NW_>(a, st)
+    if (nk1 == NK1_ && nt2 == NT2_ && kmode == MODE_) return launch_pm<NK1_, NT2_, MODE_, NW_>(a, st)
     // the SK blocks of the update block (update.py:313-339, 739-782): C = 128 / 256 / 324.  NW = waves per workgroup: 8 (128 pixels
     // share every weight stage: half the L2 -> LDS traffic per pixel) where the kernel fits 128 registers (4 waves per SIMD)
     SF_PAIR_CASE(4, 8, 1, 8);      // convf2.ffn1   128 -> 192 -> 128
@@ -416,9 +447,12 @@ extern "C" int sf_ffn_pair(const SfFfnPair* p, void* stream) {
     SF_PAIR_CASE(11, 16, 0, 4);    // convc1.ffn2   324 -> 486 -> 256
     // the flow head (update.py:744, 775): its input is the '(B T) C -> B (T C)' view of the hidden state (x_group = 128), T - 1 = 3 / 2 / 1 frames
     SF_PAIR_CASE(12, 24, 1, 4);    // flow_head.ffn1   384 -> 576 -> 384   (T = 4)
+    SF_PAIR_CASE(12, 24, 2, 4);    //   ... with the residual from the fp32 planes of the hidden state (the engine's form)
+    SF_PAIR_CASE(8, 16, 2, 4);     //   (T = 3)
+    SF_PAIR_CASE(4, 8, 2, 8);      //   (T = 2)
     SF_PAIR_CASE(12, 1, 0, 8);     // flow_head.ffn2   384 -> 576 -> 6
     SF_PAIR_CASE(8, 1, 0, 8);      //                  256 -> 384 -> 4     (T = 3; its ffn1 is the 256 -> 384 -> 256 case above)
     SF_PAIR_CASE(4, 1, 0, 8);      //                  128 -> 192 -> 2     (T = 2)
 #undef SF_PAIR_CASE
-    return sf::fail(SF_ERR_UNSUPPORTED, "sf_ffn_pair: shape K1 = %d, M2 = %d, mode %d not built", g.K1, g.M2, g.mode);
+    return sf::fail(SF_ERR_UNSUPPORTED, "sf_ffn_pair: shape K1 = %d, M2 = %d, mode %d%s not built", g.K1, g.M2, g.mode, g.R32 ? " with an fp32 residual" : "");
 }

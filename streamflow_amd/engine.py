@@ -49,6 +49,8 @@ class EngineOptions:
     ffn_pairs: bool = True           # the SK blocks' ffn1 / ffn2 pairs as one launch each where the shape is built (sf_ffn_pair)
     project_v: bool = True           # fused GMA, fp16 activations: to_v + the v pack as one launch (sf_gma_flash_project_v)
     temporal_block: bool = True      # the temporal transformer block as ONE launch (sf_temporal_block) instead of seven
+    head_pairs: bool = False         # the flow head's FFN pairs on its grouped view (sf_ffn_pair x_group / R32).  Off: +0.4 % on the step
+                                     # (382 vs 380 ff/s) against EPE samples of 3.6 / 1.9 / 2.6e-4 px instead of 2.9 / 1.7 / 2.6e-4
     mask_upsample: bool = True       # mask head's second layer + convex upsampling as ONE launch (sf_mask_upsample): the mask is never written
     clock_probe_us: int = 0          # measurement aid: > 0 forks sf_clock_probe for that long beside every forward (results in
                                      # engine.clock_counts: shader cycles, 100 MHz ticks); a graph branch like any other
@@ -159,7 +161,7 @@ def run_skblock(W: SKBlockWeights, X: Planes, Y: Planes, hid: Planes, xa: Planes
     # x1 = gelu(x + ffn1(x)); x2 = gelu(x1 + dw1x1(x1))  (both fused in the epilogue)
     # (the flow head's pairs pay with enough pixels to fill the chip at 64 per workgroup: 8 clips 63.3 vs 63.8 ms per step, one
     # clip 220 vs 226 ff/s the other way -- its GEMM launches split M for small grids)
-    head_pairs = X.group and X.shadow is not None and X.n_img * X.P >= 4 * 7040
+    head_pairs = cx.head_pairs and X.group and X.shadow is not None and X.n_img * X.P >= 4 * 7040
     if cx.ffn_pairs and a.f16 and ((X.f16 and X.koct) or head_pairs) and ops.ffn_pair_ok(W.pair1, X, 1, cx):
         # the block input exists as k-octets only (operand AND residual) -- or it is the flow head's grouped view of the hidden
         # state, whose k-octet copy is the operand and (round 5) the residual: the whole ffn1 + epilogue is one launch, the 1.5 C
@@ -502,7 +504,7 @@ class HotPathEngine:
                        split_ws=pl.splitws.tensor().view(-1) if self.auto_split_k else None,
                        shadows=o.shadows, shadow_fused=o.shadow_fused, flash_stats=o.flash_stats,
                        hidden_f16=o.hidden_f16, hidden_koct=o.hidden_koct, pw_fold=o.pw_fold, x2_f16=o.x2_f16,
-                       ffn_pairs=o.ffn_pairs)
+                       ffn_pairs=o.ffn_pairs, head_pairs=o.head_pairs)
 
     def _attention_rows(self, cx: ops.Ctx, pl: _Plan, i0: int, rows: int) -> None:
         """attn[:, :rows, :] = softmax(scale * q[:, i0:i0+rows]^T k)   (gma.py:53-65) for every image."""

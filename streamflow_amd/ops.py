@@ -66,6 +66,7 @@ class Ctx:
     pw_fold: bool = True
     x2_f16: bool = True
     ffn_pairs: bool = True      # an SK block's ffn1 / ffn2 as ONE launch where sf_ffn_pair has the shape (csrc/ffn_pair.hip)
+    head_pairs: bool = False    # ... also the flow head's (grouped view, fp32 residual)
 
     def no_split(self) -> "Ctx":
         """The same context without the split-K scratch (ONE buffer: only one stream may use it at a time)."""
@@ -567,6 +568,9 @@ def ffn_pair(pair: PackedPair, X: Planes, Y: Planes, mode: int, dw_w: Optional[t
     if mode == 1:
         assert Y.f16 and not Y.koct and dw_w is not None and dw_b is not None
         g.dw_w, g.dw_b = dw_w.data_ptr(), dw_b.data_ptr()
+        if not X.f16:                                 # fp32 planes with a k-octet copy: the residual stays the fp32 value
+            assert X.group == src.group
+            g.R32, g.strideR32, g.ldr32, g.r32_group_stride = X.ptr, X.img_stride, X.P, X.group_stride
         g.C16, g.strideC16, g.ldc16 = Y.ptr, Y.img_stride, Y.P
     elif Y.f16:
         assert Y.koct

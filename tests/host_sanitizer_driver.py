@@ -72,6 +72,9 @@ for (K1, H, M2), mode, pm1, pm2, part in itertools.product(((128, 192, 64), (128
     for xg, xs in ((128, 640 * 7040), (48, 640 * 7040), (128, 3), (-8, 0)):          # the flow head's grouped view, and what is not one
         p.x_group, p.x_group_stride = xg, xs
         call(lib.sf_ffn_pair, C.byref(p), None)
+    p.x_group, p.x_group_stride = 0, 0
+    p.R32, p.strideR32, p.ldr32 = PTR[8], M2 * 7040, 7040          # the fp32-residual form (mode 1 only)
+    call(lib.sf_ffn_pair, C.byref(p), None)
 
 # correlation, GMA, depthwise, element-wise entry points: good and bad arguments
 strides = (C.c_int64 * 4)(*[8 * 7040 * (55 >> l) * (128 >> l) for l in range(4)])

@@ -239,6 +239,25 @@ def test_flow_head_pairs_on_the_grouped_view(dev, frames, pm):
         ops.ffn_pair(pair, X, Y, 1, dw_w=dw_w, dw_b=dw_b, cx=cx)
         outs.append(Y.tensor().clone())
     assert bool(torch.isfinite(outs[0]).all()) and torch.equal(outs[0], outs[1])
+    # the engine's form: fp32 planes (grouped the same way) with the k-octet copy as Planes.shadow -- the operand is the copy, the
+    # RESIDUAL the fp32 value (SfFfnPair.R32): float64 with exactly that split
+    par32 = parent.to(dev).contiguous()
+    X32 = Planes(par32.view(-1), 0, frames * rows * P, B, C, P, group=Cg, group_stride=rows * P, shadow=Xg)
+    assert ops.ffn_pair_ok(pair, X32, 1, cx)
+    Y = Planes(torch.full((B * C * P // 2 + 8,), float("nan"), device=dev), 0, C * P, B, C, P, f16=True)
+    ops.ffn_pair(pair, X32, Y, 1, dw_w=dw_w, dw_b=dw_b, cx=cx)
+    torch.cuda.synchronize()
+    x16, x32 = plain.half().double(), plain.double()
+    hid = F.gelu(torch.einsum("hk,nkp->nhp", _weff(A1, pm[0] == 1), x16) + b1.double()[None, :, None]).half().double()
+    yv = torch.einsum("mh,nhp->nmp", _weff(A2, pm[1] == 1), hid) + b2.double()[None, :, None]
+    x1 = F.gelu(x32 + yv)
+    ref1 = F.gelu(x1 + (dw_w.double().cpu()[None, :, None] * x1 + dw_b.double().cpu()[None, :, None]))
+    got = Y.tensor().double().cpu()
+    assert bool(torch.isfinite(got).all())
+    err = (got - ref1).abs()
+    assert bool((err <= 2.0 ** -10 * ref1.abs() + 3e-3).all()), (frames, pm, err.max().item())
+    # (and it differs from the fp16-residual result where the rounding of x matters: the option is live)
+    assert not torch.equal(Y.tensor(), outs[0])
     # ffn2 pair (mode 0, 2 (T - 1) output rows, fp32 planes)
     A1, A2, pair, b1, b2, g2 = _layers(C, H, M2, 5 + frames, dev, pm)
     assert ops.ffn_pair_ok(pair, Xg, 0, cx)
