@@ -173,3 +173,39 @@ def test_integration_md_binding_examples_run(dev):
         want = orc.corr_lookup(pyr, coords[t:t + 1]).reshape(324, h * w)
         err = (got[t] - want).abs().max().item()
         assert err < 2e-2 * max(1.0, want.abs().max().item() / 8), (t, err)       # fp16 cells and fp16 hand-over
+
+
+def test_blocked_build_and_lookup_are_deterministic_at_the_headline_shape(dev):
+    """Twelve builds + lookups of the same 8-clip batch beside a competing stream: every volume byte and every looked-up feature
+    bit-identical.  (Guards the kernels whose epilogues issue 16-byte buffer stores with a register offset: csrc/mask_upsample.hip's
+    first version lost cells of its LAST workgroups that way, run to run.)"""
+    import hashlib
+    from oracle import streamflow_oracle as orc
+    from streamflow_amd import ops
+    from streamflow_amd.ops import Planes
+    B, pairs, D, h, w = 8, 3, 256, 55, 128
+    n, N = B * pairs, h * w
+    g = torch.Generator().manual_seed(3)
+    fm = torch.randn(B, pairs + 1, D, h, w, generator=g).to(dev)
+    coords = (orc.coords_grid(n, h, w) + torch.randn(n, 2, h, w, generator=g) * 6.0).to(dev).contiguous()
+    side = torch.cuda.Stream(device=dev)
+    junk = torch.randn(2048, 2048, device=dev)
+    first = None
+    vol = ops.new_blocked_volume(n, h, w, dev)
+    for rep in range(12):
+        if rep % 2:
+            with torch.cuda.stream(side):
+                junk = torch.tanh(junk) * 1.0001
+        vol.buf.zero_()
+        ops.corr_build_blocked(fm.data_ptr(), fm.data_ptr() + 4 * D * N, (pairs + 1) * D * N, D * N, vol, B, pairs, D)
+        ko = ops.new_shadow(Planes.of(torch.empty(n, 324, N, device=dev)), dev)
+        ops.corr_lookup_blocked(vol, Planes.of(coords), None, ko, B, pairs)
+        torch.cuda.synchronize()
+        # (the 3.3-GB volume is summed on the device: two integer checksums over different word sizes; the features are hashed whole)
+        raw = vol.buf.view(torch.uint8)
+        raw = raw[: raw.numel() // 4 * 4]
+        sig = (int(torch.sum(raw.view(torch.int32), dtype=torch.int64)), int(torch.sum(raw.view(torch.int16), dtype=torch.int64)),
+               hashlib.sha256(ko.base.cpu().numpy().tobytes()).hexdigest())
+        if first is None:
+            first = sig
+        assert sig == first, rep
