@@ -169,6 +169,12 @@ struct DwmArgs {
 #endif
 };
 
+#ifndef SF_DW_FOLD_SINGLE
+#define SF_DW_FOLD_SINGLE 0
+#endif
+#ifndef SF_DW_FOLD
+#define SF_DW_FOLD 1
+#endif
 #ifndef SF_DW_TG
 #define SF_DW_TG 4      // phase timers (tools/dwconv_one.py, -DSF_DW_TIMERS): with 2 tiles per wave the tile loop ran at 5.9k
                         // cycles per pair against 1.4k of MFMA issue -- every kernel row waited for its ds_read_b128 round
@@ -200,6 +206,12 @@ template <int KS, bool kOutF16, int kProd, int kIn = 0>
 __global__ __launch_bounds__(256, kProd == 1 ? 3 : ((KS == 15 && kProd == 2) ? SF_DW_MINWG : 2)) void dwconv_mfma_kernel(const DwmArgs g) {
     using namespace sf_split;
     static_assert(kIn == 0 || kProd <= 2, "fp16 input: two- and one-product forms only");
+    // Residual folded into the weights (round 5): with fp16 input the value x IS the A operand, so x + dwconv(x) = dwconv'(x) with
+    // w'[centre] = w[centre] + 1 -- exact to the split's 2^-22 with hi + lo weights (kProd = 2).  It removes the epilogue's per-output
+    // 2-byte LDS reads of x: 16 per tile group against 60 (15 x 15) / 28 (7 x 7) fragment reads, in a kernel that is LDS-bound, and
+    // they were the ones with bank conflicts (SQ_LDS_BANK_CONFLICT 9 % / 17 % of the LDS cycles: rows 4 apart are 288 dwords apart).
+    // Single-product layers (kProd = 1) would round w + 1 to fp16 (2^-12 |x| on the residual): SF_DW_FOLD_SINGLE, off.
+    constexpr bool kFoldRes = SF_DW_FOLD && (kIn == 2) && (kProd == 2 || (kProd == 1 && SF_DW_FOLD_SINGLE));
     typedef __attribute__((address_space(3))) void* lds_ptr;
     constexpr int R = KS / 2;
     constexpr int WZ = 64;                                      // zero-padded weight row: w[ky][j - 24]
@@ -250,7 +262,8 @@ __global__ __launch_bounds__(256, kProd == 1 ? 3 : ((KS == 15 && kProd == 2) ? S
     // ---- the channel's Toeplitz fragments -> registers --------------------------------------------------
     for (int i = tid; i < KS * WZ; i += 256) {
         const int ky = i / WZ, j = i % WZ - 24;
-        wz[i] = (j >= 0 && j < KS) ? g.wgt[(int64_t)c * KS * KS + ky * KS + j] : 0.f;
+        // kFoldRes: the block's residual x + dwconv(x) as the centre tap w + 1 (below)
+        wz[i] = (j >= 0 && j < KS) ? g.wgt[(int64_t)c * KS * KS + ky * KS + j] + ((kFoldRes && ky == R && j == R) ? 1.0f : 0.f) : 0.f;
     }
     __syncthreads();
     f16x8 bh[KS], bl[KS];
@@ -407,10 +420,14 @@ __global__ __launch_bounds__(256, kProd == 1 ? 3 : ((KS == 15 && kProd == 2) ? S
                     sf::f32x2 t;
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
-                        const int xo = xoff0 + (r + u) * row_step + min(j, ntx - 1 - tx0) * 32;
-                        float xv = (float)*reinterpret_cast<const _Float16*>(hb + xo);
-                        if constexpr (kIn != 2) xv += (float)*reinterpret_cast<const _Float16*>(lo + xo);
-                        t[u] = xv + (acc[j][r + u] + bv);
+                        if constexpr (kFoldRes) {
+                            t[u] = acc[j][r + u] + bv;
+                        } else {
+                            const int xo = xoff0 + (r + u) * row_step + min(j, ntx - 1 - tx0) * 32;
+                            float xv = (float)*reinterpret_cast<const _Float16*>(hb + xo);
+                            if constexpr (kIn != 2) xv += (float)*reinterpret_cast<const _Float16*>(lo + xo);
+                            t[u] = xv + (acc[j][r + u] + bv);
+                        }
                     }
                     const sf::f32x2 a = sf::gelu2<(kProd <= 2) && kOutF16 && SF_GEMM_FAST_GELU>(t);   // polynomial GELU where the result leaves as fp16
 #pragma unroll

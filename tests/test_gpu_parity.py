@@ -827,7 +827,11 @@ def test_dwconv_f16_input(dev, hw, n_img, C, k, single):
     ops.dwconv_res_gelu(Xf, wgt.to(dev).contiguous(), b.to(dev), Yf, h, w, k, single=single, cx=cx)
     torch.cuda.synchronize()
     d = (ys.float() - yf.float()).abs()
-    assert bool((d <= 2.0 ** -10 * yf.float().abs() + 1e-6).all()), float(d.max())
+    # (each may sit one fp16 spacing from the float64 value near the top of a binade -- the bound above is 2^-11 RELATIVE --, so the
+    # pair may differ by two: the DMA form folds the residual into the centre tap, the register form adds x in the epilogue)
+    # absolute slack: in the tail of the polynomial GELU (pre-activation near -4, results ~1e-4, |error| <= 5.2e-5 by construction) a
+    # 2e-6 difference of the pre-activation moves the result by up to ~2e-5 (at the clamp of the polynomial)
+    assert bool((d <= 2.0 ** -9 * torch.maximum(ys.float().abs(), yf.float().abs()) + 2.5e-5).all()), float(d.max())
 
 
 @pytest.mark.gpu
