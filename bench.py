@@ -39,10 +39,6 @@ def _load_launch():
 
 
 launch = _load_launch()
-# A rank of an N > 1 run (spawned by this file or by torch.distributed.run) takes its share of the host cores NOW, before torch
-# and OpenMP size their thread pools from the affinity mask: the cores of its GPU's NUMA node,
-# split evenly between the ranks on that node
-RANK_CPUS = launch.pin_rank_cpus(int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")))
 
 
 def _argv_option(name: str, default: str) -> str:
@@ -54,11 +50,27 @@ def _argv_option(name: str, default: str) -> str:
     return default
 
 
-if (int(os.environ.get("WORLD_SIZE", "1")) > 1 and "SF_BENCH_DEVICE" not in os.environ and "--share-device" not in sys.argv
-        and _argv_option("--pin", os.environ.get("SF_BENCH_PIN", "visible")) == "visible"):
-    # a rank under an external launcher (torch.distributed.run): restrict it to ITS device before the HIP runtime is even loaded
-    os.environ["SF_BENCH_OUTER_VISIBLE"] = os.environ.get("HIP_VISIBLE_DEVICES", "")
-    os.environ.update(launch.pinned_device_env(int(os.environ.get("LOCAL_RANK", "0")), os.environ.get("HIP_VISIBLE_DEVICES")))
+def _place_this_rank():
+    """Placement of a rank of an N > 1 run (spawned by this file or by torch.distributed.run), BEFORE torch / the HIP runtime are
+    loaded and before OpenMP sizes its pools from the affinity mask: first remember the OUTER device list (the NUMA
+    lookup maps the local rank through it), then take the rank's share of the host cores -- the cores of its GPU's NUMA node split
+    between the ranks OF THIS NODE (LOCAL_WORLD_SIZE under a multi-node launcher) -- then restrict the rank to its device.
+    Only when this file is the program: `import bench` (tests, tools) must not change the importer's affinity or devices."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    pin_device = (world > 1 and "SF_BENCH_DEVICE" not in os.environ and "--share-device" not in sys.argv
+                  and _argv_option("--pin", os.environ.get("SF_BENCH_PIN", "visible")) == "visible")
+    if pin_device:
+        os.environ["SF_BENCH_OUTER_VISIBLE"] = os.environ.get("HIP_VISIBLE_DEVICES", "")
+    cpus = launch.pin_rank_cpus(local_rank, local_world if world > 1 else 1)
+    if pin_device:
+        # a rank under an external launcher (torch.distributed.run): restricted to ITS device before the HIP runtime is even loaded
+        os.environ.update(launch.pinned_device_env(local_rank, os.environ.get("HIP_VISIBLE_DEVICES")))
+    return cpus
+
+
+RANK_CPUS = _place_this_rank() if __name__ == "__main__" else (sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else [])
 
 import torch
 import torch.distributed as dist
@@ -126,11 +138,15 @@ def timed_steps(step_fn, steps: int, warmup: int, world: int, sync_fn, barrier_f
     sync_fn()
     barrier_fn()
     t0 = time.perf_counter()
+    host = 0.0
     for _ in range(steps):
+        th = time.perf_counter()
         step_fn()
+        host += time.perf_counter() - th               # time the HOST spends inside the step (input staging + graph launch / enqueues)
     sync_fn()
     if own is not None:
         own.append(time.perf_counter() - t0)
+        own.append(host)
     barrier_fn()
     dt = time.perf_counter() - t0
     return allreduce_max_fn(dt)
@@ -165,16 +181,18 @@ def cpu_baseline(samples, iters: int, pairs: int):
 HARD_SEEDS = (21, 11, 12, 13, 31, 32)      # == tests/cases.py HARD_SEEDS (seed 21: hot params 21, frames 24, Twins 22 / 23)
 
 
-def hard_case_epe(preset_cfg, dev, seeds=HARD_SEEDS):
-    """frames -> random-init Twins_CSC features -> loop at 128 x 192, 4 iterations (tests/test_gpu_parity.py::
-    test_hard_case_sweep_vs_oracle: ill-conditioned inputs, flows of 4-40 px) against the chained CPU oracles, on SIX weight / frame
-    seeds: `value` is the MAXIMUM; the deviation of the fp16-activation arithmetic class is relative to the flow,
-    so both forms are reported per seed."""
+def hard_case_epe(preset_cfg, dev, seeds=HARD_SEEDS, iters_list=(15, 4)):
+    """frames -> random-init Twins_CSC features -> loop at 128 x 192 (tests/test_gpu_parity.py::test_hard_case_sweep_vs_oracle:
+    ill-conditioned inputs, flows of 4-40 px) against the chained CPU oracles, on SIX weight / frame seeds, at the
+    15 iterations the reference deploys (scripts/infer.sh:17) and at the 4 of the earlier rounds' reports.
+    The acceptance criterion of the config-2 (fp16-activation) arithmetic class is RELATIVE -- EPE <= 1e-3 of max(1, mean flow) --
+    not the absolute 1e-3 px of `fp32_class`; it is stated in the record.  `worst_absolute` and `worst_relative` are each ONE
+    seed's self-consistent numbers; `value` = worst_absolute at 15 iterations."""
     from oracle import streamflow_oracle as orc, twins_oracle as two
     from streamflow_amd import synthetic as syn
     from streamflow_amd.engine import HotPathEngine
-    B, T, H, W, iters = 1, 4, 128, 192, 4
-    per = []
+    B, T, H, W = 1, 4, 128, 192
+    per = {it: [] for it in iters_list}
     for seed in seeds:
         ps, fs, a, b = (21, 24, 22, 23) if seed == 21 else (seed, 100 + seed, 200 + seed, 300 + seed)
         hot = syn.make_params(ps, T)
@@ -182,20 +200,32 @@ def hard_case_epe(preset_cfg, dev, seeds=HARD_SEEDS):
         imgs = 2 * (frames / 255.0) - 1.0
         fm = two.twins_csc_forward(imgs, syn.make_twins_params(a))
         cn = two.twins_csc_forward(imgs[:, :-1], syn.make_twins_params(b))
-        ups_o, _ = orc.hotpath_forward(fm, cn, hot, iters)
         eng = HotPathEngine(hot, device=dev, T=T, **preset_cfg)
-        ups, _ = eng.forward(fm.to(dev).contiguous(), cn.to(dev).contiguous(), iters=iters)
-        e = max(orc.epe(u.cpu(), o) for u, o in zip(ups, ups_o))
-        mag = float(torch.stack([o.norm(dim=1).mean() for o in ups_o]).mean())
-        per.append({"seed": seed, "epe_px": e, "mean_flow_px": round(mag, 2), "relative_to_flow": e / mag})
+        for it in iters_list:
+            ups_o, _ = orc.hotpath_forward(fm, cn, hot, it)
+            ups, _ = eng.forward(fm.to(dev).contiguous(), cn.to(dev).contiguous(), iters=it)
+            e = max(orc.epe(u.cpu(), o) for u, o in zip(ups, ups_o))
+            mag = float(torch.stack([o.norm(dim=1).mean() for o in ups_o]).mean())
+            per[it].append({"seed": seed, "epe_px": e, "mean_flow_px": round(mag, 2), "relative_to_flow": e / max(mag, 1e-9)})
         del eng
-    worst = max(per, key=lambda p: p["epe_px"])
-    return {"value": worst["epe_px"], "unit": "px", "mean_flow_px": worst["mean_flow_px"],
-            "relative_to_flow": max(p["relative_to_flow"] for p in per),
-            "within_1e-3_of_max(1,flow)": all(p["epe_px"] <= 1e-3 * max(1.0, p["mean_flow_px"]) for p in per),
-            "seeds": per,
-            "note": "MAX over six weight / frame seeds: exact (oracle) Twins_CSC features of random frames, 128 x 192, 4 iterations; "
-                    "HIP loop vs the CPU oracle loop; relative_to_flow = the worst seed's EPE / mean flow"}
+
+    def summary(rows):
+        wa = max(rows, key=lambda p: p["epe_px"])
+        wr = max(rows, key=lambda p: p["relative_to_flow"])
+        return {"worst_absolute": wa, "worst_relative": wr,
+                "within_1e-3_of_max(1,flow)": all(p["epe_px"] <= 1e-3 * max(1.0, p["mean_flow_px"]) for p in rows),
+                "within_1e-3_px_absolute": all(p["epe_px"] <= 1e-3 for p in rows), "seeds": rows}
+
+    first = summary(per[iters_list[0]])
+    out = {"value": first["worst_absolute"]["epe_px"], "unit": "px", "iterations": iters_list[0],
+           "criterion": "config-2 presets (fp16 activations in every product): EPE <= 1e-3 x max(1, mean flow px) per seed -- a RELATIVE "
+                        "bound, weaker than north_star's absolute 1e-3 px, which only the fp32_class preset meets on this input class",
+           **first}
+    for it in iters_list[1:]:
+        out[f"at_{it}_iterations"] = summary(per[it])
+    out["note"] = ("six weight / frame seeds: exact (oracle) Twins_CSC features of random frames, 128 x 192; HIP loop vs the CPU oracle loop; "
+                   "worst_absolute / worst_relative are each one seed's own numbers")
+    return out
 
 
 def mfma_busy_from_profiles(kernel_family):
@@ -553,13 +583,18 @@ def main():
     own = []
     dt = timed_steps(step, args.steps, args.warmup, world, torch.cuda.synchronize, barrier, allreduce_max, own=own)
     log(f"timed region: {args.steps} steps in {dt:.3f}s (this rank: {own[0]:.3f}s)")
-    per_rank, rank_cores = [own[0]], [len(RANK_CPUS)]
+    per_rank, rank_cores, rank_host = [own[0]], [len(RANK_CPUS)], [own[1]]
+    pl0 = next(reversed(eng._plans.values())) if eng._plans else None
+    graph_calls = [int(getattr(pl0, "graph_calls", 0) or 0)]
     if world > 1:
-        t_own = torch.tensor([own[0], float(len(RANK_CPUS))], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
+        t_own = torch.tensor([own[0], float(len(RANK_CPUS)), own[1], float(graph_calls[0])], dtype=torch.float64,
+                             device=dev if args.dist_backend == "nccl" else "cpu")
         t_all = [torch.zeros_like(t_own) for _ in range(world)]
         dist.all_gather(t_all, t_own)
         per_rank = [float(t[0].item()) for t in t_all]
         rank_cores = [int(t[1].item()) for t in t_all]
+        rank_host = [float(t[2].item()) for t in t_all]
+        graph_calls = [int(t[3].item()) for t in t_all]
     clips_all = args.total_clips if strong else world * B
     fields = clips_all * pairs * args.steps
     result = {
@@ -570,6 +605,11 @@ def main():
         # spread of the ranks' own times (each up to its device sync, before the closing barrier) relative to their mean: what
         # the slowest rank costs the job
         "imbalance": round((max(per_rank) - min(per_rank)) / (sum(per_rank) / len(per_rank)), 4),
+        # SCALE diagnostics: the time each rank's HOST thread spends inside a step (input staging copies + ONE graph
+        # launch, or the eager enqueues) -- if this approaches ms_per_step at N = 8 the ranks are host-bound, not GPU-bound -- and the
+        # size of the replayed graph (launch calls captured per forward)
+        "host_ms_per_step": [round(1e3 * t / args.steps, 3) for t in rank_host],
+        "graph_launch_calls": graph_calls,
         "dtype": {"fp32": "fp32", "f16x3": "f16x3-split (fp32 accumulate)",
                   "f16x2": ("f16x2 (weights hi+lo, activations fp16; fp32 accumulate)" if not cfg.get("single_layers") else
                             f"f16x2 / f16 mixed (activations fp16; weights fp16 in {len(cfg['single_layers'])} of the 45 "
@@ -767,6 +807,18 @@ def main():
                                        "bytes": "SURVEY.md section 8(d), element size of the stored volume: per pair build = 2 N 256 4 + N cells e, "
                                                 "lookup = N (4 100 e + 8 + 324 4) -- the k-octet hand-over and the blocked layout's padding "
                                                 "are NOT counted"}
+            # ... and on the bytes THIS design has to move: the blocked fp16 path hands the looked-up features
+            # over as fp16 k-octets only, so its lookup writes 324 x 2 B per pixel, not section 8(d)'s 324 x 4 B; `needed` = footprints
+            # (4 levels x 100 cells x e) + coordinates + the output at the size it is stored, build = features read once + cells once
+            e_sz = 2 if args.corr_dtype == "f16" else 4
+            out_sz = 2 if (args.corr_dtype == "f16" and eng.corr_blocked) else 4
+            npx = B * pairs * h * w
+            lookup_moved = npx * (4 * 100 * e_sz + 8 + 324 * out_sz) * cl["launches_per_step"]
+            moved = summ["corr_build"]["bytes"] / reps + lookup_moved
+            result["roofline_corr"]["moved_bytes_per_step"] = int(moved)
+            result["roofline_corr"]["frac_on_moved_bytes"] = round(moved / (tot_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4)
+            result["roofline_corr"]["moved_bytes"] = ("what this design must move: build as section 8(d); lookup = N (4 100 e + 8 + 324 x "
+                                                      f"{out_sz}) -- the output at the element size it is stored in")
             if not same:
                 result["roofline_corr"]["traffic"], result["roofline_corr"]["traffic_note"] = None, traffic_why
             if same and traffic.get("corr_build") and traffic.get("corr_lookup"):
@@ -775,6 +827,7 @@ def main():
                 result["roofline_corr"]["traffic"] = int(real)
                 result["roofline_corr"]["traffic_gbps"] = round(real / (tot_ms * 1e-3) / 1e9, 1)
                 result["roofline_corr"]["traffic_over_algorithmic"] = round(real / tot_b, 3)
+                result["roofline_corr"]["traffic_over_needed"] = round(real / moved, 3)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import streamflow_oracle as orc

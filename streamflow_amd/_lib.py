@@ -166,7 +166,12 @@ def load() -> C.CDLL:
     return lib
 
 
+CALLS = 0          # entry-point calls checked so far (a diagnostic counter: HotPathEngine reads the difference over a graph capture)
+
+
 def check(status: int, what: str = "") -> None:
+    global CALLS
+    CALLS += 1
     if status != 0:
         msg = load().sf_last_error().decode(errors="replace")
         raise RuntimeError(f"libstreamflow_hip {what} failed ({status}): {msg}")

@@ -1,6 +1,9 @@
 """Build libstreamflow_hip.so (HIP kernels + C ABI) for gfx950 with hipcc, in-tree.
 
-    python -m streamflow_amd.build [--force]
+    python -m streamflow_amd.build [--force | --clean] [--resources] [--asan]
+
+``--clean`` removes every object, resource record and the library first and compiles all sources from nothing (what a fresh
+checkout does; the incremental mode compares mtimes only).
 
 hipcc cross-compiles without a GPU.  Objects go to ``streamflow_amd/csrc/build/`` and the shared
 library to ``streamflow_amd/libstreamflow_hip.so`` (git-ignored, shipped to the GPU box by gpurun).
@@ -17,6 +20,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libstreamflow_hip.so")
+ASAN_OBJ = os.path.join(CSRC, "build_asan")
+ASAN_LIB = os.path.join(HERE, "libstreamflow_hip_asan.so")
 SOURCES = ["misc.hip", "corr.hip", "corr_blocked.hip", "conv.hip", "gemm.hip", "gemm_split.hip", "gemm_bstat.hip", "ffn_pair.hip", "temporal.hip", "mask_upsample.hip", "attn.hip", "encoder.hip"]
 HEADERS = [os.path.join(CSRC, "sf_common.h"), os.path.join(CSRC, "gemm_epilogue.h"), os.path.join(CSRC, "split_operand.h"),
            os.path.join(HERE, "..", "include", "streamflow_hip.h")]
@@ -116,6 +121,33 @@ def resources_markdown() -> str:
     return "\n".join(rows) + "\n"
 
 
+def clean(asan: bool = False) -> None:
+    """Remove the objects, resource records and the shared library (the next build() starts from the sources alone)."""
+    for d, lib in ((OBJ, LIB),) + (((ASAN_OBJ, ASAN_LIB),) if asan else ()):
+        shutil.rmtree(d, ignore_errors=True)
+        if os.path.exists(lib):
+            os.remove(lib)
+
+
+def compile_source(src: str, obj_dir: str, verbose: bool = False) -> str:
+    """One translation unit from scratch into `obj_dir` (object + .res record) with the flags of the real build: the unit of
+    build(); tests/test_abi_cpu.py compiles the smallest source this way into an empty directory."""
+    os.makedirs(obj_dir, exist_ok=True)
+    s, o = os.path.join(CSRC, src), os.path.join(obj_dir, src.replace(".hip", ".o"))
+    cmd = [hipcc()] + FLAGS + ["-c", s, "-o", o]
+    if verbose:
+        print("[build]", " ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed for {s}:\n{r.stdout}\n{r.stderr}")
+    with open(o[:-2] + ".res", "w") as f:
+        f.write("\n".join(ln for ln in r.stderr.splitlines() if "kernel-resource-usage" in ln) + "\n")
+    other = _strip_remarks(r.stderr)
+    if verbose and other.strip():
+        print(other, file=sys.stderr)
+    return o
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(OBJ, exist_ok=True)
     cc = hipcc()
@@ -127,20 +159,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
             jobs.append((s, o))
 
     def compile_one(job):
-        s, o = job
-        cmd = [cc] + FLAGS + ["-c", s, "-o", o]
-        if verbose:
-            print("[build]", " ".join(cmd), flush=True)
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError(f"hipcc failed for {s}:\n{r.stdout}\n{r.stderr}")
-        remarks = [ln for ln in r.stderr.splitlines() if "kernel-resource-usage" in ln]
-        with open(o[:-2] + ".res", "w") as f:
-            f.write("\n".join(remarks) + "\n")
-        other = _strip_remarks(r.stderr)
-        if verbose and other.strip():
-            print(other, file=sys.stderr)
-        return o
+        return compile_source(os.path.basename(job[0]), OBJ, verbose)
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(compile_one, jobs))
@@ -153,10 +172,6 @@ def build(force: bool = False, verbose: bool = True) -> str:
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
     return LIB
-
-
-ASAN_OBJ = os.path.join(CSRC, "build_asan")
-ASAN_LIB = os.path.join(HERE, "libstreamflow_hip_asan.so")
 
 
 def asan_runtime() -> str:
@@ -207,6 +222,8 @@ if __name__ == "__main__":
     if "--asan" in sys.argv:
         print(build_asan(force="--force" in sys.argv))
         sys.exit(0)
+    if "--clean" in sys.argv:
+        clean()
     print(build(force="--force" in sys.argv))
     if "--resources" in sys.argv:
         print(resources_markdown())

@@ -104,12 +104,17 @@ __global__ __launch_bounds__(NW * 64, (NW == 8) ? 4 : ((NK1 > 8 && MODE >= 1) ? 
 
     // ---- the weight stream: stage s = bytes [s * 16 KB, (s + 1) * 16 KB) of the packed buffer; wave w moves pieces w, w + 4, ... ----
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.wstream), 0, (int)a.w_bytes, 0x00020000);
+    // (stages requested past the end of the stream -- the loop keeps the request count per trip constant -- re-read the LAST stage
+    // into a slot nobody reads any more: the stage offset travels in the scalar offset, which the raw-buffer range check of gfx9
+    // does not cover, so "out of range: zeros" must not be relied on: ADVICE r5)
+    const int last_stage = (int)(a.w_bytes / kStage) - 1;
     auto issue_stage = [&](int s, int slot) {
+        const int sc = min(s, last_stage);
 #pragma unroll
         for (int i = 0; i < S / kWaves; ++i) {
             const int piece = wave + kWaves * i;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(smem + slot * kStage + piece * 1024), 16, lane * 16,
-                                                     s * kStage + piece * 1024, 0, 0);
+                                                     sc * kStage + piece * 1024, 0, 0);
         }
     };
 #ifdef SF_PAIR_TIMERS
@@ -161,14 +166,14 @@ __global__ __launch_bounds__(NW * 64, (NW == 8) ? 4 : ((NK1 > 8 && MODE >= 1) ? 
         static_for<0, NSTG>([&](auto st_tag) {
             constexpr int st = decltype(st_tag)::value;
             // stage gs + RING - 1 goes into the slot every wave finished reading before the barrier that ended the previous stage
-            // (issued past the end too -- out of range: zeros -- so that the counted wait below sees the same queue every trip)
+            // (issued past the end too -- clamped to the last stage -- so that the counted wait below sees the same queue every trip)
 #if SF_PAIR_ONE_LOADER
             // (experiment: ONE wave per stage issues all its pieces -- fewer waves queueing on the CU's address path at a time)
             if (wave == gs % kWaves) {
 #pragma unroll
                 for (int i = 0; i < S; ++i)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(smem + (slot == 0 ? RING - 1 : slot - 1) * kStage + i * 1024), 16,
-                                                             lane * 16, (gs + RING - 1) * kStage + i * 1024, 0, 0);
+                                                             lane * 16, min(gs + RING - 1, last_stage) * kStage + i * 1024, 0, 0);
             }
 #else
             issue_stage(gs + RING - 1, slot == 0 ? RING - 1 : slot - 1);

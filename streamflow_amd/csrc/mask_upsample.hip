@@ -64,12 +64,17 @@ __global__ __launch_bounds__(kThreads, 2) void mask_upsample_kernel(const MuArgs
     const bool pin = px < P;
 
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.wstream), 0, (int)a.w_bytes, 0x00020000);
+    // (stages requested past the end of the stream -- the loop keeps the request count per trip constant -- re-read the LAST stage
+    // into a slot nobody reads any more: the stage offset travels in the scalar offset, which the raw-buffer range check of gfx9
+    // does not cover, so "out of range: zeros" must not be relied on: ADVICE r5)
+    const int last_stage = (int)(a.w_bytes / kStage) - 1;
     auto issue_stage = [&](int s, int slot) {
+        const int sc = min(s, last_stage);
 #pragma unroll
         for (int i = 0; i < PCS; ++i) {
             const int piece = wave + kWaves * i;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(smem + slot * kStage + piece * 1024), 16, lane * 16,
-                                                     s * kStage + piece * 1024, 0, 0);
+                                                     sc * kStage + piece * 1024, 0, 0);
         }
     };
 #pragma unroll
@@ -104,7 +109,7 @@ __global__ __launch_bounds__(kThreads, 2) void mask_upsample_kernel(const MuArgs
 
     static_for<0, kTiles / TPS>([&](auto j_tag) {
         constexpr int j = decltype(j_tag)::value, slot = j % RING;
-        issue_stage(j + RING - 1, (slot + RING - 1) % RING);      // (past the end: out of range, zeros)
+        issue_stage(j + RING - 1, (slot + RING - 1) % RING);      // (past the end: the last stage again)
         const char* sp = smem + slot * kStage + lane * 16;
         static_for<0, S>([&](auto i_tag) {
             constexpr int i = decltype(i_tag)::value, t = j * TPS + i / FT, ks = (i % FT) / PM;

@@ -99,12 +99,17 @@ __global__ __launch_bounds__(kThreads, 2) void temporal_block_kernel(const TbArg
 
     // ---- the weight stream (ffn_pair.hip's ring): stage s = bytes [16 KB s, 16 KB (s + 1)); wave w moves pieces w, w + 4, ... ----
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.wstream), 0, (int)a.w_bytes, 0x00020000);
+    // (stages requested past the end of the stream -- the loop keeps the request count per trip constant -- re-read the LAST stage
+    // into a slot nobody reads any more: the stage offset travels in the scalar offset, which the raw-buffer range check of gfx9
+    // does not cover, so "out of range: zeros" must not be relied on: ADVICE r5)
+    const int last_stage = (int)(a.w_bytes / kStage) - 1;
     auto issue_stage = [&](int s, int slot) {
+        const int sc = min(s, last_stage);
 #pragma unroll
         for (int i = 0; i < PCS; ++i) {
             const int piece = wave + kWaves * i;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(smem + slot * kStage + piece * 1024), 16, lane * 16,
-                                                     s * kStage + piece * 1024, 0, 0);
+                                                     sc * kStage + piece * 1024, 0, 0);
         }
     };
 #pragma unroll
@@ -166,7 +171,7 @@ __global__ __launch_bounds__(kThreads, 2) void temporal_block_kernel(const TbArg
 
     int gs = 0, slot = 0;                                         // global stage index, its ring slot
     auto stage_begin = [&]() -> const char* {
-        issue_stage(gs + RING - 1, slot == 0 ? RING - 1 : slot - 1);      // (past the end: out of range, zeros -- the counted wait sees the same queue)
+        issue_stage(gs + RING - 1, slot == 0 ? RING - 1 : slot - 1);      // (past the end: the last stage again -- the counted wait sees the same queue)
         return smem + slot * kStage + lane * 16;
     };
     auto stage_end = [&]() {

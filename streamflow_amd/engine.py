@@ -373,6 +373,7 @@ class _Plan:
         self.cnets_in = None
         self.graph = None
         self.graph_key = None
+        self.graph_calls = 0
 
 
 def _level_maps(self, l: int) -> torch.Tensor:
@@ -821,9 +822,11 @@ class HotPathEngine:
                 self._run(pl, pl.fmaps_in, pl.cnets_in, 1, all_masks)
             torch.cuda.current_stream().wait_stream(s)
             g = torch.cuda.CUDAGraph()
+            calls0 = _lib.CALLS
             with torch.cuda.graph(g, stream=s):
                 self._run(pl, pl.fmaps_in, pl.cnets_in, iters, all_masks)
             pl.graph, pl.graph_key = g, key
+            pl.graph_calls = _lib.CALLS - calls0           # C-ABI launch calls captured (>= kernel nodes / fused setup calls): a diagnostic
             pl.coords1.tensor().copy_(state[0])
             pl.flow.tensor().copy_(state[1])
             pl.mf.tensor().copy_(state[2])

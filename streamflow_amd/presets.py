@@ -3,8 +3,13 @@
 ``fp32_class`` -- the library default.  Every contraction in split precision (x = hi + lo in fp16, three MFMA products,
     fp32 accumulation: ~2^-20 relative), correlation pyramids kept in fp32 as the reference keeps them (corr.py:13; rows
     padded to whole cache lines where the dense maps would straddle them), GMA aggregation by the fused recompute kernel
-    with fp16 q / k / v (as precise as the materialised matrix, whose softmax weights were stored in fp16 too).  Flows agree
-    with the fp32 reference to ~2e-5 px at the headline shape and stay inside 1e-3 px on every ill-conditioned input tried.
+    with SPLIT q and k (three MFMA products per logit: the logits are fp32-class, 2^-20; only the softmax weights and v enter
+    the second contraction in fp16, as the materialised matrix of rounds 1-4 stored them).  Round 5 shipped ONE fp16 product per
+    logit here: that puts |logit| 2^-11 of absolute error on the logits, harmless for the random-weight networks of the test
+    inputs (small logits, EPE unchanged) but 12x looser on peaked attention (logits of +-40: 2.5e-2 against 2e-3 in
+    tests/test_gpu_parity.py::test_gma_flash_kernel_vs_float64) -- not fp32-class for trained GMA weights (ADVICE r5), so the
+    default went back to three products (127.9 -> 140.7 ms per step).  Flows agree with the fp32 reference to ~2e-5 px at the
+    headline shape and stay inside 1e-3 px on every ill-conditioned input tried.
 ``config2_fp16`` -- BASELINE.json configuration 2 ("Sintel-shape 436x1024 T=4 iters=15 bf16"): the arithmetic class of
     the reference's own deployment, which runs the whole network under fp16 autocast (evaluate_mf.py:1106,
     demo.py:427-456), but with fp32 accumulation everywhere and split-precision WEIGHTS: activations are rounded once
@@ -40,10 +45,10 @@ from __future__ import annotations
 from typing import Dict
 
 PRESETS: Dict[str, Dict[str, object]] = {
-    # (round 5: GMA through the fused kernel with fp16 q / k instead of the materialised fp16 attention matrix -- the matrix path
-    # stores its softmax weights in fp16 as well; EPE unchanged on the six hard seeds, profiles/r05_hard_case_ablation.jsonl row
-    # "fp32_class+flash1", 134.8 -> 127.9 ms per step)
-    "fp32_class": dict(precision="f16x3", corr_dtype="f32", gma_mode="flash", flash_qk_products=1),
+    # (GMA through the fused kernel -- no N x N matrix -- with split q / k: fp32-class logits whatever their magnitude; round 5's
+    # single fp16 product per logit was 9 % faster and indistinguishable on the random-weight test networks, but is not fp32-class
+    # on peaked attention: see the module docstring)
+    "fp32_class": dict(precision="f16x3", corr_dtype="f32", gma_mode="flash", flash_qk_products=3),
     "config2_fp16": dict(precision="f16x2", corr_dtype="f16", gma_mode="flash", flash_qk_products=1),
     "config2_mixed": dict(precision="f16x2", corr_dtype="f16", gma_mode="flash", flash_qk_products=1,
                           single_layers="all_but_keep"),

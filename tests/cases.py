@@ -124,7 +124,8 @@ def flow_io_inputs():
 # others are the held-out construction of round 4's tools/preset_select.py (params s, frames 100 + s, Twins 200 + s / 300 + s).
 # every consumer sweeps ALL of them and reports the maximum.
 HARD_SEEDS = (21, 11, 12, 13, 31, 32)
-HARD_SHAPE = (1, 4, 128, 192, 4)                      # B, T, H, W, iterations
+HARD_SHAPE = (1, 4, 128, 192, 4)                      # B, T, H, W, iterations (the round-3 ... 5 form of the sweep)
+HARD_ITERS = (4, 15)                                  # ... and the count the reference deploys (scripts/infer.sh:17, demo.py:419): VERDICT r5 #6
 
 
 def hard_case_seeds(seed):

@@ -15,7 +15,7 @@ FFN2 = [(128, 192, 64), (256, 384, 192), (256, 384, 126), (324, 486, 256), (384,
 @pytest.fixture(scope="module")
 def dev():
     if not torch.cuda.is_available():
-        pytest.skip("needs an MI355X")
+        pytest.fail("GPU tests need an MI355X; torch.cuda.is_available() is False")
     return torch.device("cuda:0")
 
 

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module")
 def dev():
     if not torch.cuda.is_available():
-        pytest.skip("needs an MI355X")
+        pytest.fail("GPU tests need an MI355X; torch.cuda.is_available() is False")
     return torch.device("cuda:0")
 
 

@@ -169,6 +169,58 @@ def test_engine_forward_vs_golden(golden, dev, tag, graph, precision):
                 close(low[i], g[f"low{i}"], 1e-3, what=f"{tag} lowres {i}")
 
 
+@pytest.mark.parametrize("tag", list(cases.FORWARD_CASES))
+@pytest.mark.parametrize("graph", [False, True])
+@pytest.mark.parametrize("preset", ["config2_fp16", "config2_mixed"])
+def test_engine_forward_config2_presets_vs_golden(golden, dev, tag, graph, preset):
+    """the kernels the HEADLINE presets run (activation-stationary GEMMs, FFN pairs, the one-launch temporal
+    block, blocked fp16 volumes, fp16-input depthwise, mask head -> upsampling) against the reference's own SKFlow_MF8.forward
+    outputs (golden fixtures), not only against the oracle.  Bound: the class's 1e-3 px (flows here are 1-3 px)."""
+    from oracle import streamflow_oracle as orc
+    from streamflow_amd import presets
+    from streamflow_amd.engine import HotPathEngine
+    g = golden(tag)
+    B, T, H, W, iters, seed, use_init = cases.FORWARD_CASES[tag]
+    P, fmaps, cnets, finit, iters = cases.forward_inputs(tag)
+    eng = HotPathEngine(P, device=dev, T=T, use_graph=graph, **presets.engine_kwargs(preset))
+    finit_d = None if finit is None else [f.to(dev) for f in finit]
+    for rep in range(2):
+        ups, low = eng.forward(fmaps.to(dev), cnets.to(dev), iters=iters, flow_init=finit_d)
+        for i in range(T - 1):
+            e = orc.epe(ups[i].cpu(), torch.from_numpy(g[f"up{i}"]))
+            print(f"{tag} {preset} graph={graph} rep={rep} pair {i}: EPE vs reference = {e:.3e}")
+            assert e <= 1e-3, f"{tag} {preset} pair {i}: EPE {e}"
+            if use_init:
+                close(low[i], g[f"low{i}"], 2e-3, what=f"{tag} {preset} lowres {i}")
+
+
+@pytest.mark.parametrize("tag", list(cases.UPDATE_CASES))
+def test_update_block_f16x2_vs_golden(golden, dev, tag):
+    """The update block's API class in the config-2 arithmetic (f16x2: fp16 activations into every product, weights hi + lo) against
+    the reference's SKUpdateBlock_TAM_v3.forward golden: tensor tolerances of the class (a chain of ~25 contractions whose operands are
+    rounded to 2^-11: 5e-3 abs + 5e-3 rel on O(1) tensors; observed values are printed)."""
+    from argparse import Namespace
+    import streamflow_amd as sfa
+    from streamflow_amd.update import SKUpdateBlock_TAM_v3
+    g = golden(tag)
+    B, T, h, w, _ = cases.UPDATE_CASES[tag]
+    P, nets, inps, corrs, flows, attn = cases.update_inputs(tag)
+    args = Namespace(decoder_dim=256, corr_levels=4, corr_radius=4, k_conv=[1, 15], PCUpdater_conv=[1, 7], T=T,
+                     use_gma=True, num_heads=1, Encoder="InjectEncoder")
+    prev = sfa.set_precision("f16x2")
+    try:
+        ub = SKUpdateBlock_TAM_v3(args).to(dev)
+        ub.load_state_dict(_sub(P, "update_block"), strict=True)
+        mf = ub.encoder(flows.to(dev), corrs.to(dev))
+        n2, masks, dflow = ub(nets.to(dev), inps.to(dev), corrs.to(dev), flows.to(dev), attn.to(dev), T=T - 1)
+    finally:
+        sfa.set_precision(prev)
+    for name, out, ref in (("motion", mf, g["motion"]), ("nets", n2, g["nets"]), ("masks", masks, g["masks"]), ("dflow", dflow, g["dflow"])):
+        err = float(np.abs(out.detach().float().cpu().numpy() - ref).max())
+        print(f"{tag} f16x2 {name}: max |err| vs reference = {err:.3e} (|ref| max {float(np.abs(ref).max()):.2f})")
+        close(out, ref, 5e-3, 5e-3, what=f"{tag} f16x2 {name}")
+
+
 def test_model_api_forward_vs_golden(golden, dev, precision):
     """SKFlow_MF8 with the reference's signature (list of frames in 0..255, test_mode), stand-in encoder."""
     from oracle import streamflow_oracle as orc
@@ -1097,18 +1149,21 @@ def test_real_frames_end_to_end_with_twins_encoder(dev):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("iters", cases.HARD_ITERS)
 @pytest.mark.parametrize("seed", cases.HARD_SEEDS)
-def test_hard_case_sweep_vs_oracle(dev, seed):
+def test_hard_case_sweep_vs_oracle(dev, seed, iters):
     """the ill-conditioned input class (frames -> exact Twins_CSC features of a random-weight encoder -> loop at
     128 x 192, 4 iterations, flows of 4-40 px) on SIX weight / frame seeds, every one against the CPU ORACLE (not against another
     engine).  Bounds: the fp32 class inside the absolute 1e-3 px budget; the config-2 class (fp16 activations entering every
     product) inside 1e-3 of the mean flow magnitude -- its deviation is relative, DESIGN.md section 6 carries the per-seed table
     (profiles/r05_hard_case_ablation.jsonl: the oracle itself moves by <= 1.1e-3 px under a 2^-11 relative perturbation of its
-    inputs, i.e. the cases are NOT chaotic; the deviation is the activations' fp16 rounding, 5-10x above everything else)."""
+    inputs, i.e. the cases are NOT chaotic; the deviation is the activations' fp16 rounding, 5-10x above everything else).
+    Round 6: swept at 4 iterations (the form every earlier round reported) AND at the 15 the reference deploys
+    (scripts/infer.sh:17, demo.py:419)."""
     from oracle import streamflow_oracle as orc, twins_oracle as two
     from streamflow_amd import presets, synthetic as syn
     from streamflow_amd.engine import HotPathEngine
-    B, T, H, W, iters = cases.HARD_SHAPE
+    B, T, H, W, _ = cases.HARD_SHAPE
     ps, _, a, b = cases.hard_case_seeds(seed)
     hot = syn.make_params(ps, T)
     imgs = 2 * (torch.stack(cases.hard_case_frames(seed), dim=1) / 255.0) - 1.0
@@ -1121,7 +1176,7 @@ def test_hard_case_sweep_vs_oracle(dev, seed):
         eng = HotPathEngine(hot, device=dev, T=T, **presets.engine_kwargs(preset))
         ups, _ = eng.forward(fm.to(dev).contiguous(), cn.to(dev).contiguous(), iters=iters)
         worst[preset] = max(orc.epe(u.cpu(), o) for u, o in zip(ups, ups_o))
-    print(f"hard case seed {seed}: mean |flow| {mag:.2f} px, EPE vs oracle {worst}")
+    print(f"hard case seed {seed}, {iters} iterations: mean |flow| {mag:.2f} px, EPE vs oracle {worst}")
     assert worst["fp32_class"] <= 1e-3, (seed, worst)
     assert worst["config2_fp16"] <= 1e-3 * max(1.0, mag), (seed, worst, mag)
     assert worst["config2_mixed"] <= 1e-3 * max(1.0, mag), (seed, worst, mag)

@@ -14,7 +14,7 @@ C, H = 128, 256
 @pytest.fixture(scope="module")
 def dev():
     if not torch.cuda.is_available():
-        pytest.skip("needs an MI355X")
+        pytest.fail("GPU tests need an MI355X; torch.cuda.is_available() is False")
     return torch.device("cuda:0")
 
 
@@ -191,3 +191,27 @@ def test_temporal_block_rejects_what_it_was_not_built_for(dev):
     g_ = _lib.SfTemporalBlock()
     assert _lib.load().sf_temporal_block(Ct.byref(g_), None) != 0
     assert _lib.load().sf_temporal_block_frags(3) == 0 and _lib.load().sf_temporal_block_frags(2) == 512
+
+
+def test_engine_with_and_without_the_fused_temporal_block_vs_oracle(dev):
+    """the one-launch temporal block takes its residual and LayerNorm input from the fp16 k-octet copy of the motion
+    features instead of the fp32 planes -- isolated accuracy evidence at the engine level: the same clip through the engine with
+    EngineOptions.temporal_block on and off (15 iterations, config2_fp16 so that nothing else differs), each against the CPU
+    oracle; the fused arm must stay within the class bound AND within 1.5x of the unfused arm (+ a floor for the noise between
+    two equivalent fp16 launch sequences)."""
+    from oracle import streamflow_oracle as orc
+    from streamflow_amd import presets, synthetic as syn
+    from streamflow_amd.engine import EngineOptions, HotPathEngine
+    T, B, h, w, iters = 4, 1, 24, 32, 15
+    params = syn.make_params(9, T)
+    fmaps, cnets = syn.make_features(79, B, T, h, w)
+    ups_o, _ = orc.hotpath_forward(fmaps, cnets, params, iters)
+    kw = presets.engine_kwargs("config2_fp16")
+    epe = {}
+    for on in (True, False):
+        eng = HotPathEngine(params, device=dev, T=T, options=EngineOptions(temporal_block=on), **kw)
+        ups, _ = eng.forward(fmaps.to(dev), cnets.to(dev), iters=iters)
+        epe[on] = max(orc.epe(u.cpu(), o) for u, o in zip(ups, ups_o))
+    print(f"temporal block fused / unfused: EPE vs oracle {epe[True]:.3e} / {epe[False]:.3e} px (15 iterations, 24 x 32 grid)")
+    assert epe[True] <= 1e-3 and epe[False] <= 1e-3
+    assert epe[True] <= 1.5 * epe[False] + 5e-5, epe
