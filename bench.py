@@ -138,15 +138,17 @@ def timed_steps(step_fn, steps: int, warmup: int, world: int, sync_fn, barrier_f
     sync_fn()
     barrier_fn()
     t0 = time.perf_counter()
-    host = 0.0
+    host, host_cpu = 0.0, 0.0
     for _ in range(steps):
-        th = time.perf_counter()
+        th, tc = time.perf_counter(), time.thread_time()
         step_fn()
-        host += time.perf_counter() - th               # time the HOST spends inside the step (input staging + graph launch / enqueues)
+        host += time.perf_counter() - th               # wall time the HOST thread spends inside the step (input staging + graph launch /
+        host_cpu += time.thread_time() - tc            # enqueues; includes blocking on a full hardware queue) and its CPU time alone
     sync_fn()
     if own is not None:
         own.append(time.perf_counter() - t0)
         own.append(host)
+        own.append(host_cpu)
     barrier_fn()
     dt = time.perf_counter() - t0
     return allreduce_max_fn(dt)
@@ -428,7 +430,7 @@ def main():
     ap.add_argument("--precision", default=None, choices=["f16x3", "fp32", "f16x2", "f16"],
                     help="f16x3: split-fp16 MFMA with fp32 accumulation (fp32-class accuracy); fp32: exact fp32 MFMA; "
                          "f16x2: weights split, activations rounded once to fp16")
-    ap.add_argument("--gma", default=None, choices=["auto", "matrix", "flash"], help="GMA aggregation path (engine gma_mode)")
+    ap.add_argument("--gma", default=None, choices=["auto", "matrix", "flash", "stored"], help="GMA aggregation path (engine gma_mode)")
     ap.add_argument("--flash-qkp", type=int, default=None, choices=[1, 2, 3], help="MFMA products per logit of the fused GMA kernel")
     ap.add_argument("--corr-dtype", default=None, choices=["f16", "f32"],
                     help="storage of the correlation pyramids: f16 = fp16 cells built with single f16 MFMA products "
@@ -583,11 +585,11 @@ def main():
     own = []
     dt = timed_steps(step, args.steps, args.warmup, world, torch.cuda.synchronize, barrier, allreduce_max, own=own)
     log(f"timed region: {args.steps} steps in {dt:.3f}s (this rank: {own[0]:.3f}s)")
-    per_rank, rank_cores, rank_host = [own[0]], [len(RANK_CPUS)], [own[1]]
+    per_rank, rank_cores, rank_host, rank_host_cpu = [own[0]], [len(RANK_CPUS)], [own[1]], [own[2]]
     pl0 = next(reversed(eng._plans.values())) if eng._plans else None
     graph_calls = [int(getattr(pl0, "graph_calls", 0) or 0)]
     if world > 1:
-        t_own = torch.tensor([own[0], float(len(RANK_CPUS)), own[1], float(graph_calls[0])], dtype=torch.float64,
+        t_own = torch.tensor([own[0], float(len(RANK_CPUS)), own[1], float(graph_calls[0]), own[2]], dtype=torch.float64,
                              device=dev if args.dist_backend == "nccl" else "cpu")
         t_all = [torch.zeros_like(t_own) for _ in range(world)]
         dist.all_gather(t_all, t_own)
@@ -595,6 +597,7 @@ def main():
         rank_cores = [int(t[1].item()) for t in t_all]
         rank_host = [float(t[2].item()) for t in t_all]
         graph_calls = [int(t[3].item()) for t in t_all]
+        rank_host_cpu = [float(t[4].item()) for t in t_all]
     clips_all = args.total_clips if strong else world * B
     fields = clips_all * pairs * args.steps
     result = {
@@ -605,10 +608,12 @@ def main():
         # spread of the ranks' own times (each up to its device sync, before the closing barrier) relative to their mean: what
         # the slowest rank costs the job
         "imbalance": round((max(per_rank) - min(per_rank)) / (sum(per_rank) / len(per_rank)), 4),
-        # SCALE diagnostics: the time each rank's HOST thread spends inside a step (input staging copies + ONE graph
-        # launch, or the eager enqueues) -- if this approaches ms_per_step at N = 8 the ranks are host-bound, not GPU-bound -- and the
-        # size of the replayed graph (launch calls captured per forward)
+        # SCALE diagnostics: the WALL time each rank's host thread spends inside a step (input staging copies + ONE graph
+        # launch, or the eager enqueues; the runtime launches a graph's nodes from the calling thread and blocks while the hardware
+        # queues are full, so this follows the GPU time) and its CPU time alone -- if host_cpu approaches ms_per_step at N = 8 the
+        # ranks are host-bound, not GPU-bound -- and the size of the replayed graph (launch calls captured per forward)
         "host_ms_per_step": [round(1e3 * t / args.steps, 3) for t in rank_host],
+        "host_cpu_ms_per_step": [round(1e3 * t / args.steps, 3) for t in rank_host_cpu],
         "graph_launch_calls": graph_calls,
         "dtype": {"fp32": "fp32", "f16x3": "f16x3-split (fp32 accumulate)",
                   "f16x2": ("f16x2 (weights hi+lo, activations fp16; fp32 accumulate)" if not cfg.get("single_layers") else
@@ -628,7 +633,9 @@ def main():
                    "corr_volume": {"f16": "fp16 cells, single f16 MFMA product, fp32 accumulate",
                                    "f32": "fp32 cells"}[args.corr_dtype],
                    "gma": f"{eng.gma_mode}" + (f" (fused recompute, {eng.flash_qk_products} MFMA product(s) per logit)"
-                                                if eng.gma_mode == "flash" else ""),
+                                                if eng.gma_mode == "flash" else
+                                                f" (softmax weights stored once per clip as fp16, {eng.flash_qk_products} MFMA product(s) per "
+                                                f"logit; streamed every iteration)" if eng.gma_mode == "stored" else ""),
                    "precision": {"fp32": "exact fp32 (v_mfma_f32_32x32x2_f32)",
                                  "f16x3": "split fp16x3 (x=hi+lo, 3x v_mfma_f32_32x32x16_f16, fp32 accumulate)",
                                  "f16x2": "weights hi+lo fp16, activations fp16 (2x v_mfma_f32_32x32x16_f16)" +

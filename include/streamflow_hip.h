@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SF_VERSION 116
+#define SF_VERSION 117
 
 enum {
     SF_OK = 0,
@@ -285,6 +285,23 @@ int sf_gma_flash_aggregate_f16v(void* ws, int64_t ws_bytes, const void* v_f16, i
 int sf_gma_flash_project_v(void* ws, int64_t ws_bytes, const void* x_koct, int64_t x_koct_img_stride, int64_t ldx,
                            const void* w_hi, const void* w_lo, int lda_h, float alpha, int products, int n_img, int P,
                            void* stream);
+
+/* ---- a6 + a7 with the attention weights KEPT (core/gma.py:53-65 computes `attn` once per clip, gma.py:99-102 multiplies it every
+ * iteration): the fused path above recomputes softmax(q k^T) in every iteration; q and k do not change over the refinement loop, so
+ * the weights can be stored once -- as fp16, unnormalised (exp2 of the logit minus the stored row maximum: bit for bit what the fused
+ * kernel multiplies), in the register image of the second contraction's B operand -- and every iteration only streams them past v:
+ * half the matrix-core work, no exponentials, HBM-bound (n_img * Ppad^2 * 2 bytes per iteration, Ppad = P rounded up to 128).
+ *   sf_gma_stored_p_bytes: size of `pbuf` (caller-owned, 16-byte aligned, persists over the clip's iterations).
+ *   sf_gma_flash_store_p: once per clip, after sf_gma_flash_pack_qk(stats_qk_products = qk_products): writes pbuf.
+ *   sf_gma_stored_aggregate: every iteration; out = mf + gamma / rowsum * v P^T.  v as in sf_gma_flash_aggregate (v_f16 = 1: fp16
+ *       rows; v == NULL: the v planes of ws are current, sf_gma_flash_project_v).  With the same ws the result is bit-identical to
+ *       sf_gma_flash_aggregate(use_stats = 1).  Weights stored by another pack call / product count poison the result (NaN). */
+int64_t sf_gma_stored_p_bytes(int n_img, int P);
+int sf_gma_flash_store_p(void* ws, int64_t ws_bytes, void* pbuf, int64_t pbuf_bytes, int n_img, int P, int qk_products,
+                         void* stream);
+int sf_gma_stored_aggregate(void* ws, int64_t ws_bytes, const void* pbuf, int64_t pbuf_bytes, const void* v, int v_f16,
+                            int64_t v_img_stride, const float* mf, int64_t mf_img_stride, const float* gamma, float* out,
+                            int64_t out_img_stride, void* out_koct, int64_t out_koct_img_stride, int n_img, int P, void* stream);
 
 /* ---- a8: one FFN pair of an SK block in ONE launch (core/update.py:14-16, 30-36; csrc/ffn_pair.hip) ---------------------------
  * y = W2 gelu(W1 x + b1) + b2 with the 1.5 C hidden tensor kept in registers (the two-launch form writes and re-reads it).

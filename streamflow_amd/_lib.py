@@ -110,6 +110,9 @@ SIGNATURES = {
     "sf_gma_flash_aggregate": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _vp]),
     "sf_gma_flash_aggregate_f16v": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _vp]),
     "sf_gma_flash_project_v": (_i, [_vp, _i64, _vp, _i64, _i64, _vp, _vp, _i, _f, _i, _i, _i, _vp]),
+    "sf_gma_stored_p_bytes": (_i64, [_i, _i]),
+    "sf_gma_flash_store_p": (_i, [_vp, _i64, _vp, _i64, _i, _i, _i, _vp]),
+    "sf_gma_stored_aggregate": (_i, [_vp, _i64, _vp, _i64, _vp, _i, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _i, _i, _vp]),
     "sf_ffn_pair": (_i, [C.POINTER(SfFfnPair), _vp]),
     "sf_ffn_pair_frags": (_i, [_i, _i, _i, _i]),
     "sf_temporal_block": (_i, [C.POINTER(SfTemporalBlock), _vp]),

@@ -33,6 +33,7 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int sf_u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lds_ptr;
 
 constexpr int HD = 128;              // head dim (GMA: heads = 1, dim_head = 128)
@@ -48,6 +49,8 @@ struct FlashArgs {
     int P, Ppad;
     float* part;                    // nsplit > 1 (statistics mode only): partial results [split][img][128][Ppad], summed by
     int nsplit;                     // flash_combine_kernel -- key ranges in parallel when the query tiles cannot fill the chip
+    char* pbuf;                     // stored softmax weights (MODE 3 writes, gma_pv_kernel reads): per image [Ppad / 32 query tiles]
+    int64_t p_img_stride;           // [Ppad / 16 key groups][64 lanes][8 halves] = the B fragments of O^T += V^T P^T; bytes per image
 };
 
 __host__ __device__ inline int64_t plane_bytes(int Ppad) { return (int64_t)256 * Ppad; }
@@ -186,10 +189,13 @@ __device__ __forceinline__ float xor32(float v) {          // value of lane ^ 32
 // MODE 0: self-contained online softmax (running maximum, rescale, row sum).  MODE 1: the statistics of the workspace are
 // used (accumulators start at -max, weights are exp2 of the accumulator, the result is scaled by the stored 1 / row sum).
 // MODE 2: the statistics pass -- logits and the online maximum / sum only (no V tile, no P V), writes (max, 1 / sum).
+// MODE 3: the store pass -- MODE 1's softmax weights (exp2 of the logit minus the stored maximum, rounded to fp16: bit for bit what
+// MODE 1 multiplies) written to g.pbuf as the B fragments of the second contraction, no V tile, no P V (gma_pv_kernel below).
 template <int QKP, int MODE>
 __global__ __launch_bounds__(256, (QKP == 3) ? 1 : ((QKP == 1 && SF_FLASH_V1) ? 3 : 2)) void gma_flash_kernel(const FlashArgs g) {
     constexpr bool kKlo = (QKP == 3);
-    constexpr bool kUseStats = MODE == 1, kStatsPass = MODE == 2;
+    constexpr bool kUseStats = MODE == 1 || MODE == 3, kStatsPass = MODE == 2, kStoreP = MODE == 3;
+    constexpr bool kNoPV = kStatsPass || kStoreP;
     constexpr int KSTAGE = KPLANE * (kKlo ? 2 : 1);
     // kV1: K tiles double-buffered, V single-buffered.  V(t) is requested at the top of tile t (every wave has finished
     // P V of tile t-1 by then) and has the logits + softmax of tile t to land; a second barrier precedes P V.
@@ -231,8 +237,12 @@ __global__ __launch_bounds__(256, (QKP == 3) ? 1 : ((QKP == 1 && SF_FLASH_V1) ? 
         const float2 st = stats[q]; st_m = st.x; st_inv = st.y;
         // statistics stored by another product count (or none at all): poison the result instead of using them
         const int* hdr = reinterpret_cast<const int*>(ws + hdr_offset(Ppad));
-        if (hdr[0] != kHdrMagic || hdr[1] != QKP || hdr[2] != P) st_inv = __builtin_nanf("");
+        if (hdr[0] != kHdrMagic || hdr[1] != QKP || hdr[2] != P) { st_inv = __builtin_nanf(""); if (kStoreP) st_m = st_inv; }
     }
+    // MODE 3: this wave's fragment stream = (query tile of 32) x all key groups of 16, 1 KB each, lane-linear
+    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(
+        kStoreP ? g.pbuf + (int64_t)img * g.p_img_stride + (int64_t)((q0 >> 5) + wave) * (Ppad / 16) * 1024 : const_cast<char*>(ws), 0,
+        kStoreP ? (Ppad / 16) * 1024 : 0, 0x00020000);
     // ---- tile DMA: K tile = 16 d-octet rows of 64 keys x 16 B (1 KB pieces), V tile = 16 KB contiguous ----
     auto issue_v = [&](int t, int buf) {
         const int j0 = t * BJ;
@@ -267,14 +277,14 @@ __global__ __launch_bounds__(256, (QKP == 3) ? 1 : ((QKP == 1 && SF_FLASH_V1) ? 
     const int nsp = (kUseStats && g.nsplit > 1) ? g.nsplit : 1, sp = (nsp > 1) ? (int)blockIdx.z : 0;
     const int tb = nt_all * sp / nsp, nt = nt_all * (sp + 1) / nsp;            // this workgroup's key tiles [tb, nt)
     issue_k(tb, tb & 1);
-    if (!kV1 && !kStatsPass) issue_v(tb, tb & 1);
+    if (!kV1 && !kNoPV) issue_v(tb, tb & 1);
     for (int t = tb; t < nt; ++t) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's pieces of tile t have landed ...
         __builtin_amdgcn_s_barrier();                             // ... everyone's; the other stage is no longer read
-        if (kV1 && !kStatsPass) issue_v(t, 0);                    // (V first: its wait below leaves the K pieces in flight)
+        if (kV1 && !kNoPV) issue_v(t, 0);                         // (V first: its wait below leaves the K pieces in flight)
         if (t + 1 < nt) {
             issue_k(t + 1, (t + 1) & 1);
-            if (!kV1 && !kStatsPass) issue_v(t + 1, (t + 1) & 1);
+            if (!kV1 && !kNoPV) issue_v(t + 1, (t + 1) & 1);
         }
         const char* kb = smem + (t & 1) * KSTAGE;
         const char* vb = smem + 2 * KSTAGE + (kV1 ? 0 : (t & 1)) * VTILE;
@@ -355,14 +365,19 @@ __global__ __launch_bounds__(256, (QKP == 3) ? 1 : ((QKP == 1 && SF_FLASH_V1) ? 
             }
         if constexpr (!kUseStats) {
             l_run = l_run * alpha + psum;
-            if (grew && !kStatsPass) {
+            if (grew && !kNoPV) {
 #pragma unroll
                 for (int td = 0; td < HD / 32; ++td)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) o[td][r] *= alpha;
             }
         }
-        if constexpr (kStatsPass) continue;                       // (no V tile was requested: nothing to wait for, no P V)
+        if constexpr (kStoreP) {                                  // the four B fragments of this key tile: 1 KB per instruction, lane-linear
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(sf_u32x4, pf[kk]), rp, lane * 16 + (t * 4 + kk) * 1024, 0, 0);
+        }
+        if constexpr (kNoPV) continue;                            // (no V tile was requested: nothing to wait for, no P V)
         if (kV1) {                                                // V(t): 4 pieces per wave, requested before the K(t+1) pieces
             if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -387,6 +402,10 @@ __global__ __launch_bounds__(256, (QKP == 3) ? 1 : ((QKP == 1 && SF_FLASH_V1) ? 
 
     // ---- epilogue: out[d][q] = mf[d][q] + gamma * O^T[d][q] / rowsum ----
     const float l_tot = l_run + xor32(l_run);
+    if constexpr (kStoreP) {                                  // the header remembers which logits the stored weights belong to
+        if (q0 == 0 && tid == 0) reinterpret_cast<int*>(const_cast<char*>(ws) + hdr_offset(Ppad))[3] = 0x100 | QKP;
+        return;
+    }
     if constexpr (kStatsPass) {
         if (khalf == 0) stats[q] = make_float2(m_run, 1.0f / l_tot);
         return;
@@ -405,6 +424,144 @@ __global__ __launch_bounds__(256, (QKP == 3) ? 1 : ((QKP == 1 && SF_FLASH_V1) ? 
         float* out = g.out + (int64_t)img * g.out_img_stride + q;
         // k-octet copy: registers 4m..4m+3 of a lane are channels 8m + 4 khalf .. + 3 of octet td*4 + m -- one 8-byte
         // store per octet; lanes l and l + 32 complete an octet, a wave instruction covers 512 contiguous bytes
+        _Float16* o16 = g.out16 ? g.out16 + (int64_t)img * g.out16_img_stride + (int64_t)q * 8 + khalf * 4 : nullptr;
+#pragma unroll
+        for (int td = 0; td < HD / 32; ++td)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                h4 hv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * m + e;
+                    const int d = td * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                    const float val = mf[(int64_t)d * P] + w * o[td][r];
+                    out[(int64_t)d * P] = val;
+                    hv[e] = (_Float16)val;
+                }
+                if (o16) *reinterpret_cast<h4*>(o16 + (int64_t)(td * 4 + m) * P * 8) = hv;
+            }
+    }
+}
+
+// ---- stored softmax weights: out = mf + gamma / rowsum * V^T P^T with P^T streamed from HBM ------------------------------------
+// q and k are constant over the refinement loop, so are the softmax weights: MODE 3 above stores them ONCE per clip (fp16, n Ppad^2
+// 2 bytes: 2.4 GB for 24 Sintel images) in the register image of the second contraction's B operand, and every iteration only
+// streams them past V: HALF the matrix-core work of the recompute kernel, no exp2, no conversions -- an HBM-bound kernel (99 MB per
+// image-iteration) on a chip whose step is power-bound.  core/gma.py:53-65 materialises the same matrix
+// once ("attn") and multiplies it every iteration (gma.py:99-102); this is that path with the matrix in fragment order.
+// A wave owns 32 queries: its fragment stream is contiguous (Ppad / 16 KB), loaded straight into registers (16 bytes per lane and
+// fragment, a ring of four key tiles = 16 KB in flight per wave); V tiles as in the recompute kernel (16 KB by LDS-DMA, shared by the
+// four waves), a ring of three.  Per key tile one barrier and, per wave, vmcnt(12): everything but the newest three request groups
+// (two P tiles and one V tile) has landed -- P tiles get two iterations, V tiles one, to arrive.  The MFMA sequence per tile is the
+// recompute kernel's: with the same statistics the results are bit-identical to MODE 1.
+#ifndef SF_PV_WAVES
+#define SF_PV_WAVES 2
+#endif
+__global__ __launch_bounds__(256, SF_PV_WAVES) void gma_pv_kernel(const FlashArgs g) {
+    constexpr int PD = 4, NVB = 3;                                 // P tiles in registers, V tiles in LDS
+    __shared__ __attribute__((aligned(1024))) char smem[NVB * VTILE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int khalf = lane >> 5, l31 = lane & 31;
+#if SF_FLASH_XCD_MAP
+    const int wg_lin = sf::xcd_linear_id((int)(blockIdx.x + gridDim.x * blockIdx.y), (int)(gridDim.x * gridDim.y));
+    const int img = wg_lin / (int)gridDim.x, q0 = (wg_lin % (int)gridDim.x) * BQ;
+#else
+    const int img = blockIdx.y, q0 = blockIdx.x * BQ;
+#endif
+    const int P = g.P, Ppad = g.Ppad;
+    const int plane = (int)plane_bytes(Ppad);
+    const char* ws = g.ws + (int64_t)img * img_ws_bytes(Ppad);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(ws) + 4 * (int64_t)plane, 0, plane, 0x00020000);
+    const int pstream = (Ppad / 16) * 1024;                          // bytes of this wave's fragment stream (< 2 GiB, host-checked)
+    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(
+        g.pbuf + (int64_t)img * g.p_img_stride + (int64_t)((q0 >> 5) + wave) * pstream, 0, pstream, 0x00020000);
+    const int q = q0 + wave * 32 + l31;
+    const float2* stats = reinterpret_cast<const float2*>(ws + 5 * (int64_t)plane);
+    float st_inv = stats[q].y;
+    {   // the stored weights must belong to the statistics in ws (same pack call, same products per logit): else poison the result
+        const int* hdr = reinterpret_cast<const int*>(ws + hdr_offset(Ppad));
+        if (hdr[0] != kHdrMagic || hdr[1] == 0 || hdr[2] != P || hdr[3] != (0x100 | hdr[1])) st_inv = __builtin_nanf("");
+    }
+    // every offset travels in the CHECKED vector offset: tiles past the end of the planes / the stream read as zeros
+    auto issue_v = [&](int t, int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int piece = wave * 4 + i;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lds_ptr)(smem + buf * VTILE + piece * 1024), 16,
+                                                     lane * 16 + t * (BJ * HD * 2) + piece * 1024, 0, 0, 0);
+        }
+    };
+    f16x8 pf[PD][4];
+    auto load_p = [&](int t, f16x8 (&dst)[4]) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+            dst[kk] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rp, lane * 16 + (t * 4 + kk) * 1024, 0, 0));
+    };
+    f32x16 o[HD / 32];
+#pragma unroll
+    for (int t = 0; t < HD / 32; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+
+    const int nt_all = Ppad / BJ;
+    const int nsp = (g.nsplit > 1) ? g.nsplit : 1, sp = (nsp > 1) ? (int)blockIdx.z : 0;
+    const int tb = nt_all * sp / nsp, nt = nt_all * (sp + 1) / nsp;
+    issue_v(tb, 0);
+    issue_v(tb + 1, 1);
+    load_p(tb, pf[0]);
+    load_p(tb + 1, pf[1]);
+    load_p(tb + 2, pf[2]);
+    for (int t0 = tb; t0 < nt; t0 += 12) {
+#pragma unroll
+        for (int u = 0; u < 12; ++u) {
+            const int t = t0 + u;
+            if (t < nt) {                                              // (wave-uniform)
+                load_p(t + 3, pf[(u + 3) % PD]);
+                // every V fragment read of the previous tile has EXECUTED before the barrier (the refill race of DESIGN 12.3)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt vmcnt(12)" ::: "memory");     // V(t), P(t) [and P(t+1)] have landed ...
+                __builtin_amdgcn_s_barrier();                         // ... everyone's V pieces; buffer (t+2) % 3 is no longer read
+                issue_v(t + 2, (u + 2) % NVB);
+                const char* vb = smem + (u % NVB) * VTILE;
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+                    for (int td = 0; td < HD / 32; ++td) {
+                        const f16x8 vf = *reinterpret_cast<const f16x8*>(vb + ((2 * kk + khalf) * HD + td * 32 + l31) * 16);
+                        o[td] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[u % PD][kk], o[td], 0, 0, 0);
+                    }
+                }
+                // issue order, pinned: the V fragment reads run kAhead MFMAs ahead of their use (left alone hipcc reads two fragments,
+                // waits for them, multiplies: the LDS latency in front of every pair)
+                {
+                    constexpr int kAhead = 4;
+                    __builtin_amdgcn_sched_group_barrier(0x100, kAhead, 0);
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        if (i + kAhead < 16) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // (V tiles requested past the end must land before the LDS is released)
+    const float w = g.gamma[0] * st_inv;
+    if (nsp > 1) {
+        float* pp = g.part + (((int64_t)sp * gridDim.y + img) * HD) * Ppad + q;
+#pragma unroll
+        for (int td = 0; td < HD / 32; ++td)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pp[(int64_t)(td * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf) * Ppad] = w * o[td][r];
+        return;
+    }
+    if (q < P) {
+        const float* mf = g.mf + (int64_t)img * g.mf_img_stride + q;
+        float* out = g.out + (int64_t)img * g.out_img_stride + q;
         _Float16* o16 = g.out16 ? g.out16 + (int64_t)img * g.out16_img_stride + (int64_t)q * 8 + khalf * 4 : nullptr;
 #pragma unroll
         for (int td = 0; td < HD / 32; ++td)
@@ -500,7 +657,7 @@ static int flash_aggregate(void* ws, int64_t ws_bytes, const void* v_, int v_f16
     else
         hipLaunchKernelGGL(flash_pack_v_kernel<float>, dim3(sf::ceil_div(Ppad / 8, 32), HD / 8, n_img), dim3(256), 0,
                            (hipStream_t)stream, v, v_img_stride, (char*)ws, P, Ppad);
-    FlashArgs g;
+    FlashArgs g = {};
     g.ws = (const char*)ws; g.mf = mf; g.gamma = gamma; g.out = out;
     g.out16 = static_cast<_Float16*>(out_koct); g.out16_img_stride = out_koct_img_stride;
     g.mf_img_stride = mf_img_stride; g.out_img_stride = out_img_stride; g.P = P; g.Ppad = Ppad;
@@ -561,4 +718,71 @@ extern "C" int sf_gma_flash_aggregate_f16v(void* ws, int64_t ws_bytes, const voi
                                            int P, int qk_products, int use_stats, void* stream) {
     return flash_aggregate(ws, ws_bytes, v_f16, 1, v_img_stride, mf, mf_img_stride, gamma, out, out_img_stride, out_koct,
                            out_koct_img_stride, n_img, P, qk_products, use_stats, stream);
+}
+
+// ---- stored softmax weights (gma.py:53-65 "attn" kept, gma.py:99-102 per iteration) ----------------------------------------------
+extern "C" int64_t sf_gma_stored_p_bytes(int n_img, int P) {
+    if (n_img <= 0 || P <= 0) return 0;
+    const int64_t Ppad = sf::ceil_div(P, BQ) * BQ;
+    return (int64_t)n_img * Ppad * Ppad * 2;
+}
+
+extern "C" int sf_gma_flash_store_p(void* ws, int64_t ws_bytes, void* pbuf, int64_t pbuf_bytes, int n_img, int P, int qk_products,
+                                    void* stream) {
+    SF_REQUIRE(ws && pbuf, "sf_gma_flash_store_p: null pointer");
+    SF_REQUIRE(n_img > 0 && P > 0 && n_img <= 65535, "sf_gma_flash_store_p: bad dims");
+    SF_REQUIRE(qk_products >= 1 && qk_products <= 3, "sf_gma_flash_store_p: qk_products must be 1, 2 or 3");
+    SF_REQUIRE(ws_bytes >= sf_gma_flash_ws_bytes(n_img, P) && (reinterpret_cast<uintptr_t>(ws) & 15) == 0,
+               "sf_gma_flash_store_p: workspace too small or misaligned");
+    SF_REQUIRE(pbuf_bytes >= sf_gma_stored_p_bytes(n_img, P) && (reinterpret_cast<uintptr_t>(pbuf) & 15) == 0,
+               "sf_gma_flash_store_p: pbuf must hold sf_gma_stored_p_bytes(n_img, P) bytes, 16-byte aligned");
+    const int Ppad = sf::ceil_div(P, BQ) * BQ;
+    SF_REQUIRE(2 * plane_bytes(Ppad) < ((int64_t)1 << 31) && (int64_t)(Ppad / 16) * 1024 < ((int64_t)1 << 31), "sf_gma_flash_store_p: image too large");
+    FlashArgs g = {};
+    g.ws = (const char*)ws; g.P = P; g.Ppad = Ppad; g.nsplit = 1;
+    g.pbuf = static_cast<char*>(pbuf); g.p_img_stride = (int64_t)Ppad * Ppad * 2;
+    dim3 grid(Ppad / BQ, n_img);
+    switch (qk_products) {
+        case 1: hipLaunchKernelGGL((gma_flash_kernel<1, 3>), grid, dim3(256), 0, (hipStream_t)stream, g); break;
+        case 2: hipLaunchKernelGGL((gma_flash_kernel<2, 3>), grid, dim3(256), 0, (hipStream_t)stream, g); break;
+        default: hipLaunchKernelGGL((gma_flash_kernel<3, 3>), grid, dim3(256), 0, (hipStream_t)stream, g); break;
+    }
+    return sf::check_launch("sf_gma_flash_store_p");
+}
+
+extern "C" int sf_gma_stored_aggregate(void* ws, int64_t ws_bytes, const void* pbuf, int64_t pbuf_bytes, const void* v, int v_f16,
+                                       int64_t v_img_stride, const float* mf, int64_t mf_img_stride, const float* gamma, float* out,
+                                       int64_t out_img_stride, void* out_koct, int64_t out_koct_img_stride, int n_img, int P,
+                                       void* stream) {
+    SF_REQUIRE(!out_koct || ((reinterpret_cast<uintptr_t>(out_koct) & 15) == 0 && (out_koct_img_stride & 7) == 0),
+               "sf_gma_stored_aggregate: out_koct must be 16-byte aligned, its image stride a multiple of 8 halves");
+    SF_REQUIRE(ws && pbuf && mf && gamma && out, "sf_gma_stored_aggregate: null pointer");   // (v == NULL: sf_gma_flash_project_v packed it)
+    SF_REQUIRE(n_img > 0 && P > 0 && n_img <= 65535, "sf_gma_stored_aggregate: bad dims");
+    SF_REQUIRE(v_f16 == 0 || v_f16 == 1, "sf_gma_stored_aggregate: v_f16 must be 0 (fp32 planes) or 1 (fp16 rows)");
+    SF_REQUIRE(ws_bytes >= sf_gma_flash_ws_bytes(n_img, P) && (reinterpret_cast<uintptr_t>(ws) & 15) == 0,
+               "sf_gma_stored_aggregate: workspace too small or misaligned");
+    SF_REQUIRE(pbuf_bytes >= sf_gma_stored_p_bytes(n_img, P) && (reinterpret_cast<uintptr_t>(pbuf) & 15) == 0,
+               "sf_gma_stored_aggregate: pbuf must hold sf_gma_stored_p_bytes(n_img, P) bytes, 16-byte aligned");
+    const int Ppad = sf::ceil_div(P, BQ) * BQ;
+    SF_REQUIRE(2 * plane_bytes(Ppad) < ((int64_t)1 << 31) && (int64_t)(Ppad / 16) * 1024 < ((int64_t)1 << 31), "sf_gma_stored_aggregate: image too large");
+    if (!v) {}                                                // the v planes of ws are current (sf_gma_flash_project_v)
+    else if (v_f16)
+        hipLaunchKernelGGL(flash_pack_v_kernel<_Float16>, dim3(sf::ceil_div(Ppad / 8, 32), HD / 8, n_img), dim3(256), 0,
+                           (hipStream_t)stream, static_cast<const _Float16*>(v), v_img_stride, (char*)ws, P, Ppad);
+    else
+        hipLaunchKernelGGL(flash_pack_v_kernel<float>, dim3(sf::ceil_div(Ppad / 8, 32), HD / 8, n_img), dim3(256), 0,
+                           (hipStream_t)stream, static_cast<const float*>(v), v_img_stride, (char*)ws, P, Ppad);
+    FlashArgs g = {};
+    g.ws = (const char*)ws; g.mf = mf; g.gamma = gamma; g.out = out;
+    g.out16 = static_cast<_Float16*>(out_koct); g.out16_img_stride = out_koct_img_stride;
+    g.mf_img_stride = mf_img_stride; g.out_img_stride = out_img_stride; g.P = P; g.Ppad = Ppad;
+    g.pbuf = const_cast<char*>(static_cast<const char*>(pbuf)); g.p_img_stride = (int64_t)Ppad * Ppad * 2;
+    g.nsplit = use_key_split(n_img, Ppad) ? kMaxSplit : 1;    // (the same predicate sizes the workspace's partial buffers)
+    g.part = reinterpret_cast<float*>(static_cast<char*>(ws) + (int64_t)n_img * img_ws_bytes(Ppad));
+    dim3 grid(Ppad / BQ, n_img, g.nsplit);
+    hipLaunchKernelGGL(gma_pv_kernel, grid, dim3(256), 0, (hipStream_t)stream, g);
+    if (g.nsplit > 1)
+        hipLaunchKernelGGL(flash_combine_kernel, dim3(sf::ceil_div(P, 256), HD / 8, n_img), dim3(256), 0, (hipStream_t)stream, g.part,
+                           g.nsplit, mf, mf_img_stride, out, out_img_stride, g.out16, g.out16_img_stride, P, Ppad);
+    return sf::check_launch("sf_gma_stored_aggregate");
 }

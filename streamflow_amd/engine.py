@@ -55,6 +55,7 @@ class EngineOptions:
     clock_probe_us: int = 0          # measurement aid: > 0 forks sf_clock_probe for that long beside every forward (results in
                                      # engine.clock_counts: shader cycles, 100 MHz ticks); a graph branch like any other
     setup_overlap: bool = True       # the context chain of the setup (split, to_qk, GMA pack / statistics) beside the volume build
+    stored_p_max_gb: int = 64        # gma_mode 'stored': largest weight buffer (n_img * Ppad^2 * 2 bytes) kept; beyond it the fused recompute runs
     max_plans: int = 4               # buffer sets (and graphs) kept, least recently used evicted
 
     @staticmethod
@@ -271,7 +272,7 @@ class _Plan:
 
     def __init__(self, W: HotPathWeights, Bc: int, h: int, w: int, D: int, device, attn_chunk_rows: int = 0,
                  attn_f16: bool = False, corr_f16: bool = False, flash: Optional[bool] = None, shadows: bool = False,
-                 corr_blocked: bool = False, koct_io: bool = False):
+                 corr_blocked: bool = False, koct_io: bool = False, stored_p: bool = False, stored_p_max_bytes: int = 0):
         Pn = W.pairs
         n, P = Bc * Pn, h * w
         self.Bc, self.Pn, self.h, self.w, self.n, self.P, self.D = Bc, Pn, h, w, n, P, D
@@ -313,9 +314,13 @@ class _Plan:
         # the CU.  flash=None: used whenever the matrix would have to be chunked (split precisions only).
         self.flash = bool(flash) if flash is not None else (attn_f16 and self.attn_rows < P and attn_chunk_rows <= 0)
         self.flash_ws = None
+        self.pbuf = None
         if self.flash:
             self.flash_ws = torch.empty(ops.gma_flash_ws_bytes(n, P), dtype=torch.uint8, device=device)
             self.attn_rows = 1                     # no attention matrix at all: placeholders only
+            # 'stored': the softmax weights kept for the loop in the fragment order of the second contraction (sf_gma_flash_store_p)
+            if stored_p and ops.gma_stored_p_bytes(n, P) <= stored_p_max_bytes:
+                self.pbuf = torch.empty(ops.gma_stored_p_bytes(n, P), dtype=torch.uint8, device=device)
         self.attn = torch.empty(n, self.attn_rows, P, dtype=torch.float32, device=device)
         # split-precision modes keep the materialised matrix in fp16 (half the bytes of the HBM-bound attn @ v that
         # every iteration repeats; measured effect on the final flow: 4e-6 px mean EPE); self.attn is then only the
@@ -402,7 +407,9 @@ class HotPathEngine:
         corr_dtype: 'f32' keeps the correlation pyramids in fp32 as the reference does (corr.py:13, arithmetic =
         `precision`); 'f16' stores them as fp16 and builds them with single f16 MFMA products (SF_PRECISION_F16).
         gma_mode: 'matrix' = attention matrix materialised once per clip (gma.py), 'flash' = fused recompute kernel every
-        iteration (demo.py:235-258), 'auto' (default) = flash exactly when the matrix cannot be kept (high resolution).
+        iteration (demo.py:235-258), 'stored' = the fused kernel's own softmax weights stored once per clip as fp16 in fragment
+        order and streamed every iteration (bit-identical to 'flash'; n_img * Ppad^2 * 2 bytes, options.stored_p_max_gb),
+        'auto' (default) = flash exactly when the matrix cannot be kept (high resolution).
         flash_qk_products: MFMA products per logit of the fused kernel (3 = split precision, 1 = fp16 q and k).
         options: scheduling / hand-over switches (EngineOptions; SF_ENGINE_OPTS overrides single fields for experiments).
         See streamflow_amd.presets for the named configurations."""
@@ -429,8 +436,8 @@ class HotPathEngine:
         # kept; 'flash' = fused recompute kernel every iteration (demo.py:235-258); 'auto' = flash exactly when the
         # matrix would have to be chunked (high resolution)
         self.gma_mode = gma_mode or "auto"
-        if self.gma_mode not in ("auto", "matrix", "flash"):
-            raise RuntimeError(f"gma_mode must be auto, matrix or flash, got {self.gma_mode!r}")
+        if self.gma_mode not in ("auto", "matrix", "flash", "stored"):
+            raise RuntimeError(f"gma_mode must be auto, matrix, flash or stored, got {self.gma_mode!r}")
         # MFMA products per logit of the fused kernel: 3 = split precision (fp32-class), 2 / 1 = k / q and k in fp16
         self.flash_qk_products = (int(flash_qk_products or 0)
                                   or {ops.PRECISION_F16X2: 2, ops.PRECISION_F16: 1}.get(self.precision, 3))
@@ -484,16 +491,18 @@ class HotPathEngine:
             while len(self._plans) >= max(1, self.max_plans):
                 self._plans.pop(next(iter(self._plans)))            # dicts keep insertion order: first = oldest
             split = self.precision != ops.PRECISION_FP32
-            if self.gma_mode == "flash" and not split:
-                raise RuntimeError("gma_mode='flash' needs a split precision (f16x3 / f16x2); the exact fp32 mode keeps "
+            if self.gma_mode in ("flash", "stored") and not split:
+                raise RuntimeError(f"gma_mode={self.gma_mode!r} needs a split precision (f16x3 / f16x2); the exact fp32 mode keeps "
                                    "the materialised / chunked attention path")
-            flash = {"auto": None, "matrix": False, "flash": True}[self.gma_mode]
+            flash = {"auto": None, "matrix": False, "flash": True, "stored": True}[self.gma_mode]
             pl = _Plan(self.W, Bc, h, w, D, self.device, self.attn_chunk_rows, attn_f16=split, corr_f16=self.corr_f16,
                        flash=flash, shadows=(self.options.shadows and (h * w) % 4 == 0 and
                                              self.precision in (ops.PRECISION_F16X2, ops.PRECISION_F16) and
                                              self.options.hidden_f16),
                        corr_blocked=self.corr_blocked,
-                       koct_io=self.options.koct_io and self.options.hidden_koct)   # (k-octet-only blocks need k-octet producers)
+                       koct_io=self.options.koct_io and self.options.hidden_koct,   # (k-octet-only blocks need k-octet producers)
+                       stored_p=(self.gma_mode == "stored" and self.options.flash_stats),
+                       stored_p_max_bytes=int(self.options.stored_p_max_gb) << 30)
         self._plans[key] = pl                                        # (re)insert as most recent
         return pl
 
@@ -543,6 +552,8 @@ class HotPathEngine:
             if pl.flash:
                 # q, k are constant over the loop: packed once, and the softmax statistics of every query with them
                 ops.gma_flash_pack_qk(pl.qk, pl.flash_ws, float(HDIM) ** -0.5, stats_qk_products=self.flash_qk_products, cx=cs)
+                if pl.pbuf is not None:             # ... and the softmax weights themselves (gma.py:53-65: `attn`), kept for the loop
+                    ops.gma_flash_store_p(pl.flash_ws, pl.pbuf, n, P, self.flash_qk_products, cx=cs)
             elif pl.attn_rows == P:
                 self._attention_rows(cs, pl, 0, P)
         # a1+a2: all pairs, one launch.  pair t = (frame t, frame t+1)
@@ -665,7 +676,10 @@ class HotPathEngine:
         ks = self.attn_k_splits if self.precision != ops.PRECISION_FP32 else 1
         attn_ptr, attn_lay = ((pl.attn16.data_ptr(), LAYOUT_F16_K_MINOR) if pl.attn16 is not None
                               else (pl.attn.data_ptr(), LAYOUT_K_MINOR))
-        if pl.flash:
+        if pl.flash and pl.pbuf is not None:
+            # the stored weights streamed past v (gma.py:99-102): half the matrix-core work of the recompute, HBM-bound
+            ops.gma_stored_aggregate(pl.flash_ws, pl.pbuf, v128, pl.mf, W.gamma, pl.mfg, cx=cx)
+        elif pl.flash:
             # fused recompute (K6' of SURVEY.md): one kernel, online softmax, logits never written
             ops.gma_flash_aggregate(pl.flash_ws, v128, pl.mf, W.gamma, pl.mfg, self.flash_qk_products, use_stats=True, cx=cx)
         elif pl.attn_rows < P:

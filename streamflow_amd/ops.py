@@ -932,6 +932,43 @@ def gma_flash_aggregate(ws: torch.Tensor, V: Optional[Planes], MF: Planes, gamma
         refresh_shadow(OUT, cx)
 
 
+def gma_stored_p_bytes(n_img: int, P: int) -> int:
+    return int(_lib.load().sf_gma_stored_p_bytes(n_img, P))
+
+
+@on_tensor_device
+def gma_flash_store_p(ws: torch.Tensor, pbuf: torch.Tensor, n_img: int, P: int, qk_products: int, cx: Optional[Ctx] = None) -> None:
+    """Once per clip, after gma_flash_pack_qk(stats_qk_products=qk_products): the softmax weights of every (query, key) as fp16 in
+    the fragment order of the second contraction -> pbuf (gma.py:53-65: `attn`, kept for the refinement loop)."""
+    assert ws.dtype == torch.uint8 and pbuf.dtype == torch.uint8
+    _launch("gma_store_p", 2.0 * n_img * P * P * 128, 2.0 * n_img * P * P,
+            lambda: _lib.check(_lib.load().sf_gma_flash_store_p(ws.data_ptr(), ws.numel(), pbuf.data_ptr(), pbuf.numel(), n_img, P,
+                                                                int(qk_products), _lib.stream()), "sf_gma_flash_store_p"),
+            products=(qk_products + 1) / 2.0)
+
+
+@on_tensor_device
+def gma_stored_aggregate(ws: torch.Tensor, pbuf: torch.Tensor, V: Optional[Planes], MF: Planes, gamma: torch.Tensor, OUT: Planes,
+                         cx: Optional[Ctx] = None) -> None:
+    """OUT = MF + gamma * attn V with the stored weights (gma.py:99-102), bit-identical to gma_flash_aggregate(use_stats=True) on the
+    same workspace.  V=None: the v planes of ws were written by gma_flash_project_v."""
+    cx = _cx(cx)
+    if V is None:
+        V = Planes(MF.base, 0, 0, MF.n_img, 128, MF.P, f16=True)             # placeholder: pointer 0 is passed below
+    assert V.rows == MF.rows == OUT.rows == 128 and V.n_img == MF.n_img == OUT.n_img and not V.koct
+    n, P = V.n_img, V.P
+    sh = OUT.shadow if (OUT.shadow is not None and cx.shadows and cx.shadow_fused) else None
+    # algorithmic: ONE contraction; bytes: the stored weights (once), v, mf in, out
+    _launch("gma_stored", 2.0 * n * P * P * 128,
+            2.0 * n * P * P + (2.0 if V.f16 else 4.0) * n * 128 * P + 4.0 * n * 128 * P * 2 + (2.0 * n * 128 * P if sh is not None else 0.0),
+            lambda: _lib.check(_lib.load().sf_gma_stored_aggregate(
+                ws.data_ptr(), ws.numel(), pbuf.data_ptr(), pbuf.numel(), (V.ptr if V.img_stride else None), int(V.f16), V.img_stride,
+                MF.ptr, MF.img_stride, gamma.data_ptr(), OUT.ptr, OUT.img_stride, None if sh is None else sh.ptr,
+                0 if sh is None else sh.img_stride, n, P, _lib.stream()), "sf_gma_stored_aggregate"), products=1.0)
+    if sh is None:
+        refresh_shadow(OUT, cx)
+
+
 @on_tensor_device
 def coords_grid(batch: int, ht: int, wd: int, device) -> torch.Tensor:
     out = torch.empty(batch, 2, ht, wd, dtype=torch.float32, device=device)

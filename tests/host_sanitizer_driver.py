@@ -91,6 +91,12 @@ for n, P, qk in ((24, 7040, 1), (3, 32640, 3), (0, 7040, 1), (24, 7040, 5)):
     call(lib.sf_gma_flash_pack_qk, PTR[0], 256 * P, PTR[1], ws, n, P, 0.088, qk if qk < 4 else 0, None)
     call(lib.sf_gma_flash_aggregate, PTR[1], ws, PTR[2], 128 * P, PTR[3], 128 * P, PTR[4], PTR[5], 128 * P, PTR[6], 128 * P, n, P, qk, 1, None)
     call(lib.sf_gma_flash_project_v, PTR[1], ws, PTR[2], 128 * P, P, PTR[3], PTR[4], 128, 1.0, min(qk, 3), n, P, None)
+    pb = lib.sf_gma_stored_p_bytes(max(n, 1), P)
+    call(lib.sf_gma_flash_store_p, PTR[1], ws, PTR[7], pb, n, P, qk, None)
+    call(lib.sf_gma_flash_store_p, PTR[1], ws, PTR[7], pb - 1, n, P, min(qk, 3), None)          # weight buffer one byte short
+    for v, vf in ((PTR[2], 0), (PTR[2], 1), (None, 0), (PTR[2], 2)):
+        call(lib.sf_gma_stored_aggregate, PTR[1], ws, PTR[7], pb, v, vf, 128 * P, PTR[3], 128 * P, PTR[4], PTR[5], 128 * P, PTR[6],
+             128 * P, n, P, None)
 for ks, prec, C_ in itertools.product((15, 7, 9), (0, 1, 2, 3), (128, 324, 640)):
     call(lib.sf_dwconv_res_gelu, PTR[0], C_ * 7040, PTR[1], PTR[2], PTR[3], C_ * 7040, 0, 24, C_, 55, 128, ks, prec, None)
     call(lib.sf_dwconv_res_gelu_f16in, PTR[0], C_ * 7040, PTR[1], PTR[2], PTR[3], C_ * 7040, 24, C_, 55, 128, ks, prec, None)

@@ -136,7 +136,7 @@ def test_timed_steps_reports_own_time():
     own = []
     dt = bench.timed_steps(lambda: time.sleep(0.002), steps=3, warmup=1, world=1, sync_fn=lambda: None, barrier_fn=lambda: None,
                            allreduce_max_fn=lambda x: x, own=own)
-    assert len(own) == 2 and 0.005 <= own[0] <= dt and 0.005 <= own[1] <= own[0]      # (own time, host time inside the steps)
+    assert len(own) == 3 and 0.005 <= own[0] <= dt and 0.005 <= own[1] <= own[0] and 0 <= own[2] <= own[1] + 1e-3   # (own time, host wall / CPU time inside the steps)
 
 
 def test_rank_cpu_sets_numa_and_fallback():

@@ -1,0 +1,115 @@
+"""GPU: the stored-weights GMA path (sf_gma_flash_store_p + sf_gma_stored_aggregate; core/gma.py:53-65 keeps `attn` for the loop,
+gma.py:99-102 multiplies it every iteration) against the fused recompute kernel it must equal BIT FOR BIT (same statistics, same
+fp16 weights, same MFMA sequence), against float64, and at the engine level."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need an MI355X; torch.cuda.is_available() is False")
+    return torch.device("cuda:0")
+
+
+def _inputs(P, n, seed, sharp):
+    gen = torch.Generator().manual_seed(seed)
+    qk = torch.randn(n, 256, P, generator=gen)
+    v = torch.randn(n, 128, P, generator=gen)
+    mf = torch.randn(n, 128, P, generator=gen)
+    if sharp:
+        qk[:, :128, : P // 2] *= 6.0                         # half of the queries with logits of +-40
+    return qk, v, mf
+
+
+@pytest.mark.parametrize("P", [64, 323, 1000, 7040])
+@pytest.mark.parametrize("qkp", [1, 3])
+@pytest.mark.parametrize("n", [3, 24])
+def test_stored_aggregate_equals_flash_bit_for_bit_and_float64(dev, P, qkp, n):
+    from dataclasses import replace
+    from streamflow_amd import ops
+    from streamflow_amd.ops import Planes
+    if n == 24 and P != 7040:
+        pytest.skip("the many-image case runs at the headline grid only")
+    qk, v, mf = _inputs(P, n, 100 + P + qkp, sharp=P >= 323)
+    gamma = torch.tensor([0.61]).to(dev)
+    scale = 128 ** -0.5
+    ws = torch.empty(ops.gma_flash_ws_bytes(n, P), dtype=torch.uint8, device=dev)
+    ws.fill_(0x7F)                                           # poison: padded keys must come out as exact zeros
+    pbuf = torch.empty(ops.gma_stored_p_bytes(n, P), dtype=torch.uint8, device=dev)
+    pbuf.fill_(0x7E)                                         # fp16 0x7E7E = NaN: every fragment the kernel reads must have been written
+    QK, V, MF = Planes.of(qk.to(dev)), Planes.of(v.to(dev)), Planes.of(mf.to(dev))
+    ops.gma_flash_pack_qk(QK, ws, scale, stats_qk_products=qkp)
+    ref = torch.full((n, 128, P), float("nan"), device=dev)
+    ops.gma_flash_aggregate(ws, V, MF, gamma, Planes.of(ref), qkp, use_stats=True)
+    ops.gma_flash_store_p(ws, pbuf, n, P, qkp)
+    out = torch.full((n, 128, P), float("nan"), device=dev)
+    sh = ops.new_shadow(Planes.of(out), dev)
+    ops.gma_stored_aggregate(ws, pbuf, V, MF, gamma, replace(Planes.of(out), shadow=sh))
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all()
+    assert torch.equal(out, ref), f"P={P} qkp={qkp}: max diff {(out - ref).abs().max().item():.3e}"
+    assert torch.equal(sh.tensor().float(), out.half().float())
+    if n == 3:
+        q64, k64 = qk[:, :128].double(), qk[:, 128:].double()
+        attn = torch.softmax(scale * torch.einsum("ndi,ndj->nij", q64, k64), dim=-1)
+        r64 = mf.double() + 0.61 * torch.einsum("nij,ndj->ndi", attn, v.double())
+        err = (out.double().cpu() - r64).abs().max().item()
+        tol = ({3: 2e-3, 1: 2.5e-2} if P >= 323 else {3: 4e-4, 1: 3e-3})[qkp]
+        print(f"stored P={P} qk_products={qkp}: max abs err vs float64 = {err:.2e}")
+        assert err < tol
+    # twenty launches beside a competing stream: bit-identical (the V ring is refilled right behind a barrier)
+    if P == 7040 and n == 3:
+        side = torch.cuda.Stream(device=dev)
+        junk = torch.empty(64 << 20, device=dev)
+        for _ in range(20):
+            with torch.cuda.stream(side):
+                junk.normal_()
+            o2 = torch.full((n, 128, P), float("nan"), device=dev)
+            ops.gma_stored_aggregate(ws, pbuf, V, MF, gamma, Planes.of(o2))
+            torch.cuda.synchronize()
+            assert torch.equal(o2, ref)
+
+
+def test_stale_weights_poison_the_result(dev):
+    """Weights stored for one pack call must not be used with the statistics of another (the header check): NaN, not silence."""
+    from streamflow_amd import ops
+    from streamflow_amd.ops import Planes
+    P, n = 256, 2
+    qk, v, mf = _inputs(P, n, 7, False)
+    gamma = torch.tensor([0.5]).to(dev)
+    ws = torch.zeros(ops.gma_flash_ws_bytes(n, P), dtype=torch.uint8, device=dev)
+    pbuf = torch.zeros(ops.gma_stored_p_bytes(n, P), dtype=torch.uint8, device=dev)
+    QK, V, MF = Planes.of(qk.to(dev)), Planes.of(v.to(dev)), Planes.of(mf.to(dev))
+    ops.gma_flash_pack_qk(QK, ws, 128 ** -0.5, stats_qk_products=1)
+    ops.gma_flash_store_p(ws, pbuf, n, P, 1)
+    ops.gma_flash_pack_qk(QK, ws, 128 ** -0.5, stats_qk_products=1)         # a new pack invalidates the stored weights
+    out = torch.zeros(n, 128, P, device=dev)
+    ops.gma_stored_aggregate(ws, pbuf, V, MF, gamma, Planes.of(out))
+    torch.cuda.synchronize()
+    assert torch.isnan(out).all()
+
+
+@pytest.mark.parametrize("preset", ["config2_mixed", "fp32_class"])
+def test_engine_stored_mode_equals_flash_mode(dev, preset):
+    """HotPathEngine(gma_mode='stored') == gma_mode='flash', bit for bit, eager and graph replay (three clips: no key split; one
+    clip at a small grid: the key-split form with its combine pass)."""
+    from streamflow_amd import presets, synthetic as syn
+    from streamflow_amd.engine import HotPathEngine
+    T = 4
+    params = syn.make_params(5, T)
+    for B, h, w in ((3, 32, 48), (1, 40, 64)):
+        fm, cn = (t.to(dev) for t in syn.make_features(81, B, T, h, w))
+        outs = {}
+        for mode in ("flash", "stored"):
+            kw = dict(presets.engine_kwargs(preset), gma_mode=mode)
+            for graph in (False, True):
+                eng = HotPathEngine(params, device=dev, T=T, use_graph=graph, **kw)
+                eng.forward(fm, cn, iters=3)
+                outs[(mode, graph)] = [f.clone() for f in eng.forward(fm, cn, iters=3)[0]]
+                assert (mode == "stored") == (next(iter(eng._plans.values())).pbuf is not None)
+        for key, val in outs.items():
+            for a, b in zip(val, outs[("flash", False)]):
+                assert torch.equal(a, b), key
