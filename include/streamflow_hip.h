@@ -289,7 +289,8 @@ int sf_gma_flash_project_v(void* ws, int64_t ws_bytes, const void* x_koct, int64
 /* ---- a6 + a7 with the attention weights KEPT (core/gma.py:53-65 computes `attn` once per clip, gma.py:99-102 multiplies it every
  * iteration): the fused path above recomputes softmax(q k^T) in every iteration; q and k do not change over the refinement loop, so
  * the weights can be stored once -- as fp16, unnormalised (exp2 of the logit minus the stored row maximum: bit for bit what the fused
- * kernel multiplies), in the register image of the second contraction's B operand -- and every iteration only streams them past v:
+ * kernel multiplies), in the register image of the second contraction's B operand ([key tile of 64][query tile of 32][4] x 1 KB per
+ * image, an opaque format between the two calls below) -- and every iteration only streams them past v:
  * half the matrix-core work, no exponentials, HBM-bound (n_img * Ppad^2 * 2 bytes per iteration, Ppad = P rounded up to 128).
  *   sf_gma_stored_p_bytes: size of `pbuf` (caller-owned, 16-byte aligned, persists over the clip's iterations).
  *   sf_gma_flash_store_p: once per clip, after sf_gma_flash_pack_qk(stats_qk_products = qk_products): writes pbuf.

@@ -239,10 +239,12 @@ __global__ __launch_bounds__(256, (QKP == 3) ? 1 : ((QKP == 1 && SF_FLASH_V1) ? 
         const int* hdr = reinterpret_cast<const int*>(ws + hdr_offset(Ppad));
         if (hdr[0] != kHdrMagic || hdr[1] != QKP || hdr[2] != P) { st_inv = __builtin_nanf(""); if (kStoreP) st_m = st_inv; }
     }
-    // MODE 3: this wave's fragment stream = (query tile of 32) x all key groups of 16, 1 KB each, lane-linear
+    // MODE 3: the image's fragments, [key tile of 64][query tile of 32][4 key groups of 16] x 1 KB (lane-linear): the workgroups of an
+    // image walk the key tiles roughly together, so what the chip reads at any time is a few contiguous regions (DRAM rows, TLB
+    // entries) instead of one private stream per wave
     const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(
-        kStoreP ? g.pbuf + (int64_t)img * g.p_img_stride + (int64_t)((q0 >> 5) + wave) * (Ppad / 16) * 1024 : const_cast<char*>(ws), 0,
-        kStoreP ? (Ppad / 16) * 1024 : 0, 0x00020000);
+        kStoreP ? g.pbuf + (int64_t)img * g.p_img_stride : const_cast<char*>(ws), 0, kStoreP ? (int)(unsigned)g.p_img_stride : 0, 0x00020000);
+    const unsigned p_lane = (unsigned)(((q0 >> 5) + wave) * 4096 + lane * 16), p_tile = (unsigned)(Ppad / 32) * 4096u;
     // ---- tile DMA: K tile = 16 d-octet rows of 64 keys x 16 B (1 KB pieces), V tile = 16 KB contiguous ----
     auto issue_v = [&](int t, int buf) {
         const int j0 = t * BJ;
@@ -375,7 +377,7 @@ __global__ __launch_bounds__(256, (QKP == 3) ? 1 : ((QKP == 1 && SF_FLASH_V1) ? 
         if constexpr (kStoreP) {                                  // the four B fragments of this key tile: 1 KB per instruction, lane-linear
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(sf_u32x4, pf[kk]), rp, lane * 16 + (t * 4 + kk) * 1024, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(sf_u32x4, pf[kk]), rp, (int)(p_lane + (unsigned)t * p_tile + kk * 1024), 0, 0);
         }
         if constexpr (kNoPV) continue;                            // (no V tile was requested: nothing to wait for, no P V)
         if (kV1) {                                                // V(t): 4 pieces per wave, requested before the K(t+1) pieces
@@ -450,13 +452,19 @@ __global__ __launch_bounds__(256, (QKP == 3) ? 1 : ((QKP == 1 && SF_FLASH_V1) ? 
 // streams them past V: HALF the matrix-core work of the recompute kernel, no exp2, no conversions -- an HBM-bound kernel (99 MB per
 // image-iteration) on a chip whose step is power-bound.  core/gma.py:53-65 materialises the same matrix
 // once ("attn") and multiplies it every iteration (gma.py:99-102); this is that path with the matrix in fragment order.
-// A wave owns 32 queries: its fragment stream is contiguous (Ppad / 16 KB), loaded straight into registers (16 bytes per lane and
-// fragment, a ring of four key tiles = 16 KB in flight per wave); V tiles as in the recompute kernel (16 KB by LDS-DMA, shared by the
+// A wave owns 32 queries: its fragments of a key tile are 4 KB, loaded straight into registers (16 bytes per lane and fragment, a
+// ring of four key tiles = 16 KB in flight per wave; layout [key tile][query tile][4] x 1 KB: see MODE 3); V tiles as in the recompute kernel (16 KB by LDS-DMA, shared by the
 // four waves), a ring of three.  Per key tile one barrier and, per wave, vmcnt(12): everything but the newest three request groups
 // (two P tiles and one V tile) has landed -- P tiles get two iterations, V tiles one, to arrive.  The MFMA sequence per tile is the
 // recompute kernel's: with the same statistics the results are bit-identical to MODE 1.
 #ifndef SF_PV_WAVES
 #define SF_PV_WAVES 2
+#endif
+#ifndef SF_PV_NT
+#define SF_PV_NT 2              // cache policy of the weight stream's loads (2 = non-temporal): A/B knob, tools/gma_stored_bench.py
+#endif
+#ifndef SF_PV_ABLATE
+#define SF_PV_ABLATE 0          // timing ablations: 1 = no V tiles requested, 2 = no weight loads, 3 = no MFMAs
 #endif
 __global__ __launch_bounds__(256, SF_PV_WAVES) void gma_pv_kernel(const FlashArgs g) {
     constexpr int PD = 4, NVB = 3;                                 // P tiles in registers, V tiles in LDS
@@ -474,9 +482,9 @@ __global__ __launch_bounds__(256, SF_PV_WAVES) void gma_pv_kernel(const FlashArg
     const int plane = (int)plane_bytes(Ppad);
     const char* ws = g.ws + (int64_t)img * img_ws_bytes(Ppad);
     const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(ws) + 4 * (int64_t)plane, 0, plane, 0x00020000);
-    const int pstream = (Ppad / 16) * 1024;                          // bytes of this wave's fragment stream (< 2 GiB, host-checked)
-    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(
-        g.pbuf + (int64_t)img * g.p_img_stride + (int64_t)((q0 >> 5) + wave) * pstream, 0, pstream, 0x00020000);
+    // the image's fragments: [key tile][query tile of 32][4 key groups] x 1 KB (< 4 GiB per image, host-checked)
+    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(g.pbuf + (int64_t)img * g.p_img_stride, 0, (int)(unsigned)g.p_img_stride, 0x00020000);
+    const unsigned p_lane = (unsigned)(((q0 >> 5) + wave) * 4096 + lane * 16), p_tile = (unsigned)(Ppad / 32) * 4096u;
     const int q = q0 + wave * 32 + l31;
     const float2* stats = reinterpret_cast<const float2*>(ws + 5 * (int64_t)plane);
     float st_inv = stats[q].y;
@@ -490,14 +498,15 @@ __global__ __launch_bounds__(256, SF_PV_WAVES) void gma_pv_kernel(const FlashArg
         for (int i = 0; i < 4; ++i) {
             const int piece = wave * 4 + i;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lds_ptr)(smem + buf * VTILE + piece * 1024), 16,
-                                                     lane * 16 + t * (BJ * HD * 2) + piece * 1024, 0, 0, 0);
+                                                     (SF_PV_ABLATE == 1) ? (int)0x7ffffff0 : lane * 16 + t * (BJ * HD * 2) + piece * 1024, 0, 0, 0);
         }
     };
     f16x8 pf[PD][4];
     auto load_p = [&](int t, f16x8 (&dst)[4]) {
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)
-            dst[kk] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rp, lane * 16 + (t * 4 + kk) * 1024, 0, 0));
+            dst[kk] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(
+                rp, (SF_PV_ABLATE == 2) ? (int)0xfffffff0u : (int)(p_lane + (unsigned)t * p_tile + kk * 1024), 0, SF_PV_NT));
     };
     f32x16 o[HD / 32];
 #pragma unroll
@@ -531,7 +540,11 @@ __global__ __launch_bounds__(256, SF_PV_WAVES) void gma_pv_kernel(const FlashArg
 #pragma unroll
                     for (int td = 0; td < HD / 32; ++td) {
                         const f16x8 vf = *reinterpret_cast<const f16x8*>(vb + ((2 * kk + khalf) * HD + td * 32 + l31) * 16);
+#if SF_PV_ABLATE == 3
+                        o[td][kk] += (float)vf[0] * (float)pf[u % PD][kk][0];
+#else
                         o[td] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[u % PD][kk], o[td], 0, 0, 0);
+#endif
                     }
                 }
                 // issue order, pinned: the V fragment reads run kAhead MFMAs ahead of their use (left alone hipcc reads two fragments,
@@ -737,7 +750,8 @@ extern "C" int sf_gma_flash_store_p(void* ws, int64_t ws_bytes, void* pbuf, int6
     SF_REQUIRE(pbuf_bytes >= sf_gma_stored_p_bytes(n_img, P) && (reinterpret_cast<uintptr_t>(pbuf) & 15) == 0,
                "sf_gma_flash_store_p: pbuf must hold sf_gma_stored_p_bytes(n_img, P) bytes, 16-byte aligned");
     const int Ppad = sf::ceil_div(P, BQ) * BQ;
-    SF_REQUIRE(2 * plane_bytes(Ppad) < ((int64_t)1 << 31) && (int64_t)(Ppad / 16) * 1024 < ((int64_t)1 << 31), "sf_gma_flash_store_p: image too large");
+    SF_REQUIRE(2 * plane_bytes(Ppad) < ((int64_t)1 << 31) && (int64_t)Ppad * Ppad * 2 + 3 * (int64_t)(Ppad / 32) * 4096 < ((int64_t)1 << 32),
+               "sf_gma_flash_store_p: image too large (the stored weights of one image must stay under 4 GiB)");
     FlashArgs g = {};
     g.ws = (const char*)ws; g.P = P; g.Ppad = Ppad; g.nsplit = 1;
     g.pbuf = static_cast<char*>(pbuf); g.p_img_stride = (int64_t)Ppad * Ppad * 2;
@@ -764,7 +778,8 @@ extern "C" int sf_gma_stored_aggregate(void* ws, int64_t ws_bytes, const void* p
     SF_REQUIRE(pbuf_bytes >= sf_gma_stored_p_bytes(n_img, P) && (reinterpret_cast<uintptr_t>(pbuf) & 15) == 0,
                "sf_gma_stored_aggregate: pbuf must hold sf_gma_stored_p_bytes(n_img, P) bytes, 16-byte aligned");
     const int Ppad = sf::ceil_div(P, BQ) * BQ;
-    SF_REQUIRE(2 * plane_bytes(Ppad) < ((int64_t)1 << 31) && (int64_t)(Ppad / 16) * 1024 < ((int64_t)1 << 31), "sf_gma_stored_aggregate: image too large");
+    SF_REQUIRE(2 * plane_bytes(Ppad) < ((int64_t)1 << 31) && (int64_t)Ppad * Ppad * 2 + 3 * (int64_t)(Ppad / 32) * 4096 < ((int64_t)1 << 32),
+               "sf_gma_stored_aggregate: image too large (the stored weights of one image must stay under 4 GiB)");
     if (!v) {}                                                // the v planes of ws are current (sf_gma_flash_project_v)
     else if (v_f16)
         hipLaunchKernelGGL(flash_pack_v_kernel<_Float16>, dim3(sf::ceil_div(Ppad / 8, 32), HD / 8, n_img), dim3(256), 0,

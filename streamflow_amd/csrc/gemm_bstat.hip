@@ -650,7 +650,6 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bstat_gk_kernel(const BsArgs
     const __amdgpu_buffer_rsrc_t rc16 = __builtin_amdgcn_make_buffer_rsrc(c16, 0, (int)((int64_t)((g.M + 7) / 8) * g.ldc * 16), 0x00020000);
     const int lane_k16 = (n < g.N) ? n * 16 + khalf * 8 : kOob;
     const int k4 = 4 * khalf, ldc16 = (int)g.ldc * 16;
-    auto rows_left = [&](int r) { return __builtin_amdgcn_readfirstlane(g.M - r); };
     auto rows_left8 = [&](int r) { return __builtin_amdgcn_readfirstlane((g.M + 7) / 8 * 8 - r); };      // up to the end of the last octet
 
     // rows tau * 32 + 8 j + 4 khalf + 0..3 of `acc` for NG consecutive groups j0 ..: gelu(alpha * acc) -> fp16 -> 8-byte stores.
