@@ -23,6 +23,7 @@
 // QKP = MFMA products per logit block: 1 (q_hi k_hi), 2 (+ q_lo k_hi), 3 (+ q_hi k_lo: the f16x3 split, fp32-class
 // logits).  P and V are single fp16 (the materialised path already stores the attention matrix in fp16).
 #include "sf_common.h"
+#include <cstdlib>
 
 #ifndef SF_FLASH_XCD_MAP
 #define SF_FLASH_XCD_MAP 1
@@ -446,6 +447,240 @@ __global__ __launch_bounds__(256, (QKP == 3) ? 1 : ((QKP == 1 && SF_FLASH_V1) ? 
     }
 }
 
+// ---- the recompute kernel, software-pipelined inside the wave (round 6; MODE 1 of the kernel above, same arithmetic) -----------
+// PMC / timers of gma_flash_kernel<1, 1>: matrix pipe 54 % busy with three waves per SIMD.  A wave there alternates phases that use
+// ONE unit each -- 16 logit MFMAs, then 32 exp2 + 16 conversions on the VALU, a barrier, then 16 P V MFMAs -- and whether another
+// wave fills the idle unit is left to chance (the workgroups of a CU drift into the same phase behind their barriers).  Here the
+// wave overlaps itself: while the softmax weights of key tile t are computed on the VALU, the matrix pipe runs the logits of tile
+// t + 1 (two logit register sets, the instruction streams interleaved with sched_group_barrier: one MFMA, one fragment read, two
+// exp2, one conversion), then P V of tile t.  K and V tiles both double-buffered, requested a whole iteration before their use,
+// ONE barrier per key tile.  Two workgroups per CU (64 KB of LDS, <= 256 registers).  Statistics mode only (accumulators start at
+// -max): the logits, the fp16 weights and the MFMA order of P V are those of gma_flash_kernel<QKP, 1> -- bit-identical results.
+#ifndef SF_FLASH_PIPE
+#define SF_FLASH_PIPE 1
+#endif
+template <int QKP>
+__global__ __launch_bounds__(256, (QKP == 1) ? 2 : 1) void gma_flash_pipe_kernel(const FlashArgs g) {
+    constexpr bool kKlo = (QKP == 3);
+    constexpr int KSTAGE = KPLANE * (kKlo ? 2 : 1);
+    constexpr int KP = kKlo ? 8 : 4;                                // DMA pieces of a K tile per wave
+    __shared__ __attribute__((aligned(1024))) char smem[2 * KSTAGE + 2 * VTILE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int khalf = lane >> 5, l31 = lane & 31;
+#if SF_FLASH_XCD_MAP
+    const int wg_lin = sf::xcd_linear_id((int)(blockIdx.x + gridDim.x * blockIdx.y), (int)(gridDim.x * gridDim.y));
+    const int img = wg_lin / (int)gridDim.x, q0 = (wg_lin % (int)gridDim.x) * BQ;
+#else
+    const int img = blockIdx.y, q0 = blockIdx.x * BQ;
+#endif
+    const int P = g.P, Ppad = g.Ppad;
+    const int plane = (int)plane_bytes(Ppad);
+    const char* ws = g.ws + (int64_t)img * img_ws_bytes(Ppad);
+    const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(ws), 0, 2 * plane, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(ws) + 2 * (int64_t)plane, 0, 2 * plane, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(ws) + 4 * (int64_t)plane, 0, plane, 0x00020000);
+    const int q = q0 + wave * 32 + l31;
+    f16x8 qh[HD / 16], ql[(QKP >= 2) ? HD / 16 : 1];
+#pragma unroll
+    for (int ks = 0; ks < HD / 16; ++ks) {
+        const int off = ((ks * 2 + khalf) * Ppad + q) * 16;
+        qh[ks] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rq, off, 0, 0));
+        if (QKP >= 2) ql[ks] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rq, off, plane, 0));
+    }
+    const float2* stats = reinterpret_cast<const float2*>(ws + 5 * (int64_t)plane);
+    float st_m, st_inv;
+    {
+        const float2 st = stats[q]; st_m = st.x; st_inv = st.y;
+        const int* hdr = reinterpret_cast<const int*>(ws + hdr_offset(Ppad));
+        if (hdr[0] != kHdrMagic || hdr[1] != QKP || hdr[2] != P) st_inv = __builtin_nanf("");
+    }
+    auto issue_v = [&](int t) {
+        char* vb = smem + 2 * KSTAGE + (t & 1) * VTILE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int piece = wave * 4 + i;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lds_ptr)(vb + piece * 1024), 16, lane * 16, t * (BJ * HD * 2) + piece * 1024, 0, 0);
+        }
+    };
+    auto issue_k = [&](int t) {
+        char* kb = smem + (t & 1) * KSTAGE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int dq = wave * 4 + i;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (lds_ptr)(kb + dq * 1024), 16, (t * BJ + lane) * 16, dq * Ppad * 16, 0, 0);
+            if (kKlo)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (lds_ptr)(kb + KPLANE + dq * 1024), 16, (t * BJ + lane) * 16,
+                                                         plane + dq * Ppad * 16, 0, 0);
+        }
+    };
+    f32x16 o[HD / 32];
+#pragma unroll
+    for (int t = 0; t < HD / 32; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+    const int nt_all = Ppad / BJ;
+    const int nsp = (g.nsplit > 1) ? g.nsplit : 1, sp = (nsp > 1) ? (int)blockIdx.z : 0;
+    const int tb = nt_all * sp / nsp, nt = nt_all * (sp + 1) / nsp;
+
+    // logits of one key tile (transposed: a lane holds ONE query, 32 of the tile's keys in its registers), accumulators start at -max
+    auto qk_tile = [&](const char* kb, f32x16 (&s)[2]) {
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[sub][r] = -st_m;
+#pragma unroll
+        for (int ks = 0; ks < HD / 16; ++ks) {
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+                const int off = ((ks * 2 + khalf) * BJ + sub * 32 + l31) * 16;
+                const f16x8 kh = *reinterpret_cast<const f16x8*>(kb + off);
+                if (QKP >= 2) s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[ks], s[sub], 0, 0, 0);
+                if (kKlo) {
+                    const f16x8 kl = *reinterpret_cast<const f16x8*>(kb + KPLANE + off);
+                    s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[ks], s[sub], 0, 0, 0);
+                }
+                s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[ks], s[sub], 0, 0, 0);
+            }
+        }
+    };
+    // fp16 softmax weights of a tile as the B fragments of the second contraction (k-step kk = sub * 2 + m)
+    typedef _Float16 hp2 __attribute__((ext_vector_type(2)));
+    auto weights = [&](const f32x16 (&s)[2], f16x8 (&pf)[4]) {
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                hp2 ph;
+                ph[0] = (_Float16)__builtin_amdgcn_exp2f(s[sub][r]);
+                ph[1] = (_Float16)__builtin_amdgcn_exp2f(s[sub][r + 1]);
+                const unsigned bits = __builtin_bit_cast(unsigned, ph);
+                pf[sub * 2 + (r >> 3)][r & 7] = __builtin_bit_cast(_Float16, (unsigned short)(bits & 0xffffu));
+                pf[sub * 2 + (r >> 3)][(r & 7) + 1] = __builtin_bit_cast(_Float16, (unsigned short)(bits >> 16));
+            }
+    };
+
+    // ---- prologue: K(tb), V(tb), K(tb + 1) requested; logits of tile tb ----
+    issue_k(tb);
+    issue_v(tb);
+    if (tb + 1 < nt) {
+        issue_k(tb + 1);
+        if (kKlo) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    static_assert(KP == 4 || KP == 8, "the prologue wait counts the pieces of K(tb + 1)");
+    __builtin_amdgcn_s_barrier();
+    f32x16 sa[2], sb[2];
+    qk_tile(smem + (tb & 1) * KSTAGE, sa);
+
+    // one key tile: `cur` = its logits (ready), `nxt` receives the logits of tile t + 1
+    auto iter = [&](f32x16 (&cur)[2], f32x16 (&nxt)[2], int t) {
+        // everyone has finished tile t - 1 (its fragment reads EXECUTED: the refill race of DESIGN 12.3); K(t + 1) and V(t), requested
+        // an iteration ago, have landed
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (t + 2 < nt) issue_k(t + 2);                           // into K(t)'s buffer
+        if (t + 1 < nt) issue_v(t + 1);                           // into V(t - 1)'s buffer
+        if ((t + 1) * BJ > P) {                                   // last tile with padded keys (workgroup-uniform)
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = t * BJ + sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                    cur[sub][r] = (key < P) ? cur[sub][r] : -1.0e30f;
+                }
+        }
+        f16x8 pf[4];
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- phase A: softmax weights of tile t on the VALU beside the logits of tile t + 1 on the matrix pipe.  Unconditional: behind
+        // the last tile the logits of a stale K buffer are computed and dropped (1 tile in Ppad / 64) -- a branch here lets hipcc hoist
+        // the exponentials out of the MFMA region ----
+        qk_tile(smem + ((t + 1) & 1) * KSTAGE, nxt);
+        weights(cur, pf);
+        {
+            constexpr int kMfma = 16 * QKP, kReads = kKlo ? 32 : 16, kAhead = 4;
+            // (the accumulator start values and the fragment address are VALU work the reads / MFMAs depend on: they need slots in front,
+            // or the pipeline has no valid order and hipcc drops it altogether)
+            __builtin_amdgcn_sched_group_barrier(0x002, 36, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, kAhead, 0);
+#pragma unroll
+            for (int i = 0; i < kMfma; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                // fragment reads: one per MFMA (QKP = 3: 32 reads for 48 MFMAs -- one behind two of every three)
+                if (kKlo) { if (i % 3 != 2 && (i / 3) * 2 + (i % 3) + kAhead < kReads) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+                else if (i / QKP + kAhead < kReads && i % QKP == 0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                // 32 exp2 + 16 conversions spread over the first MFMAs
+                if (i < 16) __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);
+                if (i < 16) __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- phase B: O^T += V^T P^T ----
+        const char* vb = smem + 2 * KSTAGE + (t & 1) * VTILE;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+            for (int td = 0; td < HD / 32; ++td) {
+                const f16x8 vf = *reinterpret_cast<const f16x8*>(vb + ((2 * kk + khalf) * HD + td * 32 + l31) * 16);
+                o[td] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[kk], o[td], 0, 0, 0);
+            }
+        }
+        {
+            constexpr int kAhead = 4;
+            __builtin_amdgcn_sched_group_barrier(0x100, kAhead, 0);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (i + kAhead < 16) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    {
+        int t = tb;
+        for (;;) {
+            iter(sa, sb, t);
+            if (++t >= nt) break;
+            iter(sb, sa, t);
+            if (++t >= nt) break;
+        }
+    }
+
+    // ---- epilogue: out[d][q] = mf[d][q] + gamma / rowsum * O^T[d][q] ----
+    const float w = g.gamma[0] * st_inv;
+    if (nsp > 1) {
+        float* pp = g.part + (((int64_t)sp * gridDim.y + img) * HD) * Ppad + q;
+#pragma unroll
+        for (int td = 0; td < HD / 32; ++td)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pp[(int64_t)(td * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf) * Ppad] = w * o[td][r];
+        return;
+    }
+    if (q < P) {
+        const float* mf = g.mf + (int64_t)img * g.mf_img_stride + q;
+        float* out = g.out + (int64_t)img * g.out_img_stride + q;
+        _Float16* o16 = g.out16 ? g.out16 + (int64_t)img * g.out16_img_stride + (int64_t)q * 8 + khalf * 4 : nullptr;
+#pragma unroll
+        for (int td = 0; td < HD / 32; ++td)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                h4 hv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * m + e;
+                    const int d = td * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                    const float val = mf[(int64_t)d * P] + w * o[td][r];
+                    out[(int64_t)d * P] = val;
+                    hv[e] = (_Float16)val;
+                }
+                if (o16) *reinterpret_cast<h4*>(o16 + (int64_t)(td * 4 + m) * P * 8) = hv;
+            }
+    }
+}
+
 // ---- stored softmax weights: out = mf + gamma / rowsum * V^T P^T with P^T streamed from HBM ------------------------------------
 // q and k are constant over the refinement loop, so are the softmax weights: MODE 3 above stores them ONCE per clip (fp16, n Ppad^2
 // 2 bytes: 2.4 GB for 24 Sintel images) in the register image of the second contraction's B operand, and every iteration only
@@ -679,6 +914,18 @@ static int flash_aggregate(void* ws, int64_t ws_bytes, const void* v_, int v_f16
     g.nsplit = (use_stats && use_key_split(n_img, Ppad)) ? kMaxSplit : 1;
     g.part = reinterpret_cast<float*>(static_cast<char*>(ws) + (int64_t)n_img * img_ws_bytes(Ppad));
     dim3 grid(Ppad / BQ, n_img, g.nsplit);
+    const char* pe = getenv("SF_FLASH_PIPE");                 // (A/B and the bit-identity test: SF_FLASH_PIPE=0 selects the round-5 kernel)
+    // measured (profiles/r06_flash_pipe_ab.txt): with ONE product per logit the pipelined form is 2-3 % SLOWER than the round-5 kernel
+    // (621 vs 605 us inside the step: the kernel sits at the chip's power budget, overlapping the units inside a wave buys nothing),
+    // with three products it is 4 % faster (1481 vs 1549 us): used for the split-precision logits only.  SF_FLASH_PIPE=2 forces it.
+    const bool pipe = SF_FLASH_PIPE && !(pe && atoi(pe) == 0) && (qk_products >= 2 || (pe && atoi(pe) == 2));
+    if (use_stats && pipe) {                                  // the software-pipelined form of the statistics mode (same results)
+        switch (qk_products) {
+            case 1: hipLaunchKernelGGL((gma_flash_pipe_kernel<1>), grid, dim3(256), 0, (hipStream_t)stream, g); break;
+            case 2: hipLaunchKernelGGL((gma_flash_pipe_kernel<2>), grid, dim3(256), 0, (hipStream_t)stream, g); break;
+            default: hipLaunchKernelGGL((gma_flash_pipe_kernel<3>), grid, dim3(256), 0, (hipStream_t)stream, g); break;
+        }
+    } else
     switch (qk_products * 2 + (use_stats ? 1 : 0)) {
         case 2: hipLaunchKernelGGL((gma_flash_kernel<1, 0>), grid, dim3(256), 0, (hipStream_t)stream, g); break;
         case 3: hipLaunchKernelGGL((gma_flash_kernel<1, 1>), grid, dim3(256), 0, (hipStream_t)stream, g); break;

@@ -113,3 +113,39 @@ def test_engine_stored_mode_equals_flash_mode(dev, preset):
         for key, val in outs.items():
             for a, b in zip(val, outs[("flash", False)]):
                 assert torch.equal(a, b), key
+
+
+@pytest.mark.parametrize("P", [64, 323, 1000, 7040])
+@pytest.mark.parametrize("qkp", [1, 2, 3])
+def test_pipelined_recompute_kernel_equals_the_round5_kernel(dev, P, qkp, monkeypatch):
+    """gma_flash_pipe_kernel (round 6: the wave overlaps the softmax of tile t with the logits of tile t + 1) computes the same
+    logits, the same fp16 weights and the same P V sequence as gma_flash_kernel<QKP, 1>: bit-identical outputs (SF_FLASH_PIPE=0
+    selects the old kernel), incl. the key-split form (n = 1) and twenty launches beside a competing stream."""
+    from streamflow_amd import ops
+    from streamflow_amd.ops import Planes
+    for n in (3, 1):
+        qk, v, mf = _inputs(P, n, 300 + P + qkp, sharp=P >= 323)
+        gamma = torch.tensor([0.61]).to(dev)
+        ws = torch.empty(ops.gma_flash_ws_bytes(n, P), dtype=torch.uint8, device=dev)
+        ws.fill_(0x7F)
+        QK, V, MF = Planes.of(qk.to(dev)), Planes.of(v.to(dev)), Planes.of(mf.to(dev))
+        ops.gma_flash_pack_qk(QK, ws, 128 ** -0.5, stats_qk_products=qkp)
+        outs = {}
+        for pipe in ("0", "2"):                              # 0: the round-5 kernel, 2: the pipelined form for every product count
+            monkeypatch.setenv("SF_FLASH_PIPE", pipe)
+            o = torch.full((n, 128, P), float("nan"), device=dev)
+            ops.gma_flash_aggregate(ws, V, MF, gamma, Planes.of(o), qkp, use_stats=True)
+            torch.cuda.synchronize()
+            outs[pipe] = o
+        assert torch.isfinite(outs["2"]).all()
+        assert torch.equal(outs["0"], outs["2"]), f"P={P} qkp={qkp} n={n}: max diff {(outs['0'] - outs['2']).abs().max().item():.3e}"
+        if P == 7040 and n == 3:
+            side = torch.cuda.Stream(device=dev)
+            junk = torch.empty(64 << 20, device=dev)
+            for _ in range(20):
+                with torch.cuda.stream(side):
+                    junk.normal_()
+                o2 = torch.full((n, 128, P), float("nan"), device=dev)
+                ops.gma_flash_aggregate(ws, V, MF, gamma, Planes.of(o2), qkp, use_stats=True)
+                torch.cuda.synchronize()
+                assert torch.equal(o2, outs["2"])
