@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SF_VERSION 117
+#define SF_VERSION 118
 
 enum {
     SF_OK = 0,
@@ -335,6 +335,34 @@ typedef struct SfFfnPair {
 } SfFfnPair;
 int sf_ffn_pair(const SfFfnPair* p, void* stream);
 int sf_ffn_pair_frags(int K1, int M2, int pm1, int pm2);
+
+/* ---- a8, back half: pw -> GELU -> ffn2.0 -> GELU -> ffn2.2 of an SK block in ONE launch (core/update.py:35-36 with ffn2 of
+ * update.py:14-16; csrc/sk_tail.hip) ------------------------------------------------------------------------------------------
+ * y = W3 gelu(W2 gelu(W1' x3 + b1) + b2) + b3,  W1' = pw + I (the residual of `x + pw(x)` folded into the weights).  x4 and the
+ * 1.5 C hidden stay in registers (the three-launch form writes and re-reads both).
+ * X: x3 as fp16 ROWS [C][ldx] per image (what sf_dwconv_res_gelu_f16in writes; strideX in halves), N pixels, `batch` images.
+ * wstream: ONE stream of 1-KB fragments (32 rows x 16 k: lane (row m, k-half) = 8 halves W[32 t + m][k(8 khalf + i)]; pm = 2:
+ *   the `lo` fragment precedes the `hi` one) in consumption order (streamflow_amd.ops.PackedTail):
+ *     for t = 0 .. C/32 - 1: W1' row tile t, k-steps 0 .. C/16 - 1 (natural column order), zero-padded to a multiple of 16 fragments;
+ *     for th = 0 .. H/32 - 1: W2 row tile th, k-steps 0 .. C/16 - 1; then for s = 0, 1: W3 row tiles 0 .. ceil(M2/32) - 1 at the
+ *       k-step (th, s) of the hidden rows; zero-padded to a multiple of 16 fragments;
+ *   the columns of a k-step (t, s) of W2 and W3 are ordered  k = 8 khalf + i <-> input row 32 t + 16 s + (i & 3) + 8 (i >> 2) + 4 khalf
+ *   (the accumulator layout of the producing tile).  sf_sk_tail_frags(C, H, M2, pm) fragments in all (0: shape not built).
+ *   Weights pre-scaled by a power of two per layer (alpha* = 1 / scale, bias* carry the scale).
+ * Y (fp32 planes [M2][ldy], optional) and / or Y16 (fp16 k-octet planes, optional; y16_partial = 1: rows >= M2 of the last octet
+ * are left alone).  gelu_out: y = gelu(...).  Built for (C, M2) = (256, 192), (256, 126), (384, 6), (128, 64), H % 32 == 0, H <= 576,
+ * pm = 1 / 2; anything else: SF_ERR_BAD_ARG (the caller keeps the three launches). */
+typedef struct SfSkTail {
+    const void* X; int64_t strideX; int64_t ldx;
+    const void* wstream; int64_t wstream_bytes;
+    const float* bias1; const float* bias2; const float* bias3;
+    float* Y; int64_t strideY; int64_t ldy;
+    void* Y16; int64_t strideY16; int64_t ldy16;
+    int32_t N, batch, C, H, M2, pm, gelu_out, y16_partial;
+    float alpha1, alpha2, alpha3;
+} SfSkTail;
+int sf_sk_tail(const SfSkTail* p, void* stream);
+int sf_sk_tail_frags(int C, int H, int M2, int pm);
 
 /* ---- a10: the temporal transformer block in ONE launch (core/update.py:459-484,502-513 -> timm Block; called at update.py:770;
  * csrc/temporal.hip) ---------------------------------------------------------------------------------------------------------

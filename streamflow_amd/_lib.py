@@ -60,6 +60,19 @@ class SfFfnPair(C.Structure):
     ]
 
 
+class SfSkTail(C.Structure):
+    _fields_ = [
+        ("X", _vp), ("strideX", _i64), ("ldx", _i64),
+        ("wstream", _vp), ("wstream_bytes", _i64),
+        ("bias1", _vp), ("bias2", _vp), ("bias3", _vp),
+        ("Y", _vp), ("strideY", _i64), ("ldy", _i64),
+        ("Y16", _vp), ("strideY16", _i64), ("ldy16", _i64),
+        ("N", C.c_int32), ("batch", C.c_int32), ("C", C.c_int32), ("H", C.c_int32), ("M2", C.c_int32), ("pm", C.c_int32),
+        ("gelu_out", C.c_int32), ("y16_partial", C.c_int32),
+        ("alpha1", _f), ("alpha2", _f), ("alpha3", _f),
+    ]
+
+
 class SfTemporalBlock(C.Structure):
     _fields_ = [
         ("X16", _vp), ("strideX", _i64), ("ldx", _i64),
@@ -115,6 +128,8 @@ SIGNATURES = {
     "sf_gma_stored_aggregate": (_i, [_vp, _i64, _vp, _i64, _vp, _i, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _i, _i, _vp]),
     "sf_ffn_pair": (_i, [C.POINTER(SfFfnPair), _vp]),
     "sf_ffn_pair_frags": (_i, [_i, _i, _i, _i]),
+    "sf_sk_tail": (_i, [C.POINTER(SfSkTail), _vp]),
+    "sf_sk_tail_frags": (_i, [_i, _i, _i, _i]),
     "sf_temporal_block": (_i, [C.POINTER(SfTemporalBlock), _vp]),
     "sf_temporal_block_frags": (_i, [_i]),
     "sf_mask_upsample": (_i, [C.POINTER(SfMaskUpsample), _vp]),

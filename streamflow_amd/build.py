@@ -22,7 +22,7 @@ OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libstreamflow_hip.so")
 ASAN_OBJ = os.path.join(CSRC, "build_asan")
 ASAN_LIB = os.path.join(HERE, "libstreamflow_hip_asan.so")
-SOURCES = ["misc.hip", "corr.hip", "corr_blocked.hip", "conv.hip", "gemm.hip", "gemm_split.hip", "gemm_bstat.hip", "ffn_pair.hip", "temporal.hip", "mask_upsample.hip", "attn.hip", "encoder.hip"]
+SOURCES = ["misc.hip", "corr.hip", "corr_blocked.hip", "conv.hip", "gemm.hip", "gemm_split.hip", "gemm_bstat.hip", "ffn_pair.hip", "sk_tail.hip", "temporal.hip", "mask_upsample.hip", "attn.hip", "encoder.hip"]
 HEADERS = [os.path.join(CSRC, "sf_common.h"), os.path.join(CSRC, "gemm_epilogue.h"), os.path.join(CSRC, "split_operand.h"),
            os.path.join(HERE, "..", "include", "streamflow_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-Wall",
@@ -32,7 +32,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vector
          "-Rpass-analysis=kernel-resource-usage"]
 # kernels that may not use scratch memory (substring of the demangled name): everything that shows up in the top rows of the
 # step's kernel table (profiles/r*_kernel_stats_sintel_serial.md)
-HOT_KERNELS = ("gemm_bstat", "ffn_pair_kernel", "temporal_block_kernel", "mask_upsample_kernel", "gemm_bdirect_kernel", "gma_flash_kernel", "flash_project_v_kernel", "dwconv_mfma_kernel",
+HOT_KERNELS = ("gemm_bstat", "ffn_pair_kernel", "sk_tail_kernel", "gma_flash_pipe_kernel", "gma_pv_kernel", "temporal_block_kernel", "mask_upsample_kernel", "gemm_bdirect_kernel", "gma_flash_kernel", "flash_project_v_kernel", "dwconv_mfma_kernel",
                "corr_lookup_blocked_kernel", "corr_build_blocked_kernel", "temporal_attn_kernel", "layernorm_cm_split_kernel",
                "flash_pack_v_kernel")
 

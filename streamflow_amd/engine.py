@@ -49,6 +49,7 @@ class EngineOptions:
     ffn_pairs: bool = True           # the SK blocks' ffn1 / ffn2 pairs as one launch each where the shape is built (sf_ffn_pair)
     project_v: bool = True           # fused GMA, fp16 activations: to_v + the v pack as one launch (sf_gma_flash_project_v)
     temporal_block: bool = True      # the temporal transformer block as ONE launch (sf_temporal_block) instead of seven
+    sk_tail: bool = True             # an SK block's back half (pw -> GELU -> ffn2.0 -> GELU -> ffn2.2) as ONE launch where the shape is built (sf_sk_tail)
     head_pairs: bool = False         # the flow head's FFN pairs on its grouped view (sf_ffn_pair x_group / R32).  Off: +0.4 % on the step
                                      # (382 vs 380 ff/s) against EPE samples of 3.6 / 1.9 / 2.6e-4 px instead of 2.9 / 1.7 / 2.6e-4
     mask_upsample: bool = True       # mask head's second layer + convex upsampling as ONE launch (sf_mask_upsample): the mask is never written
@@ -93,6 +94,8 @@ class SKBlockWeights:
         # the two FFNs as single launches (update.py:14-16: nn.Sequential(conv, GELU, conv)); weight streams are built on first use
         self.pair1 = ops.PackedPair(self.ffn1_0, self.ffn1_2)
         self.pair2 = ops.PackedPair(self.ffn2_0, self.ffn2_2)
+        # ... and the whole back half, pw (residual folded) -> ffn2.0 -> ffn2.2, as one launch (update.py:35-36; csrc/sk_tail.hip)
+        self.tail = ops.PackedTail(self.pw_res, self.ffn2_0, self.ffn2_2)
         self.c_in, self.c_mid, self.c_out = self.ffn1_0.K, self.ffn1_0.M, self.ffn2_2.M
         f32 = lambda t: t.detach().to(device=device, dtype=torch.float32).contiguous()
         w0 = g("conv_list.0.weight")
@@ -178,6 +181,10 @@ def run_skblock(W: SKBlockWeights, X: Planes, Y: Planes, hid: Planes, xa: Planes
         # the bytes, has a residual-free epilogue and may therefore write k-octets
         b16 = _scratch(xb, X.n_img, C, f16=True)
         ops.dwconv_res_gelu(a, W.dwk_w, W.dwk_b, b16, h, w, W.k, single=W.dw_single, cx=cx)   # x3 = gelu(x2 + dwKxK(x2))
+        if ops.sk_tail_ok(W.tail, b16, Y, cx):
+            # the back half as ONE launch: x4 and the 1.5 C hidden never leave the registers (csrc/sk_tail.hip; round 6)
+            ops.sk_tail(W.tail, b16, Y, gelu_out=final_gelu, cx=cx)
+            return
         a4 = _handover(cx, xa, X.n_img, C, X.P, consumer_rows=W.c_mid)
         ops.gemm(W.pw_res, b16, a4, EPI_GELU, cx=cx)                            # x4 = gelu((pw + I) x3)
     else:
@@ -458,14 +465,16 @@ class HotPathEngine:
         self.W.set_single("all" if self.single_layers == ("all",) else self.single_layers)
         # the FFN pairs' weight streams are built NOW (device-synchronous), not lazily inside a forward: a forward enqueues on several
         # streams (and may be a graph capture) -- a stream built on one of them would be read by another before it exists
-        if self.options.ffn_pairs and self.precision in (ops.PRECISION_F16X2, ops.PRECISION_F16):
+        if (self.options.ffn_pairs or self.options.sk_tail) and self.precision in (ops.PRECISION_F16X2, ops.PRECISION_F16):
             cxp = ops.Ctx(precision=self.precision)
             with torch.cuda.device(self.device):
                 for b in HotPathWeights.SK_BLOCKS:
                     blk = getattr(self.W, b)
-                    for pair in (blk.pair1, blk.pair2):
+                    for pair in (blk.pair1, blk.pair2) if self.options.ffn_pairs else ():
                         if (pair.K1, pair.M2) in ops.PAIR_SHAPES[0] | ops.PAIR_SHAPES[1]:
                             pair.stream(*pair.products(cxp))
+                    if self.options.sk_tail and blk.tail.built(blk.tail.products(cxp)):
+                        blk.tail.stream(blk.tail.products(cxp))
                 torch.cuda.synchronize(self.device)
         if self.options.mask_upsample and self.precision in (ops.PRECISION_F16X2, ops.PRECISION_F16) and self.W.mask_pack.built():
             with torch.cuda.device(self.device):
@@ -514,7 +523,7 @@ class HotPathEngine:
                        split_ws=pl.splitws.tensor().view(-1) if self.auto_split_k else None,
                        shadows=o.shadows, shadow_fused=o.shadow_fused, flash_stats=o.flash_stats,
                        hidden_f16=o.hidden_f16, hidden_koct=o.hidden_koct, pw_fold=o.pw_fold, x2_f16=o.x2_f16,
-                       ffn_pairs=o.ffn_pairs, head_pairs=o.head_pairs)
+                       ffn_pairs=o.ffn_pairs, head_pairs=o.head_pairs, sk_tail=o.sk_tail)
 
     def _attention_rows(self, cx: ops.Ctx, pl: _Plan, i0: int, rows: int) -> None:
         """attn[:, :rows, :] = softmax(scale * q[:, i0:i0+rows]^T k)   (gma.py:53-65) for every image."""

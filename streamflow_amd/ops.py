@@ -67,6 +67,7 @@ class Ctx:
     x2_f16: bool = True
     ffn_pairs: bool = True      # an SK block's ffn1 / ffn2 as ONE launch where sf_ffn_pair has the shape (csrc/ffn_pair.hip)
     head_pairs: bool = False    # ... also the flow head's (grouped view, fp32 residual)
+    sk_tail: bool = True        # an SK block's pw -> ffn2.0 -> ffn2.2 as ONE launch where sf_sk_tail has the shape (csrc/sk_tail.hip)
 
     def no_split(self) -> "Ctx":
         """The same context without the split-K scratch (ONE buffer: only one stream may use it at a time)."""
@@ -361,6 +362,120 @@ class PackedPair:
         assert st.numel() * 2 == hp * fpad * 1024
         self._streams[key] = st
         return st
+
+
+class PackedTail:
+    """The back half of an SK block -- pw (residual folded: W + I), ffn2.0, ffn2.2 (update.py:35-36, :14-16) -- as ONE weight stream for
+    sf_sk_tail (csrc/sk_tail.hip): 1-KB fragments of 32 rows x 16 k in consumption order, units padded to 16-fragment stages (layout:
+    include/streamflow_hip.h).  The PackedLinear objects stay the source of truth (rounding, power-of-two scales, biases, `single`)."""
+
+    S = 16
+
+    def __init__(self, pw_res: "PackedLinear", f0: "PackedLinear", f2: "PackedLinear"):
+        assert pw_res.M == pw_res.K == f0.K and f0.M == f2.K and not (pw_res.conv3x3 or f0.conv3x3 or f2.conv3x3)
+        self.layers = (pw_res, f0, f2)
+        self.C, self.H, self.M2 = pw_res.K, f0.M, f2.M
+        self._streams = {}
+
+    def products(self, cx: "Ctx") -> Optional[int]:
+        """MFMA products per weight: 1 or 2 -- the kernel takes ONE value for the three layers; a mixed set keeps the three launches."""
+        if cx.precision == PRECISION_F16 or all(l.single for l in self.layers):
+            return 1
+        return 2 if not any(l.single for l in self.layers) else None
+
+    def built(self, pm: Optional[int]) -> bool:
+        return pm is not None and int(_lib.load().sf_sk_tail_frags(self.C, self.H, self.M2, pm)) > 0
+
+    def stream(self, pm: int) -> torch.Tensor:
+        if pm in self._streams:
+            return self._streams[pm]
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("PackedTail.stream: weight stream requested for the first time inside a graph capture; build it before "
+                               "(HotPathEngine does at construction)")
+        nc, nh, nm = (self.C + 31) // 32, self.H // 32, (self.M2 + 31) // 32
+        ks = 2 * nc
+        w1, w2, w3 = (PackedPair._split(l, r, c) for l, (r, c) in zip(self.layers, ((nc * 32, nc * 32), (nh * 32, nc * 32), (nm * 32, nh * 32))))
+        dev = w1[0].device
+        khalf = torch.arange(2, device=dev).view(2, 1)
+        i = torch.arange(8, device=dev).view(1, 8)
+        natural = (8 * khalf + i).reshape(-1)                                          # column of (khalf, i) inside a natural k-step
+        acc_order = ((i & 3) + 8 * (i >> 2) + 4 * khalf).reshape(-1)                   # ... inside a k-step made of accumulator registers
+        out = []
+        zero = torch.zeros(512, dtype=torch.float16, device=dev)
+
+        def emit(w, r0, cols):                                                         # lo before hi; lane (khalf, row m): 8 halves
+            for plane in ((w[1], w[0]) if pm == 2 else (w[0],)):
+                out.append(plane[r0:r0 + 32][:, cols].reshape(32, 2, 8).permute(1, 0, 2).reshape(512))
+
+        def pad():
+            while (len(out) % self.S) != 0:
+                out.append(zero)
+
+        for t in range(nc):                                                            # phase 1: pw row tiles over the natural k-steps
+            for k in range(ks):
+                emit(w1, 32 * t, 16 * k + natural)
+            pad()
+        for th in range(nh):                                                           # phase 2: per 32 hidden rows
+            for k in range(ks):                                                        # ffn2.0 over x4 (k-step = (tile k / 2, half k % 2))
+                emit(w2, 32 * th, 32 * (k // 2) + 16 * (k % 2) + acc_order)
+            for s_ in range(2):                                                        # ffn2.2's two k-steps from this hidden tile
+                for m in range(nm):
+                    emit(w3, 32 * m, 32 * th + 16 * s_ + acc_order)
+            pad()
+        st = torch.cat(out).contiguous()
+        assert st.numel() == int(_lib.load().sf_sk_tail_frags(self.C, self.H, self.M2, pm)) * 512, (st.numel() // 512, self.C, self.H, self.M2, pm)
+        self._streams[pm] = st
+        return st
+
+
+def sk_tail_ok(tail: Optional[PackedTail], X: Planes, Y: Planes, cx: Optional["Ctx"] = None) -> bool:
+    """Does sf_sk_tail run this block's back half?  fp16-activation arithmetic, x3 as fp16 ROWS, one product count for the three
+    layers, a built shape, k-octet and / or fp32 outputs."""
+    cx = _cx(cx)
+    if tail is None or not cx.sk_tail or cx.precision not in (PRECISION_F16X2, PRECISION_F16) or not (cx.hidden_f16 and cx.hidden_koct):
+        return False
+    if not (X.f16 and not X.koct and X.group == 0 and Y.group == 0 and X.rows == tail.C and Y.rows == tail.M2 and X.P % 4 == 0):
+        return False
+    if Y.f16 and not Y.koct:
+        return False
+    return tail.built(tail.products(cx))
+
+
+@on_tensor_device
+def sk_tail(tail: PackedTail, X: Planes, Y: Planes, gelu_out: bool = False, cx: Optional["Ctx"] = None) -> None:
+    """Y = ffn2(gelu(x3 + pw(x3))) [gelu'ed with gelu_out] (update.py:35-36): X = x3 as fp16 rows; Y fp16 k-octet planes, or fp32 planes
+    (+ their k-octet copy Y.shadow)."""
+    cx = _cx(cx)
+    assert sk_tail_ok(tail, X, Y, cx) and Y.n_img == X.n_img and Y.P == X.P
+    pm = tail.products(cx)
+    st = tail.stream(pm)
+    A1, A2, A3 = tail.layers
+    g = _lib.SfSkTail()
+    g.X, g.strideX, g.ldx = X.ptr, X.img_stride, X.P
+    g.wstream, g.wstream_bytes = st.data_ptr(), st.numel() * 2
+    g.bias1 = None if A1.bias_split is None else A1.bias_split.data_ptr()
+    g.bias2 = None if A2.bias_split is None else A2.bias_split.data_ptr()
+    g.bias3 = None if A3.bias_split is None else A3.bias_split.data_ptr()
+    g.alpha1, g.alpha2, g.alpha3 = 1.0 / A1.split_scale, 1.0 / A2.split_scale, 1.0 / A3.split_scale
+    g.N, g.batch, g.C, g.H, g.M2, g.pm, g.gelu_out = X.P, X.n_img, tail.C, tail.H, tail.M2, pm, int(bool(gelu_out))
+    out_bytes = 2.0
+    if Y.f16:
+        g.Y16, g.strideY16, g.ldy16 = Y.ptr, Y.img_stride, Y.P
+    else:
+        g.Y, g.strideY, g.ldy = Y.ptr, Y.img_stride, Y.P
+        out_bytes = 4.0
+        if Y.shadow is not None and cx.shadows:
+            sh = Y.shadow
+            g.Y16, g.strideY16, g.ldy16 = sh.ptr, sh.img_stride, sh.P
+            g.y16_partial = 1 if tail.M2 % 8 else 0
+            out_bytes = 6.0
+    n, P = X.n_img, X.P
+    macs = tail.C * tail.C + tail.C * tail.H + tail.H * tail.M2
+    name = "sk_tail" if not PROFILE_SHAPES else f"sk_tail C{tail.C} H{tail.H} M{tail.M2} b{n}"
+    _launch(name, 2.0 * n * P * macs, n * P * (2.0 * tail.C + out_bytes * tail.M2) + 2.0 * macs * pm,
+            lambda: _lib.check(_lib.load().sf_sk_tail(C.byref(g), _lib.stream()), "sf_sk_tail"), products=float(pm))
+    if g.Y and not g.Y16:
+        refresh_shadow(Y, cx)
 
 
 class PackedTemporal:

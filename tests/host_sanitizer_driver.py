@@ -76,6 +76,23 @@ for (K1, H, M2), mode, pm1, pm2, part in itertools.product(((128, 192, 64), (128
     p.R32, p.strideR32, p.ldr32 = PTR[8], M2 * 7040, 7040          # the fp32-residual form (mode 1 only)
     call(lib.sf_ffn_pair, C.byref(p), None)
 
+# the SK block's back half in one launch: every shape x product count, outputs, bad arguments
+for (C_, H_, M2_), pm in itertools.product(((256, 384, 192), (256, 384, 126), (384, 576, 6), (128, 192, 64), (324, 486, 256), (256, 100, 192)), (1, 2, 3)):
+    t = _lib.SfSkTail()
+    fr = lib.sf_sk_tail_frags(C_, H_, M2_, pm)
+    t.X, t.strideX, t.ldx = PTR[0], C_ * 7040, 7040
+    t.wstream, t.wstream_bytes = PTR[1], max(fr, 1) * 1024
+    t.bias1, t.bias2, t.bias3 = PTR[2], PTR[3], None
+    t.N, t.batch, t.C, t.H, t.M2, t.pm = 7040, 24, C_, H_, M2_, pm
+    t.alpha1 = t.alpha2 = t.alpha3 = 1.0
+    for y, y16, part in ((PTR[4], None, 0), (None, PTR[5], 0), (PTR[4], PTR[5], 1), (None, None, 0), (PTR[4], 0x1008, 0)):
+        t.Y, t.strideY, t.ldy = y, M2_ * 7040, 7040
+        t.Y16, t.strideY16, t.ldy16, t.y16_partial = y16, (M2_ + 7) // 8 * 8 * 7040, 7040, part
+        call(lib.sf_sk_tail, C.byref(t), None)
+    t.wstream_bytes = 1024                                          # stream too small
+    call(lib.sf_sk_tail, C.byref(t), None)
+call(lib.sf_sk_tail, None, None)
+
 # correlation, GMA, depthwise, element-wise entry points: good and bad arguments
 strides = (C.c_int64 * 4)(*[8 * 7040 * (55 >> l) * (128 >> l) for l in range(4)])
 for pitch in (None, (C.c_int32 * 4)(128, 64, 32, 32), (C.c_int32 * 4)(100, 64, 32, 16)):

@@ -353,3 +353,42 @@ def test_a_translation_unit_compiles_from_a_clean_directory(tmp_path):
     assert "mask_upsample_kernel" in res and "ScratchSize" in res
     # the clean path removes what it says (on a copy of the directory names, not the real build)
     assert callable(build.clean)
+
+
+def test_sk_tail_weight_stream_layout(lib):
+    """ops.PackedTail: the stream has sf_sk_tail_frags fragments; a fragment is [k-half][row][8 halves]; the k-steps of ffn2.0 / ffn2.2
+    carry their columns in accumulator-register order (csrc/sk_tail.hip); units are zero-padded to 16-fragment stages."""
+    from streamflow_amd.ops import PackedLinear, PackedPair, PackedTail
+    C, H, M2 = 128, 192, 64
+    g = torch.Generator().manual_seed(3)
+    mk = lambda m, k: PackedLinear(torch.randn(m, k, 1, 1, generator=g), torch.randn(m, generator=g), "cpu")
+    Ap, A0, A2 = mk(C, C), mk(H, C), mk(M2, H)
+    tail = PackedTail(Ap, A0, A2)
+    for pm in (1, 2):
+        frags = lib.sf_sk_tail_frags(C, H, M2, pm)
+        st = tail.stream(pm).view(frags, 2, 32, 8)                              # [fragment][k-half][row][i]
+        nc, nh, nm, ks = 4, 6, 2, 8
+        u1, u2 = -(-ks * pm // 16) * 16, -(-(ks + 2 * nm) * pm // 16) * 16
+        assert frags == nc * u1 + nh * u2
+        h1 = PackedPair._split(Ap, C, C)[0]
+        h2 = PackedPair._split(A0, H, C)[0]
+        h3 = PackedPair._split(A2, M2, H)[0]
+        hi = pm - 1                                                             # position of the hi plane inside a (lo, hi) pair
+        # pw tile 1, k-step 3: natural columns
+        f = st[1 * u1 + 3 * pm + hi]
+        for kh in (0, 1):
+            assert torch.equal(f[kh], h1[32:64, 48 + 8 * kh: 48 + 8 * kh + 8])
+        # ffn2.0 hidden tile 2, k-step 5 = (x4 tile 2, half 1): accumulator order
+        f = st[nc * u1 + 2 * u2 + 5 * pm + hi]
+        for kh in (0, 1):
+            cols = [32 * 2 + 16 * 1 + (i & 3) + 8 * (i >> 2) + 4 * kh for i in range(8)]
+            assert torch.equal(f[kh], h2[64:96][:, cols])
+        # ffn2.2 from hidden tile 2, half s = 1, row tile m = 1
+        f = st[nc * u1 + 2 * u2 + (ks + 1 * nm + 1) * pm + hi]
+        for kh in (0, 1):
+            cols = [32 * 2 + 16 * 1 + (i & 3) + 8 * (i >> 2) + 4 * kh for i in range(8)]
+            assert torch.equal(f[kh], h3[32:64][:, cols])
+        # padding of the last stage of a unit is zero
+        if (ks + 2 * nm) * pm % 16:
+            assert bool((st[nc * u1 + u2 - 1] == 0).all())
+    assert lib.sf_sk_tail_frags(324, 486, 256, 2) == 0 and lib.sf_sk_tail_frags(256, 384, 192, 1) == 0

@@ -1,0 +1,164 @@
+"""sf_sk_tail (csrc/sk_tail.hip): the back half of an SK block -- x4 = gelu(x3 + pw(x3)); y = ffn2(x4), core/update.py:35-36 with
+ffn2 = conv1x1 -> GELU -> conv1x1 (update.py:14-16) -- as ONE launch, through the C ABI (-m gpu): against float64 on the same
+fp16-rounded operands and against the three sf_gemm launches it replaces, every built shape, both product counts, ragged pixel
+counts, every output format; determinism; the engine with and without it."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(256, 384, 192), (256, 384, 126), (384, 576, 6), (128, 192, 64)]          # (C, H, M2): convc2, conv, flow head, convf2
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need an MI355X; torch.cuda.is_available() is False")
+    return torch.device("cuda:0")
+
+
+def _weff(A, single):
+    hi = A.hi.float().permute(1, 0, 2).reshape(A.lda_h, -1)[: A.M, : A.K].double().cpu()
+    lo = A.lo.float().permute(1, 0, 2).reshape(A.lda_h, -1)[: A.M, : A.K].double().cpu()
+    return (hi if single else hi + lo) / A.split_scale
+
+
+def _block(C, H, M2, seed, dev, pm):
+    from streamflow_amd.ops import PackedLinear, PackedTail
+    g = torch.Generator().manual_seed(seed)
+    Wp, bp = torch.randn(C, C, generator=g) / C ** 0.5 * 0.7, torch.randn(C, generator=g) * 0.2
+    W0, b0 = torch.randn(H, C, generator=g) / C ** 0.5, torch.randn(H, generator=g) * 0.2
+    W2, b2 = torch.randn(M2, H, generator=g) / H ** 0.5 * 1.7, torch.randn(M2, generator=g) * 0.2
+    Ap = PackedLinear((Wp + torch.eye(C)).view(C, C, 1, 1), bp, dev)              # the residual folded into the weights (engine: pw_res)
+    A0, A2 = PackedLinear(W0.view(H, C, 1, 1), b0, dev), PackedLinear(W2.view(M2, H, 1, 1), b2, dev)
+    for A in (Ap, A0, A2):
+        A.single = pm == 1
+    return Ap, A0, A2, PackedTail(Ap, A0, A2), (bp, b0, b2), g
+
+
+def _rows16(x, dev):
+    """fp16 ROWS [n][C][P] in a float buffer (what sf_dwconv_res_gelu_f16in writes)."""
+    from streamflow_amd.ops import Planes
+    n, C, P = x.shape
+    h = x.half().to(dev).contiguous()
+    return Planes(h.view(-1).view(torch.float32), 0, C * P, n, C, P, f16=True)
+
+
+def _ref(Ap, A0, A2, bias, x, pm, gelu_out):
+    x16 = x.half().double()
+    s = pm == 1
+    x4 = F.gelu(torch.einsum("mk,nkp->nmp", _weff(Ap, s), x16) + bias[0].double()[None, :, None]).half().double()
+    hid = F.gelu(torch.einsum("hk,nkp->nhp", _weff(A0, s), x4) + bias[1].double()[None, :, None]).half().double()
+    y = torch.einsum("mh,nhp->nmp", _weff(A2, s), hid) + bias[2].double()[None, :, None]
+    return F.gelu(y) if gelu_out else y
+
+
+@pytest.mark.parametrize("pm", [1, 2])
+@pytest.mark.parametrize("P", [64, 1000, 7040])
+@pytest.mark.parametrize("shape", SHAPES)
+def test_sk_tail_vs_float64_and_three_launches(dev, shape, P, pm):
+    from dataclasses import replace
+    from streamflow_amd import ops
+    from streamflow_amd.ops import Planes
+    C, H, M2 = shape
+    n = 3 if P < 7040 else 2
+    Ap, A0, A2, tail, bias, g = _block(C, H, M2, C * 3 + M2 + P, dev, pm)
+    cx = ops.Ctx(precision=ops.PRECISION_F16X2)
+    if not tail.built(pm):
+        assert (C, M2, pm) == (256, 192, 1)                    # the one combination that is not built (8 spilled registers)
+        pytest.skip("256 -> H -> 192 with single-product weights is not built")
+    x = torch.randn(n, C, P, generator=g)
+    X = _rows16(x, dev)
+    gelu_out = M2 == 64
+    ref = _ref(Ap, A0, A2, bias, x, pm, gelu_out)
+    scale = max(1.0, ref.abs().max().item())
+    Mo = (M2 + 7) // 8 * 8
+    if M2 % 8 == 0:                                            # k-octet-only output (NaN-filled: every cell must be written)
+        Y = Planes(torch.full((n * Mo * P // 2 + 8,), float("nan"), device=dev), 0, Mo * P, n, M2, P, f16=True, koct=True)
+        assert ops.sk_tail_ok(tail, X, Y, cx)
+        ops.sk_tail(tail, X, Y, gelu_out=gelu_out, cx=cx)
+        err = (Y.tensor().double().cpu() - ref).abs()
+        assert bool((err <= 2.0 ** -10 * ref.abs() + 3e-3 * scale).all()), (shape, P, pm, err.max().item())
+    y32 = torch.full((n, M2, P), float("nan"), device=dev)     # fp32 planes + k-octet copy (rows >= M2 of the last octet left alone)
+    Y = Planes.of(y32)
+    sh = ops.new_shadow(Y, dev)
+    sh.base.view(torch.float16).fill_(7.0)
+    assert ops.sk_tail_ok(tail, X, replace(Y, shadow=sh), cx)
+    ops.sk_tail(tail, X, replace(Y, shadow=sh), gelu_out=gelu_out, cx=cx)
+    torch.cuda.synchronize()
+    err32 = (y32.double().cpu() - ref).abs().max().item()
+    print(f"sk_tail {shape} P={P} pm={pm}: max abs err vs float64 = {err32:.2e} (scale {scale:.1f})")
+    assert err32 < 3e-3 * scale, (shape, P, pm, err32)
+    assert torch.equal(sh.tensor().float(), y32.half().float())
+    if M2 % 8:
+        oc = sh.base.view(torch.float16)[: n * Mo * P].view(n, Mo // 8, P, 8)[:, -1, :, M2 % 8:]
+        assert bool((oc == 7.0).all())
+    y_only = torch.full((n, M2, P), float("nan"), device=dev)  # fp32 planes alone (the flow head's delta)
+    ops.sk_tail(tail, X, Planes.of(y_only), gelu_out=gelu_out, cx=cx)
+    torch.cuda.synchronize()
+    assert torch.equal(y_only, y32)
+    # the three launches: the same arithmetic, x4 and the hidden handed over as fp16 k-octets
+    def koct(rows):
+        ra = (rows + 7) // 8 * 8
+        return Planes(torch.zeros(n * ra * P // 2 + 8, device=dev), 0, ra * P, n, rows, P, f16=True, koct=True)
+    x4p, hidp = koct(C), koct(H)
+    ops.gemm(Ap, X, x4p, ops.EPI_GELU, cx=cx)
+    ops.gemm(A0, x4p, hidp, ops.EPI_GELU, cx=cx)
+    y3 = torch.full((n, M2, P), float("nan"), device=dev)
+    ops.gemm(A2, hidp, Planes.of(y3), ops.EPI_GELU if gelu_out else ops.EPI_NONE, cx=cx)
+    torch.cuda.synchronize()
+    d = (y3 - y32).abs().max().item()
+    print(f"   vs three launches: {d:.2e}")
+    assert d < 4e-3 * scale, (shape, P, pm, d)             # (values on an fp16 rounding boundary may round the other way, twice)
+
+
+def test_sk_tail_is_deterministic(dev):
+    """Twenty launches beside a competing stream: bit-identical (the ring's slots are refilled right behind a barrier)."""
+    from streamflow_amd import ops
+    from streamflow_amd.ops import Planes
+    C, H, M2, P, n = 256, 384, 192, 7040, 6
+    Ap, A0, A2, tail, bias, g = _block(C, H, M2, 5, dev, 2)
+    cx = ops.Ctx(precision=ops.PRECISION_F16X2)
+    X = _rows16(torch.randn(n, C, P, generator=g), dev)
+    first = None
+    side = torch.cuda.Stream(device=dev)
+    junk = torch.empty(64 << 20, device=dev)
+    for _ in range(20):
+        with torch.cuda.stream(side):
+            junk.normal_()
+        y = torch.full((n, M2, P), float("nan"), device=dev)
+        ops.sk_tail(tail, X, Planes.of(y), cx=cx)
+        torch.cuda.synchronize()
+        first = y if first is None else first
+        assert torch.equal(y, first)
+
+
+@pytest.mark.parametrize("preset", ["config2_mixed", "config2_fp16"])
+def test_engine_with_and_without_the_fused_tail_vs_oracle(dev, preset):
+    """The same clip through the engine with EngineOptions.sk_tail on and off (15 iterations), each against the CPU oracle: the fused
+    back half must stay within the class bound and within 1.5x of the unfused arm (+ a floor for the noise between two equivalent
+    fp16 launch sequences), eager and graph replay agreeing bit for bit."""
+    from oracle import streamflow_oracle as orc
+    from streamflow_amd import presets, synthetic as syn
+    from streamflow_amd.engine import EngineOptions, HotPathEngine
+    T, B, h, w, iters = 4, 2, 24, 32, 15
+    params = syn.make_params(9, T)
+    fmaps, cnets = syn.make_features(79, B, T, h, w)
+    ups_o, _ = orc.hotpath_forward(fmaps, cnets, params, iters)
+    kw = presets.engine_kwargs(preset)
+    epe, launches = {}, {}
+    for on in (True, False):
+        eng = HotPathEngine(params, device=dev, T=T, options=EngineOptions(sk_tail=on), **kw)
+        ups, _ = eng.forward(fmaps.to(dev), cnets.to(dev), iters=iters)
+        epe[on] = max(orc.epe(u.cpu(), o) for u, o in zip(ups, ups_o))
+        if on:
+            eager = [u.clone() for u in ups]
+            geng = HotPathEngine(params, device=dev, T=T, use_graph=True, options=EngineOptions(sk_tail=True), **kw)
+            geng.forward(fmaps.to(dev), cnets.to(dev), iters=iters)
+            for a, b in zip(geng.forward(fmaps.to(dev), cnets.to(dev), iters=iters)[0], eager):
+                assert torch.equal(a, b)
+            launches[on] = next(iter(geng._plans.values())).graph_calls
+    print(f"sk_tail fused / unfused [{preset}]: EPE vs oracle {epe[True]:.3e} / {epe[False]:.3e} px; launch calls per forward {launches}")
+    assert epe[True] <= 1e-3 and epe[False] <= 1e-3
+    assert epe[True] <= 1.5 * epe[False] + 5e-5, epe
