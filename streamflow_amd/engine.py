@@ -49,7 +49,8 @@ class EngineOptions:
     ffn_pairs: bool = True           # the SK blocks' ffn1 / ffn2 pairs as one launch each where the shape is built (sf_ffn_pair)
     project_v: bool = True           # fused GMA, fp16 activations: to_v + the v pack as one launch (sf_gma_flash_project_v)
     temporal_block: bool = True      # the temporal transformer block as ONE launch (sf_temporal_block) instead of seven
-    sk_tail: bool = True             # an SK block's back half (pw -> GELU -> ffn2.0 -> GELU -> ffn2.2) as ONE launch where the shape is built (sf_sk_tail)
+    sk_tail: bool = True             # an SK block's back half (pw -> GELU -> ffn2.0 -> GELU -> ffn2.2) as ONE launch where that pays (sf_sk_tail)
+    sk_tail_all: bool = False        # ... wherever the shape is built (the flow head, small launches): tests, A/B
     head_pairs: bool = False         # the flow head's FFN pairs on its grouped view (sf_ffn_pair x_group / R32).  Off: +0.4 % on the step
                                      # (382 vs 380 ff/s) against EPE samples of 3.6 / 1.9 / 2.6e-4 px instead of 2.9 / 1.7 / 2.6e-4
     mask_upsample: bool = True       # mask head's second layer + convex upsampling as ONE launch (sf_mask_upsample): the mask is never written
@@ -181,8 +182,12 @@ def run_skblock(W: SKBlockWeights, X: Planes, Y: Planes, hid: Planes, xa: Planes
         # the bytes, has a residual-free epilogue and may therefore write k-octets
         b16 = _scratch(xb, X.n_img, C, f16=True)
         ops.dwconv_res_gelu(a, W.dwk_w, W.dwk_b, b16, h, w, W.k, single=W.dw_single, cx=cx)   # x3 = gelu(x2 + dwKxK(x2))
-        if ops.sk_tail_ok(W.tail, b16, Y, cx):
-            # the back half as ONE launch: x4 and the 1.5 C hidden never leave the registers (csrc/sk_tail.hip; round 6)
+        # the back half as ONE launch: x4 and the 1.5 C hidden never leave the registers (csrc/sk_tail.hip; round 6).  Measured
+        # (profiles/r06_sk_tail_ab.txt, 24 images): 195 / 178 / 46 us against 218 / 219 / 58 us for the three launches at C = 256 / 256 /
+        # 128 -- used there; the flow head's shape (C = 384: one wave per SIMD for the registers) is 133 against 122 us, and a launch
+        # too small to fill the chip (a single clip) is faster as three launches whose grids split M: both keep the three launches
+        if (ops.sk_tail_ok(W.tail, b16, Y, cx) and W.c_in <= 256 and X.n_img * X.P >= 4 * 7040) or \
+                (cx.sk_tail_all and ops.sk_tail_ok(W.tail, b16, Y, cx)):
             ops.sk_tail(W.tail, b16, Y, gelu_out=final_gelu, cx=cx)
             return
         a4 = _handover(cx, xa, X.n_img, C, X.P, consumer_rows=W.c_mid)
@@ -523,7 +528,7 @@ class HotPathEngine:
                        split_ws=pl.splitws.tensor().view(-1) if self.auto_split_k else None,
                        shadows=o.shadows, shadow_fused=o.shadow_fused, flash_stats=o.flash_stats,
                        hidden_f16=o.hidden_f16, hidden_koct=o.hidden_koct, pw_fold=o.pw_fold, x2_f16=o.x2_f16,
-                       ffn_pairs=o.ffn_pairs, head_pairs=o.head_pairs, sk_tail=o.sk_tail)
+                       ffn_pairs=o.ffn_pairs, head_pairs=o.head_pairs, sk_tail=o.sk_tail, sk_tail_all=o.sk_tail_all)
 
     def _attention_rows(self, cx: ops.Ctx, pl: _Plan, i0: int, rows: int) -> None:
         """attn[:, :rows, :] = softmax(scale * q[:, i0:i0+rows]^T k)   (gma.py:53-65) for every image."""

@@ -68,6 +68,7 @@ class Ctx:
     ffn_pairs: bool = True      # an SK block's ffn1 / ffn2 as ONE launch where sf_ffn_pair has the shape (csrc/ffn_pair.hip)
     head_pairs: bool = False    # ... also the flow head's (grouped view, fp32 residual)
     sk_tail: bool = True        # an SK block's pw -> ffn2.0 -> ffn2.2 as ONE launch where sf_sk_tail has the shape (csrc/sk_tail.hip)
+    sk_tail_all: bool = False   # ... also where it does not pay (the flow head's shape, small launches)
 
     def no_split(self) -> "Ctx":
         """The same context without the split-K scratch (ONE buffer: only one stream may use it at a time)."""

@@ -149,12 +149,12 @@ def test_engine_with_and_without_the_fused_tail_vs_oracle(dev, preset):
     kw = presets.engine_kwargs(preset)
     epe, launches = {}, {}
     for on in (True, False):
-        eng = HotPathEngine(params, device=dev, T=T, options=EngineOptions(sk_tail=on), **kw)
+        eng = HotPathEngine(params, device=dev, T=T, options=EngineOptions(sk_tail=on, sk_tail_all=on), **kw)
         ups, _ = eng.forward(fmaps.to(dev), cnets.to(dev), iters=iters)
         epe[on] = max(orc.epe(u.cpu(), o) for u, o in zip(ups, ups_o))
         if on:
             eager = [u.clone() for u in ups]
-            geng = HotPathEngine(params, device=dev, T=T, use_graph=True, options=EngineOptions(sk_tail=True), **kw)
+            geng = HotPathEngine(params, device=dev, T=T, use_graph=True, options=EngineOptions(sk_tail=True, sk_tail_all=True), **kw)
             geng.forward(fmaps.to(dev), cnets.to(dev), iters=iters)
             for a, b in zip(geng.forward(fmaps.to(dev), cnets.to(dev), iters=iters)[0], eager):
                 assert torch.equal(a, b)
