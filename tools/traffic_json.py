@@ -8,7 +8,7 @@ attaches these bytes to a run of the same configuration."""
 import collections, csv, json, re, sys
 
 FAMILY = [(r"corr_build|split_pack|pack_f16", "corr_build"), (r"corr_lookup", "corr_lookup"),
-          (r"flash_project_v", "gma_project_v"), (r"ffn_pair_kernel", "ffn_pair"), (r"temporal_block_kernel", "temporal_block"), (r"mask_upsample_kernel", "mask_upsample"),
+          (r"flash_project_v", "gma_project_v"), (r"ffn_pair_kernel", "ffn_pair"), (r"sk_tail_kernel", "sk_tail"), (r"gma_pv_kernel", "gma_stored"), (r"temporal_block_kernel", "temporal_block"), (r"mask_upsample_kernel", "mask_upsample"),
           (r"gma_flash|flash_pack_v", "gma_flash"), (r"flash_pack_qk", "flash_pack_qk"),
           (r"gemm_f16x3_mfma<[^>]*, 1, [13], (true|false)>", "gemm_attn"), (r"gemm_f|gemm_bdirect|gemm_bstat", "gemm"),
           (r"splitk_epilogue", "gemm"), (r"splitk_combine", "splitk_combine"), (r"dwconv_mfma_kernel<7", "dwconv7"), (r"dwconv_mfma", "dwconv15"),
