@@ -430,7 +430,7 @@ def main():
     ap.add_argument("--precision", default=None, choices=["f16x3", "fp32", "f16x2", "f16"],
                     help="f16x3: split-fp16 MFMA with fp32 accumulation (fp32-class accuracy); fp32: exact fp32 MFMA; "
                          "f16x2: weights split, activations rounded once to fp16")
-    ap.add_argument("--gma", default=None, choices=["auto", "matrix", "flash", "stored"], help="GMA aggregation path (engine gma_mode)")
+    ap.add_argument("--gma", default=None, choices=["auto", "matrix", "flash", "stored", "hybrid"], help="GMA aggregation path (engine gma_mode)")
     ap.add_argument("--flash-qkp", type=int, default=None, choices=[1, 2, 3], help="MFMA products per logit of the fused GMA kernel")
     ap.add_argument("--corr-dtype", default=None, choices=["f16", "f32"],
                     help="storage of the correlation pyramids: f16 = fp16 cells built with single f16 MFMA products "

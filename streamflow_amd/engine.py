@@ -57,6 +57,10 @@ class EngineOptions:
     clock_probe_us: int = 0          # measurement aid: > 0 forks sf_clock_probe for that long beside every forward (results in
                                      # engine.clock_counts: shader cycles, 100 MHz ticks); a graph branch like any other
     setup_overlap: bool = True       # the context chain of the setup (split, to_qk, GMA pack / statistics) beside the volume build
+    gma_per_chain: bool = True       # the fused GMA kernel as one launch per half-batch chain, each chain going straight on into its GRU
+                                     # (the partial last round of one chain's GMA grid is filled by the other chain's kernels: 1320
+                                     # workgroups on 768 slots = 1.72 rounds; 62.0 -> 61.6 ms per step, bit-identical)
+    hybrid_store_pct: int = 50       # gma_mode 'hybrid': share of the images whose softmax weights are stored (the rest is recomputed beside them)
     stored_p_max_gb: int = 64        # gma_mode 'stored': largest weight buffer (n_img * Ppad^2 * 2 bytes) kept; beyond it the fused recompute runs
     max_plans: int = 4               # buffer sets (and graphs) kept, least recently used evicted
 
@@ -284,7 +288,8 @@ class _Plan:
 
     def __init__(self, W: HotPathWeights, Bc: int, h: int, w: int, D: int, device, attn_chunk_rows: int = 0,
                  attn_f16: bool = False, corr_f16: bool = False, flash: Optional[bool] = None, shadows: bool = False,
-                 corr_blocked: bool = False, koct_io: bool = False, stored_p: bool = False, stored_p_max_bytes: int = 0):
+                 corr_blocked: bool = False, koct_io: bool = False, stored_p: bool = False, stored_p_max_bytes: int = 0,
+                 stored_frac: float = 1.0):
         Pn = W.pairs
         n, P = Bc * Pn, h * w
         self.Bc, self.Pn, self.h, self.w, self.n, self.P, self.D = Bc, Pn, h, w, n, P, D
@@ -327,12 +332,20 @@ class _Plan:
         self.flash = bool(flash) if flash is not None else (attn_f16 and self.attn_rows < P and attn_chunk_rows <= 0)
         self.flash_ws = None
         self.pbuf = None
+        self.n_store = 0
         if self.flash:
             self.flash_ws = torch.empty(ops.gma_flash_ws_bytes(n, P), dtype=torch.uint8, device=device)
             self.attn_rows = 1                     # no attention matrix at all: placeholders only
             # 'stored': the softmax weights kept for the loop in the fragment order of the second contraction (sf_gma_flash_store_p)
-            if stored_p and ops.gma_stored_p_bytes(n, P) <= stored_p_max_bytes:
-                self.pbuf = torch.empty(ops.gma_stored_p_bytes(n, P), dtype=torch.uint8, device=device)
+            # ('hybrid': for the first n_store images only -- the stream of stored weights is HBM-bound, the recompute kernel is
+            # bound by the chip's power budget: run side by side on disjoint images they use different resources, section 12)
+            self.n_store = n if stored_frac >= 1.0 else max(0, min(n, int(round(n * stored_frac))))
+            if self.n_store < n and not (self.n_store > 0 and ops.gma_no_key_split(self.n_store, P) and ops.gma_no_key_split(n - self.n_store, P)):
+                self.n_store = 0                   # (a launch small enough for the key-split form keeps the recompute kernel alone)
+            if stored_p and self.n_store > 0 and ops.gma_stored_p_bytes(self.n_store, P) <= stored_p_max_bytes:
+                self.pbuf = torch.empty(ops.gma_stored_p_bytes(self.n_store, P), dtype=torch.uint8, device=device)
+            else:
+                self.n_store = 0
         self.attn = torch.empty(n, self.attn_rows, P, dtype=torch.float32, device=device)
         # split-precision modes keep the materialised matrix in fp16 (half the bytes of the HBM-bound attn @ v that
         # every iteration repeats; measured effect on the final flow: 4e-6 px mean EPE); self.attn is then only the
@@ -448,8 +461,8 @@ class HotPathEngine:
         # kept; 'flash' = fused recompute kernel every iteration (demo.py:235-258); 'auto' = flash exactly when the
         # matrix would have to be chunked (high resolution)
         self.gma_mode = gma_mode or "auto"
-        if self.gma_mode not in ("auto", "matrix", "flash", "stored"):
-            raise RuntimeError(f"gma_mode must be auto, matrix, flash or stored, got {self.gma_mode!r}")
+        if self.gma_mode not in ("auto", "matrix", "flash", "stored", "hybrid"):
+            raise RuntimeError(f"gma_mode must be auto, matrix, flash, stored or hybrid, got {self.gma_mode!r}")
         # MFMA products per logit of the fused kernel: 3 = split precision (fp32-class), 2 / 1 = k / q and k in fp16
         self.flash_qk_products = (int(flash_qk_products or 0)
                                   or {ops.PRECISION_F16X2: 2, ops.PRECISION_F16: 1}.get(self.precision, 3))
@@ -505,17 +518,18 @@ class HotPathEngine:
             while len(self._plans) >= max(1, self.max_plans):
                 self._plans.pop(next(iter(self._plans)))            # dicts keep insertion order: first = oldest
             split = self.precision != ops.PRECISION_FP32
-            if self.gma_mode in ("flash", "stored") and not split:
+            if self.gma_mode in ("flash", "stored", "hybrid") and not split:
                 raise RuntimeError(f"gma_mode={self.gma_mode!r} needs a split precision (f16x3 / f16x2); the exact fp32 mode keeps "
                                    "the materialised / chunked attention path")
-            flash = {"auto": None, "matrix": False, "flash": True, "stored": True}[self.gma_mode]
+            flash = {"auto": None, "matrix": False, "flash": True, "stored": True, "hybrid": True}[self.gma_mode]
             pl = _Plan(self.W, Bc, h, w, D, self.device, self.attn_chunk_rows, attn_f16=split, corr_f16=self.corr_f16,
                        flash=flash, shadows=(self.options.shadows and (h * w) % 4 == 0 and
                                              self.precision in (ops.PRECISION_F16X2, ops.PRECISION_F16) and
                                              self.options.hidden_f16),
                        corr_blocked=self.corr_blocked,
                        koct_io=self.options.koct_io and self.options.hidden_koct,   # (k-octet-only blocks need k-octet producers)
-                       stored_p=(self.gma_mode == "stored" and self.options.flash_stats),
+                       stored_p=(self.gma_mode in ("stored", "hybrid") and self.options.flash_stats),
+                       stored_frac=(1.0 if self.gma_mode == "stored" else float(self.options.hybrid_store_pct) / 100.0),
                        stored_p_max_bytes=int(self.options.stored_p_max_gb) << 30)
         self._plans[key] = pl                                        # (re)insert as most recent
         return pl
@@ -529,6 +543,15 @@ class HotPathEngine:
                        shadows=o.shadows, shadow_fused=o.shadow_fused, flash_stats=o.flash_stats,
                        hidden_f16=o.hidden_f16, hidden_koct=o.hidden_koct, pw_fold=o.pw_fold, x2_f16=o.x2_f16,
                        ffn_pairs=o.ffn_pairs, head_pairs=o.head_pairs, sk_tail=o.sk_tail, sk_tail_all=o.sk_tail_all)
+
+    @staticmethod
+    def _flash_ws_sub(pl: _Plan, i0: int, cnt: int) -> torch.Tensor:
+        """The section of the fused GMA workspace that belongs to images i0 .. i0 + cnt - 1 (launched as a workspace of its own: legal
+        when that launch has no key split, ops.gma_no_key_split)."""
+        if i0 == 0 and cnt == pl.n:
+            return pl.flash_ws                     # (the whole batch: with the key-split partial buffers of a small launch)
+        ib = ops.gma_flash_img_bytes(pl.P)
+        return pl.flash_ws[i0 * ib:(i0 + cnt) * ib]
 
     def _attention_rows(self, cx: ops.Ctx, pl: _Plan, i0: int, rows: int) -> None:
         """attn[:, :rows, :] = softmax(scale * q[:, i0:i0+rows]^T k)   (gma.py:53-65) for every image."""
@@ -567,7 +590,7 @@ class HotPathEngine:
                 # q, k are constant over the loop: packed once, and the softmax statistics of every query with them
                 ops.gma_flash_pack_qk(pl.qk, pl.flash_ws, float(HDIM) ** -0.5, stats_qk_products=self.flash_qk_products, cx=cs)
                 if pl.pbuf is not None:             # ... and the softmax weights themselves (gma.py:53-65: `attn`), kept for the loop
-                    ops.gma_flash_store_p(pl.flash_ws, pl.pbuf, n, P, self.flash_qk_products, cx=cs)
+                    ops.gma_flash_store_p(self._flash_ws_sub(pl, 0, pl.n_store), pl.pbuf, pl.n_store, P, self.flash_qk_products, cx=cs)
             elif pl.attn_rows == P:
                 self._attention_rows(cs, pl, 0, P)
         # a1+a2: all pairs, one launch.  pair t = (frame t, frame t+1)
@@ -682,6 +705,9 @@ class HotPathEngine:
         v128 = _scratch(pl.v128, pl.n, HDIM, f16=True) if (pl.flash and hidden_f16_ok(cx, P) and cx.x2_f16) else pl.v128
         # fused recompute path with fp16 activations: to_v and the v pack are ONE launch from mf's k-octet copy (options.project_v)
         project = pl.flash and self.options.project_v and ops.gma_flash_project_ok(W.to_v, pl.mf, cx)
+        # options.gma_per_chain: one fused launch per half-batch chain (each a workspace sub-range without the key-split form)
+        gma_in_chains = bool(self.options.gma_per_chain and pl.flash and pl.pbuf is None and project and split and
+                             all(ops.gma_no_key_split(cnt, P) for _, cnt in parts))
         if project:
             ops.gma_flash_project_v(pl.flash_ws, W.to_v, pl.mf, cx=cx)
             v128 = None
@@ -690,9 +716,25 @@ class HotPathEngine:
         ks = self.attn_k_splits if self.precision != ops.PRECISION_FP32 else 1
         attn_ptr, attn_lay = ((pl.attn16.data_ptr(), LAYOUT_F16_K_MINOR) if pl.attn16 is not None
                               else (pl.attn.data_ptr(), LAYOUT_K_MINOR))
-        if pl.flash and pl.pbuf is not None:
+        if pl.flash and pl.pbuf is not None and pl.n_store == n:
             # the stored weights streamed past v (gma.py:99-102): half the matrix-core work of the recompute, HBM-bound
             ops.gma_stored_aggregate(pl.flash_ws, pl.pbuf, v128, pl.mf, W.gamma, pl.mfg, cx=cx)
+        elif pl.flash and pl.pbuf is not None:
+            # hybrid: images [0, n_store) through the stored weights on a chain stream (HBM-bound), the rest through the recompute
+            # kernel on the main stream (power-bound): two launches that want different resources, side by side
+            ns = pl.n_store
+            assert project and v128 is None, "hybrid GMA needs the fused v projection (fp16-activation presets)"
+            sc = self._chain_streams[0] if side is not main else main
+            if sc is not main:
+                sc.wait_stream(main)
+            with torch.cuda.stream(sc):
+                ops.gma_stored_aggregate(self._flash_ws_sub(pl, 0, ns), pl.pbuf, None, _sub(pl.mf, 0, ns), W.gamma, _sub(pl.mfg, 0, ns), cx=cs)
+            ops.gma_flash_aggregate(self._flash_ws_sub(pl, ns, n - ns), None, _sub(pl.mf, ns, n - ns), W.gamma, _sub(pl.mfg, ns, n - ns),
+                                    self.flash_qk_products, use_stats=True, cx=cx)
+            if sc is not main:
+                main.wait_stream(sc)
+        elif pl.flash and gma_in_chains:
+            pass                                                    # launched per chain below, in front of each chain's GRU
         elif pl.flash:
             # fused recompute (K6' of SURVEY.md): one kernel, online softmax, logits never written
             ops.gma_flash_aggregate(pl.flash_ws, v128, pl.mf, W.gamma, pl.mfg, self.flash_qk_products, use_stats=True, cx=cx)
@@ -721,11 +763,17 @@ class HotPathEngine:
                          a_layout=LAYOUT_K_MINOR, b_layout=attn_lay, alpha=1.0, epilogue=EPI_AXPY)
         if not pl.flash:
             ops.refresh_shadow(pl.mfg, cx)                          # (the flash kernel writes the k-octet copy itself)
-        join()
+        if not gma_in_chains:
+            join()
         # "gru": SKBlock(640 -> 128) over cat[nets, inps, mf, mfg, mft]; new nets overwrite the nets slice
         if split:
             def gru_chain(i0, cnt):
                 hid, xa, xb = _part(pl.hid, i0, cnt), _part(pl.xa, i0, cnt), _part(pl.xb, i0, cnt)
+                if gma_in_chains:
+                    ops.gma_flash_aggregate(self._flash_ws_sub(pl, i0, cnt), None, _sub(pl.mf, i0, cnt), W.gamma, _sub(pl.mfg, i0, cnt),
+                                            self.flash_qk_products, use_stats=True, cx=cc)
+                    if side is not main:                            # the temporal block's output (side stream) is a GRU input
+                        torch.cuda.current_stream().wait_stream(side)
                 run_skblock(W.gru, _sub(pl.concat, i0, cnt), _sub(pl.nets, i0, cnt), hid, xa, xb, h, w, cx=cc)
                 if by_clip:     # flow head sees all T-1 hidden states of a clip jointly (update.py:774): clips i0 / Pn ..
                     run_skblock(W.flow_head, _sub(pl.nets_grouped, i0 // Pn, cnt // Pn),

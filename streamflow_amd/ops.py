@@ -988,6 +988,19 @@ def gma_flash_ws_bytes(n_img: int, P: int) -> int:
     return int(_lib.load().sf_gma_flash_ws_bytes(n_img, P))
 
 
+def gma_flash_img_bytes(P: int) -> int:
+    """Bytes of ONE image's section of the fused GMA workspace (the images lie back to back; the key-split partial buffers of a
+    small launch follow the last image and are not part of it)."""
+    big = 4096                                                        # (enough query tiles that no key split is planned)
+    return (gma_flash_ws_bytes(big, P) - gma_flash_ws_bytes(big - 1, P))
+
+
+def gma_no_key_split(n_img: int, P: int) -> bool:
+    """The fused / stored GMA launch over n_img images runs WITHOUT its key-split form (whose partial buffers live behind the last
+    image of the workspace): the condition for launching a sub-range of images out of a larger workspace."""
+    return gma_flash_ws_bytes(n_img, P) == n_img * gma_flash_img_bytes(P)
+
+
 @on_tensor_device
 def gma_flash_pack_qk(QK: Planes, ws: torch.Tensor, scale: float, stats_qk_products: int = 0, cx: Optional[Ctx] = None) -> None:
     """QK [n_img][256][P] (to_qk output) -> packed fp16 operand images in ws (once per clip); stats_qk_products = 1 / 2 / 3

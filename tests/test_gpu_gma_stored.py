@@ -149,3 +149,30 @@ def test_pipelined_recompute_kernel_equals_the_round5_kernel(dev, P, qkp, monkey
                 ops.gma_flash_aggregate(ws, V, MF, gamma, Planes.of(o2), qkp, use_stats=True)
                 torch.cuda.synchronize()
                 assert torch.equal(o2, outs["2"])
+
+
+def test_engine_hybrid_mode_equals_flash_mode_at_the_headline_grid(dev):
+    """gma_mode='hybrid' (round 6): the first half of the images through the stored weights on a chain stream, the second half through the
+    recompute kernel beside it -- same results as 'flash', bit for bit (6 clips at the 55 x 128 grid: both halves are large enough to run
+    without the key-split form, the condition of the hybrid schedule), eager and graph replay."""
+    from streamflow_amd import presets, synthetic as syn
+    from streamflow_amd.engine import HotPathEngine
+    T, B, h, w = 4, 6, 55, 128
+    params = syn.make_params(5, T)
+    fm, cn = (t.to(dev) for t in syn.make_features(83, B, T, h, w))
+    outs = {}
+    from streamflow_amd.engine import EngineOptions
+    for mode in ("flash", "flash_one_launch", "hybrid"):
+        # 'flash': one fused launch per half-batch chain (EngineOptions.gma_per_chain, the default); 'flash_one_launch': round 5's form
+        kw = dict(presets.engine_kwargs("config2_mixed"), gma_mode=mode.split("_")[0],
+                  options=EngineOptions(gma_per_chain=(mode != "flash_one_launch")))
+        for graph in (False, True):
+            eng = HotPathEngine(params, device=dev, T=T, use_graph=graph, **kw)
+            eng.forward(fm, cn, iters=2)
+            outs[(mode, graph)] = [f.clone() for f in eng.forward(fm, cn, iters=2)[0]]
+            pl = next(iter(eng._plans.values()))
+            assert pl.n_store == (9 if mode == "hybrid" else 0) and (pl.pbuf is not None) == (mode == "hybrid")
+            del eng
+    for key, val in outs.items():
+        for a, b in zip(val, outs[("flash", False)]):
+            assert torch.equal(a, b), key
