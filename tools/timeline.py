@@ -55,6 +55,25 @@ tot_gap = sum(g[0] for g in gaps.values())
 print(f"idle gaps: {tot_gap / 1e6:.3f} ms in {sum(g[1] for g in gaps.values())} gaps; by following kernel:")
 for n, g in sorted(gaps.items(), key=lambda kv: -kv[1][0])[:14]:
     print(f"   {g[0] / 1e3:9.1f} us in {g[1]:4d} gaps (avg {g[0] / g[1] / 1e3:5.2f} us)  before {n}")
+# which kernels run ALONE (k = 1), by name
+alone_t = defaultdict(int)
+ev2 = sorted([(s_, 1, n) for s_, e_, n in step] + [(e_, -1, n) for s_, e_, n in step])
+active = {}
+last = t0
+for t, d_, n in ev2:
+    if len(active) == 1:
+        alone_t[short(next(iter(active)))] += t - last
+    last = t
+    if d_ == 1:
+        active[n + str(t)] = 1
+    else:
+        for k in list(active):
+            if k.startswith(n):
+                del active[k]
+                break
+print("time alone on the GPU (k = 1) by kernel:")
+for n, d_ in sorted(alone_t.items(), key=lambda kv: -kv[1])[:12]:
+    print(f"   {d_ / 1e6:8.3f} ms  {n}")
 # time by kernel: exclusive (alone) vs overlapped
 alone = defaultdict(int); dur = defaultdict(int); cnt = defaultdict(int)
 for s, e, n in step:
