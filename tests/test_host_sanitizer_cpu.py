@@ -14,9 +14,13 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_host_side_under_asan_ubsan():
     from streamflow_amd import build
-    if not os.path.exists(build.ASAN_LIB):
+    srcs = [os.path.join(build.CSRC, f) for f in build.SOURCES] + list(build.HEADERS)
+    stale = os.path.exists(build.ASAN_LIB) and any(os.path.getmtime(f) > os.path.getmtime(build.ASAN_LIB) for f in srcs)
+    if not os.path.exists(build.ASAN_LIB) or stale:
+        # an instrumented library OLDER than the sources does not export what the header declares now: never run against it
         if os.environ.get("SF_BUILD_ASAN", "0") != "1":
-            pytest.skip("libstreamflow_hip_asan.so not built (python -m streamflow_amd.build --asan, ~10 min; or SF_BUILD_ASAN=1)")
+            pytest.skip("libstreamflow_hip_asan.so " + ("is older than the sources" if stale else "not built") +
+                        " (python -m streamflow_amd.build --asan, ~10 min; or SF_BUILD_ASAN=1)")
         build.build_asan(verbose=False)
     rt = build.asan_runtime()
     assert os.path.exists(rt), rt
