@@ -515,8 +515,11 @@ __global__ __launch_bounds__(256) void split_pack_kernel(const float* f1, const 
 
 typedef __attribute__((address_space(3))) void* lds_ptr;
 
+#ifndef SF_CORR_VEC_WAVES
+#define SF_CORR_VEC_WAVES 3      // waves per SIMD the kVec = true forms are compiled for (3: 168 registers, 6-7 of them spilled; 2: none)
+#endif
 template <bool kVec>
-__global__ __launch_bounds__(kThreads, NSTAGE == 2 ? 3 : 2) void corr_build_dma_kernel(const BuildArgs g, const char* ws, int Dp) {
+__global__ __launch_bounds__(kThreads, NSTAGE == 2 ? (kVec ? SF_CORR_VEC_WAVES : 3) : 2) void corr_build_dma_kernel(const BuildArgs g, const char* ws, int Dp) {
     using namespace sf_split;
     __shared__ __attribute__((aligned(1024))) char smem[NSTAGE * STAGE];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -610,7 +613,7 @@ __global__ __launch_bounds__(256) void pack_f16_kernel(const float* f1, const fl
 }
 
 template <bool kVec>
-__global__ __launch_bounds__(kThreads, 3) void corr_build_f16_kernel(const BuildArgs g, const char* ws, int Dp) {
+__global__ __launch_bounds__(kThreads, kVec ? SF_CORR_VEC_WAVES : 3) void corr_build_f16_kernel(const BuildArgs g, const char* ws, int Dp) {
     using namespace sf_split;
     __shared__ __attribute__((aligned(1024))) char smem[2 * FSTAGE];
 #ifdef SF_CORR_TIMERS
