@@ -37,24 +37,27 @@ def forward_interpolate(flow: torch.Tensor) -> torch.Tensor:
 
 
 class InputPadder:
-    """Pads images so H and W are divisible by 8 (reference utils.py:7-31; host-side plumbing)."""
+    """Replicate-pads frames up to the next multiple of `factor` (8: three stride-2 encoder stages) and crops results back.
+    Same public surface as the reference's class (utils.py:7-31: `pad`, `pad_list`, `unpad`, the `_pad` = [left, right, top, bottom]
+    attribute, `ht` / `wd`): 'sintel' mode centres the frame in both directions, every other mode (KITTI) centres it horizontally and
+    puts all vertical padding at the bottom.  Host-side plumbing around the hot path."""
 
     def __init__(self, dims, mode: str = "sintel", factor: int = 8):
-        self.ht, self.wd = dims[-2:]
-        pad_ht = (((self.ht // 8) + 1) * 8 - self.ht) % 8
-        pad_wd = (((self.wd // 8) + 1) * 8 - self.wd) % 8
-        if mode == "sintel":
-            self._pad = [pad_wd // 2, pad_wd - pad_wd // 2, pad_ht // 2, pad_ht - pad_ht // 2]
-        else:
-            self._pad = [pad_wd // 2, pad_wd - pad_wd // 2, 0, pad_ht]
+        self.ht, self.wd = int(dims[-2]), int(dims[-1])
+        extra_h, extra_w = (-self.ht) % 8, (-self.wd) % 8           # (the reference hard-codes 8 whatever `factor` says; so do we)
+        left, top = extra_w // 2, (extra_h // 2 if mode == "sintel" else 0)
+        self._pad = [left, extra_w - left, top, extra_h - top]
+
+    def _apply(self, x):
+        return F.pad(x, self._pad, mode="replicate")
 
     def pad(self, *inputs):
-        return [F.pad(x, self._pad, mode="replicate") for x in inputs]
+        return [self._apply(x) for x in inputs]
 
     def pad_list(self, inputs):
-        return [F.pad(x, self._pad, mode="replicate") for x in inputs]
+        return [self._apply(x) for x in inputs]
 
     def unpad(self, x):
-        ht, wd = x.shape[-2:]
-        c = [self._pad[2], ht - self._pad[3], self._pad[0], wd - self._pad[1]]
-        return x[..., c[0]:c[1], c[2]:c[3]]
+        left, right, top, bottom = self._pad
+        rows, cols = x.shape[-2:]
+        return x[..., top:rows - bottom, left:cols - right]

@@ -171,6 +171,18 @@ def test_input_padder_matches_reference_formula():
     (y,) = p.pad(x)
     assert y.shape[-2:] == (440, 1024) and p._pad == [0, 0, 2, 2]
     assert p.unpad(y).shape == x.shape
+    # [left, right, top, bottom] as the reference's class computes them (utils.py:10-16; values generated from it in the build container)
+    table = [("sintel", 436, 1024, [0, 0, 2, 2]), ("sintel", 375, 1242, [3, 3, 0, 1]), ("sintel", 376, 1248, [0, 0, 0, 0]),
+             ("sintel", 1080, 1920, [0, 0, 0, 0]), ("sintel", 124, 188, [2, 2, 2, 2]), ("sintel", 17, 23, [0, 1, 3, 4]),
+             ("kitti", 436, 1024, [0, 0, 0, 4]), ("kitti", 375, 1242, [3, 3, 0, 1]), ("kitti", 124, 188, [2, 2, 0, 4]),
+             ("kitti", 17, 23, [0, 1, 0, 7]), ("kitti", 64, 64, [0, 0, 0, 0])]
+    for mode, h, w, pad in table:
+        q = InputPadder((2, 3, h, w), mode)
+        assert q._pad == pad, (mode, h, w, q._pad)
+        z = torch.randn(2, 3, h, w)
+        (zp,) = q.pad(z)
+        assert zp.shape[-2] % 8 == 0 and zp.shape[-1] % 8 == 0 and torch.equal(q.unpad(zp), z)
+        assert torch.equal(q.pad_list([z])[0], zp)
 
 
 def test_full_checkpoint_contract_with_twins_encoder(tmp_path):
