@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SF_VERSION 118
+#define SF_VERSION 119
 
 enum {
     SF_OK = 0,
@@ -363,6 +363,10 @@ typedef struct SfSkTail {
 } SfSkTail;
 int sf_sk_tail(const SfSkTail* p, void* stream);
 int sf_sk_tail_frags(int C, int H, int M2, int pm);
+/* The stream's unit structure (what the host packer needs besides the order above): returns sf_sk_tail_frags(); *stage = fragments per
+ * stage (every unit is zero-padded to a multiple of it), *group = hidden tiles th per phase-2 unit, *pw_one_unit = 1 when the C/32 pw row
+ * tiles form ONE unit instead of a unit each.  Any pointer may be NULL. */
+int sf_sk_tail_layout(int C, int H, int M2, int pm, int* stage, int* group, int* pw_one_unit);
 
 /* ---- a10: the temporal transformer block in ONE launch (core/update.py:459-484,502-513 -> timm Block; called at update.py:770;
  * csrc/temporal.hip) ---------------------------------------------------------------------------------------------------------

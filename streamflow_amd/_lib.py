@@ -130,6 +130,7 @@ SIGNATURES = {
     "sf_ffn_pair_frags": (_i, [_i, _i, _i, _i]),
     "sf_sk_tail": (_i, [C.POINTER(SfSkTail), _vp]),
     "sf_sk_tail_frags": (_i, [_i, _i, _i, _i]),
+    "sf_sk_tail_layout": (_i, [_i, _i, _i, _i, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "sf_temporal_block": (_i, [C.POINTER(SfTemporalBlock), _vp]),
     "sf_temporal_block_frags": (_i, [_i]),
     "sf_mask_upsample": (_i, [C.POINTER(SfMaskUpsample), _vp]),

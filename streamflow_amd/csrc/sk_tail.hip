@@ -31,9 +31,12 @@ using sf::f32x2;
 
 constexpr int kThreads = 256, kWaves = 4;
 constexpr int BN = 128;                      // pixels per workgroup (4 waves x 32)
-constexpr int S = 16;                        // fragments per stage
+#ifndef SF_TAIL_V2
+#define SF_TAIL_V2 0      // 1: 32-fragment stages in a ring of TWO (half the barriers), pw as one unit, G hidden tiles per unit (A/B)
+#endif
+constexpr int S = SF_TAIL_V2 ? 32 : 16;      // fragments per stage
 constexpr int kStage = S * 1024;
-constexpr int RING = 3;
+constexpr int RING = SF_TAIL_V2 ? 2 : 3;
 constexpr int PCS = S / kWaves;              // DMA pieces per wave and stage
 constexpr int kOob = 1 << 30;
 constexpr int kMaxC = 384, kMaxH = 576, kMaxM = 192;
@@ -107,6 +110,15 @@ __device__ __forceinline__ void tile_to_frags(const f32x16& acc, float alpha, f1
     }
 }
 
+// hidden tiles per phase-2 unit (v2; 1 in v1): G * (2 NC + 2 NM) PM fragments should fill whole 32-fragment stages, G must divide NH
+// (12 at H = 384, 18 at 576, 6 at 192: host-checked)
+constexpr int tail_group(int NC, int NM, int PM) {
+    if (!SF_TAIL_V2) return 1;
+    if (NC == 8 && NM == 6) return PM == 2 ? 4 : 4;             // TF = 56 / 28: 224 / 112 -> 7 / 3.5 stages
+    if (NC == 8 && NM == 4) return PM == 2 ? 2 : 4;             // TF = 48 / 24: 96 / 96
+    return 2;                                                   // (12, 1): 104 / 52; (4, 2): 48 / 24
+}
+
 // NC = C / 32 (tiles of x4 = k-step pairs of pw and ffn2.0), NM = ceil(M2 / 32), PM = MFMA products per weight (2: lo + hi, 1: hi)
 template <int NC, int NM, int PM>
 __global__ __launch_bounds__(kThreads, NC >= 12 ? 1 : 2) void sk_tail_kernel(const TailArgs a) {
@@ -114,9 +126,13 @@ __global__ __launch_bounds__(kThreads, NC >= 12 ? 1 : 2) void sk_tail_kernel(con
     const SfSkTail& g = a.g;
     constexpr int KS = 2 * NC;                                   // k-steps of 16 over the C channels
     constexpr int NA1 = KS * PM;                                 // fragments of one pw tile
-    constexpr int U1 = (NA1 + S - 1) / S;                        // ... padded to whole stages
     constexpr int NA2 = KS * PM, NB2 = 2 * NM * PM;              // one hidden tile: ffn2.0's fragments, then ffn2.2's two k-steps
-    constexpr int U2 = (NA2 + NB2 + S - 1) / S;
+    constexpr int TF = NA2 + NB2;
+    // v1: every pw tile and every hidden tile is a unit of its own, padded to whole stages.  v2: pw is ONE unit (NC tiles), the hidden
+    // tiles come G to a unit (tail_group(): chosen so that G * TF fills whole 32-fragment stages where NH allows)
+    constexpr int G = tail_group(NC, NM, PM);
+    constexpr int U1 = SF_TAIL_V2 ? (NC * NA1 + S - 1) / S : (NA1 + S - 1) / S;
+    constexpr int U2 = (G * TF + S - 1) / S;
     __shared__ __attribute__((aligned(1024))) char smem[RING * kStage + (kMaxC + kMaxH + kMaxM) * 4];
     float* sb1 = reinterpret_cast<float*>(smem + RING * kStage);
     float* sb2 = sb1 + kMaxC;
@@ -170,12 +186,14 @@ __global__ __launch_bounds__(kThreads, NC >= 12 ? 1 : 2) void sk_tail_kernel(con
 
     int gs = 0, slot = 0;                                         // global stage index, its ring slot
     // U stages of the stream: body(fragment index in the unit, LDS address of this lane's 16 bytes of the fragment).  NF = fragments of
-    // the unit that feed an MFMA (the rest is padding), GP = the fragment in front of which the body runs a GELU block (-1: none)
-    auto run_unit = [&](auto u_tag, auto nf_tag, auto gp_tag, auto&& body) {
-        constexpr int U = decltype(u_tag)::value, NF = decltype(nf_tag)::value, GP = decltype(gp_tag)::value;
+    // the unit that feed an MFMA (the rest is padding); a GELU block runs in front of fragments GP0, GP0 + GPS, ... (GPS = 0: none) and a
+    // tile's accumulator start values (four LDS reads) are fetched in front of fragments TS, 2 TS, ... (TS = 0: none)
+    auto run_unit = [&](auto u_tag, auto nf_tag, auto gp0_tag, auto gps_tag, auto ts_tag, auto&& body) {
+        constexpr int U = decltype(u_tag)::value, NF = decltype(nf_tag)::value, GP0 = decltype(gp0_tag)::value,
+                      GPS = decltype(gps_tag)::value, TS = decltype(ts_tag)::value;
         static_for<0, U>([&](auto st_tag) {
             constexpr int st = decltype(st_tag)::value;
-            issue_stage(gs + RING - 1, slot == 0 ? RING - 1 : slot - 1);
+            issue_stage(gs + RING - 1, (RING == 2) ? (slot ^ 1) : (slot == 0 ? RING - 1 : slot - 1));
             const char* sp = smem + slot * kStage + lane * 16;
             static_for<0, S>([&](auto i_tag) {
                 constexpr int i = decltype(i_tag)::value;
@@ -186,12 +204,13 @@ __global__ __launch_bounds__(kThreads, NC >= 12 ? 1 : 2) void sk_tail_kernel(con
             {
                 constexpr int nm = (NF - st * S) < 0 ? 0 : ((NF - st * S) > S ? S : (NF - st * S));
                 constexpr int kAhead = 3;
-                constexpr int gpos = (GP >= st * S && GP < st * S + S) ? GP - st * S : -1;
                 __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);                     // (the slot's LDS address)
                 __builtin_amdgcn_sched_group_barrier(0x100, nm < kAhead ? nm : kAhead, 0);
 #pragma unroll
                 for (int i = 0; i < nm; ++i) {
-                    if (i == gpos) __builtin_amdgcn_sched_group_barrier(0x002, 200, 0); // the GELU block between the two layers
+                    const int f = st * S + i;
+                    if (GPS > 0 && f >= GP0 && (f - GP0) % GPS == 0) __builtin_amdgcn_sched_group_barrier(0x002, 200, 0);   // a GELU block
+                    if (TS > 0 && f > 0 && f % TS == 0) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);               // the next tile's bias
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                     if (i + kAhead < nm) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 }
@@ -218,33 +237,58 @@ __global__ __launch_bounds__(kThreads, NC >= 12 ? 1 : 2) void sk_tail_kernel(con
     };
 
     // ---- phase 1: x4 = gelu((pw + I) x3), tile by tile, as the B fragments of ffn2.0 ----
+    using std::integral_constant;
     f16x8 x4[KS];
+#if SF_TAIL_V2
+    {
+        f32x16 acc = bias_tile(sb1, 0);
+        run_unit(integral_constant<int, U1>{}, integral_constant<int, NC * NA1>{}, integral_constant<int, NA1>{}, integral_constant<int, NA1>{},
+                 integral_constant<int, NA1>{}, [&](auto f_tag, const char* p) {
+            constexpr int f = decltype(f_tag)::value;
+            if constexpr (f < NC * NA1) {
+                if constexpr (f > 0 && f % NA1 == 0) {              // the previous tile is complete: its fragments, the next tile's start
+                    tile_to_frags<GNP>(acc, g.alpha1, x4[2 * (f / NA1 - 1)], x4[2 * (f / NA1 - 1) + 1]);
+                    acc = bias_tile(sb1, f / NA1);
+                }
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8*>(p), x[(f % NA1) / PM], acc, 0, 0, 0);
+            }
+        });
+        tile_to_frags<GNP>(acc, g.alpha1, x4[2 * (NC - 1)], x4[2 * (NC - 1) + 1]);
+    }
+#else
     static_for<0, NC>([&](auto t_tag) {
         constexpr int t = decltype(t_tag)::value;
         f32x16 acc = bias_tile(sb1, t);
-        run_unit(std::integral_constant<int, U1>{}, std::integral_constant<int, NA1>{}, std::integral_constant<int, -1>{}, [&](auto f_tag, const char* p) {
+        run_unit(integral_constant<int, U1>{}, integral_constant<int, NA1>{}, integral_constant<int, 0>{}, integral_constant<int, 0>{},
+                 integral_constant<int, 0>{}, [&](auto f_tag, const char* p) {
             constexpr int f = decltype(f_tag)::value;
             if constexpr (f < NA1)
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8*>(p), x[f / PM], acc, 0, 0, 0);
         });
         tile_to_frags<GNP>(acc, g.alpha1, x4[2 * t], x4[2 * t + 1]);
     });
+#endif
 
-    // ---- phase 2: per 32 hidden rows: ffn2.0 -> gelu -> two k-steps of ffn2.2 ----
+    // ---- phase 2: per 32 hidden rows: ffn2.0 -> gelu -> two k-steps of ffn2.2 (G hidden tiles per unit) ----
     f32x16 acc2[NM];
 #pragma unroll
     for (int m = 0; m < NM; ++m) acc2[m] = bias_tile(sb3, m);
-    for (int th = 0; th < a.nh; ++th) {
+    for (int th = 0; th < a.nh; th += G) {
         f32x16 acch = bias_tile(sb2, th);
         f16x8 hf[2] = {};
-        run_unit(std::integral_constant<int, U2>{}, std::integral_constant<int, NA2 + NB2>{}, std::integral_constant<int, NA2>{}, [&](auto f_tag, const char* p) {
+        run_unit(integral_constant<int, U2>{}, integral_constant<int, G * TF>{}, integral_constant<int, NA2>{}, integral_constant<int, TF>{},
+                 integral_constant<int, (G > 1) ? TF : 0>{}, [&](auto f_tag, const char* p) {
             constexpr int f = decltype(f_tag)::value;
-            if constexpr (f == NA2) tile_to_frags<GNP>(acch, g.alpha2, hf[0], hf[1]);
-            if constexpr (f < NA2) {
-                acch = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8*>(p), x4[f / PM], acch, 0, 0, 0);
-            } else if constexpr (f < NA2 + NB2) {
-                constexpr int q = (f - NA2) / PM, s = q / NM, m = q % NM;
-                acc2[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8*>(p), hf[s], acc2[m], 0, 0, 0);
+            if constexpr (f < G * TF) {
+                constexpr int j = f / TF, r = f % TF;
+                if constexpr (r == 0 && j > 0) acch = bias_tile(sb2, th + j);
+                if constexpr (r == NA2) tile_to_frags<GNP>(acch, g.alpha2, hf[0], hf[1]);
+                if constexpr (r < NA2) {
+                    acch = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8*>(p), x4[r / PM], acch, 0, 0, 0);
+                } else {
+                    constexpr int q = (r - NA2) / PM, s_ = q / NM, m = q % NM;
+                    acc2[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8*>(p), hf[s_], acc2[m], 0, 0, 0);
+                }
             }
         });
     }
@@ -325,14 +369,23 @@ inline int unit_frags(int n) { return (n + S - 1) / S * S; }
 
 }  // namespace
 
-// 1-KB fragments of the packed weight stream (0: this shape is not built) -- the host packs exactly this many (ops.PackedTail)
-extern "C" int sf_sk_tail_frags(int C, int H, int M2, int pm) {
+// layout of the packed weight stream (the host packs exactly this: ops.PackedTail): total 1-KB fragments (0: shape / product count not
+// built); *stage = fragments per stage (units are padded to multiples of it), *group = hidden tiles per phase-2 unit, *pw_one_unit = 1
+// when the NC pw tiles form ONE unit (padded once) instead of a unit each
+extern "C" int sf_sk_tail_layout(int C, int H, int M2, int pm, int* stage, int* group, int* pw_one_unit) {
     const Shape* s = find_shape(C, M2);
     if (!s || (pm != 1 && pm != 2) || H <= 0 || H % 32 || H > kMaxH) return 0;
     if (s->NC == 8 && s->NM == 6 && pm == 1) return 0;           // (256 -> H -> 192 with single-product weights spills 8 registers: not built)
-    const int ks = 2 * s->NC;
-    return s->NC * unit_frags(ks * pm) + (H / 32) * unit_frags((ks + 2 * s->NM) * pm);
+    const int ks = 2 * s->NC, G = tail_group(s->NC, s->NM, pm), nh = H / 32;
+    if (nh % G) return 0;
+    if (stage) *stage = S;
+    if (group) *group = G;
+    if (pw_one_unit) *pw_one_unit = SF_TAIL_V2 ? 1 : 0;
+    const int f1 = SF_TAIL_V2 ? unit_frags(s->NC * ks * pm) : s->NC * unit_frags(ks * pm);
+    return f1 + (nh / G) * unit_frags(G * (ks + 2 * s->NM) * pm);
 }
+
+extern "C" int sf_sk_tail_frags(int C, int H, int M2, int pm) { return sf_sk_tail_layout(C, H, M2, pm, nullptr, nullptr, nullptr); }
 
 extern "C" int sf_sk_tail(const SfSkTail* p, void* stream) {
     SF_REQUIRE(p && p->X && p->wstream && (p->Y || p->Y16), "sf_sk_tail: null pointer");

@@ -395,6 +395,9 @@ class PackedTail:
                                "(HotPathEngine does at construction)")
         nc, nh, nm = (self.C + 31) // 32, self.H // 32, (self.M2 + 31) // 32
         ks = 2 * nc
+        stage, group, one = C.c_int(0), C.c_int(0), C.c_int(0)
+        total = int(_lib.load().sf_sk_tail_layout(self.C, self.H, self.M2, pm, C.byref(stage), C.byref(group), C.byref(one)))
+        assert total > 0 and nh % group.value == 0
         w1, w2, w3 = (PackedPair._split(l, r, c) for l, (r, c) in zip(self.layers, ((nc * 32, nc * 32), (nh * 32, nc * 32), (nm * 32, nh * 32))))
         dev = w1[0].device
         khalf = torch.arange(2, device=dev).view(2, 1)
@@ -409,20 +412,23 @@ class PackedTail:
                 out.append(plane[r0:r0 + 32][:, cols].reshape(32, 2, 8).permute(1, 0, 2).reshape(512))
 
         def pad():
-            while (len(out) % self.S) != 0:
+            while (len(out) % stage.value) != 0:
                 out.append(zero)
 
         for t in range(nc):                                                            # phase 1: pw row tiles over the natural k-steps
             for k in range(ks):
                 emit(w1, 32 * t, 16 * k + natural)
-            pad()
-        for th in range(nh):                                                           # phase 2: per 32 hidden rows
+            if not one.value:
+                pad()
+        pad()
+        for th in range(nh):                                                           # phase 2: per 32 hidden rows, `group` tiles per unit
             for k in range(ks):                                                        # ffn2.0 over x4 (k-step = (tile k / 2, half k % 2))
                 emit(w2, 32 * th, 32 * (k // 2) + 16 * (k % 2) + acc_order)
             for s_ in range(2):                                                        # ffn2.2's two k-steps from this hidden tile
                 for m in range(nm):
                     emit(w3, 32 * m, 32 * th + 16 * s_ + acc_order)
-            pad()
+            if (th + 1) % group.value == 0:
+                pad()
         st = torch.cat(out).contiguous()
         assert st.numel() == int(_lib.load().sf_sk_tail_frags(self.C, self.H, self.M2, pm)) * 512, (st.numel() // 512, self.C, self.H, self.M2, pm)
         self._streams[pm] = st
