@@ -598,6 +598,11 @@ def main():
         rank_host = [float(t[2].item()) for t in t_all]
         graph_calls = [int(t[3].item()) for t in t_all]
         rank_host_cpu = [float(t[4].item()) for t in t_all]
+    if pl0 is not None and getattr(pl0, "auto_stored", False):
+        gma_note = (" -> softmax weights stored once per clip and streamed (engine default for grids of >= %d px and for split-precision "
+                    "logits; same results)" % eng.options.stored_auto_px)
+    else:
+        gma_note = ""
     clips_all = args.total_clips if strong else world * B
     fields = clips_all * pairs * args.steps
     result = {
@@ -635,7 +640,7 @@ def main():
                    "gma": f"{eng.gma_mode}" + (f" (fused recompute, {eng.flash_qk_products} MFMA product(s) per logit)"
                                                 if eng.gma_mode == "flash" else
                                                 f" (softmax weights stored once per clip as fp16, {eng.flash_qk_products} MFMA product(s) per "
-                                                f"logit; streamed every iteration)" if eng.gma_mode == "stored" else ""),
+                                                f"logit; streamed every iteration)" if eng.gma_mode == "stored" else "") + gma_note,
                    "precision": {"fp32": "exact fp32 (v_mfma_f32_32x32x2_f32)",
                                  "f16x3": "split fp16x3 (x=hi+lo, 3x v_mfma_f32_32x32x16_f16, fp32 accumulate)",
                                  "f16x2": "weights hi+lo fp16, activations fp16 (2x v_mfma_f32_32x32x16_f16)" +

@@ -61,6 +61,12 @@ class EngineOptions:
                                      # (the partial last round of one chain's GMA grid is filled by the other chain's kernels: 1320
                                      # workgroups on 768 slots = 1.72 rounds; 62.0 -> 61.6 ms per step, bit-identical)
     hybrid_store_pct: int = 50       # gma_mode 'hybrid': share of the images whose softmax weights are stored (the rest is recomputed beside them)
+    stored_auto_px: int = 16384      # gma_mode 'flash': grids of at least this many pixels -- and split-precision logits (flash_qk_products >= 2)
+                                     # at any grid -- keep the softmax weights for the loop instead (the 'stored' form, bit-identical): at
+                                     # 1080p the stream is 19 % faster than the one-product recompute (1164 vs 1438 us per iteration, 49.1 vs
+                                     # 47.0 ff/s for a Spring clip), 2.5x faster than the three-product one; at Sintel / KITTI grids with
+                                     # one product it is not.  0: never
+    stored_auto_max_gb: int = 16     # ... when the weight buffer stays under this size
     stored_p_max_gb: int = 64        # gma_mode 'stored': largest weight buffer (n_img * Ppad^2 * 2 bytes) kept; beyond it the fused recompute runs
     max_plans: int = 4               # buffer sets (and graphs) kept, least recently used evicted
 
@@ -522,15 +528,23 @@ class HotPathEngine:
                 raise RuntimeError(f"gma_mode={self.gma_mode!r} needs a split precision (f16x3 / f16x2); the exact fp32 mode keeps "
                                    "the materialised / chunked attention path")
             flash = {"auto": None, "matrix": False, "flash": True, "stored": True, "hybrid": True}[self.gma_mode]
+            # high-resolution grids: the fused path keeps its softmax weights for the loop (options.stored_auto_px; same results)
+            n_img = Bc * self.W.pairs
+            # ... and so do split-precision logits at every grid (two / three MFMA products per logit make the recompute 2.5x the stream:
+            # 1483 vs 608 us per iteration at the Sintel grid, fp32_class 168 -> 182 ff/s)
+            auto_stored = (self.gma_mode == "flash" and int(self.options.stored_auto_px) > 0 and
+                           (h * w >= int(self.options.stored_auto_px) or self.flash_qk_products >= 2)
+                           and ops.gma_stored_p_bytes(n_img, h * w) <= (int(self.options.stored_auto_max_gb) << 30))
             pl = _Plan(self.W, Bc, h, w, D, self.device, self.attn_chunk_rows, attn_f16=split, corr_f16=self.corr_f16,
                        flash=flash, shadows=(self.options.shadows and (h * w) % 4 == 0 and
                                              self.precision in (ops.PRECISION_F16X2, ops.PRECISION_F16) and
                                              self.options.hidden_f16),
                        corr_blocked=self.corr_blocked,
                        koct_io=self.options.koct_io and self.options.hidden_koct,   # (k-octet-only blocks need k-octet producers)
-                       stored_p=(self.gma_mode in ("stored", "hybrid") and self.options.flash_stats),
-                       stored_frac=(1.0 if self.gma_mode == "stored" else float(self.options.hybrid_store_pct) / 100.0),
+                       stored_p=((self.gma_mode in ("stored", "hybrid") or auto_stored) and self.options.flash_stats),
+                       stored_frac=(1.0 if (self.gma_mode == "stored" or auto_stored) else float(self.options.hybrid_store_pct) / 100.0),
                        stored_p_max_bytes=int(self.options.stored_p_max_gb) << 30)
+            pl.auto_stored = bool(auto_stored and pl.pbuf is not None)
         self._plans[key] = pl                                        # (re)insert as most recent
         return pl
 

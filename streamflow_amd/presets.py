@@ -8,8 +8,10 @@
     logit here: that puts |logit| 2^-11 of absolute error on the logits, harmless for the random-weight networks of the test
     inputs (small logits, EPE unchanged) but 12x looser on peaked attention (logits of +-40: 2.5e-2 against 2e-3 in
     tests/test_gpu_parity.py::test_gma_flash_kernel_vs_float64) -- not fp32-class for trained GMA weights (ADVICE r5), so the
-    default went back to three products (127.9 -> 140.7 ms per step).  Flows agree with the fp32 reference to ~2e-5 px at the
-    headline shape and stay inside 1e-3 px on every ill-conditioned input tried.
+    default went back to three products (127.9 -> 140.7 ms per step) -- and the engine now computes them ONCE per clip: with
+    split-precision logits the fused path keeps its fp16 softmax weights for the refinement loop and streams them every iteration
+    (EngineOptions.stored_auto_px; bit-identical to the recompute, 142.8 -> 132.2 ms per step).  Flows agree with the fp32 reference
+    to ~2e-5 px at the headline shape and stay inside 1e-3 px on every ill-conditioned input tried.
 ``config2_fp16`` -- BASELINE.json configuration 2 ("Sintel-shape 436x1024 T=4 iters=15 bf16"): the arithmetic class of
     the reference's own deployment, which runs the whole network under fp16 autocast (evaluate_mf.py:1106,
     demo.py:427-456), but with fp32 accumulation everywhere and split-precision WEIGHTS: activations are rounded once

@@ -103,8 +103,10 @@ def test_engine_stored_mode_equals_flash_mode(dev, preset):
     for B, h, w in ((3, 32, 48), (1, 40, 64)):
         fm, cn = (t.to(dev) for t in syn.make_features(81, B, T, h, w))
         outs = {}
+        from streamflow_amd.engine import EngineOptions
         for mode in ("flash", "stored"):
-            kw = dict(presets.engine_kwargs(preset), gma_mode=mode)
+            # (stored_auto_px = 0: 'flash' means the recompute kernel -- by default split-precision logits keep their weights, i.e. ARE 'stored')
+            kw = dict(presets.engine_kwargs(preset), gma_mode=mode, options=EngineOptions(stored_auto_px=0))
             for graph in (False, True):
                 eng = HotPathEngine(params, device=dev, T=T, use_graph=graph, **kw)
                 eng.forward(fm, cn, iters=3)
@@ -176,3 +178,18 @@ def test_engine_hybrid_mode_equals_flash_mode_at_the_headline_grid(dev):
     for key, val in outs.items():
         for a, b in zip(val, outs[("flash", False)]):
             assert torch.equal(a, b), key
+
+
+def test_split_precision_logits_keep_their_weights_by_default(dev):
+    """EngineOptions.stored_auto_px: with flash_qk_products >= 2 (fp32_class) the fused path stores its softmax weights once per clip
+    (same results as the recompute: the engine-level equality test above); with one product at a small grid it does not."""
+    from streamflow_amd import presets, synthetic as syn
+    from streamflow_amd.engine import HotPathEngine
+    T, B, h, w = 4, 1, 16, 24
+    params = syn.make_params(5, T)
+    fm, cn = (t.to(dev) for t in syn.make_features(84, B, T, h, w))
+    for preset, stored in (("fp32_class", True), ("config2_mixed", False)):
+        eng = HotPathEngine(params, device=dev, T=T, **presets.engine_kwargs(preset))
+        eng.forward(fm, cn, iters=2)
+        pl = next(iter(eng._plans.values()))
+        assert (pl.pbuf is not None) == stored and pl.auto_stored == stored
