@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SF_VERSION 119
+#define SF_VERSION 120
 
 enum {
     SF_OK = 0,
@@ -130,6 +130,24 @@ int sf_corr_build_blocked(const float* f1, const float* f2, int64_t f_clip_strid
 int sf_corr_lookup_blocked(const void* vol, int64_t vol_img_stride_bytes, const float* coords, float* out,
                            int64_t out_img_stride, void* out_koct, int64_t out_koct_img_stride, int B, int pairs,
                            int h, int w, void* stream);
+
+/* ---- a1 + a2 + a3 with fp32 cells in a BLOCKED layout (core/corr.py:7-54 in the reference's own fp32: streamflow.py:107,110;
+ * csrc/corr_blocked32.hip) -- the volumes of the fp32-class presets and of BASELINE.json configuration 3 as worded ---------
+ * Same mathematics as sf_corr_build_pyramid(SF_PRECISION_F16X3) / sf_corr_lookup(SF_PRECISION_FP32); the memory layout is the
+ * one of sf_corr_build_blocked with fp32 cells: level l = nby[l] x nbx[l] blocks of 8 ROWS x 4 COLUMNS (nby = ceil(hl/8),
+ * nbx = ceil(wl/4)), block (by, bx) at lvl_off[l] + (by*nbx[l] + bx)*128, cell (ty, tx) at byte ((tx%4)*8 + ty%8)*4 of block
+ * (ty/8, tx/4).  A footprint touches ~6.9 cache lines per level instead of ~11.6 in the pitched row-major maps.
+ * Padding cells / records: unspecified contents, never read.
+ *   sf_corr_lookup_blocked32: out = fp32 planes [324][h*w] per image (channel order / sampling rule of sf_corr_lookup). */
+int sf_corr_blocked32_geometry(int h, int w, int64_t* rec_bytes, int64_t* lvl_off, int32_t* nby, int32_t* nbx,
+                               int64_t* src_rows);
+int64_t sf_corr_blocked32_bytes(int n_img, int h, int w);
+int64_t sf_corr_build_blocked32_ws_bytes(int n_img, int D, int h, int w);
+int sf_corr_build_blocked32(const float* f1, const float* f2, int64_t f_clip_stride, int64_t f_pair_stride,
+                            void* vol, int64_t vol_img_stride_bytes, int B, int pairs, int D, int h, int w,
+                            void* ws, int64_t ws_bytes, void* stream);
+int sf_corr_lookup_blocked32(const void* vol, int64_t vol_img_stride_bytes, const float* coords, float* out,
+                             int64_t out_img_stride, int B, int pairs, int h, int w, void* stream);
 
 /* ---- generic fused GEMM: every 1x1 conv / nn.Linear / einsum on the path ------------------------
  * C[z][m][n] = epilogue( alpha * ( sum_k A[z][m][k] * B[z][k][n] + bias[m] ) )

@@ -116,6 +116,12 @@ SIGNATURES = {
     "sf_corr_build_blocked_ws_bytes": (_i64, [_i, _i, _i, _i]),
     "sf_corr_build_blocked": (_i, [_vp, _vp, _i64, _i64, _vp, _i64, _i, _i, _i, _i, _i, _vp, _i64, _vp]),
     "sf_corr_lookup_blocked": (_i, [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _vp]),
+    "sf_corr_blocked32_geometry": (_i, [_i, _i, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                        C.POINTER(_i64)]),
+    "sf_corr_blocked32_bytes": (_i64, [_i, _i, _i]),
+    "sf_corr_build_blocked32_ws_bytes": (_i64, [_i, _i, _i, _i]),
+    "sf_corr_build_blocked32": (_i, [_vp, _vp, _i64, _i64, _vp, _i64, _i, _i, _i, _i, _i, _vp, _i64, _vp]),
+    "sf_corr_lookup_blocked32": (_i, [_vp, _i64, _vp, _vp, _i64, _i, _i, _i, _i, _vp]),
     "sf_gemm": (_i, [C.POINTER(SfGemm), _vp]),
     "sf_gemm_split_ws_floats": (_i64, [_i, _i, _i, _i]),
     "sf_gma_flash_ws_bytes": (_i64, [_i, _i]),

@@ -22,7 +22,7 @@ OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libstreamflow_hip.so")
 ASAN_OBJ = os.path.join(CSRC, "build_asan")
 ASAN_LIB = os.path.join(HERE, "libstreamflow_hip_asan.so")
-SOURCES = ["misc.hip", "corr.hip", "corr_blocked.hip", "conv.hip", "gemm.hip", "gemm_split.hip", "gemm_bstat.hip", "ffn_pair.hip", "sk_tail.hip", "temporal.hip", "mask_upsample.hip", "attn.hip", "encoder.hip"]
+SOURCES = ["misc.hip", "corr.hip", "corr_blocked.hip", "corr_blocked32.hip", "conv.hip", "gemm.hip", "gemm_split.hip", "gemm_bstat.hip", "ffn_pair.hip", "sk_tail.hip", "temporal.hip", "mask_upsample.hip", "attn.hip", "encoder.hip"]
 HEADERS = [os.path.join(CSRC, "sf_common.h"), os.path.join(CSRC, "gemm_epilogue.h"), os.path.join(CSRC, "split_operand.h"),
            os.path.join(HERE, "..", "include", "streamflow_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-Wall",

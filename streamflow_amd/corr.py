@@ -17,8 +17,8 @@ class CorrBlock:
     ``blk(coords)`` returns ``[B, 4*81, h, w]`` float32 contiguous (corr.py:23-44).
     ``dtype=torch.float16`` (an extension; the reference always keeps fp32 volumes) stores the pyramid as fp16
     cells built with single f16 MFMA products -- the bf16/fp16 volume configurations of BASELINE.json.
-    ``layout="blocked"`` (fp16 only) keeps them in the 8 x 8-cell block layout of csrc/corr_blocked.hip -- what the fused
-    engine uses; ``corr_pyramid`` is then a row-major COPY made on first access.
+    ``layout="blocked"`` keeps them in cache-line blocks -- 8 x 8 fp16 cells (csrc/corr_blocked.hip) or 8 rows x 4 columns of
+    fp32 cells (csrc/corr_blocked32.hip) -- what the fused engine uses; ``corr_pyramid`` is then a row-major COPY made on first access.
     """
 
     @ops.on_tensor_device
@@ -37,12 +37,12 @@ class CorrBlock:
         N = h * w
         if dtype not in (torch.float32, torch.float16):
             raise RuntimeError(f"CorrBlock: volume dtype must be float32 or float16, got {dtype}")
-        if layout not in ("rows", "blocked") or (layout == "blocked" and dtype != torch.float16):
-            raise RuntimeError("CorrBlock: layout must be 'rows' or 'blocked' (blocked: float16 volumes only)")
+        if layout not in ("rows", "blocked"):
+            raise RuntimeError("CorrBlock: layout must be 'rows' or 'blocked'")
         self._keep = (f1, f2)
         self.vol = None
         if layout == "blocked":
-            self.vol = ops.new_blocked_volume(B, h, w, f1.device)
+            self.vol = ops.new_blocked_volume(B, h, w, f1.device, f32=dtype == torch.float32)
             ops.corr_build_blocked(f1.data_ptr(), f2.data_ptr(), D * N, 0, self.vol, B, 1, D)
             self._pyr = self._store = self.pitch = None
             return

@@ -1,0 +1,459 @@
+// Correlation pyramids in BLOCKED fp32 layout: build (K1 + K2) and radius-4 lookup (K3) for the fp32-class presets.
+//
+// Reference: core/corr.py:7-21,46-54 (volume + avg-pool pyramid, kept in fp32: streamflow.py:107,110), :23-44 (lookup),
+// core/utils/utils.py:65-79.  BASELINE.json configuration 3 ("KITTI-shape full-res 4D volume") as worded.
+//
+// WHY (round 6).  In the reference's own layout -- one [h_l][w_l] fp32 map per source pixel, rows pitched
+// to cache lines by csrc/corr.hip -- a 10 x 10 bilinear footprint is ten 40-byte rows in ten different 128-byte lines (~11.6 lines
+// per level with the straddles): the lookup fetched 5.9 KB per pixel for 1.6 KB of footprints, and the build wrote 128-byte runs
+// with one 4-byte store per lane.  Here, as in csrc/corr_blocked.hip for fp16 cells, every pyramid level of every source pixel is
+// stored as BLOCKS of one cache line, 8 rows x 4 columns of fp32 cells, column-major inside the block:
+//
+//     record(source pixel i) = [level 0 blocks | level 1 | level 2 | level 3]                                     (rec bytes)
+//     level l: ceil(hl / 8) x ceil(wl / 4) blocks, block (by, bx) at off[l] + (by * nbx[l] + bx) * 128
+//     cell (ty, tx) of the level at block (ty / 8, tx / 4), byte ((tx % 4) * 8 + ty % 8) * 4
+//
+//  * a footprint touches (1 + 9/8) x (1 + 9/4) = 6.9 lines per level on average instead of ~11.6;
+//  * a 32-byte piece is one block COLUMN = eight vertically adjacent cells: in the build a lane of the MFMA C/D layout holds exactly
+//    those (8 patch rows of one target column), so level 0 leaves as two 16-byte stores per lane and accumulator register, 1 KB
+//    contiguous per wave instruction; in the lookup one lane owns one footprint column (vertical lerp in-lane, horizontal by DPP);
+//  * cells of a block that lie outside the level (padding) have UNSPECIFIED contents; the lookup masks them.
+//
+// Arithmetic of the build: split fp16 operands (f = hi + lo, three MFMA products, fp32 accumulation: ~2^-20 relative), the main loop
+// of corr.hip's corr_build_dma_kernel (operand stages HBM/L2 -> LDS by buffer_load ... lds, two 24-KB stages).  The lookup hands the
+// 324 correlation features over as fp32 planes [324][N] (the fp32-class presets' operand format).
+#include "sf_common.h"
+#include "split_operand.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) void* lds_ptr;
+using sf_split::f16x8;
+
+constexpr int kThreads = 256;
+constexpr int kDrop = (int)0x80000000u;          // buffer offset past any num_records: the access is dropped / reads 0
+
+struct Geom32 {
+    int hl[4], wl[4], nby[4], nbx[4], off[4];    // level sizes, blocks per level, byte offset of the level in a record
+    int rec;                                     // bytes per source pixel
+};
+
+Geom32 make_geom32(int h, int w) {
+    Geom32 g;
+    int o = 0;
+    for (int l = 0; l < 4; ++l) {
+        g.hl[l] = h >> l; g.wl[l] = w >> l;
+        g.nby[l] = (g.hl[l] + 7) / 8; g.nbx[l] = (g.wl[l] + 3) / 4;
+        g.off[l] = o;
+        o += g.nby[l] * g.nbx[l] * 128;
+    }
+    g.rec = o;
+    return g;
+}
+
+inline int src_rows_padded(int N) { return (N + 127) / 128 * 128; }
+
+__device__ __forceinline__ float dpp_xor1(float v) {     // lane ^ 1 (quad_perm [1,0,3,2])
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float dpp_xor2(float v) {     // lane ^ 2 (quad_perm [2,3,0,1])
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float dpp_shl4(float v) {     // lane + 4 inside a row of 16 (row_shl:4)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x104, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float dpp_shl1(float v) {     // lane + 1 inside a row of 16 (row_shl:1)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x101, 0xF, 0xF, true));
+}
+
+// ------------------------------------------------------------------------------------------------
+// build
+// ------------------------------------------------------------------------------------------------
+constexpr int BM = 128;          // source pixels per workgroup (4 waves x 32)
+constexpr int PR = 8, PC = 32;   // target patch: 8 rows x 32 columns = one block row of eight blocks
+constexpr int BN = PR * PC;
+constexpr int DK = 16;                              // k per stage
+constexpr int ST_A = (DK / 8) * BM * 16;            // bytes of the A_hi (= A_lo) part of a stage
+constexpr int ST_B = (DK / 8) * BN * 16;            // bytes of B_hi (= B_lo)
+constexpr int STAGE = 2 * ST_A + 2 * ST_B;          // 24576
+constexpr int NSTAGE = 2;
+
+struct Build32Args {
+    char* vol;
+    int64_t vol_img_stride;       // bytes
+    int n_img, h, w, N, Dp;
+    int pcols, np, mt, pblk;      // patch columns, patches per image, m-tiles per image, patches per L2-resident block
+    float scale;
+    Geom32 g;
+};
+
+// features fp32 [D][N] -> (hi, lo) fp16 k-octet planes: ws image (img, side) = [hi | lo], plane[(k / 8) * N + pixel][k % 8]
+__global__ __launch_bounds__(256) void split_pack32_kernel(const float* f1, const float* f2, int64_t f_clip_stride, int64_t f_pair_stride,
+                                                           char* ws, int pairs, int D, int Dp, int N) {
+    using namespace sf_split;
+    const int px = blockIdx.x * 256 + threadIdx.x, kq = blockIdx.y;
+    const int side = blockIdx.z & 1, img = blockIdx.z >> 1;             // img = b * pairs + pair
+    if (px >= N) return;
+    const float* f = (side ? f2 : f1) + (int64_t)(img / pairs) * f_clip_stride + (int64_t)(img % pairs) * f_pair_stride;
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (kq * 8 + i < D) ? f[(int64_t)(kq * 8 + i) * N + px] : 0.f;
+    const Split8 s8 = split8(v);
+    const int64_t half = (int64_t)(Dp / 8) * N * 16;
+    char* dst = ws + (int64_t)blockIdx.z * 2 * half + ((int64_t)kq * N + px) * 16;
+    *reinterpret_cast<f16x8*>(dst) = s8.hi;
+    *reinterpret_cast<f16x8*>(dst + half) = s8.lo;
+}
+
+struct TileId { int img, m_tile, patch; };
+// XCD-aware order [image][patch block][m-tile][patch in block]: the `pblk` target patches of a block stay in the XCD's L2 while all
+// m-tiles stream past them (csrc/corr.hip)
+__device__ __forceinline__ TileId build_tile(const Build32Args& g, int id) {
+    const int per_img = g.np * g.mt;
+    TileId t;
+    t.img = id / per_img;
+    int r = id % per_img;
+    const int full = g.np / g.pblk;
+    if (r < full * g.pblk * g.mt) {
+        const int blk = r / (g.pblk * g.mt), r2 = r % (g.pblk * g.mt);
+        t.m_tile = r2 / g.pblk;
+        t.patch = blk * g.pblk + r2 % g.pblk;
+    } else {
+        r -= full * g.pblk * g.mt;
+        const int rem = g.np - full * g.pblk;
+        t.m_tile = r / rem;
+        t.patch = full * g.pblk + r % rem;
+    }
+    return t;
+}
+
+__global__ __launch_bounds__(kThreads, 3) void corr_build_blocked32_kernel(const Build32Args g, const char* ws) {
+    __shared__ __attribute__((aligned(1024))) char smem[NSTAGE * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int khalf = lane >> 5, l31_ = lane & 31;
+    const TileId tile = build_tile(g, sf::xcd_linear_id(blockIdx.x, gridDim.x));
+    const int m0 = tile.m_tile * BM;
+    const int pyb = tile.patch / g.pcols, pxb = tile.patch % g.pcols;          // patch origin: block row pyb, columns 32 pxb ..
+    const int py0 = pyb * PR, px0 = pxb * PC;
+    const int half = (g.Dp / 8) * g.N * 16;                     // bytes of one hi (or lo) plane (< 2 GiB, host-checked)
+    const char* imgA = ws + (int64_t)(tile.img * 2 + 0) * 2 * half;
+    const char* imgB = ws + (int64_t)(tile.img * 2 + 1) * 2 * half;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(imgA), 0, 2 * half, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(imgB), 0, 2 * half, 0x00020000);
+    // per-thread source offsets (pixels / patch cells past the image are clamped: their products land in padding cells / records)
+    const int voa = ((tid >> 7) * g.N + min(m0 + (tid & 127), g.N - 1)) * 16;          // slot = kq * 128 + px = tid
+    const int vob = (min(py0 + tid / PC, g.h - 1) * g.w + min(px0 + tid % PC, g.w - 1)) * 16;   // slot = kq * 256 + cell
+    const int kq_step = g.N * 16;
+    auto issue = [&](int kt, int buf) {
+        char* sb = smem + buf * STAGE + wave * 1024;
+        const int so = kt * (DK / 8) * kq_step;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)(sb), 16, voa, so, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)(sb + ST_A), 16, voa + half, so, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr)(sb + 2 * ST_A), 16, vob, so, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr)(sb + 2 * ST_A + 4096), 16, vob, so + kq_step, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr)(sb + 2 * ST_A + ST_B), 16, vob + half, so, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr)(sb + 2 * ST_A + ST_B + 4096), 16, vob + half, so + kq_step, 0, 0);
+    };
+    f32x16 acc[PR];
+#pragma unroll
+    for (int t = 0; t < PR; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const int nk = g.Dp / DK;
+    const int offa = (khalf * BM + wave * 32 + l31_) * 16;
+    const int offb = 2 * ST_A + (khalf * BN + l31_) * 16;
+    issue(0, 0);
+    int cur = 0, nxt = NSTAGE - 1;
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's 6 pieces of stage kt have landed ...
+        __builtin_amdgcn_s_barrier();                           // ... everyone's; and slot nxt (stage kt - 1) is no longer read
+        if (kt + NSTAGE - 1 < nk) issue(kt + NSTAGE - 1, nxt);
+        const char* sb = smem + cur * STAGE;
+        cur = (cur == NSTAGE - 1) ? 0 : cur + 1;
+        nxt = (nxt == NSTAGE - 1) ? 0 : nxt + 1;
+        const f16x8 ah = *reinterpret_cast<const f16x8*>(sb + offa);
+        const f16x8 al = *reinterpret_cast<const f16x8*>(sb + offa + ST_A);
+#pragma unroll
+        for (int t = 0; t < PR; ++t) {
+            const f16x8 bh = *reinterpret_cast<const f16x8*>(sb + offb + t * PC * 16);
+            const f16x8 bl = *reinterpret_cast<const f16x8*>(sb + offb + ST_B + t * PC * 16);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue.  C/D layout: lane = (MFMA column l31 = patch column, k-half), register r = source row (r & 3) + 8 (r >> 2) + 4 khalf,
+    // acc[t] = patch row t: a lane's eight values of one register are one 32-byte block column of level 0 (csrc/corr_blocked.hip) ----
+    int c = l31_;
+    asm volatile("" : "+v"(c));                                  // (per-lane store offsets are not loop invariants of the k-loop)
+    const int rec = g.g.rec;
+    const int i0 = m0 + wave * 32;                               // first source pixel of the wave (records are padded to 128 sources)
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(
+        g.vol + (int64_t)tile.img * g.vol_img_stride + (int64_t)i0 * rec, 0, 32 * rec, 0x00020000);
+    const int rowh = 4 * khalf * rec;
+    const int tx0 = px0 + c;
+    const int vo0 = (pyb < g.g.nby[0] && (tx0 >> 2) < g.g.nbx[0]) ? rowh + g.g.off[0] + pyb * g.g.nbx[0] * 128 + tx0 * 32 : kDrop;
+    // level 1: lane pair (2 j, 2 j + 1) holds level-1 column tx1 after the horizontal step, four rows (rows 4 (pyb & 1) .. + 3 of
+    // level-1 block row pyb >> 1): a 16-byte piece; lane parity k1 stores source row (2 jp + k1) of a register pair
+    const int k1 = c & 1, tx1 = tx0 >> 1, by1 = pyb >> 1;
+    const int vo1 = (by1 < g.g.nby[1] && (tx1 >> 2) < g.g.nbx[1])
+                        ? rowh + k1 * rec + g.g.off[1] + by1 * g.g.nbx[1] * 128 + tx1 * 32 + (pyb & 1) * 16 : kDrop;
+    // level 2: lane quad = level-2 column tx2, rows 2 (pyb & 3) .. + 1 of block row pyb >> 2 (8 bytes); lane k2 stores source row k2
+    const int k2 = c & 3, tx2 = tx0 >> 2, by2 = pyb >> 2;
+    const int vo2 = (by2 < g.g.nby[2] && (tx2 >> 2) < g.g.nbx[2])
+                        ? rowh + k2 * rec + g.g.off[2] + by2 * g.g.nbx[2] * 128 + tx2 * 32 + (pyb & 3) * 8 : kDrop;
+    // level 3: lanes 0..3 of an octet hold level-3 column tx3, row pyb & 7 of block row pyb >> 3 (4 bytes)
+    const int k3 = c & 7, tx3 = tx0 >> 3, by3 = pyb >> 3;
+    const int vo3 = (k3 < 4 && by3 < g.g.nby[3] && (tx3 >> 2) < g.g.nbx[3])
+                        ? rowh + k3 * rec + g.g.off[3] + by3 * g.g.nbx[3] * 128 + tx3 * 32 + (pyb & 7) * 4 : kDrop;
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {                       // register group: source rows 8 rq + 4 khalf + (0..3)
+        float sel2[2] = {0.f, 0.f}, sel3 = 0.f;
+#pragma unroll
+        for (int jp = 0; jp < 2; ++jp) {                   // register pair (2 jp, 2 jp + 1) of the group
+            float sel1[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int ri = 2 * jp + u, r = 4 * rq + ri;
+                float v0[PR];
+#pragma unroll
+                for (int t = 0; t < PR; ++t) v0[t] = acc[t][r] * g.scale;
+                u32x4 oa, ob;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    oa[t] = __builtin_bit_cast(unsigned, v0[t]);
+                    ob[t] = __builtin_bit_cast(unsigned, v0[4 + t]);
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(oa, rv, vo0, (ri + 8 * rq) * rec, 2);
+                __builtin_amdgcn_raw_buffer_store_b128(ob, rv, vo0 == kDrop ? kDrop : vo0 + 16, (ri + 8 * rq) * rec, 2);
+                // (gfx950: a VALU write to the data registers of a > 64-bit buffer store with an SGPR soffset in the very next issue slots
+                // corrupts the stored data -- csrc/corr_blocked.hip; pad by hand, tied to the data registers)
+                asm volatile("s_nop 1" : "+v"(oa), "+v"(ob) : : "memory");
+                float v1[4], v2[2];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float sm = v0[2 * t] + v0[2 * t + 1];
+                    v1[t] = 0.25f * (sm + dpp_xor1(sm));
+                    sel1[t] = (k1 == u) ? v1[t] : sel1[t];
+                }
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const float sm = v1[2 * t] + v1[2 * t + 1];
+                    v2[t] = 0.25f * (sm + dpp_xor2(sm));
+                    sel2[t] = (k2 == ri) ? v2[t] : sel2[t];
+                }
+                const float sm = v2[0] + v2[1];
+                const float v3 = 0.25f * (sm + dpp_shl4(sm));
+                sel3 = (k3 == ri) ? v3 : sel3;
+            }
+            u32x4 o1;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) o1[t] = __builtin_bit_cast(unsigned, sel1[t]);
+            __builtin_amdgcn_raw_buffer_store_b128(o1, rv, vo1, (2 * jp + 8 * rq) * rec, 0);
+            asm volatile("s_nop 1" : "+v"(o1) : : "memory");
+        }
+        u32x2 o2;
+        o2[0] = __builtin_bit_cast(unsigned, sel2[0]); o2[1] = __builtin_bit_cast(unsigned, sel2[1]);
+        __builtin_amdgcn_raw_buffer_store_b64(o2, rv, vo2, (8 * rq) * rec, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, sel3), rv, vo3, (8 * rq) * rec, 0);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// lookup
+// ------------------------------------------------------------------------------------------------
+constexpr int LP = 32;                          // source pixels per workgroup
+constexpr int NCH = 324;
+constexpr int TROW = 325;                       // floats per pixel in the transpose buffer (odd: the read-back of 32 pixels is conflict-free)
+
+struct Look32Args {
+    const char* vol;
+    int64_t vol_img_stride;       // bytes
+    const float* coords;
+    float* out;                   // fp32 planes [324][N] per image
+    int64_t out_img_stride;
+    int h, w, N;
+    Geom32 g;
+};
+
+__global__ __launch_bounds__(kThreads, 3) void corr_lookup_blocked32_kernel(const Look32Args a) {
+    __shared__ float T[LP * TROW];
+    const int tid = threadIdx.x;
+    const int grp = tid >> 4, c = tid & 15;               // 16 lanes per footprint: lane c = footprint column c (10 used)
+    const int img = blockIdx.y, p0 = blockIdx.x * LP;
+    const int rec = a.g.rec;
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(a.vol) + (int64_t)img * a.vol_img_stride + (int64_t)p0 * rec, 0, LP * rec, 0x00020000);
+    float cxs[2], cys[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int p = min(p0 + e * 16 + grp, a.N - 1);
+        cxs[e] = a.coords[((int64_t)img * 2 + 0) * a.N + p];
+        cys[e] = a.coords[((int64_t)img * 2 + 1) * a.N + p];
+    }
+    int g_wl[4], g_hl[4], g_nby[4], g_rowb[4], g_off[4];
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+        g_wl[l] = a.g.wl[l]; g_hl[l] = a.g.hl[l]; g_nby[l] = a.g.nby[l]; g_rowb[l] = a.g.nbx[l] * 128; g_off[l] = a.g.off[l];
+        asm volatile("" : "+s"(g_wl[l]), "+s"(g_hl[l]), "+s"(g_nby[l]), "+s"(g_rowb[l]), "+s"(g_off[l]));
+    }
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {                      // item = (level it >> 1, pixel (it & 1) * 16 + grp)
+        const int l = it >> 1, e = it & 1, pix = e * 16 + grp;
+        const float inv = 1.0f / (float)(1 << l);
+        float cx = cxs[e] * inv, cy = cys[e] * inv;
+        if (!(cx > -1.0e6f && cx < 1.0e6f)) cx = -1.0e6f;     // (far out: zero padding only; also swallows NaN / inf)
+        if (!(cy > -1.0e6f && cy < 1.0e6f)) cy = -1.0e6f;
+        const float fx0 = floorf(cx), fy0 = floorf(cy);
+        const int x0 = (int)fx0, y0 = (int)fy0;
+        const float fx = cx - fx0, fy = cy - fy0;
+        const int tx = x0 - 4 + c, ys = y0 - 4;
+        const bool col_ok = (c < 10) & ((unsigned)tx < (unsigned)g_wl[l]);
+        const int byf = ys >> 3;
+        const int col = pix * rec + g_off[l] + tx * 32;            // block bx = tx / 4, column tx % 4: (bx * 4 + tx % 4) * 32
+        auto piece = [&](int k) {
+            const int by = byf + k;
+            return (col_ok & ((unsigned)by < (unsigned)g_nby[l])) ? col + by * g_rowb[l] : kDrop;
+        };
+        // rows 8 byf .. 8 byf + 17 of this column: two whole block columns + (when ys % 8 == 7) two rows of a third
+        unsigned W[18];
+        {
+            const int pa = piece(0), pb = piece(1), pc = ((ys & 7) == 7) ? piece(2) : kDrop;
+            const u32x4 w0 = __builtin_amdgcn_raw_buffer_load_b128(rv, pa, 0, 0);
+            const u32x4 w1 = __builtin_amdgcn_raw_buffer_load_b128(rv, pa == kDrop ? kDrop : pa + 16, 0, 0);
+            const u32x4 w2 = __builtin_amdgcn_raw_buffer_load_b128(rv, pb, 0, 0);
+            const u32x4 w3 = __builtin_amdgcn_raw_buffer_load_b128(rv, pb == kDrop ? kDrop : pb + 16, 0, 0);
+            const u32x2 w4 = __builtin_amdgcn_raw_buffer_load_b64(rv, pc, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { W[i] = w0[i]; W[4 + i] = w1[i]; W[8 + i] = w2[i]; W[12 + i] = w3[i]; }
+            W[16] = w4[0]; W[17] = w4[1];
+        }
+        // rows ys .. ys + 9 out of the 18: shift by s = ys % 8 in three select steps (bit-select masks, v_bfi_b32: written as
+        // `cond ? W[i + 4] : W[i]` hipcc turns the chain into a dynamically indexed array in SCRATCH memory -- csrc/corr_blocked.hip)
+        const int s = ys & 7;
+        const unsigned m4 = 0u - ((unsigned)(s >> 2) & 1u), m2 = 0u - ((unsigned)(s >> 1) & 1u), m1 = 0u - ((unsigned)s & 1u);
+        unsigned W1[14], W2[12];
+        float F[10];
+#pragma unroll
+        for (int i = 0; i < 14; ++i) W1[i] = (W[i + 4] & m4) | (W[i] & ~m4);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) W2[i] = (W1[i + 2] & m2) | (W1[i] & ~m2);
+        // padding rows inside the last block row (hl % 8 != 0) hold unspecified data: clear rows >= hl
+        const int nvalid = g_hl[l] - ys;                  // rows b < nvalid are inside the level (b < -ys: dropped loads read 0)
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+            const unsigned d = (W2[i + 1] & m1) | (W2[i] & ~m1);
+            F[i] = __builtin_bit_cast(float, (i < nvalid) ? d : 0u);
+        }
+        const float wy1 = fy, wy0 = 1.f - fy, wx1 = fx, wx0 = 1.f - fx;
+        float R[9];
+#pragma unroll
+        for (int b = 0; b < 9; ++b) {                      // (all lanes: lane 9 supplies column 9 to lane 8 through the DPP shift)
+            const float v = F[b] * wy0 + F[b + 1] * wy1;
+            R[b] = v * wx0 + dpp_shl1(v) * wx1;
+        }
+        if (c < 9) {
+            float* t0 = T + pix * TROW + l * 81 + c * 9;   // channel l * 81 + a * 9 + b with a = c (corr.py:31-37)
+#pragma unroll
+            for (int b = 0; b < 9; ++b) t0[b] = R[b];
+        }
+    }
+    __syncthreads();
+    // ---- (channel, pixel): 32 consecutive pixels of a channel = 128 contiguous bytes of its plane ----
+    float* o = a.out + (int64_t)img * a.out_img_stride;
+    for (int i = tid; i < NCH * LP; i += kThreads) {
+        const int pix = i % LP, ch = i / LP;
+        if (p0 + pix < a.N) o[(int64_t)ch * a.N + p0 + pix] = T[pix * TROW + ch];
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" int sf_corr_blocked32_geometry(int h, int w, int64_t* rec_bytes, int64_t* lvl_off, int32_t* nby, int32_t* nbx, int64_t* src_rows) {
+    SF_REQUIRE(h > 0 && w > 0, "sf_corr_blocked32_geometry: bad dims");
+    SF_REQUIRE((h >> 3) >= 1 && (w >> 3) >= 1, "sf_corr_blocked32_geometry: feature grid %dx%d too small for 4 levels", h, w);
+    const Geom32 g = make_geom32(h, w);
+    if (rec_bytes) *rec_bytes = g.rec;
+    for (int l = 0; l < 4; ++l) {
+        if (lvl_off) lvl_off[l] = g.off[l];
+        if (nby) nby[l] = g.nby[l];
+        if (nbx) nbx[l] = g.nbx[l];
+    }
+    if (src_rows) *src_rows = src_rows_padded(h * w);
+    return SF_OK;
+}
+
+extern "C" int64_t sf_corr_blocked32_bytes(int n_img, int h, int w) {
+    if (n_img <= 0 || h < 8 || w < 8) return 0;
+    return (int64_t)n_img * src_rows_padded(h * w) * make_geom32(h, w).rec;
+}
+
+extern "C" int64_t sf_corr_build_blocked32_ws_bytes(int n_img, int D, int h, int w) {
+    if (n_img <= 0 || D <= 0 || h <= 0 || w <= 0) return 0;
+    const int Dp = sf::ceil_div(D, 32) * 32;
+    return (int64_t)2 * n_img * 2 * (Dp / 8) * h * w * 16;       // (image, side) x (hi, lo) planes
+}
+
+extern "C" int sf_corr_build_blocked32(const float* f1, const float* f2, int64_t f_clip_stride, int64_t f_pair_stride, void* vol,
+                                       int64_t vol_img_stride_bytes, int B, int pairs, int D, int h, int w, void* ws, int64_t ws_bytes,
+                                       void* stream) {
+    SF_REQUIRE(f1 && f2 && vol && ws, "sf_corr_build_blocked32: null pointer");
+    SF_REQUIRE(B > 0 && pairs > 0 && D > 0 && h > 0 && w > 0, "sf_corr_build_blocked32: bad dims");
+    SF_REQUIRE((h >> 3) >= 1 && (w >> 3) >= 1, "sf_corr_build_blocked32: feature grid %dx%d too small for 4 levels", h, w);
+    const int n_img = B * pairs;
+    SF_REQUIRE(n_img <= 32767, "sf_corr_build_blocked32: B*pairs too large");
+    Build32Args g;
+    g.g = make_geom32(h, w);
+    g.N = h * w; g.h = h; g.w = w; g.n_img = n_img;
+    g.Dp = sf::ceil_div(D, 32) * 32;
+    SF_REQUIRE((int64_t)g.Dp * g.N * 4 < ((int64_t)1 << 31), "sf_corr_build_blocked32: feature image larger than 2 GiB");
+    SF_REQUIRE((int64_t)32 * g.g.rec < ((int64_t)1 << 31), "sf_corr_build_blocked32: feature grid %dx%d too large", h, w);
+    SF_REQUIRE(ws_bytes >= sf_corr_build_blocked32_ws_bytes(n_img, D, h, w) && (reinterpret_cast<uintptr_t>(ws) & 15) == 0,
+               "sf_corr_build_blocked32: needs a 16-byte aligned workspace of sf_corr_build_blocked32_ws_bytes() bytes");
+    SF_REQUIRE((reinterpret_cast<uintptr_t>(vol) & 127) == 0 && (vol_img_stride_bytes & 127) == 0 &&
+                   vol_img_stride_bytes >= (int64_t)src_rows_padded(g.N) * g.g.rec,
+               "sf_corr_build_blocked32: vol must be 128-byte aligned, image stride a multiple of 128 and at least sf_corr_blocked32_bytes(1, h, w)");
+    g.vol = static_cast<char*>(vol);
+    g.vol_img_stride = vol_img_stride_bytes;
+    g.pcols = sf::ceil_div(w, PC);
+    g.np = g.pcols * sf::ceil_div(h, PR);
+    g.mt = sf::ceil_div(g.N, BM);
+    g.scale = 1.0f / sqrtf((float)D);
+    const int patch_bytes = BN * g.Dp * 4;                       // patches per L2-resident block: ~1.75 MB of packed target features
+    g.pblk = (7 << 18) / patch_bytes;
+    g.pblk = g.pblk < 1 ? 1 : (g.pblk > g.np ? g.np : g.pblk);
+    const int64_t n_wg = (int64_t)g.np * g.mt * n_img;
+    SF_REQUIRE(n_wg < ((int64_t)1 << 31), "sf_corr_build_blocked32: grid too large");
+    hipLaunchKernelGGL(split_pack32_kernel, dim3(sf::ceil_div(g.N, 256), g.Dp / 8, 2 * n_img), dim3(256), 0, (hipStream_t)stream, f1, f2,
+                       f_clip_stride, f_pair_stride, (char*)ws, pairs, D, g.Dp, g.N);
+    hipLaunchKernelGGL(corr_build_blocked32_kernel, dim3((unsigned)n_wg), dim3(kThreads), 0, (hipStream_t)stream, g, (const char*)ws);
+    return sf::check_launch("sf_corr_build_blocked32");
+}
+
+extern "C" int sf_corr_lookup_blocked32(const void* vol, int64_t vol_img_stride_bytes, const float* coords, float* out, int64_t out_img_stride,
+                                        int B, int pairs, int h, int w, void* stream) {
+    SF_REQUIRE(vol && coords && out, "sf_corr_lookup_blocked32: null pointer");
+    SF_REQUIRE(B > 0 && pairs > 0 && h > 0 && w > 0, "sf_corr_lookup_blocked32: bad dims");
+    SF_REQUIRE((h >> 3) >= 1 && (w >> 3) >= 1, "sf_corr_lookup_blocked32: feature grid %dx%d too small for 4 levels", h, w);
+    SF_REQUIRE((int64_t)B * pairs <= 65535, "sf_corr_lookup_blocked32: B*pairs too large");
+    Look32Args a;
+    a.g = make_geom32(h, w);
+    SF_REQUIRE((int64_t)LP * a.g.rec < ((int64_t)1 << 31), "sf_corr_lookup_blocked32: feature grid %dx%d too large", h, w);
+    SF_REQUIRE((reinterpret_cast<uintptr_t>(vol) & 15) == 0 && (vol_img_stride_bytes & 15) == 0,
+               "sf_corr_lookup_blocked32: vol and its image stride must be 16-byte aligned");
+    a.vol = static_cast<const char*>(vol);
+    a.vol_img_stride = vol_img_stride_bytes;
+    a.coords = coords;
+    a.out = out; a.out_img_stride = out_img_stride;
+    a.h = h; a.w = w; a.N = h * w;
+    hipLaunchKernelGGL(corr_lookup_blocked32_kernel, dim3(sf::ceil_div(a.N, LP), B * pairs), dim3(kThreads), 0, (hipStream_t)stream, a);
+    return sf::check_launch("sf_corr_lookup_blocked32");
+}

@@ -1233,7 +1233,8 @@ def corr_lookup(lvls: Sequence[torch.Tensor], lvl_pair_stride: Optional[Sequence
 
 @dataclass(frozen=True)
 class BlockedVolume:
-    """Correlation pyramids of `n_img` images in the blocked fp16 layout of csrc/corr_blocked.hip (one buffer)."""
+    """Correlation pyramids of `n_img` images in the blocked layout (one buffer): fp16 cells in 8 x 8-cell blocks
+    (csrc/corr_blocked.hip) or, `f32`, fp32 cells in 8-row x 4-column blocks (csrc/corr_blocked32.hip)."""
     buf: torch.Tensor          # uint8
     img_stride: int            # bytes
     n_img: int
@@ -1244,56 +1245,62 @@ class BlockedVolume:
     nby: tuple
     nbx: tuple
     src_rows: int              # records per image (h*w rounded up to 128)
+    f32: bool = False          # fp32 cells, 8 x 4 blocks
 
     def levels(self):
-        """The four levels as [n_img, h*w, hl, wl] fp16 tensors (copies; tests and API parity only)."""
+        """The four levels as [n_img, h*w, hl, wl] tensors of the cell type (copies; tests and API parity only)."""
         N = self.h * self.w
-        recs = torch.as_strided(self.buf, (self.n_img, N, self.rec), (self.img_stride, self.rec, 1)).contiguous()
+        bw = 4 if self.f32 else 8                                         # block columns
         out = []
         for l in range(4):
             hl, wl, nby, nbx = self.h >> l, self.w >> l, self.nby[l], self.nbx[l]
-            blk = recs[:, :, self.off[l]: self.off[l] + nby * nbx * 128].contiguous().view(torch.float16)
-            blk = blk.view(self.n_img, N, nby, nbx, 8, 8)                 # [by][bx][tx % 8][ty % 8]
-            out.append(blk.permute(0, 1, 2, 5, 3, 4).reshape(self.n_img, N, nby * 8, nbx * 8)[:, :, :hl, :wl].contiguous())
+            blk = torch.as_strided(self.buf[self.off[l]:], (self.n_img, N, nby * nbx * 128), (self.img_stride, self.rec, 1))
+            blk = blk.contiguous().view(torch.float32 if self.f32 else torch.float16)
+            blk = blk.view(self.n_img, N, nby, nbx, bw, 8)                # [by][bx][tx % bw][ty % 8]
+            out.append(blk.permute(0, 1, 2, 5, 3, 4).reshape(self.n_img, N, nby * 8, nbx * bw)[:, :, :hl, :wl].contiguous())
         return out
 
 
-def blocked_geometry(h: int, w: int):
+def blocked_geometry(h: int, w: int, f32: bool = False):
     rec, src = C.c_int64(), C.c_int64()
     off, nby, nbx = (C.c_int64 * 4)(), (C.c_int32 * 4)(), (C.c_int32 * 4)()
-    _lib.check(_lib.load().sf_corr_blocked_geometry(h, w, C.byref(rec), off, nby, nbx, C.byref(src)),
-               "sf_corr_blocked_geometry")
+    name = "sf_corr_blocked32_geometry" if f32 else "sf_corr_blocked_geometry"
+    _lib.check(getattr(_lib.load(), name)(h, w, C.byref(rec), off, nby, nbx, C.byref(src)), name)
     return int(rec.value), tuple(int(v) for v in off), tuple(int(v) for v in nby), tuple(int(v) for v in nbx), int(src.value)
 
 
-def new_blocked_volume(n_img: int, h: int, w: int, device) -> BlockedVolume:
-    rec, off, nby, nbx, src = blocked_geometry(h, w)
+def new_blocked_volume(n_img: int, h: int, w: int, device, f32: bool = False) -> BlockedVolume:
+    rec, off, nby, nbx, src = blocked_geometry(h, w, f32)
     stride = src * rec                                      # a multiple of 128 (rec is)
     buf = torch.empty(n_img * stride + 128, dtype=torch.uint8, device=device)
     pad = (-buf.data_ptr()) % 128
-    return BlockedVolume(buf[pad: pad + n_img * stride], stride, n_img, h, w, rec, off, nby, nbx, src)
+    return BlockedVolume(buf[pad: pad + n_img * stride], stride, n_img, h, w, rec, off, nby, nbx, src, f32)
 
 
-def corr_build_blocked_ws_bytes(n_img: int, D: int, h: int, w: int) -> int:
+def corr_build_blocked_ws_bytes(n_img: int, D: int, h: int, w: int, f32: bool = False) -> int:
+    if f32:
+        return int(_lib.load().sf_corr_build_blocked32_ws_bytes(n_img, D, h, w))
     return int(_lib.load().sf_corr_build_blocked_ws_bytes(n_img, D, h, w))
 
 
 @on_tensor_device
 def corr_build_blocked(f1_ptr: int, f2_ptr: int, clip_stride: int, pair_stride: int, vol: BlockedVolume, B: int,
                        pairs: int, D: int, ws: Optional[torch.Tensor] = None) -> None:
-    """a1 + a2 into a BlockedVolume (fp16 cells, single f16 MFMA products, fp32 accumulation)."""
+    """a1 + a2 into a BlockedVolume: fp16 cells (single f16 MFMA products, fp32 accumulation) or, for an f32 volume, fp32
+    cells (split fp16 operands, three products, fp32 accumulation)."""
     h, w = vol.h, vol.w
     N = h * w
     assert vol.n_img == B * pairs
-    need = corr_build_blocked_ws_bytes(B * pairs, D, h, w)
+    need = corr_build_blocked_ws_bytes(B * pairs, D, h, w, vol.f32)
     if ws is None or ws.numel() * ws.element_size() < need:
         ws = torch.empty(need, dtype=torch.uint8, device=vol.buf.device)
     cells = sum((h >> l) * (w >> l) for l in range(4))
-    nbytes = B * pairs * (2.0 * N * D * 4 + 2.0 * N * cells)          # SURVEY.md section 8d, e = 2
+    e = 4.0 if vol.f32 else 2.0
+    nbytes = B * pairs * (2.0 * N * D * 4 + e * N * cells)            # SURVEY.md section 8d
+    name = "sf_corr_build_blocked32" if vol.f32 else "sf_corr_build_blocked"
     _launch("corr_build", 2.0 * N * N * D * B * pairs, nbytes, lambda: _lib.check(
-        _lib.load().sf_corr_build_blocked(f1_ptr, f2_ptr, clip_stride, pair_stride, vol.buf.data_ptr(), vol.img_stride,
-                                          B, pairs, D, h, w, ws.data_ptr(), need, _lib.stream()),
-        "sf_corr_build_blocked"))
+        getattr(_lib.load(), name)(f1_ptr, f2_ptr, clip_stride, pair_stride, vol.buf.data_ptr(), vol.img_stride,
+                                   B, pairs, D, h, w, ws.data_ptr(), need, _lib.stream()), name))
 
 
 @on_tensor_device
@@ -1305,6 +1312,13 @@ def corr_lookup_blocked(vol: BlockedVolume, coords: Planes, out: Optional[Planes
     assert coords.img_stride == 2 * N and vol.n_img == B * pairs
     assert out is None or (out.rows == 324 and out.n_img == B * pairs and not out.f16)
     assert out_koct is None or (out_koct.rows == 324 and out_koct.n_img == B * pairs and out_koct.koct)
+    if vol.f32:                                           # fp32 cells: fp32 planes out (the fp32-class operand format)
+        assert out is not None and out_koct is None
+        nbytes = B * pairs * (N * 4 * 100 * 4.0 + N * 2 * 4.0 + N * 324 * 4.0)  # SURVEY.md section 8d, e = 4
+        _launch("corr_lookup", 0, nbytes, lambda: _lib.check(_lib.load().sf_corr_lookup_blocked32(
+            vol.buf.data_ptr(), vol.img_stride, coords.ptr, out.ptr, out.img_stride, B, pairs, h, w, _lib.stream()),
+            "sf_corr_lookup_blocked32"))
+        return
     nbytes = B * pairs * (N * 4 * 100 * 2.0 + N * 2 * 4.0 + N * 324 * 4.0)      # SURVEY.md section 8d, e = 2
     _launch("corr_lookup", 0, nbytes, lambda: _lib.check(_lib.load().sf_corr_lookup_blocked(
         vol.buf.data_ptr(), vol.img_stride, coords.ptr, None if out is None else out.ptr,

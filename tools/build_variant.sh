@@ -9,7 +9,7 @@ B=streamflow_amd/csrc/build
 python -m streamflow_amd.build > /dev/null
 timeout 600 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize "$@" -c streamflow_amd/csrc/$src -o $B/variant_${name}_${src%.hip}.o
 objs=""
-for f in misc corr corr_blocked conv gemm gemm_split gemm_bstat ffn_pair sk_tail temporal mask_upsample attn encoder; do
+for f in misc corr corr_blocked corr_blocked32 conv gemm gemm_split gemm_bstat ffn_pair sk_tail temporal mask_upsample attn encoder; do
   if [ "$f.hip" = "$src" ]; then objs="$objs $B/variant_${name}_${src%.hip}.o"; else objs="$objs $B/$f.o"; fi
 done
 hipcc --offload-arch=gfx950 -shared -fPIC $objs -o $B/variant_$name.so
