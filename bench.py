@@ -345,9 +345,14 @@ def corr_only(args, dev, cfg, H, W, T, iters):
     if args.dense_volumes:
         pitch = None
     strides = [N * (h >> l) * (pitch[l] if pitch else (w >> l)) for l in range(4)]
+    blocked32 = (not f16) and args.corr_layout == "blocked"
     if f16:                # the shipped fp16 path: blocked volumes, features handed over as fp16 k-octets only (engine.py)
         vol = ops.new_blocked_volume(n, h, w, dev)
         ws = torch.empty(max(ops.corr_build_blocked_ws_bytes(n, D, h, w), 16), dtype=torch.uint8, device=dev)
+    elif blocked32:        # fp32 cells in 4-row x 8-column cache-line blocks (csrc/corr_blocked32.hip)
+        vol = ops.new_blocked_volume(n, h, w, dev, f32=True)
+        ws = torch.empty(max(ops.corr_build_blocked_ws_bytes(n, D, h, w, True), 16), dtype=torch.uint8, device=dev)
+        pitch = None
     else:
         lvls = [torch.empty(n * s, dtype=torch.float32, device=dev) for s in strides]
         ws = torch.empty(max(ops.corr_build_ws_bytes(B, pairs, D, h, w), 16), dtype=torch.uint8, device=dev)
@@ -365,12 +370,21 @@ def corr_only(args, dev, cfg, H, W, T, iters):
             for c in coords:
                 ops.corr_lookup_blocked(vol, c, None, out_k, B, pairs)
             return
+        if blocked32:
+            ops.corr_build_blocked(fmaps.data_ptr(), fmaps.data_ptr() + 4 * D * N, T * D * N, D * N, vol, B, pairs, D, ws=ws)
+            for c in coords:
+                ops.corr_lookup_blocked(vol, c, out, None, B, pairs)
+            return
         ops.corr_build(fmaps.data_ptr(), fmaps.data_ptr() + 4 * D * N, T * D * N, D * N, lvls, strides, B, pairs, D, h, w,
                        ws=ws, cx=cx, pitch=pitch)
         for c in coords:
             ops.corr_lookup(lvls, strides, c, out, B, pairs, h, w, cx=cx, pitch=pitch)
 
-    step()
+    # a 2-ms step is short against the one-off ~50-ms stall the HIP runtime takes somewhere in a process's first few hundred launches
+    # (tools/corr32_probe.py: GPU time per step unchanged, the wait sits on the host): let it happen before the W warm-up steps
+    settle = 30
+    for _ in range(settle):
+        step()
     torch.cuda.synchronize()
     dt = timed_steps(step, args.steps, args.warmup, 1, torch.cuda.synchronize, lambda: None, lambda x: x)
     ops.PROFILER = ops.Profiler()
@@ -382,13 +396,15 @@ def corr_only(args, dev, cfg, H, W, T, iters):
     tot_bytes, tot_ms = b["bytes"] + l["bytes"], b["ms"] + l["ms"]
     cell = 2 if f16 else 4
     return {
-        "metric": "corr_build_lookup_gbps", "value": tot_bytes / tot_ms / 1e6, "unit": "GB/s", "n_gpus": 1, "steps": args.steps,
+        "metric": "corr_build_lookup_gbps", "value": tot_bytes / (1e3 * dt / args.steps) / 1e6, "unit": "GB/s", "n_gpus": 1, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": ("fp16 cells (blocked layout, k-octet feature hand-over), single f16 product" if f16 else f"fp32 cells, {cfg['precision']} arithmetic"),
+        "vs_baseline": None, "dtype": ("fp16 cells (blocked layout, k-octet feature hand-over), single f16 product" if f16 else
+                                        "fp32 cells (cache-line blocks of 4 rows x 8 columns), f16x3 arithmetic" if blocked32 else f"fp32 cells, {cfg['precision']} arithmetic"),
         "data": "synthetic",
         "config": {"workload": f"{args.workload}_{H}x{W}_T{T}_corr_only", "clips_per_step": B, "pairs_per_clip": pairs,
-                   "feature_grid": [h, w], "lookups_per_step": iters, "volume_bytes_per_pair": cell * sum(strides),
-                   "map_row_pitch_cells": list(pitch) if pitch else "dense (the reference's [N, h_l, w_l])",
+                   "feature_grid": [h, w], "lookups_per_step": iters, "untimed_settle_steps_before_warmup": settle,
+                   "volume_bytes_per_pair": vol.img_stride if (f16 or blocked32) else cell * sum(strides),
+                   "map_row_pitch_cells": ("blocked" if (f16 or blocked32) else list(pitch) if pitch else "dense (the reference's [N, h_l, w_l])"),
                    "preset": args.preset or "default"},
         "roofline": {"kernel": "corr_build + corr_lookup", "bound": "hbm", "achieved": tot_bytes / tot_ms / 1e6,
                      "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": tot_bytes / tot_ms / 1e6 / PEAK_HBM_GBPS, "traffic": None,
@@ -456,6 +472,9 @@ def main():
                          "and exits before touching the GPU (tests/test_distributed_cpu.py)")
     ap.add_argument("--dense-volumes", action="store_true",
                     help="--corr-only, fp32 volumes: keep the reference's dense [N, h_l, w_l] maps instead of line-aligned row pitches")
+    ap.add_argument("--corr-layout", default="blocked", choices=["blocked", "rows"],
+                    help="fp32 volumes (--corr-only and the fp32_class engine): cache-line blocks (csrc/corr_blocked32.hip) or the "
+                         "reference's row-major maps with line-aligned row pitches (csrc/corr.hip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-runs", type=int, default=3, help="timed whole-clip runs of the CPU oracle (median reported)")
     ap.add_argument("--no-kernel-breakdown", action="store_true")

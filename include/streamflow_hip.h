@@ -134,9 +134,9 @@ int sf_corr_lookup_blocked(const void* vol, int64_t vol_img_stride_bytes, const 
 /* ---- a1 + a2 + a3 with fp32 cells in a BLOCKED layout (core/corr.py:7-54 in the reference's own fp32: streamflow.py:107,110;
  * csrc/corr_blocked32.hip) -- the volumes of the fp32-class presets and of BASELINE.json configuration 3 as worded ---------
  * Same mathematics as sf_corr_build_pyramid(SF_PRECISION_F16X3) / sf_corr_lookup(SF_PRECISION_FP32); the memory layout is the
- * one of sf_corr_build_blocked with fp32 cells: level l = nby[l] x nbx[l] blocks of 8 ROWS x 4 COLUMNS (nby = ceil(hl/8),
- * nbx = ceil(wl/4)), block (by, bx) at lvl_off[l] + (by*nbx[l] + bx)*128, cell (ty, tx) at byte ((tx%4)*8 + ty%8)*4 of block
- * (ty/8, tx/4).  A footprint touches ~6.9 cache lines per level instead of ~11.6 in the pitched row-major maps.
+ * one of sf_corr_build_blocked with fp32 cells: level l = nby[l] x nbx[l] blocks of 4 ROWS x 8 COLUMNS (nby = ceil(hl/4),
+ * nbx = ceil(wl/8)), block (by, bx) at lvl_off[l] + (by*nbx[l] + bx)*128, cell (ty, tx) at byte ((tx%8)*4 + ty%4)*4 of block
+ * (ty/4, tx/8).  A footprint touches ~6.9 cache lines per level instead of ~11.6 in the pitched row-major maps.
  * Padding cells / records: unspecified contents, never read.
  *   sf_corr_lookup_blocked32: out = fp32 planes [324][h*w] per image (channel order / sampling rule of sf_corr_lookup). */
 int sf_corr_blocked32_geometry(int h, int w, int64_t* rec_bytes, int64_t* lvl_off, int32_t* nby, int32_t* nbx,

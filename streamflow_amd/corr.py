@@ -17,7 +17,7 @@ class CorrBlock:
     ``blk(coords)`` returns ``[B, 4*81, h, w]`` float32 contiguous (corr.py:23-44).
     ``dtype=torch.float16`` (an extension; the reference always keeps fp32 volumes) stores the pyramid as fp16
     cells built with single f16 MFMA products -- the bf16/fp16 volume configurations of BASELINE.json.
-    ``layout="blocked"`` keeps them in cache-line blocks -- 8 x 8 fp16 cells (csrc/corr_blocked.hip) or 8 rows x 4 columns of
+    ``layout="blocked"`` keeps them in cache-line blocks -- 8 x 8 fp16 cells (csrc/corr_blocked.hip) or 4 rows x 8 columns of
     fp32 cells (csrc/corr_blocked32.hip) -- what the fused engine uses; ``corr_pyramid`` is then a row-major COPY made on first access.
     """
 

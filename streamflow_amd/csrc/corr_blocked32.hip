@@ -7,16 +7,18 @@
 // to cache lines by csrc/corr.hip -- a 10 x 10 bilinear footprint is ten 40-byte rows in ten different 128-byte lines (~11.6 lines
 // per level with the straddles): the lookup fetched 5.9 KB per pixel for 1.6 KB of footprints, and the build wrote 128-byte runs
 // with one 4-byte store per lane.  Here, as in csrc/corr_blocked.hip for fp16 cells, every pyramid level of every source pixel is
-// stored as BLOCKS of one cache line, 8 rows x 4 columns of fp32 cells, column-major inside the block:
+// stored as BLOCKS of one cache line, 4 rows x 8 columns of fp32 cells, column-major inside the block:
 //
 //     record(source pixel i) = [level 0 blocks | level 1 | level 2 | level 3]                                     (rec bytes)
-//     level l: ceil(hl / 8) x ceil(wl / 4) blocks, block (by, bx) at off[l] + (by * nbx[l] + bx) * 128
-//     cell (ty, tx) of the level at block (ty / 8, tx / 4), byte ((tx % 4) * 8 + ty % 8) * 4
+//     level l: ceil(hl / 4) x ceil(wl / 8) blocks, block (by, bx) at off[l] + (by * nbx[l] + bx) * 128
+//     cell (ty, tx) of the level at block (ty / 4, tx / 8), byte ((tx % 8) * 4 + ty % 4) * 4
 //
-//  * a footprint touches (1 + 9/8) x (1 + 9/4) = 6.9 lines per level on average instead of ~11.6;
-//  * a 32-byte piece is one block COLUMN = eight vertically adjacent cells: in the build a lane of the MFMA C/D layout holds exactly
-//    those (8 patch rows of one target column), so level 0 leaves as two 16-byte stores per lane and accumulator register, 1 KB
-//    contiguous per wave instruction; in the lookup one lane owns one footprint column (vertical lerp in-lane, horizontal by DPP);
+//  * a footprint touches (1 + 9/4) x (1 + 9/8) = 6.9 lines per level on average instead of ~11.6;
+//  * a 16-byte piece is one block COLUMN = four vertically adjacent cells: in the build a lane of the MFMA C/D layout holds two of
+//    those (8 patch rows of one target column), so level 0 leaves as two 16-byte stores per lane and accumulator register, each
+//    512 contiguous bytes per source row and instruction (8 rows x 4 columns, the first form, left every store instruction with
+//    half-written 32-byte sectors: 1.08 ms per KITTI build against 0.95 ms of the row-major kernel); in the lookup one lane owns
+//    one footprint column (vertical lerp in-lane, horizontal by DPP);
 //  * cells of a block that lie outside the level (padding) have UNSPECIFIED contents; the lookup masks them.
 //
 // Arithmetic of the build: split fp16 operands (f = hi + lo, three MFMA products, fp32 accumulation: ~2^-20 relative), the main loop
@@ -46,7 +48,7 @@ Geom32 make_geom32(int h, int w) {
     int o = 0;
     for (int l = 0; l < 4; ++l) {
         g.hl[l] = h >> l; g.wl[l] = w >> l;
-        g.nby[l] = (g.hl[l] + 7) / 8; g.nbx[l] = (g.wl[l] + 3) / 4;
+        g.nby[l] = (g.hl[l] + 3) / 4; g.nbx[l] = (g.wl[l] + 7) / 8;
         g.off[l] = o;
         o += g.nby[l] * g.nbx[l] * 128;
     }
@@ -73,7 +75,7 @@ __device__ __forceinline__ float dpp_shl1(float v) {     // lane + 1 inside a ro
 // build
 // ------------------------------------------------------------------------------------------------
 constexpr int BM = 128;          // source pixels per workgroup (4 waves x 32)
-constexpr int PR = 8, PC = 32;   // target patch: 8 rows x 32 columns = one block row of eight blocks
+constexpr int PR = 8, PC = 32;   // target patch: 8 rows x 32 columns = two block rows of four blocks
 constexpr int BN = PR * PC;
 constexpr int DK = 16;                              // k per stage
 constexpr int ST_A = (DK / 8) * BM * 16;            // bytes of the A_hi (= A_lo) part of a stage
@@ -197,20 +199,23 @@ __global__ __launch_bounds__(kThreads, 3) void corr_build_blocked32_kernel(const
         g.vol + (int64_t)tile.img * g.vol_img_stride + (int64_t)i0 * rec, 0, 32 * rec, 0x00020000);
     const int rowh = 4 * khalf * rec;
     const int tx0 = px0 + c;
-    const int vo0 = (pyb < g.g.nby[0] && (tx0 >> 2) < g.g.nbx[0]) ? rowh + g.g.off[0] + pyb * g.g.nbx[0] * 128 + tx0 * 32 : kDrop;
-    // level 1: lane pair (2 j, 2 j + 1) holds level-1 column tx1 after the horizontal step, four rows (rows 4 (pyb & 1) .. + 3 of
-    // level-1 block row pyb >> 1): a 16-byte piece; lane parity k1 stores source row (2 jp + k1) of a register pair
-    const int k1 = c & 1, tx1 = tx0 >> 1, by1 = pyb >> 1;
-    const int vo1 = (by1 < g.g.nby[1] && (tx1 >> 2) < g.g.nbx[1])
-                        ? rowh + k1 * rec + g.g.off[1] + by1 * g.g.nbx[1] * 128 + tx1 * 32 + (pyb & 1) * 16 : kDrop;
-    // level 2: lane quad = level-2 column tx2, rows 2 (pyb & 3) .. + 1 of block row pyb >> 2 (8 bytes); lane k2 stores source row k2
-    const int k2 = c & 3, tx2 = tx0 >> 2, by2 = pyb >> 2;
-    const int vo2 = (by2 < g.g.nby[2] && (tx2 >> 2) < g.g.nbx[2])
-                        ? rowh + k2 * rec + g.g.off[2] + by2 * g.g.nbx[2] * 128 + tx2 * 32 + (pyb & 3) * 8 : kDrop;
-    // level 3: lanes 0..3 of an octet hold level-3 column tx3, row pyb & 7 of block row pyb >> 3 (4 bytes)
-    const int k3 = c & 7, tx3 = tx0 >> 3, by3 = pyb >> 3;
-    const int vo3 = (k3 < 4 && by3 < g.g.nby[3] && (tx3 >> 2) < g.g.nbx[3])
-                        ? rowh + k3 * rec + g.g.off[3] + by3 * g.g.nbx[3] * 128 + tx3 * 32 + (pyb & 7) * 4 : kDrop;
+    // level 0: rows 0..3 of the patch = block row 2 pyb, rows 4..7 = block row 2 pyb + 1; lanes = consecutive 16-byte block columns
+    const bool c0 = (tx0 >> 3) < g.g.nbx[0];
+    const int a0 = rowh + g.g.off[0] + 2 * pyb * g.g.nbx[0] * 128 + tx0 * 16;
+    const int vo0a = (c0 && 2 * pyb < g.g.nby[0]) ? a0 : kDrop;
+    const int vo0b = (c0 && 2 * pyb + 1 < g.g.nby[0]) ? a0 + g.g.nbx[0] * 128 : kDrop;
+    // level 1: lane pair (2 j, 2 j + 1) holds level-1 column tx1 after the horizontal step, four rows = one block column of level-1
+    // block row pyb: a 16-byte piece; lane parity k1 stores source row (2 jp + k1) of a register pair
+    const int k1 = c & 1, tx1 = tx0 >> 1;
+    const int vo1 = (pyb < g.g.nby[1] && (tx1 >> 3) < g.g.nbx[1]) ? rowh + k1 * rec + g.g.off[1] + pyb * g.g.nbx[1] * 128 + tx1 * 16 : kDrop;
+    // level 2: lane quad = level-2 column tx2, rows 2 (pyb & 1) .. + 1 of block row pyb >> 1 (8 bytes); lane k2 stores source row k2
+    const int k2 = c & 3, tx2 = tx0 >> 2, by2 = pyb >> 1;
+    const int vo2 = (by2 < g.g.nby[2] && (tx2 >> 3) < g.g.nbx[2])
+                        ? rowh + k2 * rec + g.g.off[2] + by2 * g.g.nbx[2] * 128 + tx2 * 16 + (pyb & 1) * 8 : kDrop;
+    // level 3: lanes 0..3 of an octet hold level-3 column tx3, row pyb & 3 of block row pyb >> 2 (4 bytes)
+    const int k3 = c & 7, tx3 = tx0 >> 3, by3 = pyb >> 2;
+    const int vo3 = (k3 < 4 && by3 < g.g.nby[3] && (tx3 >> 3) < g.g.nbx[3])
+                        ? rowh + k3 * rec + g.g.off[3] + by3 * g.g.nbx[3] * 128 + tx3 * 16 + (pyb & 3) * 4 : kDrop;
 #pragma unroll
     for (int rq = 0; rq < 4; ++rq) {                       // register group: source rows 8 rq + 4 khalf + (0..3)
         float sel2[2] = {0.f, 0.f}, sel3 = 0.f;
@@ -229,8 +234,8 @@ __global__ __launch_bounds__(kThreads, 3) void corr_build_blocked32_kernel(const
                     oa[t] = __builtin_bit_cast(unsigned, v0[t]);
                     ob[t] = __builtin_bit_cast(unsigned, v0[4 + t]);
                 }
-                __builtin_amdgcn_raw_buffer_store_b128(oa, rv, vo0, (ri + 8 * rq) * rec, 2);
-                __builtin_amdgcn_raw_buffer_store_b128(ob, rv, vo0 == kDrop ? kDrop : vo0 + 16, (ri + 8 * rq) * rec, 2);
+                __builtin_amdgcn_raw_buffer_store_b128(oa, rv, vo0a, (ri + 8 * rq) * rec, 2);
+                __builtin_amdgcn_raw_buffer_store_b128(ob, rv, vo0b, (ri + 8 * rq) * rec, 2);
                 // (gfx950: a VALU write to the data registers of a > 64-bit buffer store with an SGPR soffset in the very next issue slots
                 // corrupts the stored data -- csrc/corr_blocked.hip; pad by hand, tied to the data registers)
                 asm volatile("s_nop 1" : "+v"(oa), "+v"(ob) : : "memory");
@@ -314,40 +319,36 @@ __global__ __launch_bounds__(kThreads, 3) void corr_lookup_blocked32_kernel(cons
         const float fx = cx - fx0, fy = cy - fy0;
         const int tx = x0 - 4 + c, ys = y0 - 4;
         const bool col_ok = (c < 10) & ((unsigned)tx < (unsigned)g_wl[l]);
-        const int byf = ys >> 3;
-        const int col = pix * rec + g_off[l] + tx * 32;            // block bx = tx / 4, column tx % 4: (bx * 4 + tx % 4) * 32
+        const int byf = ys >> 2;
+        const int col = pix * rec + g_off[l] + tx * 16;            // block bx = tx / 8, column tx % 8: (bx * 8 + tx % 8) * 16
         auto piece = [&](int k) {
             const int by = byf + k;
             return (col_ok & ((unsigned)by < (unsigned)g_nby[l])) ? col + by * g_rowb[l] : kDrop;
         };
-        // rows 8 byf .. 8 byf + 17 of this column: two whole block columns + (when ys % 8 == 7) two rows of a third
-        unsigned W[18];
+        // rows 4 byf .. 4 byf + 12 of this column: three whole block columns + (when ys % 4 == 3) the first row of a fourth
+        const int s = ys & 3;
+        unsigned W[13];
         {
-            const int pa = piece(0), pb = piece(1), pc = ((ys & 7) == 7) ? piece(2) : kDrop;
-            const u32x4 w0 = __builtin_amdgcn_raw_buffer_load_b128(rv, pa, 0, 0);
-            const u32x4 w1 = __builtin_amdgcn_raw_buffer_load_b128(rv, pa == kDrop ? kDrop : pa + 16, 0, 0);
-            const u32x4 w2 = __builtin_amdgcn_raw_buffer_load_b128(rv, pb, 0, 0);
-            const u32x4 w3 = __builtin_amdgcn_raw_buffer_load_b128(rv, pb == kDrop ? kDrop : pb + 16, 0, 0);
-            const u32x2 w4 = __builtin_amdgcn_raw_buffer_load_b64(rv, pc, 0, 0);
+            const u32x4 w0 = __builtin_amdgcn_raw_buffer_load_b128(rv, piece(0), 0, 0);
+            const u32x4 w1 = __builtin_amdgcn_raw_buffer_load_b128(rv, piece(1), 0, 0);
+            const u32x4 w2 = __builtin_amdgcn_raw_buffer_load_b128(rv, piece(2), 0, 0);
+            const unsigned w3 = __builtin_amdgcn_raw_buffer_load_b32(rv, (s == 3) ? piece(3) : kDrop, 0, 0);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { W[i] = w0[i]; W[4 + i] = w1[i]; W[8 + i] = w2[i]; W[12 + i] = w3[i]; }
-            W[16] = w4[0]; W[17] = w4[1];
+            for (int i = 0; i < 4; ++i) { W[i] = w0[i]; W[4 + i] = w1[i]; W[8 + i] = w2[i]; }
+            W[12] = w3;
         }
-        // rows ys .. ys + 9 out of the 18: shift by s = ys % 8 in three select steps (bit-select masks, v_bfi_b32: written as
-        // `cond ? W[i + 4] : W[i]` hipcc turns the chain into a dynamically indexed array in SCRATCH memory -- csrc/corr_blocked.hip)
-        const int s = ys & 7;
-        const unsigned m4 = 0u - ((unsigned)(s >> 2) & 1u), m2 = 0u - ((unsigned)(s >> 1) & 1u), m1 = 0u - ((unsigned)s & 1u);
-        unsigned W1[14], W2[12];
+        // rows ys .. ys + 9 out of the 13: shift by s in two select steps (bit-select masks, v_bfi_b32: written as
+        // `cond ? W[i + 2] : W[i]` hipcc turns the chain into a dynamically indexed array in SCRATCH memory -- csrc/corr_blocked.hip)
+        const unsigned m2 = 0u - ((unsigned)(s >> 1) & 1u), m1 = 0u - ((unsigned)s & 1u);
+        unsigned W1[11];
         float F[10];
 #pragma unroll
-        for (int i = 0; i < 14; ++i) W1[i] = (W[i + 4] & m4) | (W[i] & ~m4);
-#pragma unroll
-        for (int i = 0; i < 12; ++i) W2[i] = (W1[i + 2] & m2) | (W1[i] & ~m2);
-        // padding rows inside the last block row (hl % 8 != 0) hold unspecified data: clear rows >= hl
+        for (int i = 0; i < 11; ++i) W1[i] = (W[i + 2] & m2) | (W[i] & ~m2);
+        // padding rows inside the last block row (hl % 4 != 0) hold unspecified data: clear rows >= hl
         const int nvalid = g_hl[l] - ys;                  // rows b < nvalid are inside the level (b < -ys: dropped loads read 0)
 #pragma unroll
         for (int i = 0; i < 10; ++i) {
-            const unsigned d = (W2[i + 1] & m1) | (W2[i] & ~m1);
+            const unsigned d = (W1[i + 1] & m1) | (W1[i] & ~m1);
             F[i] = __builtin_bit_cast(float, (i < nvalid) ? d : 0u);
         }
         const float wy1 = fy, wy0 = 1.f - fy, wx1 = fx, wx0 = 1.f - fx;

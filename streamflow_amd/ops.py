@@ -1234,7 +1234,7 @@ def corr_lookup(lvls: Sequence[torch.Tensor], lvl_pair_stride: Optional[Sequence
 @dataclass(frozen=True)
 class BlockedVolume:
     """Correlation pyramids of `n_img` images in the blocked layout (one buffer): fp16 cells in 8 x 8-cell blocks
-    (csrc/corr_blocked.hip) or, `f32`, fp32 cells in 8-row x 4-column blocks (csrc/corr_blocked32.hip)."""
+    (csrc/corr_blocked.hip) or, `f32`, fp32 cells in 4-row x 8-column blocks (csrc/corr_blocked32.hip)."""
     buf: torch.Tensor          # uint8
     img_stride: int            # bytes
     n_img: int
@@ -1245,19 +1245,19 @@ class BlockedVolume:
     nby: tuple
     nbx: tuple
     src_rows: int              # records per image (h*w rounded up to 128)
-    f32: bool = False          # fp32 cells, 8 x 4 blocks
+    f32: bool = False          # fp32 cells, blocks of 4 rows x 8 columns
 
     def levels(self):
         """The four levels as [n_img, h*w, hl, wl] tensors of the cell type (copies; tests and API parity only)."""
         N = self.h * self.w
-        bw = 4 if self.f32 else 8                                         # block columns
+        bh = 4 if self.f32 else 8                                         # block rows (8 columns either way)
         out = []
         for l in range(4):
             hl, wl, nby, nbx = self.h >> l, self.w >> l, self.nby[l], self.nbx[l]
             blk = torch.as_strided(self.buf[self.off[l]:], (self.n_img, N, nby * nbx * 128), (self.img_stride, self.rec, 1))
             blk = blk.contiguous().view(torch.float32 if self.f32 else torch.float16)
-            blk = blk.view(self.n_img, N, nby, nbx, bw, 8)                # [by][bx][tx % bw][ty % 8]
-            out.append(blk.permute(0, 1, 2, 5, 3, 4).reshape(self.n_img, N, nby * 8, nbx * bw)[:, :, :hl, :wl].contiguous())
+            blk = blk.view(self.n_img, N, nby, nbx, 8, bh)                # [by][bx][tx % 8][ty % bh]
+            out.append(blk.permute(0, 1, 2, 5, 3, 4).reshape(self.n_img, N, nby * bh, nbx * 8)[:, :, :hl, :wl].contiguous())
         return out
 
 

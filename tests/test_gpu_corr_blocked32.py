@@ -26,7 +26,7 @@ def _coords(orc, B, h, w, g, scale=4.0):
     c[:, :, 3, 3] = torch.tensor([float(w - 1), float(h - 1)])       # last cell
     c[:, :, 4, 4] = torch.tensor([float("nan"), 1.0])                # swallowed: samples zero padding
     c[:, :, 5, 5] = torch.tensor([3.0, float(h) - 0.5])              # footprint crosses the padded last block row
-    c[:, :, 6, 6] = torch.tensor([5.25, 11.75])                      # ys % 8 == 7: the two-row third piece
+    c[:, :, 6, 6] = torch.tensor([5.25, 11.75])                      # ys % 4 == 3: the one-row fourth piece
     return c
 
 
