@@ -539,6 +539,10 @@ def main():
     if cfg["precision"] == "fp32" and cfg["gma_mode"] == "flash":
         cfg["gma_mode"] = "auto"                       # the exact fp32 mode keeps the materialised attention path
     args.precision, args.corr_dtype = cfg["precision"], cfg["corr_dtype"]
+    if args.corr_layout == "rows":                      # fp32 volumes as the reference's row-major maps (A/B of csrc/corr_blocked32.hip)
+        from dataclasses import replace as _replace
+        from streamflow_amd.engine import EngineOptions
+        cfg["options"] = _replace(cfg.get("options") or EngineOptions(), corr_blocked32=False)
 
     H, W, T, iters = WORKLOADS[args.workload]
     h, w, B = H // 8, W // 8, args.clips

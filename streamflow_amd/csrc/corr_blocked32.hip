@@ -67,6 +67,9 @@ __device__ __forceinline__ float dpp_xor2(float v) {     // lane ^ 2 (quad_perm 
 __device__ __forceinline__ float dpp_shl4(float v) {     // lane + 4 inside a row of 16 (row_shl:4)
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x104, 0xF, 0xF, true));
 }
+__device__ __forceinline__ float swz_xor16(float v) {    // lane ^ 16 (ds_swizzle bit mode: and 0x1F, or 0, xor 0x10)
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));
+}
 __device__ __forceinline__ float dpp_shl1(float v) {     // lane + 1 inside a row of 16 (row_shl:1)
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x101, 0xF, 0xF, true));
 }
@@ -74,7 +77,7 @@ __device__ __forceinline__ float dpp_shl1(float v) {     // lane + 1 inside a ro
 // ------------------------------------------------------------------------------------------------
 // build
 // ------------------------------------------------------------------------------------------------
-constexpr int BM = 128;          // source pixels per workgroup (4 waves x 32)
+constexpr int BM = 128;          // source pixels per workgroup (2 x 2 waves of 64 sources x 128 targets)
 constexpr int PR = 8, PC = 32;   // target patch: 8 rows x 32 columns = two block rows of four blocks
 constexpr int BN = PR * PC;
 constexpr int DK = 16;                              // k per stage
@@ -132,14 +135,21 @@ __device__ __forceinline__ TileId build_tile(const Build32Args& g, int id) {
     return t;
 }
 
+// One workgroup = 128 source pixels x one target patch of 8 rows x 32 columns; wave (wm, wn) = 64 sources x 128 targets (columns
+// 16 wn .. 16 wn + 15 of the patch): 2 x 4 accumulator tiles of 32 x 32.  Per k-step a wave reads 4 A + 8 B fragments for 24 MFMAs;
+// the first form (wave = 32 sources x the whole patch: 2 + 16 fragments) asked 96 of the LDS's 128 bytes per clock at full MFMA rate
+// on top of the DMA's writes -- its main loop alone ran 626 us per KITTI build for 334 us of MFMA issue.
+// MFMA column j of N-tile nt = target (row 4 (j >> 4) + nt, column 16 wn + (j & 15)): a lane's four tiles of one register are the four
+// rows of one 16-byte block column of level 0.
 __global__ __launch_bounds__(kThreads, 3) void corr_build_blocked32_kernel(const Build32Args g, const char* ws) {
     __shared__ __attribute__((aligned(1024))) char smem[NSTAGE * STAGE];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
     const int khalf = lane >> 5, l31_ = lane & 31;
     const TileId tile = build_tile(g, sf::xcd_linear_id(blockIdx.x, gridDim.x));
     const int m0 = tile.m_tile * BM;
-    const int pyb = tile.patch / g.pcols, pxb = tile.patch % g.pcols;          // patch origin: block row pyb, columns 32 pxb ..
+    const int pyb = tile.patch / g.pcols, pxb = tile.patch % g.pcols;          // patch origin: rows 8 pyb .., columns 32 pxb ..
     const int py0 = pyb * PR, px0 = pxb * PC;
     const int half = (g.Dp / 8) * g.N * 16;                     // bytes of one hi (or lo) plane (< 2 GiB, host-checked)
     const char* imgA = ws + (int64_t)(tile.img * 2 + 0) * 2 * half;
@@ -148,7 +158,9 @@ __global__ __launch_bounds__(kThreads, 3) void corr_build_blocked32_kernel(const
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(imgB), 0, 2 * half, 0x00020000);
     // per-thread source offsets (pixels / patch cells past the image are clamped: their products land in padding cells / records)
     const int voa = ((tid >> 7) * g.N + min(m0 + (tid & 127), g.N - 1)) * 16;          // slot = kq * 128 + px = tid
-    const int vob = (min(py0 + tid / PC, g.h - 1) * g.w + min(px0 + tid % PC, g.w - 1)) * 16;   // slot = kq * 256 + cell
+    // B slot tid = wn * 128 + nt * 32 + j  ->  target (4 (j >> 4) + nt, 16 wn + (j & 15)) of the patch
+    const int bty = 4 * ((tid >> 4) & 1) + ((tid >> 5) & 3), btx = 16 * (tid >> 7) + (tid & 15);
+    const int vob = (min(py0 + bty, g.h - 1) * g.w + min(px0 + btx, g.w - 1)) * 16;
     const int kq_step = g.N * 16;
     auto issue = [&](int kt, int buf) {
         char* sb = smem + buf * STAGE + wave * 1024;
@@ -160,14 +172,21 @@ __global__ __launch_bounds__(kThreads, 3) void corr_build_blocked32_kernel(const
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr)(sb + 2 * ST_A + ST_B), 16, vob + half, so, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr)(sb + 2 * ST_A + ST_B + 4096), 16, vob + half, so + kq_step, 0, 0);
     };
-    f32x16 acc[PR];
+    constexpr int MT = 2, NT = 4;
+    f32x16 acc[MT][NT];
 #pragma unroll
-    for (int t = 0; t < PR; ++t)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][t][r] = 0.f;
+#if defined(SF_CORRB32_ABLATE) && SF_CORRB32_ABLATE == 2     // timing ablation: one k-stage only (the epilogue alone)
+    const int nk = 1;
+#else
     const int nk = g.Dp / DK;
-    const int offa = (khalf * BM + wave * 32 + l31_) * 16;
-    const int offb = 2 * ST_A + (khalf * BN + l31_) * 16;
+#endif
+    const int offa = (khalf * BM + wm * 64 + l31_) * 16;
+    const int offb = 2 * ST_A + (khalf * BN + wn * 128 + l31_) * 16;
     issue(0, 0);
     int cur = 0, nxt = NSTAGE - 1;
     for (int kt = 0; kt < nk; ++kt) {
@@ -177,95 +196,106 @@ __global__ __launch_bounds__(kThreads, 3) void corr_build_blocked32_kernel(const
         const char* sb = smem + cur * STAGE;
         cur = (cur == NSTAGE - 1) ? 0 : cur + 1;
         nxt = (nxt == NSTAGE - 1) ? 0 : nxt + 1;
-        const f16x8 ah = *reinterpret_cast<const f16x8*>(sb + offa);
-        const f16x8 al = *reinterpret_cast<const f16x8*>(sb + offa + ST_A);
+        f16x8 ah[MT], al[MT];
 #pragma unroll
-        for (int t = 0; t < PR; ++t) {
-            const f16x8 bh = *reinterpret_cast<const f16x8*>(sb + offb + t * PC * 16);
-            const f16x8 bl = *reinterpret_cast<const f16x8*>(sb + offb + ST_B + t * PC * 16);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t], 0, 0, 0);
+        for (int mt = 0; mt < MT; ++mt) {
+            ah[mt] = *reinterpret_cast<const f16x8*>(sb + offa + mt * 512);
+            al[mt] = *reinterpret_cast<const f16x8*>(sb + offa + mt * 512 + ST_A);
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const f16x8 bh = *reinterpret_cast<const f16x8*>(sb + offb + t * 512);
+            const f16x8 bl = *reinterpret_cast<const f16x8*>(sb + offb + ST_B + t * 512);
+            // (per accumulator the order of the three products is the one of csrc/corr.hip's f16x3 build: al bh, ah bl, ah bh)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh, acc[mt][t], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl, acc[mt][t], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh, acc[mt][t], 0, 0, 0);
         }
     }
 
-    // ---- epilogue.  C/D layout: lane = (MFMA column l31 = patch column, k-half), register r = source row (r & 3) + 8 (r >> 2) + 4 khalf,
-    // acc[t] = patch row t: a lane's eight values of one register are one 32-byte block column of level 0 (csrc/corr_blocked.hip) ----
-    int c = l31_;
-    asm volatile("" : "+v"(c));                                  // (per-lane store offsets are not loop invariants of the k-loop)
+    // ---- epilogue.  C/D layout: lane = (MFMA column l31 = (row half th, patch column c), k-half), register r of tile (mt, nt) = source row
+    // 32 mt + (r & 3) + 8 (r >> 2) + 4 khalf, target row 4 th + nt ----
+    int l31 = l31_;
+    asm volatile("" : "+v"(l31));                                // (per-lane store offsets are not loop invariants of the k-loop)
+    const int c = l31 & 15, th = l31 >> 4;
     const int rec = g.g.rec;
-    const int i0 = m0 + wave * 32;                               // first source pixel of the wave (records are padded to 128 sources)
+    const int i0 = m0 + wm * 64;                                 // first source pixel of the wave (records are padded to 128 sources)
     const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(
-        g.vol + (int64_t)tile.img * g.vol_img_stride + (int64_t)i0 * rec, 0, 32 * rec, 0x00020000);
+        g.vol + (int64_t)tile.img * g.vol_img_stride + (int64_t)i0 * rec, 0, 64 * rec, 0x00020000);
     const int rowh = 4 * khalf * rec;
-    const int tx0 = px0 + c;
-    // level 0: rows 0..3 of the patch = block row 2 pyb, rows 4..7 = block row 2 pyb + 1; lanes = consecutive 16-byte block columns
-    const bool c0 = (tx0 >> 3) < g.g.nbx[0];
-    const int a0 = rowh + g.g.off[0] + 2 * pyb * g.g.nbx[0] * 128 + tx0 * 16;
-    const int vo0a = (c0 && 2 * pyb < g.g.nby[0]) ? a0 : kDrop;
-    const int vo0b = (c0 && 2 * pyb + 1 < g.g.nby[0]) ? a0 + g.g.nbx[0] * 128 : kDrop;
-    // level 1: lane pair (2 j, 2 j + 1) holds level-1 column tx1 after the horizontal step, four rows = one block column of level-1
-    // block row pyb: a 16-byte piece; lane parity k1 stores source row (2 jp + k1) of a register pair
+    const int tx0 = px0 + 16 * wn + c;
+    // level 0: the lane's four rows = one 16-byte block column of block row 2 pyb + th; 16 lanes = 256 contiguous bytes
+    const int by0 = 2 * pyb + th;
+    const int vo0 = (by0 < g.g.nby[0] && (tx0 >> 3) < g.g.nbx[0]) ? rowh + g.g.off[0] + by0 * g.g.nbx[0] * 128 + tx0 * 16 : kDrop;
+    // level 1: lane pair (2 j, 2 j + 1) holds level-1 column tx1 after the horizontal step, rows 2 th, 2 th + 1 of level-1 block row pyb:
+    // an 8-byte piece (lanes l and l + 16 of one instruction complete the 16-byte column); lane parity k1 stores source row 2 jp + k1
     const int k1 = c & 1, tx1 = tx0 >> 1;
-    const int vo1 = (pyb < g.g.nby[1] && (tx1 >> 3) < g.g.nbx[1]) ? rowh + k1 * rec + g.g.off[1] + pyb * g.g.nbx[1] * 128 + tx1 * 16 : kDrop;
-    // level 2: lane quad = level-2 column tx2, rows 2 (pyb & 1) .. + 1 of block row pyb >> 1 (8 bytes); lane k2 stores source row k2
+    const int vo1 = (pyb < g.g.nby[1] && (tx1 >> 3) < g.g.nbx[1])
+                        ? rowh + k1 * rec + g.g.off[1] + pyb * g.g.nbx[1] * 128 + tx1 * 16 + th * 8 : kDrop;
+    // level 2: lane quad = level-2 column tx2, row 2 (pyb & 1) + th of block row pyb >> 1 (4 bytes); lane k2 stores source row k2
     const int k2 = c & 3, tx2 = tx0 >> 2, by2 = pyb >> 1;
     const int vo2 = (by2 < g.g.nby[2] && (tx2 >> 3) < g.g.nbx[2])
-                        ? rowh + k2 * rec + g.g.off[2] + by2 * g.g.nbx[2] * 128 + tx2 * 16 + (pyb & 1) * 8 : kDrop;
-    // level 3: lanes 0..3 of an octet hold level-3 column tx3, row pyb & 3 of block row pyb >> 2 (4 bytes)
+                        ? rowh + k2 * rec + g.g.off[2] + by2 * g.g.nbx[2] * 128 + tx2 * 16 + (2 * (pyb & 1) + th) * 4 : kDrop;
+    // level 3: lanes 0..3 of an octet of the upper row half hold level-3 column tx3, row pyb & 3 of block row pyb >> 2 (4 bytes)
     const int k3 = c & 7, tx3 = tx0 >> 3, by3 = pyb >> 2;
-    const int vo3 = (k3 < 4 && by3 < g.g.nby[3] && (tx3 >> 3) < g.g.nbx[3])
+    const int vo3 = (th == 0 && k3 < 4 && by3 < g.g.nby[3] && (tx3 >> 3) < g.g.nbx[3])
                         ? rowh + k3 * rec + g.g.off[3] + by3 * g.g.nbx[3] * 128 + tx3 * 16 + (pyb & 3) * 4 : kDrop;
+#if defined(SF_CORRB32_ABLATE) && (SF_CORRB32_ABLATE == 1 || SF_CORRB32_ABLATE == 3)   // timing ablations: no pooled-level stores
+#define SF_VO(x) (kDrop | ((x) & 0))
+#else
+#define SF_VO(x) (x)
+#endif
+#if defined(SF_CORRB32_ABLATE) && SF_CORRB32_ABLATE == 1     // ... no store at all leaves the CU (the main loop alone)
+#define SF_VO0(x) (kDrop | ((x) & 0))
+#else
+#define SF_VO0(x) (x)
+#endif
 #pragma unroll
-    for (int rq = 0; rq < 4; ++rq) {                       // register group: source rows 8 rq + 4 khalf + (0..3)
-        float sel2[2] = {0.f, 0.f}, sel3 = 0.f;
+    for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-        for (int jp = 0; jp < 2; ++jp) {                   // register pair (2 jp, 2 jp + 1) of the group
-            float sel1[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int rq = 0; rq < 4; ++rq) {                   // register group: source rows 32 mt + 8 rq + 4 khalf + (0..3)
+            float sel2 = 0.f, sel3 = 0.f;
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int ri = 2 * jp + u, r = 4 * rq + ri;
-                float v0[PR];
+            for (int jp = 0; jp < 2; ++jp) {               // register pair (2 jp, 2 jp + 1) of the group
+                float sel1[2] = {0.f, 0.f};
 #pragma unroll
-                for (int t = 0; t < PR; ++t) v0[t] = acc[t][r] * g.scale;
-                u32x4 oa, ob;
+                for (int u = 0; u < 2; ++u) {
+                    const int ri = 2 * jp + u, r = 4 * rq + ri;
+                    float v0[NT];
+                    u32x4 o0;
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    oa[t] = __builtin_bit_cast(unsigned, v0[t]);
-                    ob[t] = __builtin_bit_cast(unsigned, v0[4 + t]);
+                    for (int t = 0; t < NT; ++t) {
+                        v0[t] = acc[mt][t][r] * g.scale;
+                        o0[t] = __builtin_bit_cast(unsigned, v0[t]);
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b128(o0, rv, SF_VO0(vo0), (32 * mt + ri + 8 * rq) * rec, 2);
+                    // (gfx950: a VALU write to the data registers of a > 64-bit buffer store with an SGPR soffset in the very next issue
+                    // slots corrupts the stored data -- csrc/corr_blocked.hip; pad by hand, tied to the data registers)
+                    asm volatile("s_nop 1" : "+v"(o0) : : "memory");
+                    float v1[2];
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const float sm = v0[2 * t] + v0[2 * t + 1];
+                        v1[t] = 0.25f * (sm + dpp_xor1(sm));
+                        sel1[t] = (k1 == u) ? v1[t] : sel1[t];
+                    }
+                    const float s2 = v1[0] + v1[1];
+                    const float v2 = 0.25f * (s2 + dpp_xor2(s2));
+                    sel2 = (k2 == ri) ? v2 : sel2;
+                    const float s3 = v2 + swz_xor16(v2);               // the other row half: level-2 rows 2 j, 2 j + 1
+                    const float v3 = 0.25f * (s3 + dpp_shl4(s3));
+                    sel3 = (k3 == ri) ? v3 : sel3;
                 }
-                __builtin_amdgcn_raw_buffer_store_b128(oa, rv, vo0a, (ri + 8 * rq) * rec, 2);
-                __builtin_amdgcn_raw_buffer_store_b128(ob, rv, vo0b, (ri + 8 * rq) * rec, 2);
-                // (gfx950: a VALU write to the data registers of a > 64-bit buffer store with an SGPR soffset in the very next issue slots
-                // corrupts the stored data -- csrc/corr_blocked.hip; pad by hand, tied to the data registers)
-                asm volatile("s_nop 1" : "+v"(oa), "+v"(ob) : : "memory");
-                float v1[4], v2[2];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const float sm = v0[2 * t] + v0[2 * t + 1];
-                    v1[t] = 0.25f * (sm + dpp_xor1(sm));
-                    sel1[t] = (k1 == u) ? v1[t] : sel1[t];
-                }
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const float sm = v1[2 * t] + v1[2 * t + 1];
-                    v2[t] = 0.25f * (sm + dpp_xor2(sm));
-                    sel2[t] = (k2 == ri) ? v2[t] : sel2[t];
-                }
-                const float sm = v2[0] + v2[1];
-                const float v3 = 0.25f * (sm + dpp_shl4(sm));
-                sel3 = (k3 == ri) ? v3 : sel3;
+                u32x2 o1;
+                o1[0] = __builtin_bit_cast(unsigned, sel1[0]); o1[1] = __builtin_bit_cast(unsigned, sel1[1]);
+                __builtin_amdgcn_raw_buffer_store_b64(o1, rv, SF_VO(vo1), (32 * mt + 2 * jp + 8 * rq) * rec, 0);
             }
-            u32x4 o1;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) o1[t] = __builtin_bit_cast(unsigned, sel1[t]);
-            __builtin_amdgcn_raw_buffer_store_b128(o1, rv, vo1, (2 * jp + 8 * rq) * rec, 0);
-            asm volatile("s_nop 1" : "+v"(o1) : : "memory");
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, sel2), rv, SF_VO(vo2), (32 * mt + 8 * rq) * rec, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, sel3), rv, SF_VO(vo3), (32 * mt + 8 * rq) * rec, 0);
         }
-        u32x2 o2;
-        o2[0] = __builtin_bit_cast(unsigned, sel2[0]); o2[1] = __builtin_bit_cast(unsigned, sel2[1]);
-        __builtin_amdgcn_raw_buffer_store_b64(o2, rv, vo2, (8 * rq) * rec, 0);
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, sel3), rv, vo3, (8 * rq) * rec, 0);
     }
 }
 
@@ -416,7 +446,7 @@ extern "C" int sf_corr_build_blocked32(const float* f1, const float* f2, int64_t
     g.N = h * w; g.h = h; g.w = w; g.n_img = n_img;
     g.Dp = sf::ceil_div(D, 32) * 32;
     SF_REQUIRE((int64_t)g.Dp * g.N * 4 < ((int64_t)1 << 31), "sf_corr_build_blocked32: feature image larger than 2 GiB");
-    SF_REQUIRE((int64_t)32 * g.g.rec < ((int64_t)1 << 31), "sf_corr_build_blocked32: feature grid %dx%d too large", h, w);
+    SF_REQUIRE((int64_t)64 * g.g.rec < ((int64_t)1 << 31), "sf_corr_build_blocked32: feature grid %dx%d too large", h, w);
     SF_REQUIRE(ws_bytes >= sf_corr_build_blocked32_ws_bytes(n_img, D, h, w) && (reinterpret_cast<uintptr_t>(ws) & 15) == 0,
                "sf_corr_build_blocked32: needs a 16-byte aligned workspace of sf_corr_build_blocked32_ws_bytes() bytes");
     SF_REQUIRE((reinterpret_cast<uintptr_t>(vol) & 127) == 0 && (vol_img_stride_bytes & 127) == 0 &&

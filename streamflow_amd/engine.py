@@ -38,6 +38,7 @@ class EngineOptions:
     attn_chunk_rows: int = 0         # > 0 forces the chunked recompute of the attention matrix
     attn_k_splits: int = 3           # split-K of attn @ v (materialised matrix), <= 4
     corr_blocked: bool = True        # fp16 volumes in the blocked layout (k-octet-only hand-over of the correlation features)
+    corr_blocked32: bool = True      # fp32 volumes in cache-line blocks of 4 rows x 8 columns (csrc/corr_blocked32.hip) instead of row-major maps
     shadows: bool = True             # fp16 k-octet copies of the SK blocks' inputs
     shadow_fused: bool = True        # ... written by their producers' epilogues instead of a pack pass
     hidden_f16: bool = True          # GEMM-to-GEMM tensors as fp16 in the f16x2 / f16 modes
@@ -295,7 +296,7 @@ class _Plan:
     def __init__(self, W: HotPathWeights, Bc: int, h: int, w: int, D: int, device, attn_chunk_rows: int = 0,
                  attn_f16: bool = False, corr_f16: bool = False, flash: Optional[bool] = None, shadows: bool = False,
                  corr_blocked: bool = False, koct_io: bool = False, stored_p: bool = False, stored_p_max_bytes: int = 0,
-                 stored_frac: float = 1.0):
+                 stored_frac: float = 1.0, corr_blocked32: bool = False):
         Pn = W.pairs
         n, P = Bc * Pn, h * w
         self.Bc, self.Pn, self.h, self.w, self.n, self.P, self.D = Bc, Pn, h, w, n, P, D
@@ -312,7 +313,14 @@ class _Plan:
         # blocked fp16 volumes (csrc/corr_blocked.hip): one buffer, 8 x 8-cell blocks = cache lines; the lookup then hands
         # the correlation features over as fp16 k-octets ONLY (operand and residual of convc1's first block)
         self.corr_blocked = bool(corr_blocked and corr_f16 and shadows)
-        if self.corr_blocked:
+        # blocked fp32 volumes (csrc/corr_blocked32.hip): same idea with 4-row x 8-column blocks; the features leave as fp32 planes
+        self.corr_blocked32 = bool(corr_blocked32 and not corr_f16)
+        if self.corr_blocked32:
+            self.vol = ops.new_blocked_volume(n, h, w, device, f32=True)
+            self.lvls = None
+            self.corr_pitch = None
+            self.corr_ws = torch.empty(max(ops.corr_build_blocked_ws_bytes(n, D, h, w, True), 16), dtype=torch.uint8, device=device)
+        elif self.corr_blocked:
             self.vol = ops.new_blocked_volume(n, h, w, device)
             self.lvls = None
             self.corr_ws = torch.empty(max(ops.corr_build_blocked_ws_bytes(n, D, h, w), 16), dtype=torch.uint8, device=device)
@@ -414,10 +422,11 @@ class _Plan:
 
 def _level_maps(self, l: int) -> torch.Tensor:
     """Level l of the row-major volumes as [pairs, clips * N, h_l, w_l] -- per pair the reference's corr_pyramid[l] (corr.py:13-21)
-    without its singleton dimension -- a strided VIEW of the (possibly row-pitched, _Plan.corr_pitch) storage."""
-    if self.lvls is None:
-        raise RuntimeError("level_maps: blocked volumes (use plan.vol.levels())")
+    without its singleton dimension -- a strided VIEW of the (possibly row-pitched, _Plan.corr_pitch) storage; a copy for blocked volumes."""
     hl, wl = self.h >> l, self.w >> l
+    if self.lvls is None:                      # blocked volumes (image = clip * pairs + pair): a row-major COPY, tests only
+        t = self.vol.levels()[l].view(self.Bc, self.Pn, self.P, hl, wl)
+        return t.permute(1, 0, 2, 3, 4).reshape(self.Pn, self.Bc * self.P, hl, wl)
     pit = self.corr_pitch[l] if self.corr_pitch else wl
     return self.lvls[l].view(self.Pn, self.Bc * self.P, hl, pit)[..., :wl]
 
@@ -453,6 +462,7 @@ class HotPathEngine:
         # fp16 volumes in the blocked layout (+ k-octet-only hand-over of the correlation features) wherever the f16x2 / f16
         # hand-over formats are active; options.corr_blocked = False keeps the row-major fp16 volumes
         self.corr_blocked = self.corr_f16 and self.options.corr_blocked
+        self.corr_blocked32 = (not self.corr_f16) and self.options.corr_blocked32
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("HotPathEngine needs an MI355X device (cuda:N); there is no CPU fallback")
@@ -539,7 +549,7 @@ class HotPathEngine:
                        flash=flash, shadows=(self.options.shadows and (h * w) % 4 == 0 and
                                              self.precision in (ops.PRECISION_F16X2, ops.PRECISION_F16) and
                                              self.options.hidden_f16),
-                       corr_blocked=self.corr_blocked,
+                       corr_blocked=self.corr_blocked, corr_blocked32=self.corr_blocked32,
                        koct_io=self.options.koct_io and self.options.hidden_koct,   # (k-octet-only blocks need k-octet producers)
                        stored_p=((self.gma_mode in ("stored", "hybrid") or auto_stored) and self.options.flash_stats),
                        stored_frac=(1.0 if (self.gma_mode == "stored" or auto_stored) else float(self.options.hybrid_store_pct) / 100.0),
@@ -608,7 +618,7 @@ class HotPathEngine:
             elif pl.attn_rows == P:
                 self._attention_rows(cs, pl, 0, P)
         # a1+a2: all pairs, one launch.  pair t = (frame t, frame t+1)
-        if pl.corr_blocked:
+        if pl.corr_blocked or pl.corr_blocked32:
             ops.corr_build_blocked(fmaps.data_ptr(), fmaps.data_ptr() + 4 * D * P, T * D * P, D * P, pl.vol, Bc, Pn, D,
                                    ws=pl.corr_ws)
         else:
@@ -647,6 +657,9 @@ class HotPathEngine:
         # ... while the main stream does a3 (correlation lookup for all pairs, streamflow.py:132) and the corr branch
         if pl.corr_blocked:
             ops.corr_lookup_blocked(pl.vol, pl.coords1, None, pl.corr, Bc, Pn)
+        elif pl.corr_blocked32:
+            ops.corr_lookup_blocked(pl.vol, pl.coords1, replace(pl.corr, shadow=None), None, Bc, Pn)
+            ops.refresh_shadow(pl.corr, cx)
         else:
             ops.corr_lookup(pl.lvls, pl.lvl_pair_stride, pl.coords1, pl.corr, Bc, Pn, h, w, cx=cx, pitch=pl.corr_pitch)
         # image ranges of the chains: whole clips when the clip count divides, else (a single clip, an odd batch) two
