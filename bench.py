@@ -359,6 +359,8 @@ def corr_only(args, dev, cfg, H, W, T, iters):
     g = torch.Generator().manual_seed(7)
     ys, xs = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing="ij")
     grid = torch.stack([xs, ys])[None]                                        # (x, y) like coords_grid (utils.py)
+    if args.corr_lookups >= 0:                      # experiments: a different build : lookup ratio (0 = builds alone)
+        iters = args.corr_lookups
     coords = [Planes.of((grid + 4.0 * torch.randn(n, 2, h, w, generator=g)).reshape(n, 2, N).contiguous().to(dev))
               for _ in range(iters)]
     out = Planes.of(torch.empty(n, 324, N, device=dev))
@@ -391,8 +393,8 @@ def corr_only(args, dev, cfg, H, W, T, iters):
     step()
     prof = ops.PROFILER.summary()
     ops.PROFILER = None
-    b, l = prof["corr_build"], prof["corr_lookup"]
-    gb = lambda d: d["bytes"] / d["ms"] / 1e6
+    b, l = prof["corr_build"], prof.get("corr_lookup", {"bytes": 0.0, "ms": 0.0, "launches": 1})
+    gb = lambda d: d["bytes"] / d["ms"] / 1e6 if d["ms"] else 0.0
     tot_bytes, tot_ms = b["bytes"] + l["bytes"], b["ms"] + l["ms"]
     cell = 2 if f16 else 4
     return {
@@ -472,6 +474,7 @@ def main():
                          "and exits before touching the GPU (tests/test_distributed_cpu.py)")
     ap.add_argument("--dense-volumes", action="store_true",
                     help="--corr-only, fp32 volumes: keep the reference's dense [N, h_l, w_l] maps instead of line-aligned row pitches")
+    ap.add_argument("--corr-lookups", type=int, default=-1, help="--corr-only: lookups per step (default: the workload's iterations)")
     ap.add_argument("--corr-layout", default="blocked", choices=["blocked", "rows"],
                     help="fp32 volumes (--corr-only and the fp32_class engine): cache-line blocks (csrc/corr_blocked32.hip) or the "
                          "reference's row-major maps with line-aligned row pitches (csrc/corr.hip)")

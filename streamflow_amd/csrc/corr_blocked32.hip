@@ -84,7 +84,13 @@ constexpr int DK = 16;                              // k per stage
 constexpr int ST_A = (DK / 8) * BM * 16;            // bytes of the A_hi (= A_lo) part of a stage
 constexpr int ST_B = (DK / 8) * BN * 16;            // bytes of B_hi (= B_lo)
 constexpr int STAGE = 2 * ST_A + 2 * ST_B;          // 24576
-constexpr int NSTAGE = 2;
+#ifndef SF_CORRB32_NSTAGE
+#define SF_CORRB32_NSTAGE 2
+#endif
+#ifndef SF_CORRB32_WGS
+#define SF_CORRB32_WGS 3                            // workgroups per CU the register / LDS budget is sized for
+#endif
+constexpr int NSTAGE = SF_CORRB32_NSTAGE;
 
 struct Build32Args {
     char* vol;
@@ -139,9 +145,13 @@ __device__ __forceinline__ TileId build_tile(const Build32Args& g, int id) {
 // 16 wn .. 16 wn + 15 of the patch): 2 x 4 accumulator tiles of 32 x 32.  Per k-step a wave reads 4 A + 8 B fragments for 24 MFMAs;
 // the first form (wave = 32 sources x the whole patch: 2 + 16 fragments) asked 96 of the LDS's 128 bytes per clock at full MFMA rate
 // on top of the DMA's writes -- its main loop alone ran 626 us per KITTI build for 334 us of MFMA issue.
+// Measured (KITTI, 8 pairs): 870-900 us per build; epilogue alone 500 us (2.5 GB written: 4.7 TB/s), k-loops alone 610 us, of
+// which operand DMA alone 310 us and fragment reads + MFMA alone 440 us -- at 1.64 GHz: a loop of builds holds the package at its 1400 W cap
+// (1.97 GHz), the MFMA-only variant is clock-limited further.  Three stages / two workgroups per CU, and a pseudo-random start stagger of the
+// first round of workgroups (against lockstep of k-loops and epilogues) measured the same or worse.
 // MFMA column j of N-tile nt = target (row 4 (j >> 4) + nt, column 16 wn + (j & 15)): a lane's four tiles of one register are the four
 // rows of one 16-byte block column of level 0.
-__global__ __launch_bounds__(kThreads, 3) void corr_build_blocked32_kernel(const Build32Args g, const char* ws) {
+__global__ __launch_bounds__(kThreads, SF_CORRB32_WGS) void corr_build_blocked32_kernel(const Build32Args g, const char* ws) {
     __shared__ __attribute__((aligned(1024))) char smem[NSTAGE * STAGE];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -187,15 +197,25 @@ __global__ __launch_bounds__(kThreads, 3) void corr_build_blocked32_kernel(const
 #endif
     const int offa = (khalf * BM + wm * 64 + l31_) * 16;
     const int offb = 2 * ST_A + (khalf * BN + wn * 128 + l31_) * 16;
-    issue(0, 0);
+#pragma unroll
+    for (int s0 = 0; s0 < NSTAGE - 1; ++s0)
+        if (s0 < nk) issue(s0, s0);
     int cur = 0, nxt = NSTAGE - 1;
     for (int kt = 0; kt < nk; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's 6 pieces of stage kt have landed ...
+        // this wave's 6 pieces of stage kt have landed (the NSTAGE - 2 newer stages may still be in flight) ...
+        if (NSTAGE == 2 || kt + NSTAGE - 2 >= nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (NSTAGE == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
         __builtin_amdgcn_s_barrier();                           // ... everyone's; and slot nxt (stage kt - 1) is no longer read
+#if !(defined(SF_CORRB32_ABLATE) && SF_CORRB32_ABLATE == 4)   // timing ablation 4: no operand loads after the prologue (+ no stores)
         if (kt + NSTAGE - 1 < nk) issue(kt + NSTAGE - 1, nxt);
+#endif
         const char* sb = smem + cur * STAGE;
         cur = (cur == NSTAGE - 1) ? 0 : cur + 1;
         nxt = (nxt == NSTAGE - 1) ? 0 : nxt + 1;
+#if defined(SF_CORRB32_ABLATE) && SF_CORRB32_ABLATE == 5      // timing ablation 5: operand loads only, no fragment reads / MFMA (+ no stores)
+        continue;
+#endif
         f16x8 ah[MT], al[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
@@ -243,12 +263,12 @@ __global__ __launch_bounds__(kThreads, 3) void corr_build_blocked32_kernel(const
     const int k3 = c & 7, tx3 = tx0 >> 3, by3 = pyb >> 2;
     const int vo3 = (th == 0 && k3 < 4 && by3 < g.g.nby[3] && (tx3 >> 3) < g.g.nbx[3])
                         ? rowh + k3 * rec + g.g.off[3] + by3 * g.g.nbx[3] * 128 + tx3 * 16 + (pyb & 3) * 4 : kDrop;
-#if defined(SF_CORRB32_ABLATE) && (SF_CORRB32_ABLATE == 1 || SF_CORRB32_ABLATE == 3)   // timing ablations: no pooled-level stores
+#if defined(SF_CORRB32_ABLATE) && (SF_CORRB32_ABLATE == 1 || SF_CORRB32_ABLATE >= 3)   // timing ablations: no pooled-level stores
 #define SF_VO(x) (kDrop | ((x) & 0))
 #else
 #define SF_VO(x) (x)
 #endif
-#if defined(SF_CORRB32_ABLATE) && SF_CORRB32_ABLATE == 1     // ... no store at all leaves the CU (the main loop alone)
+#if defined(SF_CORRB32_ABLATE) && (SF_CORRB32_ABLATE == 1 || SF_CORRB32_ABLATE >= 4)     // ... no store at all leaves the CU (the main loop alone)
 #define SF_VO0(x) (kDrop | ((x) & 0))
 #else
 #define SF_VO0(x) (x)
@@ -302,7 +322,14 @@ __global__ __launch_bounds__(kThreads, 3) void corr_build_blocked32_kernel(const
 // ------------------------------------------------------------------------------------------------
 // lookup
 // ------------------------------------------------------------------------------------------------
-constexpr int LP = 32;                          // source pixels per workgroup
+#ifndef SF_LOOK32_AUX
+#define SF_LOOK32_AUX 2                         // cache policy bits of the footprint loads (experiments: 1 = glc, 2 = slc, 3 = both)
+#endif
+#ifndef SF_LOOK32_LP
+#define SF_LOOK32_LP 32
+#endif
+constexpr int LP = SF_LOOK32_LP;                // source pixels per workgroup (8 threads each)
+constexpr int kLookThreads = LP * 8;
 constexpr int NCH = 324;
 constexpr int TROW = 325;                       // floats per pixel in the transpose buffer (odd: the read-back of 32 pixels is conflict-free)
 
@@ -316,7 +343,7 @@ struct Look32Args {
     Geom32 g;
 };
 
-__global__ __launch_bounds__(kThreads, 3) void corr_lookup_blocked32_kernel(const Look32Args a) {
+__global__ __launch_bounds__(kLookThreads, 768 / kLookThreads) void corr_lookup_blocked32_kernel(const Look32Args a) {
     __shared__ float T[LP * TROW];
     const int tid = threadIdx.x;
     const int grp = tid >> 4, c = tid & 15;               // 16 lanes per footprint: lane c = footprint column c (10 used)
@@ -327,7 +354,7 @@ __global__ __launch_bounds__(kThreads, 3) void corr_lookup_blocked32_kernel(cons
     float cxs[2], cys[2];
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
-        const int p = min(p0 + e * 16 + grp, a.N - 1);
+        const int p = min(p0 + e * (LP / 2) + grp, a.N - 1);
         cxs[e] = a.coords[((int64_t)img * 2 + 0) * a.N + p];
         cys[e] = a.coords[((int64_t)img * 2 + 1) * a.N + p];
     }
@@ -337,17 +364,25 @@ __global__ __launch_bounds__(kThreads, 3) void corr_lookup_blocked32_kernel(cons
         g_wl[l] = a.g.wl[l]; g_hl[l] = a.g.hl[l]; g_nby[l] = a.g.nby[l]; g_rowb[l] = a.g.nbx[l] * 128; g_off[l] = a.g.off[l];
         asm volatile("" : "+s"(g_wl[l]), "+s"(g_hl[l]), "+s"(g_nby[l]), "+s"(g_rowb[l]), "+s"(g_off[l]));
     }
+    // item it = (level it >> 1, pixel (it & 1) * 16 + grp).  ALL of a thread's 32 loads are issued before the first footprint is
+    // touched (104 VGPRs of data in flight: the kernel holds 3 waves per SIMD for its LDS anyway) -- memory-level parallelism is what a
+    // gather of cache lines that nobody else reads lives on
+    struct Item { int ys; float fx, fy; };
+    struct Foot { u32x4 w0, w1, w2; unsigned w3; };
+    Item q[8];
+    Foot f[8];
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {                      // item = (level it >> 1, pixel (it & 1) * 16 + grp)
-        const int l = it >> 1, e = it & 1, pix = e * 16 + grp;
+    for (int it = 0; it < 8; ++it) {
+        const int l = it >> 1, e = it & 1, pix = e * (LP / 2) + grp;
         const float inv = 1.0f / (float)(1 << l);
         float cx = cxs[e] * inv, cy = cys[e] * inv;
         if (!(cx > -1.0e6f && cx < 1.0e6f)) cx = -1.0e6f;     // (far out: zero padding only; also swallows NaN / inf)
         if (!(cy > -1.0e6f && cy < 1.0e6f)) cy = -1.0e6f;
         const float fx0 = floorf(cx), fy0 = floorf(cy);
         const int x0 = (int)fx0, y0 = (int)fy0;
-        const float fx = cx - fx0, fy = cy - fy0;
+        q[it].fx = cx - fx0; q[it].fy = cy - fy0;
         const int tx = x0 - 4 + c, ys = y0 - 4;
+        q[it].ys = ys;
         const bool col_ok = (c < 10) & ((unsigned)tx < (unsigned)g_wl[l]);
         const int byf = ys >> 2;
         const int col = pix * rec + g_off[l] + tx * 16;            // block bx = tx / 8, column tx % 8: (bx * 8 + tx % 8) * 16
@@ -356,17 +391,20 @@ __global__ __launch_bounds__(kThreads, 3) void corr_lookup_blocked32_kernel(cons
             return (col_ok & ((unsigned)by < (unsigned)g_nby[l])) ? col + by * g_rowb[l] : kDrop;
         };
         // rows 4 byf .. 4 byf + 12 of this column: three whole block columns + (when ys % 4 == 3) the first row of a fourth
-        const int s = ys & 3;
-        unsigned W[13];
-        {
-            const u32x4 w0 = __builtin_amdgcn_raw_buffer_load_b128(rv, piece(0), 0, 0);
-            const u32x4 w1 = __builtin_amdgcn_raw_buffer_load_b128(rv, piece(1), 0, 0);
-            const u32x4 w2 = __builtin_amdgcn_raw_buffer_load_b128(rv, piece(2), 0, 0);
-            const unsigned w3 = __builtin_amdgcn_raw_buffer_load_b32(rv, (s == 3) ? piece(3) : kDrop, 0, 0);
+        f[it].w0 = __builtin_amdgcn_raw_buffer_load_b128(rv, piece(0), 0, SF_LOOK32_AUX);
+        f[it].w1 = __builtin_amdgcn_raw_buffer_load_b128(rv, piece(1), 0, SF_LOOK32_AUX);
+        f[it].w2 = __builtin_amdgcn_raw_buffer_load_b128(rv, piece(2), 0, SF_LOOK32_AUX);
+        f[it].w3 = __builtin_amdgcn_raw_buffer_load_b32(rv, ((ys & 3) == 3) ? piece(3) : kDrop, 0, SF_LOOK32_AUX);
+    }
+    __builtin_amdgcn_sched_barrier(0);                     // (hipcc would sink every load next to its use)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { W[i] = w0[i]; W[4 + i] = w1[i]; W[8 + i] = w2[i]; }
-            W[12] = w3;
-        }
+    for (int it = 0; it < 8; ++it) {
+        const int l = it >> 1, pix = (it & 1) * (LP / 2) + grp;
+        const int ys = q[it].ys, s = ys & 3;
+        unsigned W[13];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { W[i] = f[it].w0[i]; W[4 + i] = f[it].w1[i]; W[8 + i] = f[it].w2[i]; }
+        W[12] = f[it].w3;
         // rows ys .. ys + 9 out of the 13: shift by s in two select steps (bit-select masks, v_bfi_b32: written as
         // `cond ? W[i + 2] : W[i]` hipcc turns the chain into a dynamically indexed array in SCRATCH memory -- csrc/corr_blocked.hip)
         const unsigned m2 = 0u - ((unsigned)(s >> 1) & 1u), m1 = 0u - ((unsigned)s & 1u);
@@ -381,7 +419,7 @@ __global__ __launch_bounds__(kThreads, 3) void corr_lookup_blocked32_kernel(cons
             const unsigned d = (W1[i + 1] & m1) | (W1[i] & ~m1);
             F[i] = __builtin_bit_cast(float, (i < nvalid) ? d : 0u);
         }
-        const float wy1 = fy, wy0 = 1.f - fy, wx1 = fx, wx0 = 1.f - fx;
+        const float wy1 = q[it].fy, wy0 = 1.f - q[it].fy, wx1 = q[it].fx, wx0 = 1.f - q[it].fx;
         float R[9];
 #pragma unroll
         for (int b = 0; b < 9; ++b) {                      // (all lanes: lane 9 supplies column 9 to lane 8 through the DPP shift)
@@ -397,7 +435,7 @@ __global__ __launch_bounds__(kThreads, 3) void corr_lookup_blocked32_kernel(cons
     __syncthreads();
     // ---- (channel, pixel): 32 consecutive pixels of a channel = 128 contiguous bytes of its plane ----
     float* o = a.out + (int64_t)img * a.out_img_stride;
-    for (int i = tid; i < NCH * LP; i += kThreads) {
+    for (int i = tid; i < NCH * LP; i += kLookThreads) {
         const int pix = i % LP, ch = i / LP;
         if (p0 + pix < a.N) o[(int64_t)ch * a.N + p0 + pix] = T[pix * TROW + ch];
     }
@@ -485,6 +523,6 @@ extern "C" int sf_corr_lookup_blocked32(const void* vol, int64_t vol_img_stride_
     a.coords = coords;
     a.out = out; a.out_img_stride = out_img_stride;
     a.h = h; a.w = w; a.N = h * w;
-    hipLaunchKernelGGL(corr_lookup_blocked32_kernel, dim3(sf::ceil_div(a.N, LP), B * pairs), dim3(kThreads), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(corr_lookup_blocked32_kernel, dim3(sf::ceil_div(a.N, LP), B * pairs), dim3(kLookThreads), 0, (hipStream_t)stream, a);
     return sf::check_launch("sf_corr_lookup_blocked32");
 }
