@@ -33,7 +33,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vector
 # kernels that may not use scratch memory (substring of the demangled name): everything that shows up in the top rows of the
 # step's kernel table (profiles/r*_kernel_stats_sintel_serial.md)
 HOT_KERNELS = ("gemm_bstat", "ffn_pair_kernel", "sk_tail_kernel", "gma_flash_pipe_kernel", "gma_pv_kernel", "temporal_block_kernel", "mask_upsample_kernel", "gemm_bdirect_kernel", "gma_flash_kernel", "flash_project_v_kernel", "dwconv_mfma_kernel",
-               "corr_lookup_blocked_kernel", "corr_build_blocked_kernel", "temporal_attn_kernel", "layernorm_cm_split_kernel",
+               "corr_lookup_blocked_kernel", "corr_build_blocked_kernel", "corr_lookup_blocked32_kernel", "corr_build_blocked32_kernel", "temporal_attn_kernel", "layernorm_cm_split_kernel",
                "flash_pack_v_kernel")
 
 

@@ -35,6 +35,9 @@ for h, w in ((55, 128), (47, 156), (136, 240), (7, 64), (8, 8), (1, 1)):
     lib.sf_corr_build_ws_bytes(2, 3, 256, h, w)
     lib.sf_corr_build_blocked_ws_bytes(6, 256, h, w)
     lib.sf_corr_blocked_bytes(6, h, w)
+    call(lib.sf_corr_blocked32_geometry, h, w, C.byref(rec), off, nby, nbx, C.byref(src))
+    lib.sf_corr_build_blocked32_ws_bytes(6, 256, h, w)
+    lib.sf_corr_blocked32_bytes(6, h, w)
     lib.sf_gma_flash_ws_bytes(6, h * w)
 for K1, M2, a, b in itertools.product((128, 256, 324, 640, 0), (6, 64, 126, 256, 324), (1, 2, 3), (1, 2)):
     lib.sf_ffn_pair_frags(K1, M2, a, b)
@@ -103,6 +106,11 @@ for pitch in (None, (C.c_int32 * 4)(128, 64, 32, 32), (C.c_int32 * 4)(100, 64, 3
          4, 4, 0, None)
 call(lib.sf_corr_build_blocked, PTR[0], PTR[1], 4 * 256 * 7040, 256 * 7040, PTR[2], 7040 * 19712, 8, 3, 256, 55, 128, PTR[3], 1 << 30, None)
 call(lib.sf_corr_lookup_blocked, PTR[2], 7040 * 19712, PTR[3], None, 0, PTR[4], 328 * 7040, 8, 3, 55, 128, None)
+for stride in (7040 * 38400, 7040 * 38400 - 128, 100):
+    call(lib.sf_corr_build_blocked32, PTR[0], PTR[1], 4 * 256 * 7040, 256 * 7040, PTR[2], stride, 8, 3, 256, 55, 128, PTR[3], 1 << 30, None)
+    call(lib.sf_corr_lookup_blocked32, PTR[2], stride, PTR[3], PTR[4], 324 * 7040, 8, 3, 55, 128, None)
+call(lib.sf_corr_build_blocked32, PTR[0], PTR[1], 4 * 256 * 7040, 256 * 7040, PTR[2], 7040 * 38400, 8, 3, 256, 55, 128, PTR[3], 1000, None)
+call(lib.sf_corr_lookup_blocked32, PTR[2], 7040 * 38400, None, PTR[4], 324 * 7040, 8, 3, 55, 128, None)
 for n, P, qk in ((24, 7040, 1), (3, 32640, 3), (0, 7040, 1), (24, 7040, 5)):
     ws = lib.sf_gma_flash_ws_bytes(max(n, 1), P)
     call(lib.sf_gma_flash_pack_qk, PTR[0], 256 * P, PTR[1], ws, n, P, 0.088, qk if qk < 4 else 0, None)

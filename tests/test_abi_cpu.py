@@ -59,6 +59,15 @@ def test_blocked_volume_geometry(lib):
     assert lib.sf_corr_blocked_geometry(7, 64, None, None, None, None, None) == -1
     assert b"too small" in lib.sf_last_error()
     assert lib.sf_corr_build_blocked_ws_bytes(2, 256, 55, 128) == 2 * 2 * 32 * 7048 * 16
+    # fp32 cells (csrc/corr_blocked32.hip): blocks of 4 rows x 8 columns
+    rec, off, nby, nbx, src = ops.blocked_geometry(55, 128, f32=True)
+    assert (nby, nbx) == ((14, 7, 4, 2), (16, 8, 4, 2)) and rec == 128 * (224 + 56 + 16 + 4) == 38400 and src == 7040
+    assert off == (0, 224 * 128, 280 * 128, 296 * 128)
+    rec, off, nby, nbx, src = ops.blocked_geometry(47, 156, f32=True)
+    assert (nby, nbx) == ((12, 6, 3, 2), (20, 10, 5, 3)) and rec == 128 * (240 + 60 + 15 + 6) and src == 7424
+    assert lib.sf_corr_blocked32_bytes(3, 55, 128) == 3 * 7040 * 38400
+    assert lib.sf_corr_blocked32_geometry(7, 64, None, None, None, None, None) == -1
+    assert lib.sf_corr_build_blocked32_ws_bytes(2, 256, 55, 128) == 2 * 2 * 2 * 32 * 7040 * 16
 
 
 def test_gemm_output_format_rules_hold_for_every_b_layout(lib):

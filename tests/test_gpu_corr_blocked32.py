@@ -143,3 +143,44 @@ def test_blocked32_is_deterministic_at_the_kitti_shape(dev):
         res.append((vol.buf.clone(), out))
     for v, o in res[1:]:
         assert torch.equal(v, res[0][0]) and torch.equal(o, res[0][1])
+
+
+def test_blocked32_at_the_spring_grid_last_pair(dev):
+    """1080p feature grid (136 x 240, N = 32,640): 5.6 GB of blocked fp32 pyramids per pair -- 64-bit image / record addressing.
+    Records of source pixels of the LAST of two pairs (highest addresses) against a direct float64 contraction and their own
+    2 x 2 pooling; lookups of the same pixels against the oracle lookup on those records."""
+    from oracle import streamflow_oracle as orc
+    from streamflow_amd import ops
+    from streamflow_amd.ops import Planes
+    B, pairs, D, h, w = 1, 2, 256, 136, 240
+    N, n = h * w, 2
+    g = torch.Generator().manual_seed(11)
+    fm = torch.randn(B, pairs + 1, D, h, w, generator=g)
+    fmd = fm.to(dev)
+    vol = ops.new_blocked_volume(n, h, w, dev, f32=True)
+    assert vol.img_stride > (1 << 32)
+    ops.corr_build_blocked(fmd.data_ptr(), fmd.data_ptr() + 4 * D * N, (pairs + 1) * D * N, D * N, vol, B, pairs, D)
+    coords = (orc.coords_grid(n, h, w) + torch.randn(n, 2, h, w, generator=g) * 6.0).contiguous()
+    out = torch.empty(n, 324, N, device=dev)
+    ops.corr_lookup_blocked(vol, Planes.of(coords.to(dev)), Planes.of(out), None, B, pairs)
+    torch.cuda.synchronize()
+    img = 1
+    f2 = fm[0, 2].reshape(D, N).double()
+    for i in (0, 12345, N - 1):
+        rec = torch.as_strided(vol.buf, (vol.rec,), (1,), img * vol.img_stride + i * vol.rec).clone().cpu()
+        lv = []
+        for l in range(4):
+            nby, nbx = vol.nby[l], vol.nbx[l]
+            blk = rec[vol.off[l]: vol.off[l] + nby * nbx * 128].view(torch.float32).view(nby, nbx, 8, 4)    # [by][bx][tx % 8][ty % 4]
+            lv.append(blk.permute(0, 3, 1, 2).reshape(nby * 4, nbx * 8)[: h >> l, : w >> l])
+        ref = (fm[0, 1].reshape(D, N)[:, i].double() @ f2) / 16.0
+        assert (lv[0].reshape(-1).double() - ref).abs().max().item() < 1e-5
+        for l in range(3):
+            hl, wl = h >> (l + 1), w >> (l + 1)
+            pooled = lv[l][: 2 * hl, : 2 * wl].reshape(hl, 2, wl, 2).mean(dim=(1, 3))
+            assert (pooled - lv[l + 1]).abs().max().item() < 1e-6, (i, l)
+        c = coords[img, :, i // w, i % w].reshape(1, 2, 1, 1)
+        want = orc.corr_lookup([t.reshape(1, 1, *t.shape) for t in lv], c, 4).reshape(324)
+        assert (out[img, :, i].cpu() - want).abs().max().item() < 2e-4, i
+    del vol, out
+    torch.cuda.empty_cache()
