@@ -435,6 +435,15 @@ constexpr int TROW = NOCT * 8;                  // halves per pixel in the trans
 #ifndef SF_LOOKB_W2_ALWAYS
 #define SF_LOOKB_W2_ALWAYS 0
 #endif
+#ifndef SF_LOOKB_STREAM_BYTES
+// Volumes past this size are read with the streaming cache policy (slc): every line of a footprint is used once per lookup, and past
+// ~2.5 GB nothing of one iteration's lines survives to the next anyway -- Sintel, 24 images = 3.3 GB: 78-81 -> 68.7 us per lookup; below
+// it the default policy keeps some of them in the 256-MB infinity cache (KITTI, 8 images = 1.2 GB: 27.0 us, 29.7 us when streamed).
+#define SF_LOOKB_STREAM_BYTES (5ll << 29)
+#endif
+#ifndef SF_LOOKB_PF
+#define SF_LOOKB_PF 1                           // items (footprints) prefetched ahead of the one being processed (1 .. 8)
+#endif
 #ifndef SF_LOOKB_WAVES
 #define SF_LOOKB_WAVES 4                        // waves per SIMD the register budget is sized for
 #endif
@@ -456,6 +465,7 @@ struct Foot {                     // one lane's share of one footprint: a column
     unsigned w2;
 };
 
+template <int AUX>
 __global__ __launch_bounds__(kThreads, SF_LOOKB_WAVES) void corr_lookup_blocked_kernel(const LookArgs a) {
     __shared__ __attribute__((aligned(16))) _Float16 T[LP * TROW];
     const int tid = threadIdx.x;
@@ -506,27 +516,35 @@ __global__ __launch_bounds__(kThreads, SF_LOOKB_WAVES) void corr_lookup_blocked_
             return (col_ok & ((unsigned)by < (unsigned)g_nby[l])) ? col + by * g_rowb[l] : kDrop;
         };
         Foot f;
-        f.w0 = __builtin_amdgcn_raw_buffer_load_b128(rv, piece(0), 0, 0);
-        f.w1 = __builtin_amdgcn_raw_buffer_load_b128(rv, piece(1), 0, 0);
+        f.w0 = __builtin_amdgcn_raw_buffer_load_b128(rv, piece(0), 0, AUX);
+        f.w1 = __builtin_amdgcn_raw_buffer_load_b128(rv, piece(1), 0, AUX);
         // rows 16, 17 (a third block row) are part of the footprint only when ys % 8 == 7: requested only then -- an unconditional
         // 4-byte request pulled two more 128-byte lines per level into L2 for seven footprints of eight (round 5)
 #if SF_LOOKB_W2_ALWAYS
-        f.w2 = __builtin_amdgcn_raw_buffer_load_b32(rv, piece(2), 0, 0);
+        f.w2 = __builtin_amdgcn_raw_buffer_load_b32(rv, piece(2), 0, AUX);
 #else
-        f.w2 = __builtin_amdgcn_raw_buffer_load_b32(rv, ((ys & 7) == 7) ? piece(2) : kDrop, 0, 0);
+        f.w2 = __builtin_amdgcn_raw_buffer_load_b32(rv, ((ys & 7) == 7) ? piece(2) : kDrop, 0, AUX);
 #endif
         return f;
     };
 
-    Item qn = locate(0);
-    Foot fn = fetch(0, qn);
+    // footprints of the next SF_LOOKB_PF items are in flight while one is processed
+    constexpr int PF = SF_LOOKB_PF;
+    Item qs[8];
+    Foot fs[8];
+#pragma unroll
+    for (int it = 0; it < PF; ++it) {
+        qs[it] = locate(it);
+        fs[it] = fetch(it, qs[it]);
+    }
+    if (PF > 1) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
-        const Item q = qn;
-        const Foot f = fn;
-        if (it + 1 < 8) {
-            qn = locate(it + 1);
-            fn = fetch(it + 1, qn);
+        const Item q = qs[it];
+        const Foot f = fs[it];
+        if (it + PF < 8) {
+            qs[it + PF] = locate(it + PF);
+            fs[it + PF] = fetch(it + PF, qs[it + PF]);
         }
         const int l = it >> 1, pix = (it & 1) * 16 + grp;
         const int ys = q.y0 - 4, s = ys & 7;
@@ -727,7 +745,10 @@ extern "C" int sf_corr_lookup_blocked(const void* vol, int64_t vol_img_stride_by
     a.out = out; a.out_img_stride = out_img_stride;
     a.out16 = static_cast<_Float16*>(out_koct); a.out16_img_stride = out_koct_img_stride;
     a.h = h; a.w = w; a.N = h * w;
-    hipLaunchKernelGGL(corr_lookup_blocked_kernel, dim3(sf::ceil_div(a.N, LP), B * pairs), dim3(kThreads), 0,
-                       (hipStream_t)stream, a);
+    const dim3 grid(sf::ceil_div(a.N, LP), B * pairs);
+    if ((int64_t)B * pairs * vol_img_stride_bytes >= SF_LOOKB_STREAM_BYTES)
+        hipLaunchKernelGGL(corr_lookup_blocked_kernel<2>, grid, dim3(kThreads), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(corr_lookup_blocked_kernel<0>, grid, dim3(kThreads), 0, (hipStream_t)stream, a);
     return sf::check_launch("sf_corr_lookup_blocked");
 }

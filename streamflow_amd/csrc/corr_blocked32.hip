@@ -322,8 +322,10 @@ __global__ __launch_bounds__(kThreads, SF_CORRB32_WGS) void corr_build_blocked32
 // ------------------------------------------------------------------------------------------------
 // lookup
 // ------------------------------------------------------------------------------------------------
-#ifndef SF_LOOK32_AUX
-#define SF_LOOK32_AUX 2                         // cache policy bits of the footprint loads (experiments: 1 = glc, 2 = slc, 3 = both)
+#ifndef SF_LOOK32_STREAM_BYTES
+// volumes past this size are read with the streaming cache policy (slc; csrc/corr_blocked.hip): Sintel, 24 images = 6.7 GB: 126 -> 110 us per
+// lookup; KITTI, 8 images = 2.4 GB: 51-53 us either way
+#define SF_LOOK32_STREAM_BYTES (5ll << 29)
 #endif
 #ifndef SF_LOOK32_LP
 #define SF_LOOK32_LP 32
@@ -343,6 +345,7 @@ struct Look32Args {
     Geom32 g;
 };
 
+template <int AUX>
 __global__ __launch_bounds__(kLookThreads, 768 / kLookThreads) void corr_lookup_blocked32_kernel(const Look32Args a) {
     __shared__ float T[LP * TROW];
     const int tid = threadIdx.x;
@@ -391,10 +394,10 @@ __global__ __launch_bounds__(kLookThreads, 768 / kLookThreads) void corr_lookup_
             return (col_ok & ((unsigned)by < (unsigned)g_nby[l])) ? col + by * g_rowb[l] : kDrop;
         };
         // rows 4 byf .. 4 byf + 12 of this column: three whole block columns + (when ys % 4 == 3) the first row of a fourth
-        f[it].w0 = __builtin_amdgcn_raw_buffer_load_b128(rv, piece(0), 0, SF_LOOK32_AUX);
-        f[it].w1 = __builtin_amdgcn_raw_buffer_load_b128(rv, piece(1), 0, SF_LOOK32_AUX);
-        f[it].w2 = __builtin_amdgcn_raw_buffer_load_b128(rv, piece(2), 0, SF_LOOK32_AUX);
-        f[it].w3 = __builtin_amdgcn_raw_buffer_load_b32(rv, ((ys & 3) == 3) ? piece(3) : kDrop, 0, SF_LOOK32_AUX);
+        f[it].w0 = __builtin_amdgcn_raw_buffer_load_b128(rv, piece(0), 0, AUX);
+        f[it].w1 = __builtin_amdgcn_raw_buffer_load_b128(rv, piece(1), 0, AUX);
+        f[it].w2 = __builtin_amdgcn_raw_buffer_load_b128(rv, piece(2), 0, AUX);
+        f[it].w3 = __builtin_amdgcn_raw_buffer_load_b32(rv, ((ys & 3) == 3) ? piece(3) : kDrop, 0, AUX);
     }
     __builtin_amdgcn_sched_barrier(0);                     // (hipcc would sink every load next to its use)
 #pragma unroll
@@ -523,6 +526,10 @@ extern "C" int sf_corr_lookup_blocked32(const void* vol, int64_t vol_img_stride_
     a.coords = coords;
     a.out = out; a.out_img_stride = out_img_stride;
     a.h = h; a.w = w; a.N = h * w;
-    hipLaunchKernelGGL(corr_lookup_blocked32_kernel, dim3(sf::ceil_div(a.N, LP), B * pairs), dim3(kLookThreads), 0, (hipStream_t)stream, a);
+    const dim3 grid(sf::ceil_div(a.N, LP), B * pairs);
+    if ((int64_t)B * pairs * vol_img_stride_bytes >= SF_LOOK32_STREAM_BYTES)
+        hipLaunchKernelGGL(corr_lookup_blocked32_kernel<2>, grid, dim3(kLookThreads), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(corr_lookup_blocked32_kernel<0>, grid, dim3(kLookThreads), 0, (hipStream_t)stream, a);
     return sf::check_launch("sf_corr_lookup_blocked32");
 }

@@ -12,16 +12,20 @@ timeout 300 python bench.py $N --clips 1 > $O/r06_bench_clip1.json 2>/dev/null
 timeout 300 python bench.py $N --preset fp32_class > $O/r06_bench_fp32class.json 2>/dev/null
 timeout 300 python bench.py $N --preset config2_fp16 > $O/r06_bench_config2_fp16.json 2>/dev/null
 timeout 300 python bench.py --corr-only --workload kitti --preset fp32_class > $O/r06_bench_kitti_fp32_corr.json 2>/dev/null
-timeout 300 python bench.py --corr-only --workload kitti --preset fp32_class --dense-volumes > $O/r06_bench_kitti_fp32_corr_dense.json 2>/dev/null
+timeout 300 python bench.py --corr-only --workload kitti --preset fp32_class --corr-layout rows $N > $O/r06_bench_kitti_fp32_corr_rows.json 2>/dev/null
+timeout 300 python bench.py --corr-only --workload sintel --preset fp32_class $N > $O/r06_bench_sintel_fp32_corr.json 2>/dev/null
+timeout 300 python bench.py --corr-only --workload sintel --preset fp32_class --corr-layout rows $N > $O/r06_bench_sintel_fp32_corr_rows.json 2>/dev/null
+timeout 300 python bench.py --corr-only --workload sintel $N > $O/r06_bench_sintel_fp16_corr.json 2>/dev/null
+timeout 300 python bench.py $N --preset fp32_class --workload spring --clips 1 > $O/r06_bench_spring_fp32class.json 2>/dev/null
 timeout 300 python bench.py --corr-only --workload kitti > $O/r06_bench_kitti_fp16_corr.json 2>/dev/null
 timeout 300 python bench.py $N --gpus 2 --share-device --dist-backend gloo --steps 5 > $O/r06_bench_2ranks_shared.json 2>/dev/null
 timeout 600 python bench.py $N --no-kernel-breakdown --gpus 8 --share-device --dist-backend gloo --steps 3 --warmup 1 > $O/r06_bench_8ranks_shared.json 2>/dev/null
 timeout 300 python bench.py $N --gma stored > $O/r06_bench_gma_stored.json 2>/dev/null
-for f in kitti spring clip1 fp32class config2_fp16 gma_stored; do python -c "
+for f in kitti spring clip1 fp32class spring_fp32class config2_fp16 gma_stored; do python -c "
 import json,sys
 d=json.loads(open('$O/r06_bench_$f.json').read().strip().splitlines()[-1])
 print('$f', round(d['value'],1), 'ff/s', round(d['ms_per_step'],2), 'ms/step corr frac', d.get('roofline_corr',{}).get('frac'), 'enc', d.get('encoder_ms_per_clip'))"; done
-for f in kitti_fp32_corr kitti_fp32_corr_dense kitti_fp16_corr; do python -c "
+for f in kitti_fp32_corr kitti_fp32_corr_rows sintel_fp32_corr sintel_fp32_corr_rows kitti_fp16_corr sintel_fp16_corr; do python -c "
 import json
 d=json.loads(open('$O/r06_bench_$f.json').read().strip().splitlines()[-1]); r=d['roofline']
 print('$f', round(r['frac'],4), 'build', round(r['build']['avg_us'],1), round(r['build']['gbps'],0), 'lookup', round(r['lookup']['avg_us'],1), round(r['lookup']['gbps'],0))"; done
