@@ -332,8 +332,17 @@ __global__ __launch_bounds__(kThreads, SF_CORRB32_WGS) void corr_build_blocked32
 #endif
 constexpr int LP = SF_LOOK32_LP;                // source pixels per workgroup (8 threads each)
 constexpr int kLookThreads = LP * 8;
+#ifndef SF_LOOK32_PASSES
+#define SF_LOOK32_PASSES 1                      // 2: levels 0-1 and 2-3 leave through a half-size transpose buffer (4 workgroups per CU)
+#endif
 constexpr int NCH = 324;
-constexpr int TROW = 325;                       // floats per pixel in the transpose buffer (odd: the read-back of 32 pixels is conflict-free)
+constexpr int NP = SF_LOOK32_PASSES;
+constexpr int CH_PASS = NCH / NP;               // channels per pass through the transpose buffer
+constexpr int TROW = CH_PASS + 1;               // floats per pixel in the transpose buffer (odd: the read-back of 32 pixels is conflict-free)
+#ifndef SF_LOOK32_PF0
+#define SF_LOOK32_PF0 (SF_LOOK32_PASSES == 1 ? 8 : 5)
+#endif
+constexpr int PF0 = SF_LOOK32_PF0;              // items whose loads are issued up front
 
 struct Look32Args {
     const char* vol;
@@ -346,7 +355,7 @@ struct Look32Args {
 };
 
 template <int AUX>
-__global__ __launch_bounds__(kLookThreads, 768 / kLookThreads) void corr_lookup_blocked32_kernel(const Look32Args a) {
+__global__ __launch_bounds__(kLookThreads, (NP == 1 ? 768 : 1024) / kLookThreads) void corr_lookup_blocked32_kernel(const Look32Args a) {
     __shared__ float T[LP * TROW];
     const int tid = threadIdx.x;
     const int grp = tid >> 4, c = tid & 15;               // 16 lanes per footprint: lane c = footprint column c (10 used)
@@ -367,15 +376,14 @@ __global__ __launch_bounds__(kLookThreads, 768 / kLookThreads) void corr_lookup_
         g_wl[l] = a.g.wl[l]; g_hl[l] = a.g.hl[l]; g_nby[l] = a.g.nby[l]; g_rowb[l] = a.g.nbx[l] * 128; g_off[l] = a.g.off[l];
         asm volatile("" : "+s"(g_wl[l]), "+s"(g_hl[l]), "+s"(g_nby[l]), "+s"(g_rowb[l]), "+s"(g_off[l]));
     }
-    // item it = (level it >> 1, pixel (it & 1) * 16 + grp).  ALL of a thread's 32 loads are issued before the first footprint is
-    // touched (104 VGPRs of data in flight: the kernel holds 3 waves per SIMD for its LDS anyway) -- memory-level parallelism is what a
-    // gather of cache lines that nobody else reads lives on
+    // item it = (level it >> 1, pixel (it & 1) * 16 + grp).  The loads of PF0 items are issued before the first footprint is touched
+    // (one pass: all 32 loads of a thread, 104 VGPRs of data in flight) -- memory-level parallelism is what a gather of cache lines
+    // that nobody else reads lives on
     struct Item { int ys; float fx, fy; };
     struct Foot { u32x4 w0, w1, w2; unsigned w3; };
     Item q[8];
     Foot f[8];
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
+    auto issue = [&](int it) {
         const int l = it >> 1, e = it & 1, pix = e * (LP / 2) + grp;
         const float inv = 1.0f / (float)(1 << l);
         float cx = cxs[e] * inv, cy = cys[e] * inv;
@@ -398,7 +406,18 @@ __global__ __launch_bounds__(kLookThreads, 768 / kLookThreads) void corr_lookup_
         f[it].w1 = __builtin_amdgcn_raw_buffer_load_b128(rv, piece(1), 0, AUX);
         f[it].w2 = __builtin_amdgcn_raw_buffer_load_b128(rv, piece(2), 0, AUX);
         f[it].w3 = __builtin_amdgcn_raw_buffer_load_b32(rv, ((ys & 3) == 3) ? piece(3) : kDrop, 0, AUX);
-    }
+    };
+    float* o = a.out + (int64_t)img * a.out_img_stride;
+    auto write_out = [&](int ch0) {                        // (channel, pixel): 32 consecutive pixels of a channel = 128 contiguous bytes
+        __syncthreads();
+        for (int i = tid; i < CH_PASS * LP; i += kLookThreads) {
+            const int pix = i % LP, ch = i / LP;
+            if (p0 + pix < a.N) o[(int64_t)(ch0 + ch) * a.N + p0 + pix] = T[pix * TROW + ch];
+        }
+        if (ch0 + CH_PASS < NCH) __syncthreads();
+    };
+#pragma unroll
+    for (int it = 0; it < PF0; ++it) issue(it);
     __builtin_amdgcn_sched_barrier(0);                     // (hipcc would sink every load next to its use)
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
@@ -408,6 +427,7 @@ __global__ __launch_bounds__(kLookThreads, 768 / kLookThreads) void corr_lookup_
 #pragma unroll
         for (int i = 0; i < 4; ++i) { W[i] = f[it].w0[i]; W[4 + i] = f[it].w1[i]; W[8 + i] = f[it].w2[i]; }
         W[12] = f[it].w3;
+        if (it + PF0 < 8) issue(it + PF0);
         // rows ys .. ys + 9 out of the 13: shift by s in two select steps (bit-select masks, v_bfi_b32: written as
         // `cond ? W[i + 2] : W[i]` hipcc turns the chain into a dynamically indexed array in SCRATCH memory -- csrc/corr_blocked.hip)
         const unsigned m2 = 0u - ((unsigned)(s >> 1) & 1u), m1 = 0u - ((unsigned)s & 1u);
@@ -430,18 +450,13 @@ __global__ __launch_bounds__(kLookThreads, 768 / kLookThreads) void corr_lookup_
             R[b] = v * wx0 + dpp_shl1(v) * wx1;
         }
         if (c < 9) {
-            float* t0 = T + pix * TROW + l * 81 + c * 9;   // channel l * 81 + a * 9 + b with a = c (corr.py:31-37)
+            float* t0 = T + pix * TROW + (l * 81 - (NP == 2 && l >= 2 ? CH_PASS : 0)) + c * 9;   // channel l * 81 + a * 9 + b with a = c (corr.py:31-37)
 #pragma unroll
             for (int b = 0; b < 9; ++b) t0[b] = R[b];
         }
+        if (NP == 2 && it == 3) write_out(0);
     }
-    __syncthreads();
-    // ---- (channel, pixel): 32 consecutive pixels of a channel = 128 contiguous bytes of its plane ----
-    float* o = a.out + (int64_t)img * a.out_img_stride;
-    for (int i = tid; i < NCH * LP; i += kLookThreads) {
-        const int pix = i % LP, ch = i / LP;
-        if (p0 + pix < a.N) o[(int64_t)ch * a.N + p0 + pix] = T[pix * TROW + ch];
-    }
+    write_out(NCH - CH_PASS);
 }
 
 }  // namespace
