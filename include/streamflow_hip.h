@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SF_VERSION 120
+#define SF_VERSION 121
 
 enum {
     SF_OK = 0,
@@ -170,6 +170,13 @@ enum { SF_LAYOUT_K_MAJOR = 0,   /* A[k*lda + m]   /  B[k*ldb + n]   (rows of k) 
                                     one MFMA operand octet of one pixel: the consumer moves its B tiles HBM/L2 -> LDS with
                                     buffer_load ... lds like the weights (no registers, no conversion, no ds_write).
                                     Octets past ceil(K/8) read as zero; rows K..8*ceil(K/8)-1 must be finite.          */
+       SF_LAYOUT_SPLIT_KOCT = 6,  /* B only, F16X3 with a SPLIT_F16 A and M > 96 (the 128-row tile), no grouping: the activation
+                                    ALREADY split, x = hi + lo, as two k-octet images of the F16_KOCT form -- hi planes
+                                    [ceil(K/8)][ldb][8] at B, lo planes right behind them (ceil(K/8)*ldb*8 halves further);
+                                    strideB in halves, 16-byte aligned -- what a producing sf_gemm stores with c_f16 = 4.  The
+                                    same (hi, lo) the consumer would compute from the fp32 value (bit-identical results), at the
+                                    same 4 bytes per element, but both operands now move HBM/L2 -> LDS by DMA: no conversion and
+                                    no ds_write in the loop (fp32_class: the GEMM-to-GEMM tensors of an SK block).        */
        SF_LAYOUT_F16_K_MAJOR = 4 };/* B only, SF_PRECISION_F16X2 with a SPLIT_F16 A: IEEE fp16 rows B[k*ldb + n]
                                     (ldb, strideB in halfs; N, ldb, strideB even) -- what a producing sf_gemm stores
                                     with c_f16 = 1.  Bit-identical to handing the fp32 values over (F16X2 rounds a
@@ -228,7 +235,9 @@ typedef struct SfGemm {
        8*ceil(M/8) rows are written: the caller provides room for them).
        c_f16 = 3: C is written in fp32 as usual AND a second time as fp16 k-octet planes at C16 (ldc pixels per plane,
        strideC16 halves between images; same alignment rules as c_f16 = 1 for C and c_f16 = 2 for C16; every epilogue).
-       Only rows < M are written to C16: a last, partial octet keeps its other rows. */
+       Only rows < M are written to C16: a last, partial octet keeps its other rows.
+       c_f16 = 4 (F16X3 only): the result split as the next sf_gemm would split it, x = hi + lo, stored as the two k-octet images
+       of SF_LAYOUT_SPLIT_KOCT (hi planes at C, lo planes ceil(M/8)*ldc*8 halves behind; strideC in halves; rules of c_f16 = 2). */
     int32_t c_f16;
     void* C16; int64_t strideC16;
     /* r_f16 = 2 (split precisions, vector epilogue: the alignment rules of c_f16 = 1 for C): the residual R is not fp32

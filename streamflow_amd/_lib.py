@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SF_HIP_LIB: load an alternative build of the same library (A/B timing of kernel variants)
 LIB_PATH = os.environ.get("SF_HIP_LIB") or os.path.join(_HERE, "libstreamflow_hip.so")
 
-LAYOUT_K_MAJOR, LAYOUT_K_MINOR, LAYOUT_SPLIT_F16, LAYOUT_F16_K_MINOR, LAYOUT_F16_K_MAJOR, LAYOUT_F16_KOCT = 0, 1, 2, 3, 4, 5
+LAYOUT_K_MAJOR, LAYOUT_K_MINOR, LAYOUT_SPLIT_F16, LAYOUT_F16_K_MINOR, LAYOUT_F16_K_MAJOR, LAYOUT_F16_KOCT, LAYOUT_SPLIT_KOCT = 0, 1, 2, 3, 4, 5, 6
 PRECISION_FP32, PRECISION_F16X3, PRECISION_F16X2, PRECISION_F16 = 0, 1, 2, 3
 EPI_NONE, EPI_GELU, EPI_RELU, EPI_RES, EPI_RES_GELU, EPI_RES_GELU_DW1, EPI_AXPY = range(7)
 ALGO_AUTO, ALGO_TILED, ALGO_BSTAT = 0, 1, 2

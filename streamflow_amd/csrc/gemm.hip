@@ -298,11 +298,13 @@ extern "C" int sf_gemm(const SfGemm* gp, void* stream) {
     SF_REQUIRE(g.A || (g.a_layout == SF_LAYOUT_SPLIT_F16 && g.A_hi && g.A_lo), "sf_gemm: null A");
     SF_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0 && g.batch > 0, "sf_gemm: bad dims M=%d N=%d K=%d batch=%d", g.M, g.N,
                g.K, g.batch);
-    SF_REQUIRE(g.a_layout >= 0 && g.a_layout <= 2 && g.b_layout >= 0 && g.b_layout <= 5 && g.b_layout != 2, "sf_gemm: bad layout");
+    SF_REQUIRE(g.a_layout >= 0 && g.a_layout <= 2 && g.b_layout >= 0 && g.b_layout <= 6 && g.b_layout != 2, "sf_gemm: bad layout");
+    SF_REQUIRE((g.b_layout != SF_LAYOUT_SPLIT_KOCT && g.c_f16 != 4) || g.precision == SF_PRECISION_F16X3,
+               "sf_gemm: a split k-octet operand / result (SF_LAYOUT_SPLIT_KOCT, c_f16 = 4) needs SF_PRECISION_F16X3");
     SF_REQUIRE((g.b_layout != SF_LAYOUT_F16_K_MAJOR && g.b_layout != SF_LAYOUT_F16_KOCT) ||
                    g.precision == SF_PRECISION_F16X2 || g.precision == SF_PRECISION_F16,
                "sf_gemm: a stored-fp16 activation operand needs SF_PRECISION_F16X2 or SF_PRECISION_F16");
-    SF_REQUIRE(g.c_f16 >= 0 && g.c_f16 <= 3, "sf_gemm: c_f16 must be 0 .. 3");
+    SF_REQUIRE(g.c_f16 >= 0 && g.c_f16 <= 4, "sf_gemm: c_f16 must be 0 .. 4");
     SF_REQUIRE(g.c_f16 != 3 || g.C16, "sf_gemm: c_f16 = 3 needs C16");
     SF_REQUIRE(!g.c_f16 || g.precision != SF_PRECISION_FP32, "sf_gemm: c_f16 needs a split precision");
     SF_REQUIRE(!g.r_f16 || g.precision != SF_PRECISION_FP32, "sf_gemm: r_f16 needs a split precision");

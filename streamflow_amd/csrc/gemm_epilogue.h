@@ -349,14 +349,17 @@ __device__ __forceinline__ void gemm_epilogue_vec_impl(const SfGemm& g, f32x16 (
 // 8 channels of one k-octet (lane = (octet half, pixel)): eight ds_read_b32, the epilogue arithmetic on packed pairs,
 // one 16-byte store; 32 consecutive lanes = 32 consecutive pixels = 512 contiguous bytes.  Rows past M inside the last
 // octet are written too (finite values from clamped parameters; the consumer's weights are zero there).
-template <int EPI, int WM, int WN, int TM, int TN, bool kFast>
+// kSplit (c_f16 = 4): the value leaves as the (hi, lo) fp16 pair sf_split::split8 would make of it -- hi = the fp32 value with its
+// mantissa truncated to 10 bits, lo = the rest, both narrowed with round-to-zero -- in two k-octet images, lo behind hi.
+template <int EPI, int WM, int WN, int TM, int TN, bool kFast, bool kSplit = false>
 __device__ __forceinline__ void gemm_epilogue_koct_impl(const SfGemm& g, f32x16 (&acc)[TM][TN], int m0, int n0, int z,
                                                         int wm, int wn, int lane, float* scratch) {
     constexpr bool kNeedsR = (EPI == SF_EPI_RES || EPI == SF_EPI_RES_GELU || EPI == SF_EPI_RES_GELU_DW1 ||
                               EPI == SF_EPI_AXPY);
     const int khalf = lane >> 5, l31 = lane & 31;
     const int moct = (g.M + 7) / 8;
-    const int c_bytes = (int)((int64_t)moct * g.ldc * 16);
+    const int c_plane = (int)((int64_t)moct * g.ldc * 16);      // bytes of the hi (= lo) image
+    const int c_bytes = kSplit ? 2 * c_plane : c_plane;
     __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(
         reinterpret_cast<char*>(g.C) + (int64_t)z * g.strideC * 2, 0, c_bytes, 0x00020000);
     __amdgpu_buffer_rsrc_t rr = rc;
@@ -382,7 +385,7 @@ __device__ __forceinline__ void gemm_epilogue_koct_impl(const SfGemm& g, f32x16 
 #pragma unroll
             for (int q = 0; q < 2; ++q) {                         // octets (2q + khalf) of the 32-row tile
                 const int mo = mt0 + (2 * q + khalf) * 8;         // first row of this lane's octet
-                epi_u32x4 o;
+                epi_u32x4 o, ol;
 #pragma unroll
                 for (int e = 0; e < 8; e += 2) {
                     f32x2 v, r;
@@ -402,26 +405,36 @@ __device__ __forceinline__ void gemm_epilogue_koct_impl(const SfGemm& g, f32x16 
                     const int mc0 = (mo + e < g.M) ? mo + e : g.M - 1;
                     const f32x2 res = epi_apply2<EPI, kFast>(v, r, EPI == SF_EPI_RES_GELU_DW1 ? g.dw_w[mc0] : 0.f,
                                                       EPI == SF_EPI_RES_GELU_DW1 ? g.dw_b[mc0] : 0.f, gam);
-                    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-                    h2 hv;
-                    hv[0] = (_Float16)res[0];
-                    hv[1] = (_Float16)res[1];
-                    o[e >> 1] = __builtin_bit_cast(unsigned, hv);
+                    if (kSplit) {
+                        const float r0 = res[0], r1 = res[1];    // (scalars first: a bit_cast of a vector ELEMENT reads element 0)
+                        const float ah = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, r0) & 0xFFFFE000u);
+                        const float bh = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, r1) & 0xFFFFE000u);
+                        o[e >> 1] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(ah, bh));
+                        ol[e >> 1] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(r0 - ah, r1 - bh));
+                    } else {
+                        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                        h2 hv;
+                        hv[0] = (_Float16)res[0];
+                        hv[1] = (_Float16)res[1];
+                        o[e >> 1] = __builtin_bit_cast(unsigned, hv);
+                    }
                 }
                 const bool ok = n < g.N && mo < g.M;
-                __builtin_amdgcn_raw_buffer_store_b128(o, rc, ok ? ((mo >> 3) * (int)g.ldc + n) * 16 : kOobTerm, 0, SF_EPI_STORE_AUX);
+                const int vo = ok ? ((mo >> 3) * (int)g.ldc + n) * 16 : kOobTerm;
+                __builtin_amdgcn_raw_buffer_store_b128(o, rc, vo, 0, SF_EPI_STORE_AUX);
+                if (kSplit) __builtin_amdgcn_raw_buffer_store_b128(ol, rc, ok ? vo + c_plane : kOobTerm, 0, SF_EPI_STORE_AUX);
             }
         }
     }
 }
 
-template <int WM, int WN, int TM, int TN, bool kFast = false>
+template <int WM, int WN, int TM, int TN, bool kFast = false, bool kSplit = false>
 __device__ __forceinline__ void gemm_epilogue_koct(const SfGemm& g, f32x16 (&acc)[TM][TN], int m0, int n0, int z, int wm,
                                                    int wn, int lane, float* scratch) {
     switch (g.epilogue) {     // wave-uniform; the hand-over tensors are produced with these three epilogues only
-        case SF_EPI_GELU: gemm_epilogue_koct_impl<SF_EPI_GELU, WM, WN, TM, TN, kFast>(g, acc, m0, n0, z, wm, wn, lane, scratch); break;
-        case SF_EPI_RES_GELU: gemm_epilogue_koct_impl<SF_EPI_RES_GELU, WM, WN, TM, TN, kFast>(g, acc, m0, n0, z, wm, wn, lane, scratch); break;
-        default: gemm_epilogue_koct_impl<SF_EPI_NONE, WM, WN, TM, TN, kFast>(g, acc, m0, n0, z, wm, wn, lane, scratch); break;
+        case SF_EPI_GELU: gemm_epilogue_koct_impl<SF_EPI_GELU, WM, WN, TM, TN, kFast, kSplit>(g, acc, m0, n0, z, wm, wn, lane, scratch); break;
+        case SF_EPI_RES_GELU: gemm_epilogue_koct_impl<SF_EPI_RES_GELU, WM, WN, TM, TN, kFast, kSplit>(g, acc, m0, n0, z, wm, wn, lane, scratch); break;
+        default: gemm_epilogue_koct_impl<SF_EPI_NONE, WM, WN, TM, TN, kFast, kSplit>(g, acc, m0, n0, z, wm, wn, lane, scratch); break;
     }
 }
 
@@ -456,7 +469,7 @@ __device__ __forceinline__ bool epilogue_vec_ok(const SfGemm& g, int z) {
 
 // host-side guard for the 32-bit buffer offsets used above
 inline bool epilogue_spans_ok(const SfGemm& g) {
-    const int64_t c = (g.c_f16 == 2) ? (int64_t)((g.M + 7) / 8) * g.ldc * 16
+    const int64_t c = (g.c_f16 == 2 || g.c_f16 == 4) ? (int64_t)((g.M + 7) / 8) * g.ldc * 16 * (g.c_f16 == 4 ? 2 : 1)
                                      : ((int64_t)(g.M - 1) * g.ldc + g.N) * (g.c_f16 == 1 ? 2 : 4);
     if (g.c_f16 == 3 && (int64_t)((g.M + 7) / 8) * g.ldc * 16 >= kOobTerm) return false;
     int64_t r = 0;

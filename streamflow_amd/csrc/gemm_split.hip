@@ -59,7 +59,8 @@ struct SplitArgs {
 // PM = MFMA products per element product: 3 = f16x3 (A and B hi + lo), 2 = f16x2 (A hi + lo, B one fp16), 1 = f16 (both one
 // fp16: the arithmetic of an fp16-autocast deployment, with fp32 accumulation)
 template <int WM, int WN, int TM, int TN, int ALAY, int BLAY, int PM>
-__global__ __launch_bounds__(kThreads, (TM * TN >= 8) ? 2 : SF_GEMM_WAVES) void gemm_f16x3_mfma(const SplitArgs args) {
+// (the split k-octet form holds 64 KB of stages: two workgroups per CU)
+__global__ __launch_bounds__(kThreads, (TM * TN >= 8 || BLAY == SF_LAYOUT_SPLIT_KOCT) ? 2 : SF_GEMM_WAVES) void gemm_f16x3_mfma(const SplitArgs args) {
     constexpr bool SB = (PM == 3), SA = (PM >= 2);
     const SfGemm& g = args.g;
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -77,9 +78,12 @@ __global__ __launch_bounds__(kThreads, (TM * TN >= 8) ? 2 : SF_GEMM_WAVES) void 
     // MFMAs of tile kt (nobody reads that stage: it was last read in tile kt-1, a barrier ago), so the barrier that
     // separated "everyone is done reading" from the store disappears.
     // kDmaB: B arrives as fp16 k-octet planes (SF_LAYOUT_F16_KOCT) and is DMA-fed like A: two stages [4 k-octets][BN][8]
-    constexpr bool kDmaB = (BLAY == SF_LAYOUT_F16_KOCT);
-    static_assert(!kDmaB || (kDmaA && !SB), "KOCT B needs the DMA-fed 128-row tile and no lo plane");
-    constexpr int kBStage = (BK / 8) * BN * 8;                                   // halfs of one DMA stage of B
+    // kDmaB2 (SF_LAYOUT_SPLIT_KOCT, f16x3): the activation arrives ALREADY split, hi and lo k-octet images: a stage is [hi | lo]
+    constexpr bool kDmaB2 = (BLAY == SF_LAYOUT_SPLIT_KOCT);
+    constexpr bool kDmaB = (BLAY == SF_LAYOUT_F16_KOCT) || kDmaB2;
+    static_assert(!kDmaB || (kDmaA && SB == kDmaB2), "k-octet B needs the DMA-fed 128-row tile; a lo plane exactly in the split form");
+    constexpr int kBPlane = (BK / 8) * BN * 8;                                   // halfs of one plane of a DMA stage of B
+    constexpr int kBStage = (kDmaB2 ? 2 : 1) * kBPlane;                          // halfs of one DMA stage of B (hi [+ lo])
     constexpr bool kB2 = SF_GEMM_B2 && !SB && kDmaA && !kDmaB;
     constexpr int kMainHalfs = kAHalfs + (kDmaB ? 2 * kBStage : (SB ? 2 : (kB2 ? 2 : 1)) * BN * LDK);   // SB = false: no lo part
     constexpr int kEpiHalfs = 4 * sf::kEpiScratchFloats * 2;
@@ -158,6 +162,7 @@ __global__ __launch_bounds__(kThreads, (TM * TN >= 8) ? 2 : SF_GEMM_WAVES) void 
     // b_group > 0 ('(B T) C -> B (T C)' views): rows come in groups of b_group (a multiple of 32, so a k-tile never
     // straddles two), group gi starts b_group_stride halves after group gi - 1
     const int b_goct = g.b_group > 0 ? g.b_group / 8 : 0;
+    const int b_lo_off = ((g.K + 7) / 8) * (int)g.ldb * 16;                        // (kDmaB2) bytes from the hi image to the lo image
     auto issue_b = [&](int kt, int buf) {
         char* dst = reinterpret_cast<char*>(smem + kAHalfs) + buf * kBStage * 2 + wave_u * 1024;
         const int o = kt * (BK / 8), gi = b_goct ? o / b_goct : 0;
@@ -165,6 +170,11 @@ __global__ __launch_bounds__(kThreads, (TM * TN >= 8) ? 2 : SF_GEMM_WAVES) void 
 #pragma unroll
         for (int j = 0; j < kBPieces; ++j)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rbd, (lds_ptr)(dst + j * 4096), 16, vob0 + j * vobs, so, 0, 0);
+        if (kDmaB2) {
+#pragma unroll
+            for (int j = 0; j < kBPieces; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rbd, (lds_ptr)(dst + kBPlane * 2 + j * 4096), 16, vob0 + b_lo_off + j * vobs, so, 0, 0);
+        }
     };
 
     // the A piece is requested BEFORE the B loads of the same k-tile: vmcnt retires in order, so the wait that the B
@@ -209,7 +219,7 @@ __global__ __launch_bounds__(kThreads, (TM * TN >= 8) ? 2 : SF_GEMM_WAVES) void 
         constexpr int kBStep = kDmaB ? 2 * BN * 8 : 16;          // halfs per 16-deep k-step
         const _Float16* pbh = kDmaB ? smem + kAHalfs + abuf * kBStage + (khalf * BN + wn * TN * 32 + l31) * 8
                                     : sB[bbuf] + (wn * TN * 32 + l31) * LDK + khalf * 8;
-        const _Float16* pbl = sB[SB ? 1 : 0] + (wn * TN * 32 + l31) * LDK + khalf * 8;
+        const _Float16* pbl = kDmaB2 ? pbh + kBPlane : sB[SB ? 1 : 0] + (wn * TN * 32 + l31) * LDK + khalf * 8;
 #if SF_GEMM_FRAG_PREFETCH
         // all fragment reads of the k-tile are issued before its first MFMA (2 k-steps x 8 x ds_read_b128 = 64 VGPRs):
         // the LDS latency is exposed once per k-tile instead of once per register reuse (hipcc otherwise recycles 24
@@ -225,7 +235,7 @@ __global__ __launch_bounds__(kThreads, (TM * TN >= 8) ? 2 : SF_GEMM_WAVES) void 
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 bh[ks][j] = *reinterpret_cast<const f16x8*>(pbh + j * kBTile + ks * kBStep);
-                if (SB) bl[ks][j] = *reinterpret_cast<const f16x8*>(pbl + j * 32 * LDK + ks * 16);
+                if (SB) bl[ks][j] = *reinterpret_cast<const f16x8*>(pbl + j * kBTile + ks * kBStep);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -261,7 +271,7 @@ __global__ __launch_bounds__(kThreads, (TM * TN >= 8) ? 2 : SF_GEMM_WAVES) void 
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 bh[j] = *reinterpret_cast<const f16x8*>(pbh + j * kBTile + ks * kBStep);
-                if (SB) bl[j] = *reinterpret_cast<const f16x8*>(pbl + j * 32 * LDK + ks * 16);
+                if (SB) bl[j] = *reinterpret_cast<const f16x8*>(pbl + j * kBTile + ks * kBStep);
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -297,6 +307,10 @@ __global__ __launch_bounds__(kThreads, (TM * TN >= 8) ? 2 : SF_GEMM_WAVES) void 
         __syncthreads();                                         // the main-loop LDS becomes the transpose scratch
         sf::gemm_epilogue_koct<WM, WN, TM, TN, kFastGelu>(gs, acc, m0, n0, z, wm, wn, lane,
                                                reinterpret_cast<float*>(smem) + wave * sf::kEpiScratchFloats);
+    } else if (PM == 3 && gs.c_f16 == 4) {                       // the (hi, lo) pair the next f16x3 GEMM takes by DMA
+        __syncthreads();
+        sf::gemm_epilogue_koct<WM, WN, TM, TN, false, PM == 3>(gs, acc, m0, n0, z, wm, wn, lane,
+                                                               reinterpret_cast<float*>(smem) + wave * sf::kEpiScratchFloats);
     } else if (sf::epilogue_vec_ok(gs, z)) {
         __syncthreads();                                         // the main-loop LDS becomes the transpose scratch
         sf::gemm_epilogue_vec<WM, WN, TM, TN>(gs, acc, m0, n0, z, wm, wn, lane,
@@ -542,6 +556,13 @@ int launch_cfg(const SplitArgs& a, hipStream_t st) {
         }
         return sf::fail(SF_ERR_UNSUPPORTED, "sf_gemm: SF_LAYOUT_F16_KOCT B needs the 128-row tile (M > 96) and F16X2 / F16");
     }
+    if (lay == 14) {                                     // split weights x split k-octet activations (F16X3): both operands by LDS-DMA
+        if constexpr (SB && WM * TM * 32 == 128 && TM * TN == 4) {
+            hipLaunchKernelGGL((gemm_f16x3_mfma<WM, WN, TM, TN, 2, 6, 3>), grid, dim3(kThreads), 0, st, a);
+            return sf::check_launch("sf_gemm(f16x3, split k-octet B)");
+        }
+        return sf::fail(SF_ERR_UNSUPPORTED, "sf_gemm: SF_LAYOUT_SPLIT_KOCT B needs the 128-row tile (M > 96) and F16X3");
+    }
     if (lay == 12) {                                     // split weights x stored-fp16 K-major activations (F16X2 only)
         if constexpr (!SB) {
             hipLaunchKernelGGL((gemm_f16x3_mfma<WM, WN, TM, TN, 2, 4, PM>), grid, dim3(kThreads), 0, st, a);
@@ -582,6 +603,7 @@ int pick_tile(const SplitArgs& a, hipStream_t st) {
 int64_t span_bytes(int layout, int X, int K, int64_t ld, int group, int64_t group_stride) {
     if (layout == SF_LAYOUT_F16_K_MINOR) return ((int64_t)(X - 1) * ld + K) * 2;
     if (layout == SF_LAYOUT_F16_K_MAJOR) return ((int64_t)(K - 1) * ld + X) * 2;
+    if (layout == SF_LAYOUT_SPLIT_KOCT) return (int64_t)((K + 7) / 8) * ld * 16 * 2;
     if (layout == SF_LAYOUT_F16_KOCT)
         return (group > 0) ? ((int64_t)((K - 1) / group) * group_stride * 2 + (int64_t)(((K - 1) % group) / 8 + 1) * ld * 16)
                            : (int64_t)((K + 7) / 8) * ld * 16;
@@ -672,10 +694,12 @@ int check_output_formats(const SfGemm& g) {
                                             "ldr, strideR %% 4 == 0, 16-byte aligned C / R), 16-byte aligned C16, strideC16 %% 8 == 0, "
                                             "no split-K");
     }
-    if (g.c_f16 == 2 && (g.ldc < g.N || (g.strideC & 7) || (reinterpret_cast<uintptr_t>(g.C) & 15) || g.k_splits > 1 ||
+    if ((g.c_f16 == 2 || g.c_f16 == 4) && (g.ldc < g.N || (g.strideC & 7) || (reinterpret_cast<uintptr_t>(g.C) & 15) || g.k_splits > 1 ||
                          (g.epilogue != SF_EPI_NONE && g.epilogue != SF_EPI_GELU && g.epilogue != SF_EPI_RES_GELU)))
-        return fail(SF_ERR_UNSUPPORTED, "sf_gemm: c_f16 = 2 (k-octet output) needs ldc >= N, strideC %% 8 == 0, 16-byte aligned C, "
+        return fail(SF_ERR_UNSUPPORTED, "sf_gemm: c_f16 = 2 / 4 (k-octet output) needs ldc >= N, strideC %% 8 == 0, 16-byte aligned C, "
                                         "no split-K, epilogue NONE / GELU / RES_GELU");
+    if (g.c_f16 == 4 && (g.precision != SF_PRECISION_F16X3 || g.r_f16))
+        return fail(SF_ERR_UNSUPPORTED, "sf_gemm: c_f16 = 4 (split k-octet output) needs SF_PRECISION_F16X3 and an fp32 residual");
     if (g.r_f16 != 0 && g.r_f16 != 2) return fail(SF_ERR_BAD_ARG, "sf_gemm: r_f16 must be 0 or 2");
     if (g.r_f16 == 2) {
         const bool ok = g.R && g.epilogue == SF_EPI_RES_GELU_DW1 && g.c_f16 != 2 && vec_c && g.r_group == 0 && g.ldr >= g.N &&
@@ -764,6 +788,13 @@ int gemm_split_dispatch_inner(const SfGemm& g, hipStream_t st) {
             return fail(SF_ERR_UNSUPPORTED, "sf_gemm: SF_LAYOUT_F16_KOCT B needs F16X2 / F16, a SPLIT_F16 A, groups of a multiple of "
                                             "32 rows, 16-byte aligned B, strideB and group stride, ldb >= N");
         return (g.precision == SF_PRECISION_F16) ? pick_tile<1>(a, st) : pick_tile<2>(a, st);
+    }
+    if (g.b_layout == SF_LAYOUT_SPLIT_KOCT) {
+        if (g.a_layout != SF_LAYOUT_SPLIT_F16 || g.precision != SF_PRECISION_F16X3 || g.b_group || g.conv3x3 || (g.strideB & 7) ||
+            (reinterpret_cast<uintptr_t>(g.B) & 15) || g.ldb < g.N || (g.M + 127) / 128 * 128 * 4 > g.M * 5)
+            return fail(SF_ERR_UNSUPPORTED, "sf_gemm: SF_LAYOUT_SPLIT_KOCT B needs F16X3, a SPLIT_F16 A on the 128-row tile (M > 96), no "
+                                            "grouping, 16-byte aligned B, strideB %% 8 == 0, ldb >= N");
+        return pick_tile<3>(a, st);
     }
     if (g.b_layout == SF_LAYOUT_F16_K_MAJOR) {
         if (g.a_layout != SF_LAYOUT_SPLIT_F16 || (g.precision != SF_PRECISION_F16X2 && g.precision != SF_PRECISION_F16) || (g.N & 1) || (g.ldb & 1) || (g.strideB & 1) ||

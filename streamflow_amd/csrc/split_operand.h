@@ -292,6 +292,8 @@ struct OperandSel { typedef Operand<BX, LAY> type; };
 template <int BX>
 struct OperandSel<BX, SF_LAYOUT_F16_KOCT> { typedef OperandDma type; };
 template <int BX>
+struct OperandSel<BX, SF_LAYOUT_SPLIT_KOCT> { typedef OperandDma type; };
+template <int BX>
 struct OperandSel<BX, SF_LAYOUT_F16_K_MAJOR> { typedef OperandF16KMajor<BX> type; };
 
 // element offset of K-major row k0 (start of a k-tile) for a possibly grouped operand; tiles never straddle

@@ -43,6 +43,9 @@ class EngineOptions:
     shadow_fused: bool = True        # ... written by their producers' epilogues instead of a pack pass
     hidden_f16: bool = True          # GEMM-to-GEMM tensors as fp16 in the f16x2 / f16 modes
     hidden_koct: bool = True         # ... as k-octet planes where the consumer takes them
+    split_handover: bool = False     # f16x3 (fp32_class): GEMM-to-GEMM tensors stored already split, hi + lo k-octet images (SF_LAYOUT_SPLIT_KOCT):
+                                     # bit-identical; the consumers run 7-10 % faster on two DMA-fed operands, the producers' k-octet epilogue
+                                     # costs more than that (fp32_class 182.6 -> 178.2 ff/s; tools/gemm_split_koct_bench.py): off
     pw_fold: bool = True             # pw residual folded into the weights (x3 handed over in fp16)
     koct_io: bool = True             # motion-encoder tensors between SK blocks as fp16 k-octets only (no fp32 planes)
     x2_f16: bool = True              # single-reader tensors as fp16 ROWS: x2 (ffn1.2 -> depthwise), qkv (-> temporal attention), v (-> GMA pack)
@@ -122,12 +125,15 @@ class SKBlockWeights:
         self.dw_single = False                # the K x K depthwise weights as one fp16 value (layer name '<block>.dw')
 
 
-def _scratch(buf: Planes, n_img: int, rows: int, f16: bool = False, koct: bool = False) -> Planes:
+def _scratch(buf: Planes, n_img: int, rows: int, f16: bool = False, koct: bool = False, split: bool = False) -> Planes:
     """Reinterpret a scratch allocation as contiguous [n_img][rows][P] planes (fp32, or fp16 values in the same memory;
-    koct: fp16 k-octet planes [ceil(rows/8)][P][8], the DMA-able image of the consuming GEMM)."""
+    koct: fp16 k-octet planes [ceil(rows/8)][P][8], the DMA-able image of the consuming GEMM; split: two such images per
+    image, hi then lo -- the f16x3 hand-over, as many bytes as the fp32 planes)."""
     rows_alloc = (rows + 7) // 8 * 8 if koct else rows
-    assert n_img * rows_alloc * (1 if not f16 else 0.5) <= buf.n_img * buf.rows, "scratch too small"
-    return Planes(buf.base, buf.off, rows_alloc * buf.P, n_img, rows, buf.P, f16=f16, koct=f16 and koct)
+    assert not split or (f16 and koct)
+    assert n_img * rows_alloc * (1 if (not f16 or split) else 0.5) <= buf.n_img * buf.rows, "scratch too small"
+    return Planes(buf.base, buf.off, rows_alloc * buf.P * (2 if split else 1), n_img, rows, buf.P, f16=f16, koct=f16 and koct,
+                  split=split)
 
 
 def _handover(cx: ops.Ctx, buf: Planes, n_img: int, rows: int, P: int, consumer_rows: int, allow_koct: bool = True) -> Planes:
@@ -135,6 +141,9 @@ def _handover(cx: ops.Ctx, buf: Planes, n_img: int, rows: int, P: int, consumer_
     """Scratch view for a tensor that is written by one GEMM and read only as the B operand of the next: fp32 planes in
     the exact / f16x3 modes; in f16x2 fp16 values -- as k-octet planes when the consumer runs on the DMA-fed 128-row tile
     (both of its operands then go HBM/L2 -> LDS without touching registers), as fp16 rows otherwise."""
+    if cx.precision == ops.PRECISION_F16X3 and cx.split_handover and ops.uses_dma_tile(consumer_rows) and P % 4 == 0:
+        # f16x3: the (hi, lo) pair the consumer would compute, stored by the producer: same bytes, same values, both operands by DMA
+        return _scratch(buf, n_img, rows, f16=True, koct=True, split=True)
     f16 = hidden_f16_ok(cx, P)
     koct = f16 and allow_koct and ops.takes_koct(consumer_rows, rows) and cx.hidden_koct
     return _scratch(buf, n_img, rows, f16=f16, koct=koct)
@@ -565,7 +574,7 @@ class HotPathEngine:
         return ops.Ctx(precision=self.precision,
                        split_ws=pl.splitws.tensor().view(-1) if self.auto_split_k else None,
                        shadows=o.shadows, shadow_fused=o.shadow_fused, flash_stats=o.flash_stats,
-                       hidden_f16=o.hidden_f16, hidden_koct=o.hidden_koct, pw_fold=o.pw_fold, x2_f16=o.x2_f16,
+                       hidden_f16=o.hidden_f16, hidden_koct=o.hidden_koct, split_handover=o.split_handover, pw_fold=o.pw_fold, x2_f16=o.x2_f16,
                        ffn_pairs=o.ffn_pairs, head_pairs=o.head_pairs, sk_tail=o.sk_tail, sk_tail_all=o.sk_tail_all)
 
     @staticmethod
@@ -714,7 +723,7 @@ class HotPathEngine:
                 ops.temporal_block(W.temporal, pl.mf, pl.mft, Pn, (W.ln1_w, W.ln1_b), (W.ln2_w, W.ln2_b), cx=cs)
             else:
                 # LayerNorm / attention outputs have ONE reader, a GEMM: in the f16x2 mode they leave as its k-octet operand
-                ko = lambda buf, M: (lambda t: t if t.koct else buf)(_handover(cs, buf, pl.n, HDIM, P, consumer_rows=M))
+                ko = lambda buf, M: (lambda t: t if (t.koct and not t.split) else buf)(_handover(cs, buf, pl.n, HDIM, P, consumer_rows=M))
                 ln, att = ko(pl.ln128, W.qkv.M), ko(pl.att128, W.proj.M)
                 ops.layernorm_cm(pl.mf, W.ln1_w, W.ln1_b, ln)
                 # qkv has ONE reader, the attention core: fp16 rows where the fp16 hand-over is active (EPE-neutral)

@@ -63,6 +63,7 @@ class Ctx:
     flash_stats: bool = True
     hidden_f16: bool = True
     hidden_koct: bool = True
+    split_handover: bool = False     # f16x3: GEMM-to-GEMM tensors stored already split (hi, lo k-octet images) for the consumer's DMA (measured slower: off)
     pw_fold: bool = True
     x2_f16: bool = True
     ffn_pairs: bool = True      # an SK block's ffn1 / ffn2 as ONE launch where sf_ffn_pair has the shape (csrc/ffn_pair.hip)
@@ -193,6 +194,8 @@ class Planes:
                             # the underlying fp32 allocation): GEMM-to-GEMM hand-over in the f16x2 mode (SfGemm.c_f16)
     koct: bool = False      # (with f16) k-octet planes [ceil(rows/8)][P][8] instead of rows [rows][P]: the consumer GEMM's
                             # LDS image, moved there by DMA (SF_LAYOUT_F16_KOCT / c_f16 = 2)
+    split: bool = False     # (with f16 and koct, f16x3 mode) the values ALREADY split for the next GEMM, x = hi + lo: two k-octet images
+                            # per image, lo behind hi (SF_LAYOUT_SPLIT_KOCT / c_f16 = 4) -- 4 bytes per element like fp32 planes
     shadow: Optional["Planes"] = None   # fp16 k-octet COPY of these fp32 planes, kept current by every producer (f16x2 mode):
                                         # a GEMM on the DMA-fed tile reads it as its B operand, everything else (residuals,
                                         # element-wise kernels) keeps reading the fp32 planes
@@ -215,7 +218,7 @@ class Planes:
         slice would otherwise leave the parent's copy stale without any error."""
         assert 0 <= r0 < r1 <= self.rows and self.group == 0
         if self.f16:                                # k-octet planes: whole octets only
-            assert self.koct and r0 % 8 == 0 and self.shadow is None
+            assert self.koct and r0 % 8 == 0 and self.shadow is None and not self.split
             return replace(self, off=self.off + (r0 // 8) * self.P * 4, rows=r1 - r0)
         if self.shadow is not None and r0 % 8 != 0 and not unshadowed:
             raise RuntimeError(f"Planes.slice({r0}, {r1}): shadowed planes can only be sliced at octet boundaries "
@@ -226,6 +229,11 @@ class Planes:
     def tensor(self) -> torch.Tensor:
         """Materialise as a [n_img, rows, P] torch view (only for contiguous-row, ungrouped views)."""
         assert self.group == 0
+        if self.f16 and self.koct and self.split:      # hi + lo as float32 (tests only)
+            oc = (self.rows + 7) // 8
+            hi = replace(self, split=False)
+            lo = replace(self, split=False, off=self.off + oc * self.P * 4)
+            return hi.tensor().float() + lo.tensor().float()
         if self.f16 and self.koct:                     # logical [n_img, rows, P] copy out of the octet planes (tests only)
             h = self.base.view(torch.float16)
             oc = (self.rows + 7) // 8
@@ -783,7 +791,16 @@ def gemm(A: PackedLinear, X: Planes, Y: Planes, epilogue: int = EPI_NONE, R: Opt
     prec = PRECISION
     if A.single and prec == PRECISION_F16X2:
         prec = PRECISION_F16                          # per-layer single-product weights (same operand formats)
-    if X.f16 or Y.f16:
+    if X.split or Y.split:                            # f16x3: the GEMM-to-GEMM tensor already split (hi, lo k-octet images)
+        if prec != PRECISION_F16X3 or (X.f16 and not X.split) or (Y.f16 and not Y.split):
+            raise RuntimeError("split k-octet planes are a hand-over format of the f16x3 mode only")
+        if X.split:
+            assert X.koct and X.group == 0
+            g.b_layout = _lib.LAYOUT_SPLIT_KOCT
+        if Y.split:
+            assert Y.koct
+            g.c_f16 = 4
+    elif X.f16 or Y.f16:
         if prec not in (PRECISION_F16X2, PRECISION_F16):
             raise RuntimeError("fp16 activation planes are a hand-over format of the f16x2 / f16 modes only")
         if X.f16:
@@ -818,7 +835,7 @@ def gemm(A: PackedLinear, X: Planes, Y: Planes, epilogue: int = EPI_NONE, R: Opt
         g.split_ws, g.split_ws_floats = SPLIT_WS.data_ptr(), SPLIT_WS.numel()
     name = "gemm" if not PROFILE_SHAPES else f"gemm M{g.M} K{g.K} b{g.batch} e{g.epilogue}"
     # algorithmic bytes: activations in (each input row once) + result out (+ residual in) per image, weights once
-    nbytes = (g.batch * g.N * ((2.0 if X.f16 else 4.0) * X.rows + (2.0 if Y.f16 else 6.0 if fused_shadow else 4.0) * g.M +
+    nbytes = (g.batch * g.N * ((2.0 if (X.f16 and not X.split) else 4.0) * X.rows + (2.0 if (Y.f16 and not Y.split) else 6.0 if fused_shadow else 4.0) * g.M +
                                ((2.0 if R.f16 else 4.0) * g.M if R is not None else 0.0)) + 4.0 * g.M * g.K)
     _launch(name, 2.0 * g.M * g.N * g.K * g.batch, nbytes,
             lambda: _lib.check(_lib.load().sf_gemm(C.byref(g), _lib.stream()), "sf_gemm"), products=_products(prec))

@@ -45,9 +45,10 @@ class PCBlock4_Deep_nopool_res(nn.Module, _Packed):
     def run(self, X: Planes, Y: Planes, h: int, w: int, final_gelu: bool = False) -> None:
         W = self.weights(X.base.device)
         dev = X.base.device
-        hid = _planes_like(X.n_img, W.c_mid, X.P, dev)
-        xa = _planes_like(X.n_img, W.c_in, X.P, dev)
-        xb = _planes_like(X.n_img, W.c_in, X.P, dev)
+        r8 = lambda r: (r + 7) // 8 * 8               # (whole k-octets: the split hand-over of the f16x3 mode writes them)
+        hid = _planes_like(X.n_img, r8(W.c_mid), X.P, dev)
+        xa = _planes_like(X.n_img, r8(W.c_in), X.P, dev)
+        xb = _planes_like(X.n_img, r8(W.c_in), X.P, dev)
         run_skblock(W, X, Y, hid, xa, xb, h, w, final_gelu)
 
     @ops.on_tensor_device

@@ -44,7 +44,7 @@ for K1, M2, a, b in itertools.product((128, 256, 324, 640, 0), (6, 64, 126, 256,
 
 # sf_gemm: every layout / epilogue / precision / algo combination over the update block's layer shapes
 shapes = [(960, 640), (640, 960), (486, 324), (256, 384), (128, 128), (6, 576), (126, 384), (576, 256), (64, 192), (256, 1152)]
-for (M, K), bl, epi, prec, algo, cf in itertools.product(shapes, (0, 1, 4, 5), range(7), (0, 1, 2, 3), (0, 1, 2), (0, 1, 2, 3)):
+for (M, K), bl, epi, prec, algo, cf in itertools.product(shapes, (0, 1, 4, 5, 6), range(7), (0, 1, 2, 3), (0, 1, 2), (0, 1, 2, 3, 4)):
     g = _lib.SfGemm()
     g.A, g.B, g.C, g.bias, g.R, g.dw_w, g.dw_b, g.gamma = PTR[0], PTR[1], PTR[2], PTR[3], PTR[4], PTR[5], PTR[6], PTR[7]
     g.M, g.N, g.K, g.batch = M, 7040, K, 24

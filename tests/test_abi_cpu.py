@@ -96,6 +96,14 @@ def test_gemm_output_format_rules_hold_for_every_b_layout(lib):
     assert lib.sf_gemm(ctypes.byref(g), None) == -2 and b"c_f16 = 2" in lib.sf_last_error()
     g = desc(b_layout=_lib.LAYOUT_F16_KOCT, N=8, ldb=8, ldc=8, k_splits=2, c_f16=1)
     assert lib.sf_gemm(ctypes.byref(g), None) == -2
+    # the split k-octet hand-over (SF_LAYOUT_SPLIT_KOCT / c_f16 = 4) belongs to F16X3 and to the 128-row tile
+    for kw in (dict(b_layout=_lib.LAYOUT_SPLIT_KOCT), dict(c_f16=4)):
+        g = desc(N=8, ldb=8, ldc=8, **kw)
+        assert lib.sf_gemm(ctypes.byref(g), None) != 0 and b"F16X3" in lib.sf_last_error(), kw
+    g = desc(b_layout=_lib.LAYOUT_SPLIT_KOCT, precision=_lib.PRECISION_F16X3, M=64, N=8, ldb=8, ldc=8)
+    assert lib.sf_gemm(ctypes.byref(g), None) == -2 and b"SPLIT_KOCT" in lib.sf_last_error()
+    g = desc(c_f16=4, precision=_lib.PRECISION_F16X3, N=8, ldb=8, ldc=8, epilogue=_lib.EPI_RELU)
+    assert lib.sf_gemm(ctypes.byref(g), None) == -2 and b"c_f16 = 2 / 4" in lib.sf_last_error()
     # k-octet residual: only with the RES_GELU_DW1 vector epilogue
     g = desc(b_layout=_lib.LAYOUT_F16_KOCT, N=8, ldb=8, ldc=8, ldr=8, R=4096, r_f16=2, epilogue=_lib.EPI_RES_GELU)
     assert lib.sf_gemm(ctypes.byref(g), None) == -2 and b"r_f16" in lib.sf_last_error()
