@@ -2,6 +2,8 @@
 # round-6 final evidence: GPU suite, smoke, bench lines for every configuration quoted in DESIGN.md / README.md
 cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/r06f; mkdir -p $O
+# (when tools/r06/profiles.sh ran earlier in the same call: bench.py quotes PMC traffic only from files taken on these sources)
+cp gpurun_out/r06p/r06_traffic_*.json gpurun_out/r06p/r06_mfma_busy_*.json profiles/ 2>/dev/null
 timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -4
 timeout 300 python __graft_entry__.py smoke 2>&1 | tail -3
 timeout 900 python bench.py > $O/r06_bench_default.json 2> $O/bench_default.err; tail -c 400 $O/r06_bench_default.json; echo
