@@ -34,6 +34,9 @@ class EngineOptions:
     `HotPathEngine(options=EngineOptions(split_solo=0))`, or from the shell for an experiment: SF_ENGINE_OPTS="split_solo=0,pw_fold=0"."""
     parallel_branches: bool = True   # independent chains of an iteration on a second stream
     split_solo: int = 2              # 0 / 2 / 4: sections without a concurrent branch run as half-batch chains on own streams
+    split_uneven: bool = False       # ... also when the clip count does not divide (a single clip, an odd batch: two unequal ranges of images).
+                                     # Off (round 6): one chain is faster there -- 1 clip 229.8 -> 237.2 ff/s, 3 clips 341.7 -> 348.9, one Spring
+                                     # clip 50.0 -> 50.8; even splits keep their chains (2 / 6 / 8 clips: +2-3 %; tools/clip_split_sweep.sh)
     auto_split_k: bool = True        # let sf_gemm split K for small grids (changes summation order at toy shapes only)
     attn_chunk_rows: int = 0         # > 0 forces the chunked recompute of the attention matrix
     attn_k_splits: int = 3           # split-K of attn @ v (materialised matrix), <= 4
@@ -676,7 +679,7 @@ class HotPathEngine:
         nch = self.split_solo if (self.split_solo in (2, 4) and side is not main) else 1
         if nch > 1 and Bc % nch == 0:
             parts, by_clip = [(c * (n // nch), n // nch) for c in range(nch)], True
-        elif nch > 1 and n >= 2:
+        elif nch > 1 and n >= 2 and self.options.split_uneven:
             parts, by_clip = [(0, (n + 1) // 2), ((n + 1) // 2, n // 2)], False
         else:
             parts, by_clip = [(0, n)], True

@@ -508,7 +508,7 @@ def test_two_chain_schedule_is_bitwise_the_one_chain_schedule(dev, preset):
         fmaps, cnets = syn.make_features(40 + B, B, T, h, w)
         outs = {}
         for chains in ("0", "2", "4"):
-            eng = HotPathEngine(P, device=dev, T=T, use_graph=graph, options=EngineOptions(auto_split_k=False, split_solo=int(chains)), **kw)
+            eng = HotPathEngine(P, device=dev, T=T, use_graph=graph, options=EngineOptions(auto_split_k=False, split_solo=int(chains), split_uneven=True), **kw)
             for _ in range(2):
                 ups = eng.forward(fmaps.to(dev), cnets.to(dev), iters=iters)[0]
             outs[chains] = [u.clone() for u in ups]
