@@ -436,10 +436,13 @@ constexpr int TROW = NOCT * 8;                  // halves per pixel in the trans
 #define SF_LOOKB_W2_ALWAYS 0
 #endif
 #ifndef SF_LOOKB_STREAM_BYTES
-// Volumes past this size are read with the streaming cache policy (slc): every line of a footprint is used once per lookup, and past
-// ~2.5 GB nothing of one iteration's lines survives to the next anyway -- Sintel, 24 images = 3.3 GB: 78-81 -> 68.7 us per lookup; below
-// it the default policy keeps some of them in the 256-MB infinity cache (KITTI, 8 images = 1.2 GB: 27.0 us, 29.7 us when streamed).
-#define SF_LOOKB_STREAM_BYTES (5ll << 29)
+// Volumes of at least this size are read with the streaming cache policy (slc): every line of a footprint is used once per lookup.
+// Alone (bench.py --corr-only: 15 lookups back to back) that pays from ~2.5 GB on -- Sintel, 24 images = 3.3 GB: 78-81 -> 66-69 us per
+// lookup; KITTI, 8 images = 1.2 GB: 27.0 -> 29.7 us, part of one lookup's lines survives to the next in the 256-MB infinity cache.
+// INSIDE the step thirty other kernels run between two lookups and nothing survives anyway: streaming is then faster at every size
+// (roofline_corr.frac KITTI 0.44-0.48 -> 0.49-0.50, 4 Sintel clips 0.49-0.51 -> 0.54-0.55, one clip 0.37-0.38 -> 0.39) -- the step is
+// what ships, so: always.
+#define SF_LOOKB_STREAM_BYTES 0
 #endif
 #ifndef SF_LOOKB_PF
 #define SF_LOOKB_PF 1                           // items (footprints) prefetched ahead of the one being processed (1 .. 8)
