@@ -150,7 +150,7 @@ def test_integration_md_binding_examples_run(dev):
     md = open(os.path.join(root, "INTEGRATION.md")).read()
     sec = md[md.index("## 2. Binding the C ABI"):md.index("## 3. Build")]
     blocks = re.findall(r"```python\n(.*?)```", sec, flags=re.S)
-    assert len(blocks) == 2
+    assert len(blocks) == 3
     ns = {}
     for code in blocks:
         exec(code.replace('"streamflow_amd/libstreamflow_hip.so"', repr(_lib.LIB_PATH)), ns)
@@ -173,6 +173,14 @@ def test_integration_md_binding_examples_run(dev):
         want = orc.corr_lookup(pyr, coords[t:t + 1]).reshape(324, h * w)
         err = (got[t] - want).abs().max().item()
         assert err < 2e-2 * max(1.0, want.abs().max().item() / 8), (t, err)       # fp16 cells and fp16 hand-over
+    # blocked fp32 volume + lookup into the reference's [n_img, 324, h, w] tensor
+    vol32, img_bytes32 = ns["corr_blocked32"](fmaps, B, T, D, h, w)
+    out32 = ns["lookup_blocked32"](vol32, img_bytes32, coords.to(dev).contiguous(), n_img, pairs, h, w)
+    torch.cuda.synchronize()
+    for t in range(pairs):
+        pyr = orc.corr_pyramid(fmaps[:, t].cpu(), fmaps[:, t + 1].cpu())
+        want = orc.corr_lookup(pyr, coords[t:t + 1])[0]
+        assert (out32[t].cpu() - want).abs().max().item() < 5e-5, t
 
 
 def test_blocked_build_and_lookup_are_deterministic_at_the_headline_shape(dev):
