@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--workload", default="sintel")
     ap.add_argument("--clips", type=int, default=8)
     ap.add_argument("--secs", type=float, default=0.6)
+    ap.add_argument("--gma", default=None, help="gma_mode override (flash / stored / hybrid / matrix)")
     args = ap.parse_args()
     import bench
     from streamflow_amd import ops, presets, synthetic as syn
@@ -112,6 +113,8 @@ def main():
     sampler = Sampler(pfiles[g])
     sampler.start()
     cfg = presets.engine_kwargs(args.preset or presets.BENCH_PRESET)
+    if args.gma:
+        cfg["gma_mode"] = args.gma
     params = syn.make_params(0, T)
     fmaps, cnets = syn.make_features(1000, B, T, h, w)
     fmaps, cnets = fmaps.to(dev), cnets.to(dev)
