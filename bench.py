@@ -154,6 +154,66 @@ def timed_steps(step_fn, steps: int, warmup: int, world: int, sync_fn, barrier_f
     return allreduce_max_fn(dt)
 
 
+class PowerSampler:
+    """Package power of every GPU of the node (amdgpu hwmon) every 20 ms from a thread, for the `power` object of the JSON line: the step is
+    bound by the package power cap, so watts x time = joules per step is the quantity a kernel change has to lower.
+    The box shows all GPUs of its node; ours is the one whose power rises most over its first sample.  Any failure -> `power: null`."""
+
+    def __init__(self):
+        import glob
+        import threading
+        self.dirs = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"))
+        self.files = [d + ("/power1_average" if os.path.exists(d + "/power1_average") else "/power1_input") for d in self.dirs]
+        self.rows, self.on, self.stop = [], False, False
+        self.first = self._read()
+        self.thread = threading.Thread(target=self._run, daemon=True)
+        self.thread.start()
+
+    def _read(self):
+        out = []
+        for f in self.files:
+            try:
+                with open(f) as fh:
+                    out.append(int(fh.read().strip()) / 1e6)
+            except (OSError, ValueError):
+                out.append(None)
+        return out
+
+    def _run(self):
+        while not self.stop:
+            if self.on:
+                self.rows.append(self._read())
+            time.sleep(0.02)
+
+    def summary(self, ms_per_step: float):
+        self.stop = True
+        try:
+            if not self.files or len(self.rows) < 4:
+                return None
+            rows = self.rows[len(self.rows) // 4:]                 # (the sensor settles over the first samples)
+            mean = [None if any(r[i] is None for r in rows) else sum(r[i] for r in rows) / len(rows) for i in range(len(self.files))]
+            rise = [(-1.0 if (m is None or f0 is None) else m - f0) for m, f0 in zip(mean, self.first)]
+            g = max(range(len(rise)), key=lambda i: rise[i])
+            if mean[g] is None:
+                return None
+            cap = None
+            try:
+                with open(self.dirs[g] + "/power1_cap") as fh:
+                    cap = int(fh.read().strip()) / 1e6
+            except (OSError, ValueError):
+                pass
+            idle = self.first[g]
+            return {"watts_under_step": round(mean[g], 1), "watts_idle_before_the_run": round(idle, 1), "cap_watts": cap,
+                    "joules_per_step": round(mean[g] * ms_per_step / 1e3, 2),
+                    "joules_per_step_above_idle": round((mean[g] - idle) * ms_per_step / 1e3, 2), "samples": len(rows),
+                    "source": self.files[g],
+                    "note": "package power sampled every 20 ms over the timed region; the step's energy above idle equals the sum of its launches' "
+                            "energies measured alone (tools/energy_table.py, DESIGN.md 12.11): on this power-capped part a kernel change pays "
+                            "in the step only if it lowers joules"}
+        except Exception:                                          # measurement aid only: never fatal
+            return None
+
+
 def cpu_baseline(samples, iters: int, pairs: int):
     """The CPU oracle (PyTorch-CPU restatement of the reference path, kind='port') on the host cores: a WHOLE clip (setup + all
     `iters` iterations, mask head, upsampling) per timed run, after one short warm-up pass; the median is reported (SURVEY.md
@@ -506,6 +566,8 @@ def main():
         os.environ.update(pinned_device_env(local_rank, os.environ.get("HIP_VISIBLE_DEVICES")))
     if "SF_BENCH_DEVICE" in os.environ and not args.share_device:
         local_rank = int(os.environ["SF_BENCH_DEVICE"])
+    # (first power reading = the idle draw: before this process touches the GPU)
+    power = PowerSampler() if (world == 1 and not args.corr_only) else None
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
     if args.share_device:
         local_rank %= torch.cuda.device_count()
@@ -609,7 +671,11 @@ def main():
     torch.cuda.synchronize()
     log("first step done (includes graph capture)")
     own = []
+    if power is not None:
+        power.on = True
     dt = timed_steps(step, args.steps, args.warmup, world, torch.cuda.synchronize, barrier, allreduce_max, own=own)
+    if power is not None:
+        power.on = False
     log(f"timed region: {args.steps} steps in {dt:.3f}s (this rank: {own[0]:.3f}s)")
     per_rank, rank_cores, rank_host, rank_host_cpu = [own[0]], [len(RANK_CPUS)], [own[1]], [own[2]]
     pl0 = next(reversed(eng._plans.values())) if eng._plans else None
@@ -643,6 +709,7 @@ def main():
         # launch, or the eager enqueues; the runtime launches a graph's nodes from the calling thread and blocks while the hardware
         # queues are full, so this follows the GPU time) and its CPU time alone -- if host_cpu approaches ms_per_step at N = 8 the
         # ranks are host-bound, not GPU-bound -- and the size of the replayed graph (launch calls captured per forward)
+        "power": power.summary(1e3 * dt / args.steps) if power is not None else None,
         "host_ms_per_step": [round(1e3 * t / args.steps, 3) for t in rank_host],
         "host_cpu_ms_per_step": [round(1e3 * t / args.steps, 3) for t in rank_host_cpu],
         "graph_launch_calls": graph_calls,
